@@ -1,0 +1,247 @@
+"""Generate golden vectors from the REAL reference (runs only in the build container).
+
+TEST INFRASTRUCTURE ONLY.  Imports ``/root/reference/neural_networks.py`` and
+``utils.py`` unmodified (read-only, no bytecode written), runs the reference
+classes on CPU fp32 on seeded inputs and stores inputs, parameters, drop masks,
+outputs and gradients as small ``.npz`` fixtures under ``tests/golden/``.
+``/root/reference`` does not exist on the GPU box, so these committed fixtures
+are what pins both the oracle (oracle/pk_oracle.py) and the HIP engine to the
+reference.
+
+    python oracle/make_golden.py            # regenerates tests/golden/*.npz
+"""
+
+import configparser
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("PK_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import neural_networks as ref_nn  # noqa: E402  (the reference itself)
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+class _MaskTap:
+    """Records every torch.bernoulli() result the reference draws in forward."""
+
+    def __init__(self):
+        self.masks = []
+        self._orig = torch.bernoulli
+
+    def __enter__(self):
+        def tapped(*a, **k):
+            m = self._orig(*a, **k)
+            self.masks.append(m.clone())
+            return m
+
+        torch.bernoulli = tapped
+        return self
+
+    def __exit__(self, *exc):
+        torch.bernoulli = self._orig
+
+
+def _perturb(net, seed):
+    """Make BN/LN affine parameters, biases and running stats non-trivial."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if name.endswith("gamma") or (".weight" in name and name.split(".")[0].startswith("bn")):
+                p.add_(0.2 * torch.randn(p.shape, generator=g))
+            elif name.endswith("beta") or name.endswith(".bias"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+        for name, b in net.named_buffers():
+            if name.endswith("running_mean"):
+                b.add_(0.1 * torch.randn(b.shape, generator=g))
+            elif name.endswith("running_var"):
+                b.mul_(1.0 + 0.3 * torch.rand(b.shape, generator=g))
+
+
+def _save(name, meta, arrays):
+    os.makedirs(OUT, exist_ok=True)
+    meta = dict(meta)
+    meta["torch"] = torch.__version__
+    meta["threads"] = torch.get_num_threads()
+    arrays = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%d bytes)" % (path, os.path.getsize(path)))
+
+
+def module_case(name, arch_class, options, inp_dim, x_shape, seed, to_do="train", training=True,
+                x_scale=1.0, noncontig=False):
+    options = dict(options)
+    options["use_cuda"] = "False"
+    options["to_do"] = to_do
+    torch.manual_seed(seed)
+    net = getattr(ref_nn, arch_class)(options, inp_dim)
+    init_sd = {k: v.clone() for k, v in net.state_dict().items()}  # what seed -> init gives
+    _perturb(net, seed + 1)
+    net.train() if training else net.eval()
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(seed + 2)
+    x = (torch.randn(*x_shape, generator=g) * x_scale)
+    if noncontig:  # forward_model hands column slices of a wider tensor (utils.py:2321)
+        wide = torch.randn(*x_shape[:-1], x_shape[-1] + 2, generator=g)
+        wide[..., : x_shape[-1]] = x
+        x = wide[..., : x_shape[-1]]
+    x = x.clone().requires_grad_(True)
+    torch.manual_seed(seed + 3)  # RNG state the drop masks are drawn from
+    with _MaskTap() as tap:
+        y = net(x)
+    cot = torch.randn(y.shape, generator=g)
+    arrays = {"x": x, "y": y, "cot": cot}
+    if to_do == "train" or training:
+        loss = (y * cot).sum()
+        loss.backward()
+        arrays["dx"] = x.grad
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                arrays["grad/" + k] = p.grad
+    for k, v in sd0.items():
+        arrays["sd/" + k] = v
+    for k, v in init_sd.items():
+        arrays["init/" + k] = v
+    for k, v in net.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            arrays["sd_after/" + k] = v
+    for i, m in enumerate(tap.masks):
+        arrays["mask/%d" % i] = m
+    meta = {"arch_class": arch_class, "options": options, "inp_dim": inp_dim, "to_do": to_do,
+            "training": training, "seed": seed, "n_masks": len(tap.masks)}
+    _save(name, meta, arrays)
+
+
+def rec_opts(pre, lay, act, bn=True, ln=False, bidir=True, drop=0.2, orth=True, ln_inp=False, bn_inp=False):
+    n = len(lay)
+    j = lambda v: ",".join([str(v)] * n)  # noqa: E731
+    return {
+        pre + "_lay": ",".join(map(str, lay)),
+        pre + "_drop": j(drop),
+        pre + "_use_laynorm_inp": str(ln_inp),
+        pre + "_use_batchnorm_inp": str(bn_inp),
+        pre + "_use_laynorm": j(ln),
+        pre + "_use_batchnorm": j(bn),
+        pre + "_bidir": str(bidir),
+        pre + "_act": j(act),
+        pre + "_orthinit": str(orth),
+    }
+
+
+def e2e_case(name, seed, T, B, H, n_cd, n_mono):
+    """Drive the reference one level up: utils.model_init / forward_model on the
+    shipped Li-GRU recipe scaled down."""
+    import utils as ref_utils
+
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(REF, "cfg/TIMIT_baselines/TIMIT_liGRU_fmllr.cfg"))
+    cfg["exp"]["to_do"] = "train"
+    cfg["exp"]["use_cuda"] = "False"
+    cfg["architecture1"]["ligru_lay"] = "%d,%d" % (H, H)
+    for k in ("ligru_drop", "ligru_use_laynorm", "ligru_use_batchnorm", "ligru_act"):
+        cfg["architecture1"][k] = ",".join(cfg["architecture1"][k].split(",")[:2])
+    cfg["architecture2"]["dnn_lay"] = str(n_cd)
+    cfg["architecture3"]["dnn_lay"] = str(n_mono)
+    nfea = 11
+    fea_dict = {"fmllr": ["fmllr", "lst", "opts", "0", "0", 0, nfea, nfea]}
+    lab_dict = {"lab_cd": ["lab_cd", "f", "o", nfea], "lab_mono": ["lab_mono", "f", "o", nfea + 1]}
+    arch_dict = {
+        "liGRU_layers": ["architecture1", "liGRU_layers", True],
+        "MLP_layers": ["architecture2", "MLP_layers", False],
+        "MLP_layers2": ["architecture3", "MLP_layers2", False],
+    }
+    model = cfg["model"]["model"].split("\n")
+    inp_out_dict = {"fmllr": fea_dict["fmllr"][5:]}  # as utils.dict_fea_lab_arch builds it ([start,end,dim])
+    torch.manual_seed(seed)
+    nns, costs = ref_utils.model_init(inp_out_dict, model, cfg, arch_dict, False, False, "train")
+    for k, net in nns.items():
+        _perturb(net, seed + len(k))
+    g = torch.Generator().manual_seed(seed + 2)
+    inp = torch.randn(T, B, nfea + 2, generator=g)
+    inp[:, :, nfea] = torch.randint(0, n_cd, (T, B), generator=g).float()
+    inp[:, :, nfea + 1] = torch.randint(0, n_mono, (T, B), generator=g).float()
+    sd0 = {n: {k: v.clone() for k, v in net.state_dict().items()} for n, net in nns.items()}
+    torch.manual_seed(seed + 3)
+    with _MaskTap() as tap:
+        outs = ref_utils.forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out_dict,
+                                       T, B, "train", [])
+    outs["loss_final"].backward()
+    arrays = {"inp": inp, "loss_final": outs["loss_final"], "err_final": outs["err_final"],
+              "out_dnn1": outs["out_dnn1"], "out_dnn2": outs["out_dnn2"], "out_dnn3": outs["out_dnn3"]}
+    for n, net in nns.items():
+        for k, v in sd0[n].items():
+            arrays["sd/%s/%s" % (n, k)] = v
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                arrays["grad/%s/%s" % (n, k)] = p.grad
+    for i, m in enumerate(tap.masks):
+        arrays["mask/%d" % i] = m
+    opts = {sec: dict(cfg[sec]) for sec in ("architecture1", "architecture2", "architecture3")}
+    meta = {"options": opts, "model": model, "nfea": nfea, "T": T, "B": B, "seed": seed,
+            "n_cd": n_cd, "n_mono": n_mono, "n_masks": len(tap.masks)}
+    _save(name, meta, arrays)
+
+
+def main():
+    torch.set_num_threads(1)  # bit-stable fixtures
+    # --- recurrent family -----------------------------------------------------
+    module_case("ligru_bidir_bn", "liGRU", rec_opts("ligru", [24, 16], "relu"), 7, (9, 3, 7), 100)
+    module_case("ligru_uni_ln_bias", "liGRU", rec_opts("ligru", [20, 12], "relu", bn=False, ln=True, bidir=False,
+                                                       drop=0.1, ln_inp=True), 6, (8, 4, 6), 110)
+    module_case("ligru_plain_tanh_bninp", "liGRU", rec_opts("ligru", [18], "tanh", bn=False, ln=False, bidir=True,
+                                                            drop=0.0, bn_inp=True), 5, (7, 2, 5), 120)
+    module_case("ligru_bidir_bn_wide", "liGRU", rec_opts("ligru", [40, 40, 40], "relu"), 13, (16, 8, 13), 130,
+                noncontig=True)
+    module_case("ligru_eval", "liGRU", rec_opts("ligru", [24, 16], "relu"), 7, (9, 3, 7), 140,
+                to_do="valid", training=False)
+    module_case("lstm_bidir_bn", "LSTM", rec_opts("lstm", [20, 14], "tanh"), 7, (9, 3, 7), 200)
+    module_case("lstm_uni_nobn", "LSTM", rec_opts("lstm", [16], "tanh", bn=False, bidir=False, drop=0.3), 5,
+                (6, 4, 5), 210)
+    module_case("gru_bidir_bn", "GRU", rec_opts("gru", [20, 14], "tanh"), 7, (9, 3, 7), 300)
+    module_case("gru_uni_relu", "GRU", rec_opts("gru", [12], "relu", bn=False, bidir=False, drop=0.1), 4,
+                (7, 3, 4), 310)
+    module_case("mingru_bidir_bn", "minimalGRU", rec_opts("minimalgru", [20, 14], "relu"), 7, (9, 3, 7), 400)
+    module_case("rnn_bidir_bn", "RNN", rec_opts("rnn", [20, 14], "relu"), 7, (9, 3, 7), 500)
+    module_case("rnn_uni_ln_tanh", "RNN", rec_opts("rnn", [14], "tanh", bn=False, ln=True, bidir=False, drop=0.0), 5,
+                (6, 3, 5), 510)
+
+    # --- MLP --------------------------------------------------------------------
+    mlp = {"dnn_lay": "32,24,17", "dnn_drop": "0.0,0.0,0.0", "dnn_use_laynorm_inp": "False",
+           "dnn_use_batchnorm_inp": "False", "dnn_use_batchnorm": "True,True,False",
+           "dnn_use_laynorm": "False,False,False", "dnn_act": "relu,relu,softmax"}
+    module_case("mlp_bn_relu_softmax", "MLP", mlp, 20, (16, 20), 600)
+    mlp2 = dict(mlp, dnn_use_batchnorm="False,True,False", dnn_use_laynorm="True,True,False",
+                dnn_use_laynorm_inp="True", dnn_use_batchnorm_inp="True", dnn_act="tanh,leaky_relu,linear")
+    module_case("mlp_ln_bn_mixed", "MLP", mlp2, 20, (16, 20), 610)
+    mlp3 = dict(mlp, dnn_lay="16,9", dnn_drop="0.0,0.0", dnn_use_batchnorm="False,False",
+                dnn_use_laynorm="False,False", dnn_act="sigmoid,elu")
+    module_case("mlp_plain_sigmoid_elu", "MLP", mlp3, 10, (8, 10), 620)
+    module_case("mlp_eval", "MLP", mlp, 20, (16, 20), 630, to_do="valid", training=False)
+
+    # --- CNN / SincNet ----------------------------------------------------------
+    sinc = {"sinc_N_filt": "8,6,5", "sinc_len_filt": "33,5,3", "sinc_max_pool_len": "3,2,2",
+            "sinc_use_laynorm_inp": "True", "sinc_use_batchnorm_inp": "False",
+            "sinc_use_laynorm": "True,True,True", "sinc_use_batchnorm": "False,False,False",
+            "sinc_act": "relu,relu,leaky_relu", "sinc_drop": "0.0,0.0,0.0",
+            "sinc_sample_rate": "16000", "sinc_min_low_hz": "50", "sinc_min_band_hz": "50"}
+    module_case("sincnet_ln", "SincNet", sinc, 200, (4, 200), 700, x_scale=0.1)
+    cnn = {"cnn_N_filt": "8,6", "cnn_len_filt": "9,5", "cnn_max_pool_len": "3,2",
+           "cnn_use_laynorm_inp": "False", "cnn_use_batchnorm_inp": "False",
+           "cnn_use_laynorm": "False,True", "cnn_use_batchnorm": "True,False",
+           "cnn_act": "relu,tanh", "cnn_drop": "0.0,0.0"}
+    module_case("cnn_bn_ln", "CNN", cnn, 120, (5, 120), 710, x_scale=0.5)
+
+    # --- one level up: the shipped recipe through utils.forward_model ------------
+    e2e_case("e2e_ligru_two_heads", 800, T=10, B=4, H=16, n_cd=23, n_mono=7)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,395 @@
+"""CPU oracle for the PyTorch-Kaldi `neural_networks.py` hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``pytorch-kaldi_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg
+of ``bench.py`` use it, and there only as the checker / the reported CPU baseline.
+
+It is a plain torch-CPU restatement (fp32 or fp64, autograd for gradients) of the
+reference algorithm, written from the reference's behaviour and citing the lines
+it follows (paths relative to the reference checkout):
+
+    LayerNorm                neural_networks.py:23-33
+    act_fun                  neural_networks.py:36-57
+    MLP.forward              neural_networks.py:126-150
+    LSTM.forward             neural_networks.py:402-483
+    GRU.forward              neural_networks.py:579-655
+    liGRU.forward            neural_networks.py:1082-1155
+    minimalGRU.forward       neural_networks.py:1243-1316
+    RNN.forward              neural_networks.py:1396-1461
+    CNN.forward              neural_networks.py:1530-1556
+    SincNet.forward          neural_networks.py:1639-1665
+    SincConv.forward/sinc    neural_networks.py:1763-1813
+    flip                     neural_networks.py:1962-1970
+    forward_model (glue)     utils.py:2296-2420
+
+Parity pin: the reference ships no tests or golden vectors for this path
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference
+itself, generated in the build container by ``oracle/make_golden.py`` (which
+imports ``/root/reference/neural_networks.py`` unmodified) and committed under
+``tests/golden/``.  ``tests/test_oracle_golden.py`` checks every fixture.
+
+Parameters are passed as a ``dict`` that uses the reference's ``state_dict`` key
+names (``wh.0.weight``, ``bn_wz.3.running_var``, ``ln.0.gamma`` ...), so a
+reference checkpoint can be fed to the oracle unchanged.
+"""
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------
+# option parsing (the reference reads everything from strings)
+# ----------------------------------------------------------------------------
+def _tobool(s):
+    s = str(s).strip().lower()
+    if s in ("y", "yes", "t", "true", "on", "1"):
+        return 1
+    if s in ("n", "no", "f", "false", "off", "0"):
+        return 0
+    raise ValueError("invalid truth value %r" % (s,))
+
+
+def _ints(s):
+    return [int(v) for v in str(s).split(",")]
+
+
+def _floats(s):
+    return [float(v) for v in str(s).split(",")]
+
+
+def _bools(s):
+    return [_tobool(v) for v in str(s).split(",")]
+
+
+def _strs(s):
+    return str(s).split(",")
+
+
+def _opt(options, key):
+    # configparser lower-cases option names; accept either spelling
+    if key in options:
+        return options[key]
+    return options[key.lower()]
+
+
+# ----------------------------------------------------------------------------
+# primitives
+# ----------------------------------------------------------------------------
+def layer_norm(x, gamma, beta, eps=1e-6):
+    """neural_networks.py:30-33 - unbiased std, eps added to the std."""
+    mean = x.mean(-1, keepdim=True)
+    std = x.std(-1, keepdim=True)
+    return gamma * (x - mean) / (std + eps) + beta
+
+
+def activation(name, x):
+    """neural_networks.py:36-57.  'softmax' is LogSoftmax(dim=1); 'linear' is
+    LeakyReLU(1) i.e. identity."""
+    if name == "relu":
+        return torch.relu(x)
+    if name == "tanh":
+        return torch.tanh(x)
+    if name == "sigmoid":
+        return torch.sigmoid(x)
+    if name == "leaky_relu":
+        return F.leaky_relu(x, 0.2)
+    if name == "elu":
+        return F.elu(x)
+    if name == "softmax":
+        return F.log_softmax(x, dim=1)
+    if name == "linear":
+        return F.leaky_relu(x, 1.0)
+    raise ValueError("unknown activation " + name)
+
+
+def batch_norm(x, sd, prefix, training, momentum=0.05, eps=1e-5):
+    """nn.BatchNorm1d(momentum=0.05) semantics on (N, C) or (N, C, L) input;
+    running buffers in ``sd`` are updated in place in training mode."""
+    w = sd[prefix + ".weight"]
+    b = sd[prefix + ".bias"]
+    rm = sd.get(prefix + ".running_mean")
+    rv = sd.get(prefix + ".running_var")
+    out = F.batch_norm(x, rm, rv, w, b, training, momentum, eps)
+    key = prefix + ".num_batches_tracked"
+    if training and key in sd:
+        sd[key] += 1
+    return out
+
+
+def flip_time(x):
+    """neural_networks.py:1962-1970 with dim=0."""
+    return torch.flip(x, dims=[0])
+
+
+def _linear(x, sd, prefix):
+    b = sd.get(prefix + ".bias")
+    return F.linear(x, sd[prefix + ".weight"], b)
+
+
+def _dropout(x, p, training, mask):
+    if mask is not None:
+        return x * mask
+    if training and p > 0.0:
+        return F.dropout(x, p, True)
+    return x
+
+
+# ----------------------------------------------------------------------------
+# MLP
+# ----------------------------------------------------------------------------
+def mlp_forward(options, sd, x, training=True, drop_masks=None):
+    """neural_networks.py:126-150.  ``drop_masks[i]`` (already scaled by
+    1/(1-p)) replaces nn.Dropout of layer i when given."""
+    lay = _ints(_opt(options, "dnn_lay"))
+    drop = _floats(_opt(options, "dnn_drop"))
+    use_bn = _bools(_opt(options, "dnn_use_batchnorm"))
+    use_ln = _bools(_opt(options, "dnn_use_laynorm"))
+    acts = _strs(_opt(options, "dnn_act"))
+    if _tobool(_opt(options, "dnn_use_laynorm_inp")):
+        x = layer_norm(x, sd["ln0.gamma"], sd["ln0.beta"])
+    if _tobool(_opt(options, "dnn_use_batchnorm_inp")):
+        x = batch_norm(x, sd, "bn0", training)
+    for i in range(len(lay)):
+        z = _linear(x, sd, "wx.%d" % i)
+        if use_ln[i]:
+            z = layer_norm(z, sd["ln.%d.gamma" % i], sd["ln.%d.beta" % i])
+        if use_bn[i]:
+            z = batch_norm(z, sd, "bn.%d" % i, training)
+        z = activation(acts[i], z)
+        m = None if drop_masks is None else drop_masks[i]
+        x = _dropout(z, drop[i], training, m)
+    return x
+
+
+# ----------------------------------------------------------------------------
+# recurrent family
+# ----------------------------------------------------------------------------
+_REC = {
+    # kind: (option prefix, [(input-proj name, recurrent name, bn name)...])
+    "liGRU": ("ligru", [("wz", "uz", "bn_wz"), ("wh", "uh", "bn_wh")]),
+    "minimalGRU": ("minimalgru", [("wz", "uz", "bn_wz"), ("wh", "uh", "bn_wh")]),
+    "GRU": ("gru", [("wz", "uz", "bn_wz"), ("wr", "ur", "bn_wr"), ("wh", "uh", "bn_wh")]),
+    "LSTM": ("lstm", [("wfx", "ufh", "bn_wfx"), ("wix", "uih", "bn_wix"),
+                      ("wox", "uoh", "bn_wox"), ("wcx", "uch", "bn_wcx")]),
+    "RNN": ("rnn", [("wh", "uh", "bn_wh")]),
+}
+
+
+def make_drop_masks(kind, options, batch, to_do="train", generator=None):
+    """The reference samples one Bernoulli(1-p) mask of shape (rows, H) per layer
+    per forward call on the CPU RNG, unscaled, constant over time; in test mode
+    it uses the scalar (1-p) (e.g. neural_networks.py:1102-1107)."""
+    pre = _REC[kind][0]
+    lay = _ints(_opt(options, pre + "_lay"))
+    drop = _floats(_opt(options, pre + "_drop"))
+    bidir = _tobool(_opt(options, pre + "_bidir"))
+    rows = 2 * batch if bidir else batch
+    masks = []
+    for i, h in enumerate(lay):
+        if to_do == "train":
+            masks.append(torch.bernoulli(torch.Tensor(rows, h).fill_(1 - drop[i]), generator=generator))
+        else:
+            masks.append(torch.FloatTensor([1 - drop[i]]))
+    return masks
+
+
+def recurrent_forward(kind, options, sd, x, training=True, to_do="train", drop_masks=None,
+                      index_like_reference=False, return_all=False):
+    """Forward of LSTM/GRU/liGRU/minimalGRU/RNN exactly as the reference orders
+    it: pack bidirectional on the batch axis, per-gate Linear over all steps,
+    per-gate BatchNorm over the T*rows rows, python time loop from h=0, stack,
+    unpack (neural_networks.py:402-483, 579-655, 1082-1155, 1243-1316, 1396-1461).
+
+    ``index_like_reference=True`` indexes the projections with ``w_out[k]`` inside
+    the loop as the reference does (this is what makes its backward O(T^2));
+    the default unbinds once, which is arithmetically identical and faster.
+    """
+    pre, gates = _REC[kind]
+    lay = _ints(_opt(options, pre + "_lay"))
+    use_bn = _bools(_opt(options, pre + "_use_batchnorm"))
+    use_ln = _bools(_opt(options, pre + "_use_laynorm"))
+    acts = _strs(_opt(options, pre + "_act"))
+    bidir = _tobool(_opt(options, pre + "_bidir"))
+    if drop_masks is None:
+        drop_masks = make_drop_masks(kind, options, x.shape[1], to_do)
+
+    if _tobool(_opt(options, pre + "_use_laynorm_inp")):
+        x = layer_norm(x, sd["ln0.gamma"], sd["ln0.beta"])
+    if _tobool(_opt(options, pre + "_use_batchnorm_inp")):
+        xb = batch_norm(x.reshape(x.shape[0] * x.shape[1], x.shape[2]), sd, "bn0", training)
+        x = xb.view(x.shape[0], x.shape[1], x.shape[2])
+
+    per_layer = []
+    for i, H in enumerate(lay):
+        if bidir:
+            x = torch.cat([x, flip_time(x)], 1)
+        T, R = x.shape[0], x.shape[1]
+        h0 = torch.zeros(R, H, dtype=x.dtype)
+        mask = drop_masks[i].to(x.dtype)
+
+        proj = {}
+        for (wn, un, bnn) in gates:
+            p = _linear(x, sd, "%s.%d" % (wn, i))
+            if use_bn[i]:
+                pb = batch_norm(p.reshape(T * R, H), sd, "%s.%d" % (bnn, i), training)
+                p = pb.view(T, R, H)
+            proj[wn] = p
+        if not index_like_reference:
+            proj = {k: v.unbind(0) for k, v in proj.items()}
+
+        def U(name, h):
+            return F.linear(h, sd["%s.%d.weight" % (name, i)])
+
+        hs = []
+        ht = h0
+        ct = h0
+        for k in range(T):
+            if kind == "liGRU":  # :1133-1136
+                zt = torch.sigmoid(proj["wz"][k] + U("uz", ht))
+                at = proj["wh"][k] + U("uh", ht)
+                hcand = activation(acts[i], at) * mask
+                ht = zt * ht + (1 - zt) * hcand
+            elif kind == "minimalGRU":  # :1294-1297
+                zt = torch.sigmoid(proj["wz"][k] + U("uz", ht))
+                at = proj["wh"][k] + U("uh", zt * ht)
+                hcand = activation(acts[i], at) * mask
+                ht = zt * ht + (1 - zt) * hcand
+            elif kind == "GRU":  # :632-636
+                zt = torch.sigmoid(proj["wz"][k] + U("uz", ht))
+                rt = torch.sigmoid(proj["wr"][k] + U("ur", ht))
+                at = proj["wh"][k] + U("uh", rt * ht)
+                hcand = activation(acts[i], at) * mask
+                ht = zt * ht + (1 - zt) * hcand
+            elif kind == "LSTM":  # :460-464
+                ft = torch.sigmoid(proj["wfx"][k] + U("ufh", ht))
+                it = torch.sigmoid(proj["wix"][k] + U("uih", ht))
+                ot = torch.sigmoid(proj["wox"][k] + U("uoh", ht))
+                ct = it * activation(acts[i], proj["wcx"][k] + U("uch", ht)) * mask + ft * ct
+                ht = ot * activation(acts[i], ct)
+            elif kind == "RNN":  # :1441-1442
+                at = proj["wh"][k] + U("uh", ht)
+                ht = activation(acts[i], at) * mask
+            else:
+                raise ValueError(kind)
+            if use_ln[i]:
+                ht = layer_norm(ht, sd["ln.%d.gamma" % i], sd["ln.%d.beta" % i])
+            hs.append(ht)
+        h = torch.stack(hs)
+        if bidir:
+            B = R // 2
+            h = torch.cat([h[:, :B], flip_time(h[:, B:].contiguous())], 2)
+        x = h
+        per_layer.append(h)
+    if return_all:
+        return x, per_layer
+    return x
+
+
+# ----------------------------------------------------------------------------
+# CNN / SincNet
+# ----------------------------------------------------------------------------
+def sinc_filters(low_hz_, band_hz_, kernel_size, sample_rate, min_low_hz, min_band_hz):
+    """SincConv bank synthesis, neural_networks.py:1754-1803 (window grid is
+    linspace(0, K, K), not the textbook Hamming grid; division by the row max
+    is differentiated through)."""
+    K = kernel_size + 1 if kernel_size % 2 == 0 else kernel_size
+    dt = low_hz_.dtype
+    n_lin = torch.linspace(0, K, steps=K).to(dt)
+    window = 0.54 - 0.46 * torch.cos(2 * math.pi * n_lin / K)
+    n = (K - 1) / 2
+    n_ = (torch.arange(-n, n + 1).view(1, -1) / sample_rate).to(dt)
+
+    def sinc(v):
+        left = v[:, 0:int((v.shape[1] - 1) / 2)]
+        yl = torch.sin(left) / left
+        return torch.cat([yl, torch.ones([v.shape[0], 1], dtype=dt), torch.flip(yl, dims=[1])], dim=1)
+
+    low = min_low_hz / sample_rate + torch.abs(low_hz_)
+    high = low + min_band_hz / sample_rate + torch.abs(band_hz_)
+    lp1 = 2 * low * sinc(2 * math.pi * torch.matmul(low, n_) * sample_rate)
+    lp2 = 2 * high * sinc(2 * math.pi * torch.matmul(high, n_) * sample_rate)
+    bp = lp2 - lp1
+    mx, _ = torch.max(bp, dim=1, keepdim=True)
+    bp = bp / mx
+    return (bp * window).view(low_hz_.shape[0], 1, K)
+
+
+def conv_stack_forward(kind, options, sd, x, training=True, drop_masks=None):
+    """CNN.forward (:1530-1556) / SincNet.forward (:1639-1665).  Note the
+    reference constructs its BatchNorm1d with eps = pooled length (positional
+    slip at :1515-1517 / :1615-1617) and runs the block twice when both
+    laynorm and batchnorm are set; both quirks are kept."""
+    pre = "cnn" if kind == "CNN" else "sinc"
+    n_filt = _ints(_opt(options, pre + "_N_filt"))
+    len_filt = _ints(_opt(options, pre + "_len_filt"))
+    pool = _ints(_opt(options, pre + "_max_pool_len"))
+    acts = _strs(_opt(options, pre + "_act"))
+    drop = _floats(_opt(options, pre + "_drop"))
+    use_ln = _bools(_opt(options, pre + "_use_laynorm"))
+    use_bn = _bools(_opt(options, pre + "_use_batchnorm"))
+    batch, seq_len = x.shape[0], x.shape[1]
+    if _tobool(_opt(options, pre + "_use_laynorm_inp")):
+        x = layer_norm(x, sd["ln0.gamma"], sd["ln0.beta"])
+    if _tobool(_opt(options, pre + "_use_batchnorm_inp")):
+        x = batch_norm(x, sd, "bn0", training)
+    x = x.view(batch, 1, seq_len)
+    cur = seq_len
+    for i in range(len(n_filt)):
+        pooled = int((cur - len_filt[i] + 1) / pool[i])
+
+        def conv(v):
+            if kind == "SincNet" and i == 0:
+                w = sinc_filters(sd["conv.0.low_hz_"], sd["conv.0.band_hz_"], len_filt[0],
+                                 int(_opt(options, "sinc_sample_rate")),
+                                 int(_opt(options, "sinc_min_low_hz")),
+                                 int(_opt(options, "sinc_min_band_hz")))
+                return F.conv1d(v, w)
+            return F.conv1d(v, sd["conv.%d.weight" % i], sd["conv.%d.bias" % i])
+
+        m = None if drop_masks is None else drop_masks[i]
+        x_in = x
+        if use_ln[i]:
+            z = F.max_pool1d(conv(x_in), pool[i])
+            z = layer_norm(z, sd["ln.%d.gamma" % i], sd["ln.%d.beta" % i])
+            x = _dropout(activation(acts[i], z), drop[i], training, m)
+        if use_bn[i]:
+            z = F.max_pool1d(conv(x), pool[i])
+            z = batch_norm(z, sd, "bn.%d" % i, training, eps=float(pooled))
+            x = _dropout(activation(acts[i], z), drop[i], training, m)
+        if not use_bn[i] and not use_ln[i]:
+            z = F.max_pool1d(conv(x_in), pool[i])
+            x = _dropout(activation(acts[i], z), drop[i], training, m)
+        cur = pooled
+    return x.view(batch, -1)
+
+
+# ----------------------------------------------------------------------------
+# dispatcher + forward_model glue
+# ----------------------------------------------------------------------------
+def arch_forward(arch_class, options, sd, x, training=True, to_do="train", drop_masks=None,
+                 index_like_reference=False):
+    if arch_class == "MLP":
+        return mlp_forward(options, sd, x, training, drop_masks)
+    if arch_class in _REC:
+        return recurrent_forward(arch_class, options, sd, x, training, to_do, drop_masks,
+                                 index_like_reference)
+    if arch_class in ("CNN", "SincNet"):
+        return conv_stack_forward(arch_class, options, sd, x, training, drop_masks)
+    raise ValueError("oracle does not cover arch_class " + arch_class)
+
+
+def two_head_loss(rec_out, sd_cd, opt_cd, sd_mono, opt_mono, lab_cd, lab_mono, mono_weight=1.0):
+    """The [model] section of cfg/TIMIT_baselines/TIMIT_liGRU_fmllr.cfg:189-197 as
+    forward_model evaluates it (utils.py:2333-2339, 2344-2361, 2379-2381, 2395-2401):
+    out_dnn2/out_dnn3 = MLP heads on the (T*B, D) view, NLLLoss (mean) on each,
+    loss_final = loss_cd + w * loss_mono, err_final on the cd head."""
+    flat = rec_out.reshape(rec_out.shape[0] * rec_out.shape[1], -1) if rec_out.dim() == 3 else rec_out
+    out_cd = mlp_forward(opt_cd, sd_cd, flat)
+    out_mono = mlp_forward(opt_mono, sd_mono, flat)
+    loss_cd = F.nll_loss(out_cd, lab_cd)
+    loss_mono = F.nll_loss(out_mono, lab_mono)
+    loss = loss_cd + loss_mono * mono_weight
+    err = torch.mean((torch.max(out_cd, dim=1)[1] != lab_cd).float())
+    return loss, err, out_cd, out_mono

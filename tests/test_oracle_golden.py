@@ -1,0 +1,80 @@
+"""Pins oracle/pk_oracle.py to the reference: every fixture in tests/golden was
+produced by the reference's own classes (oracle/make_golden.py)."""
+import pytest
+import torch
+
+import pk_oracle as O
+from golden_util import Golden, check_grads, list_cases, rel_err
+
+MODULE_CASES = [c for c in list_cases() if not c.startswith("e2e_")]
+TOL = 2e-6  # same arithmetic, same library: only summation-order noise is allowed
+
+
+def _run(g, dtype, index_like_reference=False):
+    m = g.meta
+    sd = g.group("sd/", dtype)
+    for k in sd:
+        if sd[k].is_floating_point() and "running" not in k:
+            sd[k].requires_grad_(True)
+    x = g.t("x", dtype).clone().requires_grad_(True)
+    masks = g.masks(dtype) or None
+    y = O.arch_forward(m["arch_class"], m["options"], sd, x, training=m["training"], to_do=m["to_do"],
+                       drop_masks=masks, index_like_reference=index_like_reference)
+    return sd, x, y
+
+
+@pytest.mark.parametrize("case", MODULE_CASES)
+def test_oracle_matches_reference(case):
+    g = Golden(case)
+    sd, x, y = _run(g, torch.float32)
+    assert rel_err(y, g.t("y")) < TOL
+    if "dx" in g.arrays:
+        (y * g.t("cot")).sum().backward()
+        assert rel_err(x.grad, g.t("dx")) < 2e-5
+        check_grads({k: v.grad for k, v in sd.items()}, g.group("grad/"), g.meta, 2e-5)
+    for k, ref in g.group("sd_after/").items():
+        if ref.is_floating_point():
+            assert rel_err(sd[k], ref) < TOL, k
+        else:
+            assert int(sd[k]) == int(ref), k
+
+
+@pytest.mark.parametrize("case", ["ligru_bidir_bn", "lstm_bidir_bn"])
+def test_oracle_fp64_and_reference_indexing_agree(case):
+    g = Golden(case)
+    _, _, y32 = _run(g, torch.float32, index_like_reference=True)
+    _, _, y64 = _run(g, torch.float64)
+    assert rel_err(y32, g.t("y")) < TOL
+    assert rel_err(y64.float(), g.t("y")) < 5e-6
+
+
+def test_oracle_e2e_forward_model():
+    g = Golden("e2e_ligru_two_heads")
+    m = g.meta
+    opts = m["options"]
+    nfea = m["nfea"]
+    inp = g.t("inp")
+    sds = {}
+    for arch in ("liGRU_layers", "MLP_layers", "MLP_layers2"):
+        sd = g.group("sd/%s/" % arch)
+        for k in sd:
+            if sd[k].is_floating_point() and "running" not in k:
+                sd[k].requires_grad_(True)
+        sds[arch] = sd
+    x = inp[:, :, :nfea]
+    out1 = O.recurrent_forward("liGRU", opts["architecture1"], sds["liGRU_layers"], x, drop_masks=g.masks())
+    lab_cd = inp[:, :, nfea].reshape(-1).long()
+    lab_mono = inp[:, :, nfea + 1].reshape(-1).long()
+    loss, err, out2, out3 = O.two_head_loss(out1, sds["MLP_layers"], opts["architecture2"], sds["MLP_layers2"],
+                                            opts["architecture3"], lab_cd, lab_mono)
+    assert rel_err(out1, g.t("out_dnn1")) < TOL
+    assert rel_err(out2, g.t("out_dnn2")) < TOL
+    assert rel_err(out3, g.t("out_dnn3")) < TOL
+    assert abs(float(loss) - float(g.t("loss_final"))) < 1e-6 * abs(float(g.t("loss_final")))
+    assert float(err) == float(g.t("err_final"))
+    loss.backward()
+    for arch, sd in sds.items():
+        for k, ref in g.group("grad/%s/" % arch).items():
+            if float(ref.norm()) < 1e-9:
+                continue
+            assert rel_err(sd[k].grad, ref) < 5e-5, (arch, k)

@@ -1,0 +1,197 @@
+/* pk_amd.h - C ABI of libpk_amd.so: the MI355X (gfx950) engine behind the
+ * PyTorch-Kaldi `neural_networks.py` hot path.
+ *
+ * Boundary rules:
+ *  - plain pointers + sizes only; no torch types.  Every pointer is a DEVICE
+ *    pointer unless its name starts with `h_`.  The caller (the Python host
+ *    layer, or any other FFI) owns all memory; the library borrows it for the
+ *    duration of the work it enqueues on `stream`.
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream()).
+ *  - every entry point returns 0 on success, non-zero on failure and never
+ *    throws; pk_last_error() gives the message of the calling thread's last
+ *    failure.
+ *  - all matrices are fp32 row-major.  `prec` selects the MFMA operand type of
+ *    the GEMM-shaped work: PK_PREC_F32 = exact fp32 (v_mfma_f32_32x32x2_f32 /
+ *    16x16x4_f32), PK_PREC_BF16 = bf16 operands with fp32 accumulation.
+ *
+ * Each group cites the reference code it replaces (paths relative to the
+ * mravanelli/pytorch-kaldi checkout).
+ */
+#ifndef PK_AMD_H
+#define PK_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PK_PREC_F32 0
+#define PK_PREC_BF16 1
+
+/* activations: neural_networks.py:36-57 (act_fun) */
+#define PK_ACT_LINEAR 0
+#define PK_ACT_RELU 1
+#define PK_ACT_TANH 2
+#define PK_ACT_SIGMOID 3
+#define PK_ACT_LEAKY_RELU 4 /* slope 0.2 */
+#define PK_ACT_ELU 5
+
+/* recurrent cells: gate order of the concatenated [G*H] axis */
+#define PK_CELL_LIGRU 0  /* [z, a]        neural_networks.py:1133-1136 */
+#define PK_CELL_RNN 1    /* [a]           neural_networks.py:1441-1442 */
+#define PK_CELL_LSTM 2   /* [f, i, o, c]  neural_networks.py:460-464   */
+#define PK_CELL_GRU 3    /* [z, r, a]     neural_networks.py:632-636   */
+#define PK_CELL_MINGRU 4 /* [z, a]        neural_networks.py:1294-1297 */
+
+/* recurrence algorithms */
+#define PK_REC_STEPWISE 0   /* one GEMM + one gate kernel per time step */
+#define PK_REC_PERSISTENT 1 /* one launch per layer, CU clusters, h_t exchanged through L2 */
+
+/* ---- library ---------------------------------------------------------- */
+int pk_version(void);
+const char* pk_last_error(void);
+/* number of CUs of the current device (cached) */
+int pk_num_cu(void);
+
+/* ---- GEMM: replaces nn.Linear forward and its autograd (F.linear / addmm /
+ * mm), neural_networks.py:111,139-148 (MLP), :432-435, :609-611, :1114-1115
+ * (input projections) and the per-step recurrent Linear.
+ *   C[M,N] = alpha * sum_k A(m,k) * B(k,n) + beta * C + bias[n]
+ * A(m,k) = A[m*a_rs + k*a_cs], B(k,n) = B[k*b_rs + n*b_cs] (one stride of each
+ * must be 1), C row-major with leading dimension ldc.  bias may be NULL.
+ * splitk > 1 partitions K over gridDim.z through `workspace`
+ * (>= splitk*M*N floats, deterministic reduction); splitk <= 1 ignores it. */
+int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha, const float* A, int64_t a_rs,
+            int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
+            const float* bias, int splitk, float* workspace);
+
+/* ---- column statistics / BatchNorm: replaces nn.BatchNorm1d(momentum=0.05)
+ * at neural_networks.py:85,105,142-145 (MLP) and :438-450, :614-623,
+ * :1118-1124 (per-gate BN over the T*rows projection rows).
+ * pk_bn_stats: per column mean and biased variance of x[M,N] (+ optional
+ * second operand x2 added element-wise first); robust pairwise/Chan merge.
+ * `partial` is scratch of >= pk_bn_partial_floats(M,N) floats. */
+int64_t pk_bn_partial_floats(int64_t M, int64_t N);
+int pk_bn_stats(void* stream, const float* x, int64_t ldx, int64_t M, int64_t N, float* partial, float* mean,
+                float* var);
+/* scale = gamma * rsqrt(var+eps), shift = beta - mean*scale (gamma/beta NULL = 1/0);
+ * if running_mean != NULL also updates running stats with `momentum` and the
+ * unbiased factor count/(count-1) (count = rows that the reference would have
+ * normalised over, e.g. 2*T*B for a bidirectional layer). */
+int pk_bn_finalize(void* stream, int64_t N, const float* mean, const float* var, const float* gamma,
+                   const float* beta, float eps, float* scale, float* shift, float* running_mean,
+                   float* running_var, float momentum, double count);
+/* y = dropmask * act(x*scale[n] + shift[n]); scale/shift NULL = identity;
+ * mask NULL = no dropout (mask holds 0 or 1/(1-p)).  In-place allowed. */
+int pk_affine_act_fwd(void* stream, const float* x, int64_t ldx, int64_t M, int64_t N, const float* scale,
+                      const float* shift, int act, const float* mask, float* y, int64_t ldy);
+/* g = dy * mask * act'(y_saved) where y_saved is the pre-dropout activation
+ * output `a` (act' is evaluated from the output).  In-place allowed. */
+int pk_act_bwd(void* stream, const float* dy, const float* a, const float* mask, int act, int64_t n, float* g);
+/* BatchNorm backward over g (+ optional g2 added element-wise, used for the
+ * two time directions): sum_g[n] = sum_m g, sum_gx[n] = sum_m g * xhat,
+ * xhat = (x - mean) * invstd.  partial >= pk_bn_partial_floats floats. */
+int pk_bn_bwd_reduce(void* stream, const float* g, const float* g2, int64_t ldg, const float* x, int64_t ldx,
+                     int64_t M, int64_t N, const float* mean, const float* var, float eps, float* partial,
+                     float* sum_g, float* sum_gx);
+/* dx = gamma*invstd * (g - sum_g/count - xhat*sum_gx/count)  (g = g + g2). */
+int pk_bn_bwd_apply(void* stream, const float* g, const float* g2, int64_t ldg, const float* x, int64_t ldx,
+                    int64_t M, int64_t N, const float* mean, const float* var, float eps, const float* gamma,
+                    const float* sum_g, const float* sum_gx, double count, float* dx, int64_t lddx);
+/* column sums of g (+g2): bias gradient when there is no BatchNorm. */
+int pk_colsum(void* stream, const float* g, const float* g2, int64_t ldg, int64_t M, int64_t N, float* partial,
+              float* out);
+/* out = a + b (element-wise, n floats) */
+int pk_add(void* stream, const float* a, const float* b, int64_t n, float* out);
+
+/* ---- LayerNorm: neural_networks.py:23-33 (unbiased std, eps added to std).
+ * Rows of length F; saves mean and 1/(std+eps) per row for backward. */
+int pk_layernorm_fwd(void* stream, const float* x, int64_t rows, int64_t F, const float* gamma, const float* beta,
+                     float eps, float* y, float* mean, float* rinv);
+/* dx; dgamma/dbeta are produced as per-row-block partials reduced by pk_colsum
+ * on the caller side: dgamma_rows[r,f] = dy*xhat, dbeta = dy (the kernel writes
+ * xhat*dy into `dgx` so that colsum(dgx) = dgamma, colsum(dy) = dbeta). */
+int pk_layernorm_bwd(void* stream, const float* dy, const float* x, int64_t rows, int64_t F, const float* gamma,
+                     const float* mean, const float* rinv, float eps, float* dx, float* dgx);
+
+/* ---- LogSoftmax(dim=1): neural_networks.py:53-54 ('softmax' activation) */
+int pk_logsoftmax_fwd(void* stream, const float* x, int64_t rows, int64_t N, float* y);
+int pk_logsoftmax_bwd(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, float* dx);
+
+/* ---- recurrent layers (LSTM / GRU / liGRU / minimalGRU / RNN time loops):
+ * neural_networks.py:457-469, 629-641, 1130-1141, 1291-1302, 1438-1447, with
+ * the bidirectional pack/unpack of :415-417/:475-478 (cat + flip) folded into
+ * the indexing.
+ *
+ * Geometry: T steps, B sequences, `bidir` (0/1): R = B*(1+bidir) rows; rows
+ * >= B are the time-reversed copies.  H units, G gates (cell-dependent).
+ *   P      [T*B, G*H]  raw input projections of the NON-duplicated batch
+ *                      (row t*B+b); the kernel applies pscale/pshift [G*H]
+ *                      (BatchNorm folded, or 1/bias) while loading, and reads
+ *                      row (T-1-t)*B+b for the reversed half.
+ *   U      [G*H, H]    recurrent weights, gate-major (nn.Linear layout).
+ *   mask   [R, H] or NULL with mask_scalar (test mode: scalar 1-p).
+ *   Y      [T, B, (1+bidir)*H]  output in the reference's unpacked layout:
+ *                      Y[t,b,0:H] forward half, Y[t,b,H:2H] reversed half
+ *                      stored at its ORIGINAL time index.
+ *   S      [T, R, NS*H] saved per-step tensors for backward (cell-dependent:
+ *                      liGRU z,a; RNN a; LSTM f,i,o,g,c; GRU z,r,a; minGRU z,a)
+ *   ln_gamma/ln_beta [H] or NULL: per-step LayerNorm of h_t (stepwise only).
+ *   LNS    [T, R, 2+H]   saved LN stats + pre-LN h when LayerNorm is on.
+ * work: scratch, >= pk_rec_work_floats() floats.
+ * algo: PK_REC_STEPWISE handles everything; PK_REC_PERSISTENT handles
+ * liGRU/RNN/LSTM without per-step LayerNorm and returns an error otherwise. */
+int pk_rec_num_saved(int cell);
+int pk_rec_num_gates(int cell);
+int64_t pk_rec_work_floats(int cell, int T, int B, int bidir, int H);
+int pk_rec_fwd(void* stream, int algo, int prec, int cell, int act, int T, int B, int bidir, int H,
+               const float* P, const float* pscale, const float* pshift, const float* U, const float* mask,
+               float mask_scalar, const float* ln_gamma, const float* ln_beta, float* Y, float* S, float* LNS,
+               float* work);
+/* Backward through time.  dY [T,B,(1+bidir)*H] is the gradient of Y.
+ * Outputs: dP2 [1+bidir][T*B][G*H]: gradient w.r.t. the (scaled+shifted)
+ * projections, one slab per direction, both indexed by ORIGINAL time; the
+ * caller adds the slabs (pk_bn_bwd_* take g and g2).  dU [G*H, H] (overwritten).
+ * dln_gamma/dln_beta [H] (overwritten) when LayerNorm is on.
+ * Hprev for dU and the carry come from Y / LNS. */
+int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, int T, int B, int bidir, int H,
+               const float* U, const float* mask, float mask_scalar, const float* ln_gamma, const float* Y,
+               const float* S, const float* LNS, const float* dY, float* dP2, float* dU, float* dln_gamma,
+               float* dln_beta, float* work);
+
+/* ---- conv1d (valid, stride 1) fused with max_pool1d(kernel=stride=pool):
+ * replaces F.conv1d + F.max_pool1d at neural_networks.py:1546-1552,
+ * :1655-1661, :1805-1813.  x [B,Cin,L], w [Cout,Cin,K], bias [Cout] or NULL,
+ * y [B,Cout,Lp] with Lp = (L-K+1)/pool, argmax [B,Cout,Lp] (int32 position in
+ * the un-pooled conv output) for backward. */
+int pk_conv1d_pool_fwd(void* stream, const float* x, const float* w, const float* bias, int B, int Cin, int L,
+                       int Cout, int K, int pool, float* y, int32_t* argmax);
+/* dw [Cout,Cin,K], dbias [Cout] (may be NULL), dx [B,Cin,L] (may be NULL, e.g.
+ * first layer).  partial: scratch >= pk_conv_partial_floats(). */
+int64_t pk_conv_partial_floats(int B, int Cin, int L, int Cout, int K, int pool);
+int pk_conv1d_pool_bwd(void* stream, const float* x, const float* w, const float* dy, const int32_t* argmax, int B,
+                       int Cin, int L, int Cout, int K, int pool, float* dw, float* dbias, float* dx,
+                       float* partial);
+
+/* ---- fused optimizers on flat parameter buckets (next row):
+ * torch.optim.RMSprop / SGD as utils.optimizer_init configures them
+ * (utils.py:2106-2164).  p, g, state: n floats. */
+int pk_rmsprop_step(void* stream, float* p, const float* g, float* square_avg, int64_t n, float lr, float alpha,
+                    float eps, float weight_decay);
+int pk_sgd_step(void* stream, float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
+                float weight_decay, int first_step);
+
+/* persistent-recurrence health: number of spin time-outs since the last reset
+ * (host-mapped counter, readable without a device sync). */
+unsigned pk_persist_error_count(void);
+void pk_persist_error_reset(void);
+
+/* ---- self tests (tests/ only): MFMA fragment-layout check on the device.
+ * Writes 0 to *h_bad_count if every layout assumption holds. */
+int pk_selftest_mfma(void* stream, int* h_bad_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PK_AMD_H */

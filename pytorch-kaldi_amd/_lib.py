@@ -1,0 +1,111 @@
+"""ctypes binding of libpk_amd.so (include/pk_amd.h).
+
+The library is the product: if it cannot be loaded the engine raises - there is
+no CPU or eager-torch fallback anywhere in this package.  ctypes releases the
+GIL around every call, so PyTorch-Kaldi's chunk-prefetch thread (core.py:25-34,
+510-512) keeps running while kernels are enqueued.
+"""
+import ctypes
+import os
+import re
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libpk_amd.so")
+HEADER = os.path.join(HERE, "..", "include", "pk_amd.h")
+
+_lock = threading.Lock()
+_lib = None
+
+c_void_p, c_int, c_float, c_double, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_int64
+P = c_void_p  # every device pointer crosses the ABI as a plain address
+
+# name -> (restype, argtypes); mirrors include/pk_amd.h one to one
+SIGNATURES = {
+    "pk_version": (c_int, []),
+    "pk_last_error": (ctypes.c_char_p, []),
+    "pk_num_cu": (c_int, []),
+    "pk_gemm": (c_int, [P, c_int, c_int, c_int, c_int, c_float, P, c_int64, c_int64, P, c_int64, c_int64, c_float, P,
+                        c_int64, P, c_int, P]),
+    "pk_bn_partial_floats": (c_int64, [c_int64, c_int64]),
+    "pk_bn_stats": (c_int, [P, P, c_int64, c_int64, c_int64, P, P, P]),
+    "pk_bn_finalize": (c_int, [P, c_int64, P, P, P, P, c_float, P, P, P, P, c_float, c_double]),
+    "pk_affine_act_fwd": (c_int, [P, P, c_int64, c_int64, c_int64, P, P, c_int, P, P, c_int64]),
+    "pk_act_bwd": (c_int, [P, P, P, P, c_int, c_int64, P]),
+    "pk_bn_bwd_reduce": (c_int, [P, P, P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_float, P, P, P]),
+    "pk_bn_bwd_apply": (c_int, [P, P, P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_float, P, P, P, c_double, P,
+                                c_int64]),
+    "pk_colsum": (c_int, [P, P, P, c_int64, c_int64, c_int64, P, P]),
+    "pk_add": (c_int, [P, P, P, c_int64, P]),
+    "pk_layernorm_fwd": (c_int, [P, P, c_int64, c_int64, P, P, c_float, P, P, P]),
+    "pk_layernorm_bwd": (c_int, [P, P, P, c_int64, c_int64, P, P, P, c_float, P, P]),
+    "pk_logsoftmax_fwd": (c_int, [P, P, c_int64, c_int64, P]),
+    "pk_logsoftmax_bwd": (c_int, [P, P, P, c_int64, c_int64, P]),
+    "pk_rec_num_saved": (c_int, [c_int]),
+    "pk_rec_num_gates": (c_int, [c_int]),
+    "pk_rec_work_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "pk_rec_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, P,
+                           P, P, P]),
+    "pk_rec_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P,
+                           P, P, P, P]),
+    "pk_conv1d_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "pk_conv_partial_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "pk_conv1d_pool_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "pk_rmsprop_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float]),
+    "pk_sgd_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_int]),
+    "pk_persist_error_count": (ctypes.c_uint, []),
+    "pk_persist_error_reset": (None, []),
+    "pk_selftest_mfma": (c_int, [P, ctypes.POINTER(c_int)]),
+}
+
+
+def declared_symbols():
+    """Every function name declared in include/pk_amd.h (used by the ABI test)."""
+    with open(HEADER) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(pk_[a-z0-9_]+)\s*\(", text)))
+
+
+class PkError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises PkError when the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise PkError(
+                "libpk_amd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                "this engine has no CPU fallback." % LIB_PATH)
+        try:  # bind to the HIP runtime torch already mapped (same soname, libamdhip64.so.7)
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is always present in this image
+            pass
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().pk_last_error()
+        raise PkError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def raise_if_persist_failed():
+    """Spin time-outs of the persistent recurrence land in a host-mapped counter."""
+    lib = load()
+    n = lib.pk_persist_error_count()
+    if n:
+        lib.pk_persist_error_reset()
+        raise PkError("persistent recurrent kernel: %d wave(s) timed out waiting for a peer workgroup "
+                      "(results of that launch are invalid)" % n)

@@ -1,0 +1,382 @@
+// pk_gemm.hip - MFMA GEMMs for gfx950 (CDNA4), fp32 global operands.
+//
+// Replaces nn.Linear forward/backward of the reference hot path
+// (neural_networks.py:111/139-148 MLP layers, :432-435 / :609-611 / :1114-1115
+// input projections, per-step recurrent Linear) - see include/pk_amd.h.
+//
+//   C[M,N] = alpha * A(M,K) . B(K,N) + beta*C + bias
+//
+// Two operand precisions share the same staging skeleton:
+//   PREC_F32  v_mfma_f32_32x32x2_f32   exact fp32 (bitwise an fmaf chain)  - parity mode
+//   PREC_BF16 v_mfma_f32_32x32x16_bf16 operands rounded to bf16 while staging
+//             fp32 tiles into LDS, fp32 accumulate                          - perf mode
+//
+// Block tile 128x128, 4 waves (2x2), wave tile 64x64 = 2x2 MFMA 32x32 tiles.
+// LDS layouts:  f32 : [BK=16][128+4] floats  (fragment reads = consecutive lanes, conflict free)
+//               bf16: [128][BK=32+8] bf16    (fragment reads = ds_read_b128, odd 16-B row stride)
+// Operands may be contiguous along k (KC) or along m/n; the loader vectorises
+// along the contiguous direction and falls back to guarded scalar loads at
+// ragged edges / unaligned leading dimensions.
+#include "pk_common.h"
+
+namespace {
+
+struct GemmArgs {
+    int M, N, K;
+    float alpha, beta;
+    const float* A;
+    long a_rs, a_cs;
+    const float* B;
+    long b_rs, b_cs;
+    float* C;
+    long ldc;
+    const float* bias;
+    float* ws;      // split-K partials [splitk][M][N] or nullptr
+    int k_per_split;  // multiple of BK
+    int vecA, vecB;   // 16-B vector loads allowed for A / B
+};
+
+constexpr int BM = 128, BN = 128;
+
+// ---------------------------------------------------------------------------
+// global -> register staging of one operand tile (rows = m or n index, 128 of
+// them; kdim = BK).  `KC` = contiguous along k.
+//   element(r, k) = base[r * rs + k * cs]
+// Each thread owns NV float4 "vectors" laid along the contiguous direction.
+// ---------------------------------------------------------------------------
+template <int BK, bool KC>
+struct TileLoader {
+    static constexpr int NV = (128 * BK) / (256 * 4);  // float4 per thread
+    float4 v[NV];
+
+    // vector index -> (row, k) of its first element
+    __device__ __forceinline__ static void coord(int idx, int& r, int& k) {
+        if (KC) {
+            constexpr int QK = BK / 4;  // float4 per row
+            r = idx / QK;
+            k = (idx % QK) * 4;
+        } else {
+            r = (idx % 32) * 4;  // 32 float4 along the 128 rows
+            k = idx / 32;
+        }
+    }
+
+    __device__ __forceinline__ void load(const float* __restrict__ base, long rs, long cs, int r0, int k0, int rmax,
+                                         int kmax, int vec_ok, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int r, k;
+            coord(tid + 256 * i, r, k);
+            const int gr = r0 + r, gk = k0 + k;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KC) {
+                if (gr < rmax) {
+                    const float* p = base + (long)gr * rs + (long)gk * cs;
+                    if (vec_ok && gk + 3 < kmax) {
+                        t = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (gk + 0 < kmax) t.x = p[0];
+                        if (gk + 1 < kmax) t.y = p[cs];
+                        if (gk + 2 < kmax) t.z = p[2 * cs];
+                        if (gk + 3 < kmax) t.w = p[3 * cs];
+                    }
+                }
+            } else {
+                if (gk < kmax) {
+                    const float* p = base + (long)gr * rs + (long)gk * cs;
+                    if (vec_ok && gr + 3 < rmax) {
+                        t = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (gr + 0 < rmax) t.x = p[0];
+                        if (gr + 1 < rmax) t.y = p[rs];
+                        if (gr + 2 < rmax) t.z = p[2 * rs];
+                        if (gr + 3 < rmax) t.w = p[3 * rs];
+                    }
+                }
+            }
+            v[i] = t;
+        }
+    }
+
+    // f32 LDS image: tile[k][row], leading dimension LD floats
+    template <int LD>
+    __device__ __forceinline__ void store_f32(float* __restrict__ tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int r, k;
+            coord(tid + 256 * i, r, k);
+            if (KC) {
+                tile[(k + 0) * LD + r] = v[i].x;
+                tile[(k + 1) * LD + r] = v[i].y;
+                tile[(k + 2) * LD + r] = v[i].z;
+                tile[(k + 3) * LD + r] = v[i].w;
+            } else {
+                *reinterpret_cast<float4*>(&tile[k * LD + r]) = v[i];
+            }
+        }
+    }
+
+    // bf16 LDS image: tile[row][k], leading dimension LD bf16 elements
+    template <int LD>
+    __device__ __forceinline__ void store_bf16(unsigned short* __restrict__ tile, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int r, k;
+            coord(tid + 256 * i, r, k);
+            if (KC) {
+                uint2 pk;
+                pk.x = pk_pack_bf2(v[i].x, v[i].y);
+                pk.y = pk_pack_bf2(v[i].z, v[i].w);
+                *reinterpret_cast<uint2*>(&tile[r * LD + k]) = pk;  // 8-B aligned: LD*2 and k*2 multiples of 8
+            } else {
+                tile[(r + 0) * LD + k] = pk_f2bf(v[i].x);
+                tile[(r + 1) * LD + k] = pk_f2bf(v[i].y);
+                tile[(r + 2) * LD + k] = pk_f2bf(v[i].z);
+                tile[(r + 3) * LD + k] = pk_f2bf(v[i].w);
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// epilogue shared by both precisions
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void store_acc(const GemmArgs& p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+                                          int lane, int split) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= p.N) continue;
+            const float bv = (p.bias != nullptr && p.ws == nullptr) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= p.M) continue;
+                const float a = acc[i][j][r];
+                if (p.ws != nullptr) {
+                    p.ws[((long)split * p.M + row) * p.N + col] = a;
+                } else {
+                    float* c = p.C + (long)row * p.ldc + col;
+                    float o = p.alpha * a + bv;
+                    if (p.beta != 0.f) o += p.beta * (*c);
+                    *c = o;
+                }
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------
+// fp32 kernel
+// ---------------------------------------------------------------------------
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+    constexpr int BK = 16, LD = BM + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int split = blockIdx.z;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TileLoader<BK, A_KC> la;
+    TileLoader<BK, B_KC> lb;
+    // B operand viewed as rows = n: element(n, k) = B[k*b_rs + n*b_cs]
+    if (nk > 0) {
+        la.load(p.A, p.a_rs, p.a_cs, m0, kbeg, p.M, kend, p.vecA, tid);
+        lb.load(p.B, p.b_cs, p.b_rs, n0, kbeg, p.N, kend, p.vecB, tid);
+        la.template store_f32<LD>(As[0], tid);
+        lb.template store_f32<LD>(Bs[0], tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            la.load(p.A, p.a_rs, p.a_cs, m0, kbeg + (kt + 1) * BK, p.M, kend, p.vecA, tid);
+            lb.load(p.B, p.b_cs, p.b_rs, n0, kbeg + (kt + 1) * BK, p.N, kend, p.vecB, tid);
+        }
+        const float* as = As[cur];
+        const float* bs = Bs[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int kidx = 2 * kk + (lane >> 5);
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = as[kidx * LD + wm * 64 + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = bs[kidx * LD + wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            la.template store_f32<LD>(As[cur ^ 1], tid);
+            lb.template store_f32<LD>(Bs[cur ^ 1], tid);
+        }
+        __syncthreads();
+    }
+    store_acc(p, acc, m0, n0, wm, wn, lane, split);
+}
+
+// ---------------------------------------------------------------------------
+// bf16-operand kernel (fp32 in HBM, rounded to bf16 while staging)
+// ---------------------------------------------------------------------------
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
+    constexpr int BK = 32, LD = BK + 8;  // 80-byte rows: odd multiple of 16 B
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int split = blockIdx.z;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TileLoader<BK, A_KC> la;
+    TileLoader<BK, B_KC> lb;
+    if (nk > 0) {
+        la.load(p.A, p.a_rs, p.a_cs, m0, kbeg, p.M, kend, p.vecA, tid);
+        lb.load(p.B, p.b_cs, p.b_rs, n0, kbeg, p.N, kend, p.vecB, tid);
+        la.template store_bf16<LD>(As[0], tid);
+        lb.template store_bf16<LD>(Bs[0], tid);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            la.load(p.A, p.a_rs, p.a_cs, m0, kbeg + (kt + 1) * BK, p.M, kend, p.vecA, tid);
+            lb.load(p.B, p.b_cs, p.b_rs, n0, kbeg + (kt + 1) * BK, p.N, kend, p.vecB, tid);
+        }
+        const unsigned short* as = As[cur];
+        const unsigned short* bs = Bs[cur];
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            // 32x32x16: lane supplies A[row = lane&31][k = (lane>>5)*8 .. +8], same for B columns
+            const int koff = ks * 16 + (lane >> 5) * 8;
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[i] = *reinterpret_cast<const bf16x8*>(&as[(wm * 64 + i * 32 + (lane & 31)) * LD + koff]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                b[j] = *reinterpret_cast<const bf16x8*>(&bs[(wn * 64 + j * 32 + (lane & 31)) * LD + koff]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            la.template store_bf16<LD>(As[cur ^ 1], tid);
+            lb.template store_bf16<LD>(Bs[cur ^ 1], tid);
+        }
+        __syncthreads();
+    }
+    store_acc(p, acc, m0, n0, wm, wn, lane, split);
+}
+
+// split-K reduction: C = alpha * sum_s ws[s] + beta*C + bias
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, int M, int N, float alpha, float beta,
+                                     const float* __restrict__ bias, float* __restrict__ C, long ldc) {
+    const long total = (long)M * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / N), col = (int)(i % N);
+        float s = 0.f;
+        for (int k = 0; k < splitk; ++k) s += ws[(long)k * total + i];
+        float o = alpha * s + (bias ? bias[col] : 0.f);
+        float* c = C + (long)row * ldc + col;
+        if (beta != 0.f) o += beta * (*c);
+        *c = o;
+    }
+}
+
+template <template <bool, bool> class K>
+struct Dummy {};
+
+}  // namespace
+
+extern "C" int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha, const float* A, int64_t a_rs,
+                       int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
+                       const float* bias, int splitk, float* workspace) {
+    if (M <= 0 || N <= 0) return 0;
+    PK_REQUIRE(K >= 0, "pk_gemm: negative K");
+    PK_REQUIRE(a_rs == 1 || a_cs == 1, "pk_gemm: A must be contiguous along m or k (strides %ld,%ld)", (long)a_rs,
+               (long)a_cs);
+    PK_REQUIRE(b_rs == 1 || b_cs == 1, "pk_gemm: B must be contiguous along k or n (strides %ld,%ld)", (long)b_rs,
+               (long)b_cs);
+    PK_REQUIRE(prec == PK_PREC_F32 || prec == PK_PREC_BF16, "pk_gemm: bad prec %d", prec);
+    hipStream_t st = pk_stream(stream);
+    GemmArgs p;
+    p.M = M; p.N = N; p.K = K;
+    p.alpha = alpha; p.beta = beta;
+    p.A = A; p.a_rs = a_rs; p.a_cs = a_cs;
+    p.B = B; p.b_rs = b_rs; p.b_cs = b_cs;
+    p.C = C; p.ldc = ldc; p.bias = bias;
+    const bool a_kc = (a_cs == 1);   // contiguous along k
+    const bool b_kc = (b_rs == 1);
+    // 16-byte vector loads need an aligned base and a leading dimension that keeps rows aligned
+    const long a_ld = a_kc ? a_rs : a_cs, b_ld = b_kc ? b_cs : b_rs;
+    p.vecA = (((uintptr_t)A & 15) == 0 && (a_ld % 4) == 0) ? 1 : 0;
+    p.vecB = (((uintptr_t)B & 15) == 0 && (b_ld % 4) == 0) ? 1 : 0;
+    const int BKmax = 32;
+    if (splitk < 1) splitk = 1;
+    if (splitk > 1) {
+        PK_REQUIRE(workspace != nullptr, "pk_gemm: split-K needs a workspace");
+        int kps = (K + splitk - 1) / splitk;
+        kps = ((kps + BKmax - 1) / BKmax) * BKmax;
+        splitk = (K + kps - 1) / kps;
+        p.k_per_split = kps;
+    }
+    if (splitk <= 1) {
+        splitk = 1;
+        p.k_per_split = ((K + BKmax - 1) / BKmax) * BKmax;
+        if (p.k_per_split == 0) p.k_per_split = BKmax;
+    }
+    p.ws = (splitk > 1) ? workspace : nullptr;
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splitk), block(256);
+#define PK_LAUNCH_GEMM(KERN)                                                              \
+    do {                                                                                  \
+        if (a_kc && b_kc) hipLaunchKernelGGL((KERN<true, true>), grid, block, 0, st, p);   \
+        else if (a_kc && !b_kc) hipLaunchKernelGGL((KERN<true, false>), grid, block, 0, st, p); \
+        else if (!a_kc && b_kc) hipLaunchKernelGGL((KERN<false, true>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((KERN<false, false>), grid, block, 0, st, p);              \
+    } while (0)
+    if (prec == PK_PREC_F32) PK_LAUNCH_GEMM(gemm_f32_kernel);
+    else PK_LAUNCH_GEMM(gemm_bf16_kernel);
+#undef PK_LAUNCH_GEMM
+    PK_LAUNCH_CHECK();
+    if (splitk > 1) {
+        const long total = (long)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, splitk, M, N, alpha, beta, bias,
+                           C, (long)ldc);
+        PK_LAUNCH_CHECK();
+    }
+    return 0;
+}

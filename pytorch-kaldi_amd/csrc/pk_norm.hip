@@ -1,0 +1,458 @@
+// pk_norm.hip - HBM-bound row/column kernels of the hot path (gfx950):
+// BatchNorm statistics / affine+activation+dropout / BatchNorm backward,
+// LayerNorm (reference flavour), LogSoftmax, small element-wise helpers.
+// All of them stream their operands once with coalesced (column-fastest)
+// accesses; reductions are two-stage and deterministic (no atomics).
+#include "pk_common.h"
+
+namespace {
+
+constexpr int COLS = 64;   // columns per block (one wave-width, coalesced 256-B rows)
+constexpr int RLANES = 4;  // row lanes per block (256 threads)
+constexpr int MAX_RB = 256;
+
+__host__ __device__ inline int row_blocks(long M) {
+    long rb = (M + 63) / 64;
+    if (rb < 1) rb = 1;
+    if (rb > MAX_RB) rb = MAX_RB;
+    return (int)rb;
+}
+
+// ---- BatchNorm statistics: per-column (count, mean, M2), Chan merge ----------
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long ldx, long M, long N,
+                                                                float* __restrict__ partial) {
+    const int cx = threadIdx.x & (COLS - 1), ry = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * COLS + cx;
+    const int rb = gridDim.y;
+    const long rows_per = (M + rb - 1) / rb;
+    const long r0 = (long)blockIdx.y * rows_per;
+    const long r1 = min(M, r0 + rows_per);
+    float n = 0.f, shift = 0.f, s = 0.f, ss = 0.f;
+    if (c < N) {
+        for (long r = r0 + ry; r < r1; r += RLANES) {
+            const float v = x[r * ldx + c];
+            if (n == 0.f) shift = v;
+            const float d = v - shift;
+            s += d;
+            ss += d * d;
+            n += 1.f;
+        }
+    }
+    float mean = 0.f, m2 = 0.f;
+    if (n > 0.f) {
+        mean = shift + s / n;
+        m2 = fmaxf(ss - s * s / n, 0.f);
+    }
+    __shared__ float sh[RLANES][COLS][3];
+    sh[ry][cx][0] = n;
+    sh[ry][cx][1] = mean;
+    sh[ry][cx][2] = m2;
+    __syncthreads();
+    if (ry == 0 && c < N) {
+        float na = sh[0][cx][0], ma = sh[0][cx][1], qa = sh[0][cx][2];
+        for (int k = 1; k < RLANES; ++k) {
+            const float nb = sh[k][cx][0], mb = sh[k][cx][1], qb = sh[k][cx][2];
+            if (nb > 0.f) {
+                const float nt = na + nb, d = mb - ma;
+                ma += d * (nb / nt);
+                qa += qb + d * d * (na * nb / nt);
+                na = nt;
+            }
+        }
+        float* o = partial + ((long)blockIdx.y * N + c) * 3;
+        o[0] = na;
+        o[1] = ma;
+        o[2] = qa;
+    }
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ partial, int rb, long N, float* __restrict__ mean,
+                                      float* __restrict__ var) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float na = 0.f, ma = 0.f, qa = 0.f;
+    for (int k = 0; k < rb; ++k) {
+        const float* o = partial + ((long)k * N + c) * 3;
+        const float nb = o[0], mb = o[1], qb = o[2];
+        if (nb > 0.f) {
+            const float nt = na + nb, d = mb - ma;
+            ma += d * (nb / nt);
+            qa += qb + d * d * (na * nb / nt);
+            na = nt;
+        }
+    }
+    mean[c] = ma;
+    var[c] = na > 0.f ? qa / na : 0.f;  // biased, as BatchNorm normalises with
+}
+
+__global__ void bn_finalize_kernel(long N, const float* __restrict__ mean, const float* __restrict__ var,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, float momentum, float unbias) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const float m = mean[c], v = var[c];
+    const float inv = 1.0f / sqrtf(v + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * inv;
+    scale[c] = sc;
+    shift[c] = b - m * sc;
+    if (rmean) {
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (v * unbias);
+    }
+}
+
+// ---- y = mask * act(x*scale + shift) ----------------------------------------
+__global__ void affine_act_fwd_kernel(const float* __restrict__ x, long ldx, long M, long N,
+                                      const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                      const float* __restrict__ mask, float* __restrict__ y, long ldy) {
+    const long total = M * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / N, c = i - r * N;
+        float v = x[r * ldx + c];
+        if (scale) v = v * scale[c] + shift[c];
+        v = pk_act(act, v);
+        if (mask) v *= mask[i];
+        y[r * ldy + c] = v;
+    }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ a,
+                               const float* __restrict__ mask, int act, long n, float* __restrict__ g) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = dy[i];
+        if (mask) v *= mask[i];
+        // `a` is the activation output BEFORE dropout when mask is given
+        g[i] = v * pk_act_grad_from_out(act, a[i]);
+    }
+}
+
+// ---- BatchNorm backward reductions --------------------------------------------
+// MODE 0: sum_g, sum_g*xhat   MODE 1: column sum only
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_partial_kernel(const float* __restrict__ g,
+                                                                  const float* __restrict__ g2, long ldg,
+                                                                  const float* __restrict__ x, long ldx, long M, long N,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ var, float eps,
+                                                                  float* __restrict__ partial) {
+    const int cx = threadIdx.x & (COLS - 1), ry = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * COLS + cx;
+    const int rb = gridDim.y;
+    const long rows_per = (M + rb - 1) / rb;
+    const long r0 = (long)blockIdx.y * rows_per;
+    const long r1 = min(M, r0 + rows_per);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < N) {
+        float mu = 0.f, inv = 0.f;
+        if (MODE == 0) {
+            mu = mean[c];
+            inv = 1.0f / sqrtf(var[c] + eps);
+        }
+        for (long r = r0 + ry; r < r1; r += RLANES) {
+            float gv = g[r * ldg + c];
+            if (g2) gv += g2[r * ldg + c];
+            s0 += gv;
+            if (MODE == 0) s1 += gv * ((x[r * ldx + c] - mu) * inv);
+        }
+    }
+    __shared__ float sh[RLANES][COLS][2];
+    sh[ry][cx][0] = s0;
+    sh[ry][cx][1] = s1;
+    __syncthreads();
+    if (ry == 0 && c < N) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int k = 0; k < RLANES; ++k) {
+            a0 += sh[k][cx][0];
+            a1 += sh[k][cx][1];
+        }
+        float* o = partial + ((long)blockIdx.y * N + c) * 2;
+        o[0] = a0;
+        o[1] = a1;
+    }
+}
+
+__global__ void col_reduce_final_kernel(const float* __restrict__ partial, int rb, long N, float* __restrict__ out0,
+                                        float* __restrict__ out1) {
+    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float a0 = 0.f, a1 = 0.f;
+    for (int k = 0; k < rb; ++k) {
+        const float* o = partial + ((long)k * N + c) * 2;
+        a0 += o[0];
+        a1 += o[1];
+    }
+    out0[c] = a0;
+    if (out1) out1[c] = a1;
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ g2, long ldg,
+                                    const float* __restrict__ x, long ldx, long M, long N,
+                                    const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                    const float* __restrict__ gamma, const float* __restrict__ sum_g,
+                                    const float* __restrict__ sum_gx, float inv_count, float* __restrict__ dx,
+                                    long lddx) {
+    const long total = M * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / N, c = i - r * N;
+        const float inv = 1.0f / sqrtf(var[c] + eps);
+        const float xh = (x[r * ldx + c] - mean[c]) * inv;
+        float gv = g[r * ldg + c];
+        if (g2) gv += g2[r * ldg + c];
+        const float ga = gamma ? gamma[c] : 1.f;
+        dx[r * lddx + c] = ga * inv * (gv - sum_g[c] * inv_count - xh * sum_gx[c] * inv_count);
+    }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ o) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        o[i] = a[i] + b[i];
+}
+
+// ---- block reductions -----------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = pk_wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    const int nw = blockDim.x >> 6;
+    for (int k = 0; k < nw; ++k) t += sh[k];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = pk_wave_max(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    float t = -INFINITY;
+    const int nw = blockDim.x >> 6;
+    for (int k = 0; k < nw; ++k) t = fmaxf(t, sh[k]);
+    return t;
+}
+
+// ---- LayerNorm of the reference: gamma*(x-mean)/(std_unbiased+eps)+beta ----------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, long rows, long F,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps,
+                                                             float* __restrict__ y, float* __restrict__ mean_o,
+                                                             float* __restrict__ rinv_o) {
+    __shared__ float sh[8];
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* xr = x + r * F;
+        float s = 0.f;
+        for (long f = threadIdx.x; f < F; f += blockDim.x) s += xr[f];
+        const float mu = block_sum(s, sh) / (float)F;
+        float q = 0.f;
+        for (long f = threadIdx.x; f < F; f += blockDim.x) {
+            const float d = xr[f] - mu;
+            q += d * d;
+        }
+        const float var = block_sum(q, sh) / (float)(F - 1);
+        const float rinv = 1.0f / (sqrtf(var) + eps);
+        for (long f = threadIdx.x; f < F; f += blockDim.x)
+            y[r * F + f] = gamma[f] * ((xr[f] - mu) * rinv) + beta[f];
+        if (threadIdx.x == 0) {
+            mean_o[r] = mu;
+            rinv_o[r] = rinv;
+        }
+    }
+}
+
+// dx_i = rinv*(g_i - mean(g)) - rinv^2 * (sum_j g_j d_j) * d_i / ((F-1) * std),  g = dy*gamma, d = x-mean
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             long rows, long F, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rinv_i, float eps,
+                                                             float* __restrict__ dx, float* __restrict__ dgx) {
+    __shared__ float sh[8];
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float mu = mean[r], rinv = rinv_i[r];
+        const float stdv = 1.0f / rinv - eps;
+        float sg = 0.f, sgd = 0.f;
+        for (long f = threadIdx.x; f < F; f += blockDim.x) {
+            const float g = dy[r * F + f] * gamma[f];
+            sg += g;
+            sgd += g * (x[r * F + f] - mu);
+        }
+        sg = block_sum(sg, sh);
+        sgd = block_sum(sgd, sh);
+        const float mg = sg / (float)F;
+        const float k2 = rinv * rinv * sgd / ((float)(F - 1) * stdv);
+        for (long f = threadIdx.x; f < F; f += blockDim.x) {
+            const float d = x[r * F + f] - mu;
+            const float dyv = dy[r * F + f];
+            dx[r * F + f] = rinv * (dyv * gamma[f] - mg) - k2 * d;
+            if (dgx) dgx[r * F + f] = dyv * (d * rinv);
+        }
+    }
+}
+
+// ---- LogSoftmax(dim=1) -------------------------------------------------------------
+__global__ __launch_bounds__(256) void logsoftmax_fwd_kernel(const float* __restrict__ x, long rows, long N,
+                                                              float* __restrict__ y) {
+    __shared__ float sh[8];
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* xr = x + r * N;
+        float m = -INFINITY;
+        for (long c = threadIdx.x; c < N; c += blockDim.x) m = fmaxf(m, xr[c]);
+        m = block_max(m, sh);
+        float s = 0.f;
+        for (long c = threadIdx.x; c < N; c += blockDim.x) s += expf(xr[c] - m);
+        s = block_sum(s, sh);
+        const float lse = m + logf(s);
+        for (long c = threadIdx.x; c < N; c += blockDim.x) y[r * N + c] = xr[c] - lse;
+    }
+}
+
+__global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              long rows, long N, float* __restrict__ dx) {
+    __shared__ float sh[8];
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        float s = 0.f;
+        for (long c = threadIdx.x; c < N; c += blockDim.x) s += dy[r * N + c];
+        s = block_sum(s, sh);
+        for (long c = threadIdx.x; c < N; c += blockDim.x) dx[r * N + c] = dy[r * N + c] - expf(y[r * N + c]) * s;
+    }
+}
+
+inline int ew_blocks(long n) {
+    long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int64_t pk_bn_partial_floats(int64_t M, int64_t N) { return (int64_t)row_blocks(M) * N * 3; }
+
+extern "C" int pk_bn_stats(void* stream, const float* x, int64_t ldx, int64_t M, int64_t N, float* partial, float* mean,
+                           float* var) {
+    PK_REQUIRE(M > 0 && N > 0, "pk_bn_stats: empty input");
+    hipStream_t st = pk_stream(stream);
+    const int rb = row_blocks(M);
+    dim3 grid((unsigned)((N + COLS - 1) / COLS), rb);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, grid, dim3(256), 0, st, x, (long)ldx, (long)M, (long)N, partial);
+    PK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partial, rb, (long)N,
+                       mean, var);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_bn_finalize(void* stream, int64_t N, const float* mean, const float* var, const float* gamma,
+                              const float* beta, float eps, float* scale, float* shift, float* running_mean,
+                              float* running_var, float momentum, double count) {
+    hipStream_t st = pk_stream(stream);
+    const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.0f;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (long)N, mean, var, gamma,
+                       beta, eps, scale, shift, running_mean, running_var, momentum, unbias);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_affine_act_fwd(void* stream, const float* x, int64_t ldx, int64_t M, int64_t N, const float* scale,
+                                 const float* shift, int act, const float* mask, float* y, int64_t ldy) {
+    if (M * N == 0) return 0;
+    hipLaunchKernelGGL(affine_act_fwd_kernel, dim3(ew_blocks(M * N)), dim3(256), 0, pk_stream(stream), x, (long)ldx,
+                       (long)M, (long)N, scale, shift, act, mask, y, (long)ldy);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_act_bwd(void* stream, const float* dy, const float* a, const float* mask, int act, int64_t n,
+                          float* g) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, pk_stream(stream), dy, a, mask, act, (long)n, g);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_bn_bwd_reduce(void* stream, const float* g, const float* g2, int64_t ldg, const float* x, int64_t ldx,
+                                int64_t M, int64_t N, const float* mean, const float* var, float eps, float* partial,
+                                float* sum_g, float* sum_gx) {
+    hipStream_t st = pk_stream(stream);
+    const int rb = row_blocks(M);
+    dim3 grid((unsigned)((N + COLS - 1) / COLS), rb);
+    hipLaunchKernelGGL(col_reduce_partial_kernel<0>, grid, dim3(256), 0, st, g, g2, (long)ldg, x, (long)ldx, (long)M,
+                       (long)N, mean, var, eps, partial);
+    PK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partial, rb, (long)N,
+                       sum_g, sum_gx);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_bn_bwd_apply(void* stream, const float* g, const float* g2, int64_t ldg, const float* x, int64_t ldx,
+                               int64_t M, int64_t N, const float* mean, const float* var, float eps, const float* gamma,
+                               const float* sum_g, const float* sum_gx, double count, float* dx, int64_t lddx) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * N)), dim3(256), 0, pk_stream(stream), g, g2, (long)ldg, x,
+                       (long)ldx, (long)M, (long)N, mean, var, eps, gamma, sum_g, sum_gx, (float)(1.0 / count), dx,
+                       (long)lddx);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_colsum(void* stream, const float* g, const float* g2, int64_t ldg, int64_t M, int64_t N,
+                         float* partial, float* out) {
+    hipStream_t st = pk_stream(stream);
+    const int rb = row_blocks(M);
+    dim3 grid((unsigned)((N + COLS - 1) / COLS), rb);
+    hipLaunchKernelGGL(col_reduce_partial_kernel<1>, grid, dim3(256), 0, st, g, g2, (long)ldg, (const float*)nullptr, 0L,
+                       (long)M, (long)N, (const float*)nullptr, (const float*)nullptr, 0.f, partial);
+    PK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partial, rb, (long)N,
+                       out, (float*)nullptr);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_add(void* stream, const float* a, const float* b, int64_t n, float* out) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, pk_stream(stream), a, b, (long)n, out);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_layernorm_fwd(void* stream, const float* x, int64_t rows, int64_t F, const float* gamma,
+                                const float* beta, float eps, float* y, float* mean, float* rinv) {
+    if (rows == 0) return 0;
+    PK_REQUIRE(F > 1, "pk_layernorm_fwd: needs at least 2 features (unbiased std)");
+    int blocks = (int)(rows < 4096 ? rows : 4096);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, pk_stream(stream), x, (long)rows, (long)F, gamma,
+                       beta, eps, y, mean, rinv);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_layernorm_bwd(void* stream, const float* dy, const float* x, int64_t rows, int64_t F,
+                                const float* gamma, const float* mean, const float* rinv, float eps, float* dx,
+                                float* dgx) {
+    if (rows == 0) return 0;
+    int blocks = (int)(rows < 4096 ? rows : 4096);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, pk_stream(stream), dy, x, (long)rows, (long)F,
+                       gamma, mean, rinv, eps, dx, dgx);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_logsoftmax_fwd(void* stream, const float* x, int64_t rows, int64_t N, float* y) {
+    if (rows == 0) return 0;
+    int blocks = (int)(rows < 8192 ? rows : 8192);
+    hipLaunchKernelGGL(logsoftmax_fwd_kernel, dim3(blocks), dim3(256), 0, pk_stream(stream), x, (long)rows, (long)N, y);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_logsoftmax_bwd(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, float* dx) {
+    if (rows == 0) return 0;
+    int blocks = (int)(rows < 8192 ? rows : 8192);
+    hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(blocks), dim3(256), 0, pk_stream(stream), dy, y, (long)rows, (long)N,
+                       dx);
+    PK_LAUNCH_CHECK();
+    return 0;
+}

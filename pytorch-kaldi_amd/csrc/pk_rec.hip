@@ -1,0 +1,468 @@
+// pk_rec.hip - recurrent time loops of the reference (LSTM / GRU / liGRU /
+// minimalGRU / RNN; neural_networks.py:457-469, 629-641, 1130-1141, 1291-1302,
+// 1438-1447) with the bidirectional cat/flip (:415-417, :475-478) folded into
+// the indexing: rows n >= B are the time-reversed copies and read/write
+// "storage time" ts = T-1-t, so P, Y, S and dP2 all share (ts, b) indexing.
+//
+// This file holds the STEP-WISE algorithm (one recurrent GEMM + one fused gate
+// kernel per step; exact fp32 when prec = F32) and the parts shared with the
+// persistent algorithm (pk_rec_persist.hip): argument checks, the deferred
+// dU = sum_t dgate_t^T . h_{t-1} GEMMs and the C entry points.
+#include "pk_cell.h"
+
+// persistent algorithm (pk_rec_persist.hip)
+int pk_rec_fwd_persistent(hipStream_t st, int prec, int cell, int act, int T, int B, int bidir, int H, const float* P,
+                          const float* pscale, const float* pshift, const float* U, const float* mask,
+                          float mask_scalar, float* Y, float* S, float* work);
+int pk_rec_bwd_persistent(hipStream_t st, int prec, int cell, int act, int T, int B, int bidir, int H, const float* U,
+                          const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
+                          float* dP2, float* work);
+
+namespace {
+
+struct StepGeom {
+    int T, B, R, H, G, NS, YH;  // R = rows incl. reversed copies, YH = width of Y rows
+};
+
+__device__ __forceinline__ void row_index(const StepGeom& g, int t, int n, int& dir, int& b, int& ts) {
+    dir = n >= g.B ? 1 : 0;
+    b = n - dir * g.B;
+    ts = dir ? (g.T - 1 - t) : t;
+}
+
+// ---- forward gate kernels -------------------------------------------------------
+template <int CELL>
+__global__ __launch_bounds__(256) void step_fwd_kernel(StepGeom g, int t, int act, const float* __restrict__ P,
+                                                        const float* __restrict__ pscale,
+                                                        const float* __restrict__ pshift,
+                                                        const float* __restrict__ urec,  // [R, G*H] or null (t == 0)
+                                                        const float* __restrict__ hcur, const float* __restrict__ ccur,
+                                                        const float* __restrict__ mask, float mask_scalar,
+                                                        float* __restrict__ hnext, float* __restrict__ cnext,
+                                                        float* __restrict__ Y, float* __restrict__ S) {
+    constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
+    const long total = (long)g.R * g.H;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / g.H), j = (int)(idx - (long)n * g.H);
+        int dir, b, ts;
+        row_index(g, t, n, dir, b, ts);
+        const long prow = (long)ts * g.B + b;
+        float pre[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int col = k * g.H + j;
+            pre[k] = P[prow * (G * g.H) + col] * pscale[col] + pshift[col];
+            if (urec) pre[k] += urec[(long)n * (G * g.H) + col];
+        }
+        const float hp = urec ? hcur[idx] : 0.f;
+        const float cp = (urec && CELL == PK_CELL_LSTM) ? ccur[idx] : 0.f;
+        const float m = mask ? mask[idx] : mask_scalar;
+        float h, c, s[NS];
+        pk_cell_fwd<CELL>(act, pre, hp, cp, m, h, c, s);
+        hnext[idx] = h;
+        if (CELL == PK_CELL_LSTM) cnext[idx] = c;
+        Y[prow * g.YH + dir * g.H + j] = h;
+        float* sp = S + ((long)dir * g.T * g.B + prow) * (NS * g.H) + j;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) sp[k * g.H] = s[k];
+    }
+}
+
+// two-phase cells, phase 1: z (and r); writes the vector fed to U_h into `gh`
+template <int CELL>
+__global__ __launch_bounds__(256) void step_fwd_p1_kernel(StepGeom g, int t, const float* __restrict__ P,
+                                                           const float* __restrict__ pscale,
+                                                           const float* __restrict__ pshift,
+                                                           const float* __restrict__ urec,  // [R, (G-1)*H] or null
+                                                           const float* __restrict__ hcur, float* __restrict__ gh,
+                                                           float* __restrict__ S) {
+    constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL), G1 = G - 1;
+    const long total = (long)g.R * g.H;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / g.H), j = (int)(idx - (long)n * g.H);
+        int dir, b, ts;
+        row_index(g, t, n, dir, b, ts);
+        const long prow = (long)ts * g.B + b;
+        float pre[G1];
+#pragma unroll
+        for (int k = 0; k < G1; ++k) {
+            const int col = k * g.H + j;
+            pre[k] = P[prow * (G * g.H) + col] * pscale[col] + pshift[col];
+            if (urec) pre[k] += urec[(long)n * (G1 * g.H) + col];
+        }
+        const float hp = urec ? hcur[idx] : 0.f;
+        float s[NS];
+        gh[idx] = pk_cell_fwd_p1<CELL>(pre, hp, s);
+        float* sp = S + ((long)dir * g.T * g.B + prow) * (NS * g.H) + j;
+        sp[0] = s[0];
+        if (CELL == PK_CELL_GRU) {
+            sp[1 * g.H] = s[1];
+            sp[3 * g.H] = s[3];
+        } else {
+            sp[2 * g.H] = s[2];
+        }
+    }
+}
+
+template <int CELL>
+__global__ __launch_bounds__(256) void step_fwd_p2_kernel(StepGeom g, int t, int act, const float* __restrict__ P,
+                                                           const float* __restrict__ pscale,
+                                                           const float* __restrict__ pshift,
+                                                           const float* __restrict__ ua,  // [R, H] or null (t == 0)
+                                                           const float* __restrict__ hcur,
+                                                           const float* __restrict__ mask, float mask_scalar,
+                                                           float* __restrict__ hnext, float* __restrict__ Y,
+                                                           float* __restrict__ S) {
+    constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
+    constexpr int ASLOT = (CELL == PK_CELL_GRU) ? 2 : 1;
+    const long total = (long)g.R * g.H;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / g.H), j = (int)(idx - (long)n * g.H);
+        int dir, b, ts;
+        row_index(g, t, n, dir, b, ts);
+        const long prow = (long)ts * g.B + b;
+        const int col = (G - 1) * g.H + j;
+        float a = P[prow * (G * g.H) + col] * pscale[col] + pshift[col];
+        if (ua) a += ua[idx];
+        float* sp = S + ((long)dir * g.T * g.B + prow) * (NS * g.H) + j;
+        const float z = sp[0];
+        const float hp = ua ? hcur[idx] : 0.f;
+        const float m = mask ? mask[idx] : mask_scalar;
+        const float h = pk_cell_fwd_p2<CELL>(act, a, z, hp, m);
+        sp[ASLOT * g.H] = a;
+        hnext[idx] = h;
+        Y[prow * g.YH + dir * g.H + j] = h;
+    }
+}
+
+// ---- backward gate kernels ------------------------------------------------------
+// previous hidden state of row (dir, ts, b): stored one step "earlier" in step time
+__device__ __forceinline__ float load_hprev(const StepGeom& g, const float* __restrict__ Y, int t, int dir, int b,
+                                            int ts, int j) {
+    if (t == 0) return 0.f;
+    const int tsp = dir ? ts + 1 : ts - 1;
+    return Y[((long)tsp * g.B + b) * g.YH + dir * g.H + j];
+}
+
+template <int CELL>
+__global__ __launch_bounds__(256) void step_bwd_kernel(StepGeom g, int t, int act, const float* __restrict__ Y,
+                                                        const float* __restrict__ S, const float* __restrict__ dY,
+                                                        const float* __restrict__ mask, float mask_scalar,
+                                                        const float* __restrict__ carry_h,  // [R,H] or null (t == T-1)
+                                                        const float* __restrict__ carry_c,
+                                                        float* __restrict__ dG,      // [R, G*H] contiguous copy
+                                                        float* __restrict__ dP2,     // [ndir][T*B][G*H]
+                                                        float* __restrict__ next_h,  // direct part of dL/dh_{t-1}
+                                                        float* __restrict__ next_c) {
+    constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
+    const long total = (long)g.R * g.H;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / g.H), j = (int)(idx - (long)n * g.H);
+        int dir, b, ts;
+        row_index(g, t, n, dir, b, ts);
+        const long prow = (long)ts * g.B + b;
+        const long srow = (long)dir * g.T * g.B + prow;
+        float s[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = S[srow * (NS * g.H) + k * g.H + j];
+        const float hp = load_hprev(g, Y, t, dir, b, ts, j);
+        float cp = 0.f;
+        if (CELL == PK_CELL_LSTM && t > 0) {
+            const int tsp = dir ? ts + 1 : ts - 1;
+            cp = S[((long)dir * g.T * g.B + (long)tsp * g.B + b) * (NS * g.H) + 4 * g.H + j];
+        }
+        const float m = mask ? mask[idx] : mask_scalar;
+        float dh = dY[prow * g.YH + dir * g.H + j];
+        float dc = 0.f;
+        if (carry_h) {
+            dh += carry_h[idx];
+            if (CELL == PK_CELL_LSTM) dc = carry_c[idx];
+        }
+        float dg[G], dh_direct, dc_prev;
+        pk_cell_bwd<CELL>(act, s, hp, cp, m, dh, dc, dg, dh_direct, dc_prev);
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            dG[(long)n * (G * g.H) + k * g.H + j] = dg[k];
+            dP2[srow * (G * g.H) + k * g.H + j] = dg[k];
+        }
+        next_h[idx] = dh_direct;
+        if (CELL == PK_CELL_LSTM) next_c[idx] = dc_prev;
+    }
+}
+
+// two-phase backward, phase A: da -> `dA` (operand of q = da.U_h), dz_part, direct carry
+template <int CELL>
+__global__ __launch_bounds__(256) void step_bwd_pa_kernel(StepGeom g, int t, int act, const float* __restrict__ Y,
+                                                           const float* __restrict__ S, const float* __restrict__ dY,
+                                                           const float* __restrict__ mask, float mask_scalar,
+                                                           const float* __restrict__ carry_h, float* __restrict__ dA,
+                                                           float* __restrict__ dzp, float* __restrict__ next_h) {
+    constexpr int NS = pk_cell_saved(CELL);
+    const long total = (long)g.R * g.H;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / g.H), j = (int)(idx - (long)n * g.H);
+        int dir, b, ts;
+        row_index(g, t, n, dir, b, ts);
+        const long prow = (long)ts * g.B + b;
+        const long srow = (long)dir * g.T * g.B + prow;
+        float s[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = S[srow * (NS * g.H) + k * g.H + j];
+        const float hp = load_hprev(g, Y, t, dir, b, ts, j);
+        const float m = mask ? mask[idx] : mask_scalar;
+        float dh = dY[prow * g.YH + dir * g.H + j];
+        if (carry_h) dh += carry_h[idx];
+        float dz_part, dh_direct;
+        dA[idx] = pk_cell_bwd_pa<CELL>(act, s, hp, m, dh, dz_part, dh_direct);
+        dzp[idx] = dz_part;
+        next_h[idx] = dh_direct;
+    }
+}
+
+template <int CELL>
+__global__ __launch_bounds__(256) void step_bwd_pb_kernel(StepGeom g, int t, const float* __restrict__ Y,
+                                                           const float* __restrict__ S, const float* __restrict__ q,
+                                                           const float* __restrict__ dA, const float* __restrict__ dzp,
+                                                           float* __restrict__ dG,  // [R, (G-1)*H]
+                                                           float* __restrict__ dP2, float* __restrict__ next_h) {
+    constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
+    const long total = (long)g.R * g.H;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / g.H), j = (int)(idx - (long)n * g.H);
+        int dir, b, ts;
+        row_index(g, t, n, dir, b, ts);
+        const long prow = (long)ts * g.B + b;
+        const long srow = (long)dir * g.T * g.B + prow;
+        float s[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] = S[srow * (NS * g.H) + k * g.H + j];
+        const float hp = load_hprev(g, Y, t, dir, b, ts, j);
+        float dg[G];
+        float dh_direct = next_h[idx];
+        pk_cell_bwd_pb<CELL>(s, hp, q[idx], dA[idx], dzp[idx], dg, dh_direct);
+#pragma unroll
+        for (int k = 0; k < G; ++k) dP2[srow * (G * g.H) + k * g.H + j] = dg[k];
+#pragma unroll
+        for (int k = 0; k < G - 1; ++k) dG[(long)n * ((G - 1) * g.H) + k * g.H + j] = dg[k];
+        next_h[idx] = dh_direct;
+    }
+}
+
+inline int ew_blocks(long n) {
+    long b = (n + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+struct Work {
+    float *h0, *h1, *c0, *c1, *urec, *gh, *ua, *dg, *ws;
+};
+inline Work carve(float* w, long R, long H, long G) {
+    Work k;
+    long o = 0;
+    auto take = [&](long n) {
+        float* p = w + o;
+        o += (n + 63) / 64 * 64;
+        return p;
+    };
+    k.h0 = take(R * H);
+    k.h1 = take(R * H);
+    k.c0 = take(R * H);
+    k.c1 = take(R * H);
+    k.urec = take(R * G * H);
+    k.gh = take(R * H);
+    k.ua = take(R * H);
+    k.dg = take(R * G * H);
+    k.ws = w + o;
+    return k;
+}
+constexpr int DU_SPLITK = 16;
+
+#define PK_TRY(expr)          \
+    do {                      \
+        int _rc = (expr);     \
+        if (_rc) return _rc;  \
+    } while (0)
+
+template <int CELL>
+int fwd_stepwise(hipStream_t st, int prec, int act, StepGeom g, const float* P, const float* pscale,
+                 const float* pshift, const float* U, const float* mask, float mask_scalar, float* Y, float* S,
+                 float* work) {
+    constexpr int G = pk_cell_gates(CELL);
+    constexpr bool TWO = pk_cell_two_phase(CELL);
+    Work w = carve(work, g.R, g.H, G);
+    float *hcur = w.h0, *hnext = w.h1, *ccur = w.c0, *cnext = w.c1;
+    const int blocks = ew_blocks((long)g.R * g.H);
+    const int H = g.H;
+    for (int t = 0; t < g.T; ++t) {
+        const bool first = (t == 0);
+        if constexpr (!TWO) {
+            if (!first)  // urec[R, G*H] = hcur[R,H] . U[G*H,H]^T
+                PK_TRY(pk_gemm(st, prec, g.R, G * H, H, 1.f, hcur, H, 1, U, 1, H, 0.f, w.urec, G * H, nullptr, 1, nullptr));
+            hipLaunchKernelGGL((step_fwd_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, act, P, pscale, pshift,
+                               first ? (const float*)nullptr : w.urec, hcur, ccur, mask, mask_scalar, hnext, cnext, Y, S);
+            PK_LAUNCH_CHECK();
+        } else {
+            constexpr int G1 = G - 1;
+            if (!first)
+                PK_TRY(pk_gemm(st, prec, g.R, G1 * H, H, 1.f, hcur, H, 1, U, 1, H, 0.f, w.urec, G1 * H, nullptr, 1, nullptr));
+            hipLaunchKernelGGL((step_fwd_p1_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, P, pscale, pshift,
+                               first ? (const float*)nullptr : w.urec, hcur, w.gh, S);
+            PK_LAUNCH_CHECK();
+            if (!first)  // ua[R,H] = gh[R,H] . U_h[H,H]^T   (gh = r*h or z*h; zero at t = 0)
+                PK_TRY(pk_gemm(st, prec, g.R, H, H, 1.f, w.gh, H, 1, U + (long)G1 * H * H, 1, H, 0.f, w.ua, H, nullptr, 1,
+                               nullptr));
+            hipLaunchKernelGGL((step_fwd_p2_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, act, P, pscale, pshift,
+                               first ? (const float*)nullptr : w.ua, hcur, mask, mask_scalar, hnext, Y, S);
+            PK_LAUNCH_CHECK();
+        }
+        float* tmp = hcur; hcur = hnext; hnext = tmp;
+        tmp = ccur; ccur = cnext; cnext = tmp;
+    }
+    return 0;
+}
+
+template <int CELL>
+int bwd_stepwise(hipStream_t st, int prec, int act, StepGeom g, const float* U, const float* mask, float mask_scalar,
+                 const float* Y, const float* S, const float* dY, float* dP2, float* work) {
+    constexpr int G = pk_cell_gates(CELL);
+    constexpr bool TWO = pk_cell_two_phase(CELL);
+    Work w = carve(work, g.R, g.H, G);
+    float *ch = w.h0, *nh = w.h1, *cc = w.c0, *nc = w.c1;
+    const int blocks = ew_blocks((long)g.R * g.H);
+    const int H = g.H;
+    for (int t = g.T - 1; t >= 0; --t) {
+        const bool last = (t == g.T - 1);
+        if constexpr (!TWO) {
+            hipLaunchKernelGGL((step_bwd_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, act, Y, S, dY, mask,
+                               mask_scalar, last ? (const float*)nullptr : ch, cc, w.dg, dP2, nh, nc);
+            PK_LAUNCH_CHECK();
+            if (t > 0)  // nh[R,H] += dG[R,G*H] . U[G*H,H]
+                PK_TRY(pk_gemm(st, prec, g.R, H, G * H, 1.f, w.dg, G * H, 1, U, H, 1, 1.f, nh, H, nullptr, 1, nullptr));
+        } else {
+            constexpr int G1 = G - 1;
+            hipLaunchKernelGGL((step_bwd_pa_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, act, Y, S, dY, mask,
+                               mask_scalar, last ? (const float*)nullptr : ch, w.gh, w.ua, nh);
+            PK_LAUNCH_CHECK();
+            // q[R,H] = dA[R,H] . U_h[H,H]
+            PK_TRY(pk_gemm(st, prec, g.R, H, H, 1.f, w.gh, H, 1, U + (long)G1 * H * H, H, 1, 0.f, w.urec, H, nullptr, 1,
+                           nullptr));
+            hipLaunchKernelGGL((step_bwd_pb_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, Y, S, w.urec, w.gh, w.ua,
+                               w.dg, dP2, nh);
+            PK_LAUNCH_CHECK();
+            if (t > 0)
+                PK_TRY(pk_gemm(st, prec, g.R, H, G1 * H, 1.f, w.dg, G1 * H, 1, U, H, 1, 1.f, nh, H, nullptr, 1, nullptr));
+        }
+        float* tmp = ch; ch = nh; nh = tmp;
+        tmp = cc; cc = nc; nc = tmp;
+    }
+    return 0;
+}
+
+// dU[G*H, H] = sum over directions and steps of dgate^T . (vector that fed U_g)
+int deferred_dU(hipStream_t st, int prec, int cell, StepGeom g, const float* Y, const float* S, const float* dP2,
+                float* dU, float* ws) {
+    const int G = g.G, H = g.H, NS = g.NS;
+    const long TB = (long)g.T * g.B;
+    const int ndir = g.R / g.B;
+    const int Gh = pk_cell_two_phase(cell) ? G - 1 : G;  // gates fed by h_{t-1}
+    const long Kh = (long)(g.T - 1) * g.B;
+    bool first = true;
+    if (Kh == 0) PK_CHECK_HIP(hipMemsetAsync(dU, 0, sizeof(float) * (size_t)Gh * H * H, st));
+    for (int dir = 0; dir < ndir && Kh > 0; ++dir) {
+        // rows whose previous state exists: dir 0 -> ts >= 1 (h at ts-1); dir 1 -> ts <= T-2 (h at ts+1)
+        const float* A = dP2 + ((long)dir * TB + (dir ? 0 : g.B)) * (G * H);
+        const float* Bm = Y + (long)(dir ? g.B : 0) * g.YH + (long)dir * H;
+        PK_TRY(pk_gemm(st, prec, Gh * H, H, (int)Kh, 1.f, A, 1, (long)G * H, Bm, g.YH, 1, first ? 0.f : 1.f, dU, H,
+                       nullptr, DU_SPLITK, ws));
+        first = false;
+    }
+    if (pk_cell_two_phase(cell)) {
+        // candidate gate: dU_h = sum dA^T . (r*h) or (z*h), saved in S, same row
+        const int slot = (cell == PK_CELL_GRU) ? 3 : 2;
+        for (int dir = 0; dir < ndir; ++dir) {
+            const float* A = dP2 + (long)dir * TB * (G * H) + (long)Gh * H;
+            const float* Bm = S + (long)dir * TB * (NS * H) + (long)slot * H;
+            PK_TRY(pk_gemm(st, prec, H, H, (int)TB, 1.f, A, 1, (long)G * H, Bm, (long)NS * H, 1, dir ? 1.f : 0.f,
+                           dU + (long)Gh * H * H, H, nullptr, DU_SPLITK, ws));
+        }
+    }
+    return 0;
+}
+
+int check_common(const char* who, int algo, int prec, int cell, int act, int T, int B, int bidir, int H) {
+    PK_REQUIRE(cell >= 0 && cell <= 4, "%s: bad cell %d", who, cell);
+    PK_REQUIRE(act >= 0 && act <= 5, "%s: bad activation %d", who, act);
+    PK_REQUIRE(prec == PK_PREC_F32 || prec == PK_PREC_BF16, "%s: bad prec %d", who, prec);
+    PK_REQUIRE(algo == PK_REC_STEPWISE || algo == PK_REC_PERSISTENT, "%s: bad algo %d", who, algo);
+    PK_REQUIRE(T > 0 && B > 0 && H > 0 && (bidir == 0 || bidir == 1), "%s: bad geometry T=%d B=%d H=%d bidir=%d", who,
+               T, B, H, bidir);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pk_rec_num_saved(int cell) { return pk_cell_saved(cell); }
+extern "C" int pk_rec_num_gates(int cell) { return pk_cell_gates(cell); }
+
+extern "C" int64_t pk_rec_work_floats(int cell, int T, int B, int bidir, int H) {
+    const long R = (long)B * (1 + bidir), G = pk_cell_gates(cell);
+    (void)T;
+    long n = 6 * ((R * H + 63) / 64 * 64) + 2 * ((R * G * H + 63) / 64 * 64);
+    n += (long)DU_SPLITK * G * H * H + 64;
+    // persistent algorithm: error/timeout words + slack
+    n += 4096;
+    return n;
+}
+
+extern "C" int pk_rec_fwd(void* stream, int algo, int prec, int cell, int act, int T, int B, int bidir, int H,
+                          const float* P, const float* pscale, const float* pshift, const float* U, const float* mask,
+                          float mask_scalar, const float* ln_gamma, const float* ln_beta, float* Y, float* S, float* LNS,
+                          float* work) {
+    PK_TRY(check_common("pk_rec_fwd", algo, prec, cell, act, T, B, bidir, H));
+    PK_REQUIRE(ln_gamma == nullptr && ln_beta == nullptr && LNS == nullptr,
+               "pk_rec_fwd: per-step LayerNorm is not implemented in this build");
+    hipStream_t st = pk_stream(stream);
+    StepGeom g;
+    g.T = T; g.B = B; g.R = B * (1 + bidir); g.H = H;
+    g.G = pk_cell_gates(cell); g.NS = pk_cell_saved(cell); g.YH = (1 + bidir) * H;
+    if (algo == PK_REC_PERSISTENT)
+        return pk_rec_fwd_persistent(st, prec, cell, act, T, B, bidir, H, P, pscale, pshift, U, mask, mask_scalar, Y, S,
+                                     work);
+    switch (cell) {
+        case PK_CELL_LIGRU: return fwd_stepwise<PK_CELL_LIGRU>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, Y, S, work);
+        case PK_CELL_RNN: return fwd_stepwise<PK_CELL_RNN>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, Y, S, work);
+        case PK_CELL_LSTM: return fwd_stepwise<PK_CELL_LSTM>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, Y, S, work);
+        case PK_CELL_GRU: return fwd_stepwise<PK_CELL_GRU>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, Y, S, work);
+        default: return fwd_stepwise<PK_CELL_MINGRU>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, Y, S, work);
+    }
+}
+
+extern "C" int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, int T, int B, int bidir, int H,
+                          const float* U, const float* mask, float mask_scalar, const float* ln_gamma, const float* Y,
+                          const float* S, const float* LNS, const float* dY, float* dP2, float* dU, float* dln_gamma,
+                          float* dln_beta, float* work) {
+    PK_TRY(check_common("pk_rec_bwd", algo, prec, cell, act, T, B, bidir, H));
+    PK_REQUIRE(ln_gamma == nullptr && LNS == nullptr && dln_gamma == nullptr && dln_beta == nullptr,
+               "pk_rec_bwd: per-step LayerNorm is not implemented in this build");
+    hipStream_t st = pk_stream(stream);
+    StepGeom g;
+    g.T = T; g.B = B; g.R = B * (1 + bidir); g.H = H;
+    g.G = pk_cell_gates(cell); g.NS = pk_cell_saved(cell); g.YH = (1 + bidir) * H;
+    int rc;
+    if (algo == PK_REC_PERSISTENT) {
+        rc = pk_rec_bwd_persistent(st, prec, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dP2, work);
+    } else {
+        switch (cell) {
+            case PK_CELL_LIGRU: rc = bwd_stepwise<PK_CELL_LIGRU>(st, prec, act, g, U, mask, mask_scalar, Y, S, dY, dP2, work); break;
+            case PK_CELL_RNN: rc = bwd_stepwise<PK_CELL_RNN>(st, prec, act, g, U, mask, mask_scalar, Y, S, dY, dP2, work); break;
+            case PK_CELL_LSTM: rc = bwd_stepwise<PK_CELL_LSTM>(st, prec, act, g, U, mask, mask_scalar, Y, S, dY, dP2, work); break;
+            case PK_CELL_GRU: rc = bwd_stepwise<PK_CELL_GRU>(st, prec, act, g, U, mask, mask_scalar, Y, S, dY, dP2, work); break;
+            default: rc = bwd_stepwise<PK_CELL_MINGRU>(st, prec, act, g, U, mask, mask_scalar, Y, S, dY, dP2, work); break;
+        }
+    }
+    if (rc) return rc;
+    Work w = carve(work, g.R, g.H, g.G);
+    return deferred_dU(st, prec, cell, g, Y, S, dP2, dU, w.ws);
+}

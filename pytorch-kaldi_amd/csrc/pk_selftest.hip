@@ -1,0 +1,116 @@
+// pk_selftest.hip - on-device check of the MFMA fragment layouts the kernels
+// assume (tests/ only).  One wave computes a 16x16 / 32x32 product with
+// asymmetric operands; the host compares against a scalar reference.
+#include <math.h>
+#include <string.h>
+
+#include "pk_common.h"
+
+namespace {
+
+// out layout: [0..255] 16x16x32 bf16, [256..511] 16x16x4 f32, [512..1535] 32x32x2 f32, [1536..2559] 32x32x16 bf16
+__global__ void mfma_layout_kernel(const float* __restrict__ A16, const float* __restrict__ B16,  // [16][32], [32][16]
+                                   const float* __restrict__ A32, const float* __restrict__ B32,  // [32][16], [16][32]
+                                   float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    {   // v_mfma_f32_16x16x32_bf16: lane supplies A[row=lane&15][k=(lane>>4)*8+e], B[k][col=lane&15]
+        bf16x8 a, b;
+        for (int e = 0; e < 8; ++e) {
+            const int k = (lane >> 4) * 8 + e;
+            a[e] = (short)pk_f2bf(A16[(lane & 15) * 32 + k]);
+            b[e] = (short)pk_f2bf(B16[k * 16 + (lane & 15)]);
+        }
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+        for (int r = 0; r < 4; ++r) out[((lane >> 4) * 4 + r) * 16 + (lane & 15)] = c[r];
+    }
+    {   // v_mfma_f32_16x16x4_f32: A[row=lane&15][k=lane>>4], B[k=lane>>4][col=lane&15]; use k 0..3 of the 16x32 operands
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = kk * 4 + (lane >> 4);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(A16[(lane & 15) * 32 + k], B16[k * 16 + (lane & 15)], c, 0, 0, 0);
+        }
+        for (int r = 0; r < 4; ++r) out[256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = c[r];
+    }
+    {   // v_mfma_f32_32x32x2_f32: A[i=lane&31][k=lane>>5], B[k=lane>>5][j=lane&31]
+        f32x16 c;
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = kk * 2 + (lane >> 5);
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(A32[(lane & 31) * 16 + k], B32[k * 32 + (lane & 31)], c, 0, 0, 0);
+        }
+        for (int r = 0; r < 16; ++r)
+            out[512 + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = c[r];
+    }
+    {   // v_mfma_f32_32x32x16_bf16: A[row=lane&31][k=(lane>>5)*8+e], B[k][col=lane&31]
+        bf16x8 a, b;
+        for (int e = 0; e < 8; ++e) {
+            const int k = (lane >> 5) * 8 + e;
+            a[e] = (short)pk_f2bf(A32[(lane & 31) * 16 + k]);
+            b[e] = (short)pk_f2bf(B32[k * 32 + (lane & 31)]);
+        }
+        f32x16 c;
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        for (int r = 0; r < 16; ++r)
+            out[1536 + ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = c[r];
+    }
+}
+
+float bf(float x) {
+    unsigned u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    float y;
+    memcpy(&y, &u, 4);
+    return y;
+}
+
+}  // namespace
+
+extern "C" int pk_selftest_mfma(void* stream, int* h_bad_count) {
+    hipStream_t st = pk_stream(stream);
+    float hA16[16 * 32], hB16[32 * 16], hA32[32 * 16], hB32[16 * 32], hout[2560];
+    unsigned s = 12345u;
+    auto rnd = [&]() {
+        s = s * 1664525u + 1013904223u;
+        return ((int)(s >> 20) % 17 - 8) / 8.0f;  // exactly representable in bf16
+    };
+    for (float& v : hA16) v = rnd();
+    for (float& v : hB16) v = rnd();
+    for (float& v : hA32) v = rnd();
+    for (float& v : hB32) v = rnd();
+    float *dA16, *dB16, *dA32, *dB32, *dout;
+    PK_CHECK_HIP(hipMalloc((void**)&dA16, sizeof(hA16)));
+    PK_CHECK_HIP(hipMalloc((void**)&dB16, sizeof(hB16)));
+    PK_CHECK_HIP(hipMalloc((void**)&dA32, sizeof(hA32)));
+    PK_CHECK_HIP(hipMalloc((void**)&dB32, sizeof(hB32)));
+    PK_CHECK_HIP(hipMalloc((void**)&dout, sizeof(hout)));
+    PK_CHECK_HIP(hipMemcpyAsync(dA16, hA16, sizeof(hA16), hipMemcpyHostToDevice, st));
+    PK_CHECK_HIP(hipMemcpyAsync(dB16, hB16, sizeof(hB16), hipMemcpyHostToDevice, st));
+    PK_CHECK_HIP(hipMemcpyAsync(dA32, hA32, sizeof(hA32), hipMemcpyHostToDevice, st));
+    PK_CHECK_HIP(hipMemcpyAsync(dB32, hB32, sizeof(hB32), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mfma_layout_kernel, dim3(1), dim3(64), 0, st, dA16, dB16, dA32, dB32, dout);
+    PK_LAUNCH_CHECK();
+    PK_CHECK_HIP(hipMemcpyAsync(hout, dout, sizeof(hout), hipMemcpyDeviceToHost, st));
+    PK_CHECK_HIP(hipStreamSynchronize(st));
+    (void)hipFree(dA16); (void)hipFree(dB16); (void)hipFree(dA32); (void)hipFree(dB32); (void)hipFree(dout);
+    int bad = 0;
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            float r = 0.f;
+            for (int k = 0; k < 32; ++k) r += bf(hA16[i * 32 + k]) * bf(hB16[k * 16 + j]);
+            if (fabsf(hout[i * 16 + j] - r) > 1e-4f) ++bad;
+            if (fabsf(hout[256 + i * 16 + j] - r) > 1e-4f) ++bad;
+        }
+    for (int i = 0; i < 32; ++i)
+        for (int j = 0; j < 32; ++j) {
+            float r = 0.f;
+            for (int k = 0; k < 16; ++k) r += hA32[i * 16 + k] * hB32[k * 32 + j];
+            if (fabsf(hout[512 + i * 32 + j] - r) > 1e-4f) ++bad;
+            if (fabsf(hout[1536 + i * 32 + j] - r) > 1e-4f) ++bad;
+        }
+    *h_bad_count = bad;
+    return 0;
+}

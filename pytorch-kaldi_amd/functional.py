@@ -1,0 +1,500 @@
+"""Host-side autograd wrappers around the C-ABI kernels of libpk_amd.so.
+
+Everything here is plumbing: torch owns the memory, autograd owns the graph,
+and each ``torch.autograd.Function`` hands raw device pointers plus the current
+HIP stream to ``include/pk_amd.h`` entry points.  There is deliberately no
+torch-op fallback: a CPU tensor or a missing library raises.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+
+PREC = {"fp32": 0, "bf16": 1}
+ACT = {"linear": 0, "relu": 1, "tanh": 2, "sigmoid": 3, "leaky_relu": 4, "elu": 5}
+CELL = {"liGRU": 0, "RNN": 1, "LSTM": 2, "GRU": 3, "minimalGRU": 4}
+REC_STEPWISE, REC_PERSISTENT = 0, 1
+
+
+class _Settings:
+    """Process-wide numerics / algorithm switches.
+
+    precision : "fp32" (exact fp32 MFMA - parity mode, default) or "bf16"
+                (bf16 MFMA operands, fp32 accumulate / state / master weights).
+    rec_algo  : "auto" | "stepwise" | "persistent".
+    """
+
+    def __init__(self):
+        self.precision = os.environ.get("PK_PRECISION", "fp32")
+        self.rec_algo = os.environ.get("PK_REC_ALGO", "auto")
+        assert self.precision in PREC, self.precision
+        assert self.rec_algo in ("auto", "stepwise", "persistent"), self.rec_algo
+
+
+settings = _Settings()
+
+
+def set_precision(p):
+    assert p in PREC, p
+    settings.precision = p
+
+
+def set_rec_algo(a):
+    assert a in ("auto", "stepwise", "persistent"), a
+    settings.rec_algo = a
+
+
+# ----------------------------------------------------------------------------
+# small helpers
+# ----------------------------------------------------------------------------
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.PkError("pytorch-kaldi_amd runs on the GPU only (got a %s tensor); there is no CPU fallback. "
+                               "Set use_cuda=True in the cfg." % t.device)
+        if t is not None and t.dtype != torch.float32:
+            raise _lib.PkError("pytorch-kaldi_amd kernels take fp32 tensors (got %s)" % t.dtype)
+
+
+def _rows2d(x):
+    """View x as [rows, cols] with unit column stride (copy only if it must)."""
+    if x.dim() != 2:
+        x = x.reshape(-1, x.shape[-1])
+    if x.stride(1) != 1 or (x.shape[0] > 1 and x.stride(0) < x.shape[1]):
+        x = x.contiguous()
+    return x
+
+
+def _new(*shape, like):
+    return torch.empty(*shape, device=like.device, dtype=torch.float32)
+
+
+def _splitk(out_tiles, K):
+    """Split the reduction when a GEMM has few output tiles and a long K (dW, dU)."""
+    if K < 4096:
+        return 1
+    ncu = 256
+    s = max(1, ncu // max(1, out_tiles))
+    return int(min(16, s, max(1, K // 1024)))
+
+
+def gemm(M, N, K, A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, alpha=1.0, beta=0.0, bias=None, splitk=1, prec=None):
+    lib = _lib.load()
+    ws = None
+    if splitk > 1:
+        ws = torch.empty(splitk * M * N, device=C.device, dtype=torch.float32)
+    rc = lib.pk_gemm(_stream(), PREC[prec or settings.precision], M, N, K, alpha, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs,
+                     beta, _p(C), ldc, _p(bias), splitk, _p(ws))
+    _lib.check(rc, "pk_gemm")
+    return C
+
+
+def _tiles(M, N):
+    return ((M + 127) // 128) * ((N + 127) // 128)
+
+
+# ----------------------------------------------------------------------------
+# Linear:  y = x W^T + b        (nn.Linear; neural_networks.py:111, 139-148)
+# ----------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, weight, bias)
+        x2 = _rows2d(x)
+        weight = weight.contiguous()
+        M, K = x2.shape
+        N = weight.shape[0]
+        y = _new(M, N, like=x2)
+        gemm(M, N, K, x2, x2.stride(0), 1, weight, 1, K, y, N, bias=bias)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        ctx.in_shape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        M, K = x2.shape
+        N = weight.shape[0]
+        dy2 = _rows2d(dy.contiguous())
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _new(M, K, like=dy2)
+            gemm(M, K, N, dy2, N, 1, weight, K, 1, dx, K)
+            dx = dx.view(ctx.in_shape)
+        if ctx.needs_input_grad[1]:
+            dw = _new(N, K, like=dy2)
+            gemm(N, K, M, dy2, 1, N, x2, x2.stride(0), 1, dw, K, splitk=_splitk(_tiles(N, K), M))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return LinearFn.apply(x, weight, bias)
+
+
+def colsum(g, g2=None):
+    lib = _lib.load()
+    M, N = g.shape
+    out = _new(N, like=g)
+    part = _new(int(lib.pk_bn_partial_floats(M, N)), like=g)
+    _lib.check(lib.pk_colsum(_stream(), _p(g), _p(g2), g.stride(0), M, N, _p(part), _p(out)), "pk_colsum")
+    return out
+
+
+# ----------------------------------------------------------------------------
+# BatchNorm1d(momentum=0.05) + activation + dropout mask, fused element-wise
+# (neural_networks.py:139-148 MLP; :1546-1552 CNN after pooling)
+# ----------------------------------------------------------------------------
+def bn_stats(x2):
+    lib = _lib.load()
+    M, N = x2.shape
+    mean, var = _new(N, like=x2), _new(N, like=x2)
+    part = _new(int(lib.pk_bn_partial_floats(M, N)), like=x2)
+    _lib.check(lib.pk_bn_stats(_stream(), _p(x2), x2.stride(0), M, N, _p(part), _p(mean), _p(var)), "pk_bn_stats")
+    return mean, var
+
+
+def bn_finalize(mean, var, gamma, beta, eps, running_mean=None, running_var=None, momentum=0.05, count=1.0):
+    lib = _lib.load()
+    N = mean.numel()
+    scale, shift = torch.empty_like(mean), torch.empty_like(mean)
+    _lib.check(lib.pk_bn_finalize(_stream(), N, _p(mean), _p(var), _p(gamma), _p(beta), eps, _p(scale), _p(shift),
+                                  _p(running_mean), _p(running_var), momentum, float(count)), "pk_bn_finalize")
+    return scale, shift
+
+
+class NormActDropFn(torch.autograd.Function):
+    """y = mask * act(BN(x))   (BN optional).  x: [M, N]."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, use_bn, training, eps, momentum, act, mask):
+        _need_gpu(x, gamma, beta, mask)
+        lib = _lib.load()
+        x2 = _rows2d(x)
+        M, N = x2.shape
+        scale = shift = mean = var = None
+        if use_bn:
+            if training:
+                mean, var = bn_stats(x2)
+                scale, shift = bn_finalize(mean, var, gamma, beta, eps, running_mean, running_var, momentum, M)
+            else:
+                mean, var = running_mean, running_var
+                scale, shift = bn_finalize(mean, var, gamma, beta, eps)
+        a = _new(M, N, like=x2)
+        _lib.check(lib.pk_affine_act_fwd(_stream(), _p(x2), x2.stride(0), M, N, _p(scale), _p(shift), ACT[act], None,
+                                         _p(a), N), "pk_affine_act_fwd")
+        y = a
+        if mask is not None:
+            y = _new(M, N, like=x2)
+            _lib.check(lib.pk_affine_act_fwd(_stream(), _p(a), N, M, N, None, None, 0, _p(mask), _p(y), N),
+                       "pk_affine_act_fwd")
+        ctx.save_for_backward(x2, gamma, mean, var, a, mask, scale)
+        ctx.cfg = (use_bn, training, eps, act)
+        ctx.in_shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2, gamma, mean, var, a, mask, scale = ctx.saved_tensors
+        use_bn, training, eps, act = ctx.cfg
+        M, N = x2.shape
+        dy2 = _rows2d(dy.contiguous())
+        g = _new(M, N, like=x2)
+        _lib.check(lib.pk_act_bwd(_stream(), _p(dy2), _p(a), _p(mask), ACT[act], M * N, _p(g)), "pk_act_bwd")
+        dgamma = dbeta = None
+        if not use_bn:
+            return g.view(ctx.in_shape), None, None, None, None, None, None, None, None, None, None
+        part = _new(int(lib.pk_bn_partial_floats(M, N)), like=x2)
+        sum_g, sum_gx = _new(N, like=x2), _new(N, like=x2)
+        _lib.check(lib.pk_bn_bwd_reduce(_stream(), _p(g), None, N, _p(x2), x2.stride(0), M, N, _p(mean), _p(var), eps,
+                                        _p(part), _p(sum_g), _p(sum_gx)), "pk_bn_bwd_reduce")
+        dgamma, dbeta = sum_gx, sum_g
+        dx = _new(M, N, like=x2)
+        if training:
+            _lib.check(lib.pk_bn_bwd_apply(_stream(), _p(g), None, N, _p(x2), x2.stride(0), M, N, _p(mean), _p(var), eps,
+                                           _p(gamma), _p(sum_g), _p(sum_gx), float(M), _p(dx), N), "pk_bn_bwd_apply")
+        else:  # running statistics are constants: dx = g * gamma * invstd
+            zero = torch.zeros_like(scale)
+            _lib.check(lib.pk_affine_act_fwd(_stream(), _p(g), N, M, N, _p(scale), _p(zero), 0, None, _p(dx), N),
+                       "pk_affine_act_fwd")
+        return dx.view(ctx.in_shape), dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def norm_act_drop(x, bn, use_bn, training, act, mask=None, eps=None):
+    """bn: an nn.BatchNorm1d used as a parameter container (or None)."""
+    if use_bn:
+        if training:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+        return NormActDropFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, training,
+                                   bn.eps if eps is None else eps, bn.momentum, act, mask)
+    return NormActDropFn.apply(x, None, None, None, None, False, training, 0.0, 0.0, act, mask)
+
+
+# ----------------------------------------------------------------------------
+# LayerNorm of the reference (neural_networks.py:23-33)
+# ----------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _need_gpu(x, gamma, beta)
+        lib = _lib.load()
+        F_ = gamma.numel()
+        x2 = x.contiguous().view(-1, F_)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean, rinv = _new(rows, like=x2), _new(rows, like=x2)
+        g = gamma.contiguous().view(-1)
+        b = beta.contiguous().view(-1)
+        _lib.check(lib.pk_layernorm_fwd(_stream(), _p(x2), rows, F_, _p(g), _p(b), eps, _p(y), _p(mean), _p(rinv)),
+                   "pk_layernorm_fwd")
+        ctx.save_for_backward(x2, g, mean, rinv)
+        ctx.eps = eps
+        ctx.shapes = (x.shape, gamma.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2, g, mean, rinv = ctx.saved_tensors
+        rows, F_ = x2.shape
+        dy2 = dy.contiguous().view(rows, F_)
+        dx, dgx = torch.empty_like(x2), torch.empty_like(x2)
+        _lib.check(lib.pk_layernorm_bwd(_stream(), _p(dy2), _p(x2), rows, F_, _p(g), _p(mean), _p(rinv), ctx.eps, _p(dx),
+                                        _p(dgx)), "pk_layernorm_bwd")
+        xs, gs = ctx.shapes
+        return dx.view(xs), colsum(dgx).view(gs), colsum(dy2).view(gs), None
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+def layer_norm_last(x, gamma, beta, eps=1e-6):
+    """LayerNorm whose affine parameters are [C, L] but whose statistics run over
+    the last dim only (the CNN/SincNet flavour, neural_networks.py:1510-1512):
+    normalise rows of length L without affine, then apply gamma/beta with torch
+    broadcasting (tiny element-wise plumbing)."""
+    L = x.shape[-1]
+    ones = torch.ones(L, device=x.device)
+    zeros = torch.zeros(L, device=x.device)
+    xn = LayerNormFn.apply(x, ones, zeros, eps)
+    return gamma * xn + beta
+
+
+# ----------------------------------------------------------------------------
+# LogSoftmax(dim=1)  ('softmax' activation, neural_networks.py:53-54)
+# ----------------------------------------------------------------------------
+class LogSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        lib = _lib.load()
+        x2 = x.contiguous()
+        rows, N = x2.shape
+        y = torch.empty_like(x2)
+        _lib.check(lib.pk_logsoftmax_fwd(_stream(), _p(x2), rows, N, _p(y)), "pk_logsoftmax_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        rows, N = y.shape
+        dy2 = dy.contiguous()
+        dx = torch.empty_like(y)
+        _lib.check(lib.pk_logsoftmax_bwd(_stream(), _p(dy2), _p(y), rows, N, _p(dx)), "pk_logsoftmax_bwd")
+        return dx
+
+
+def log_softmax(x):
+    if x.dim() != 2:
+        raise _lib.PkError("log_softmax expects a 2-D (rows, classes) input as the reference's LogSoftmax(dim=1)")
+    return LogSoftmaxFn.apply(x)
+
+
+# ----------------------------------------------------------------------------
+# One recurrent layer: projections + (BatchNorm) + time loop, both directions.
+# neural_networks.py:412-481 (LSTM), 589-653 (GRU), 1092-1153 (liGRU), ...
+# ----------------------------------------------------------------------------
+def choose_rec_algo(cell, H, use_ln):
+    want = settings.rec_algo
+    ok = cell in ("liGRU", "RNN", "LSTM") and H % 2 == 0 and H <= 576 and not use_ln
+    if want == "persistent":
+        if not ok:
+            raise _lib.PkError("persistent recurrence does not cover cell=%s H=%d laynorm=%s" % (cell, H, use_ln))
+        return REC_PERSISTENT
+    if want == "stepwise":
+        return REC_STEPWISE
+    return REC_PERSISTENT if ok else REC_STEPWISE
+
+
+class RecLayerFn(torch.autograd.Function):
+    """y, bn_mean, bn_var = f(x, Wcat, bcat, Ucat, gamma, beta, mask)
+
+    x [T,B,D]; Wcat [G*H, D]; bcat [G*H] or None; Ucat [G*H, H]; gamma/beta
+    [G*H] or None (BatchNorm on the projections); mask [R,H] or None.
+    """
+
+    @staticmethod
+    def forward(ctx, x, Wcat, bcat, Ucat, gamma, beta, running_mean, running_var, mask, cfg):
+        _need_gpu(x, Wcat, bcat, Ucat, gamma, beta, mask)
+        lib = _lib.load()
+        cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar = cfg
+        T, B, D = x.shape
+        x2 = _rows2d(x)
+        G = lib.pk_rec_num_gates(CELL[cell])
+        NS = lib.pk_rec_num_saved(CELL[cell])
+        ndir = 2 if bidir else 1
+        TB, GH = T * B, G * H
+        Wcat = Wcat.contiguous()
+        Ucat = Ucat.contiguous()
+        # K1: input projections for all steps at once, on the NON-duplicated batch (the reversed
+        # half of the reference's cat([x, flip(x)]) is the same rows read backwards in time)
+        P = _new(TB, GH, like=x2)
+        gemm(TB, GH, D, x2, x2.stride(0), 1, Wcat, 1, D, P, GH)
+        mean = var = None
+        if use_bn:
+            if training:
+                mean, var = bn_stats(P)
+                # duplicating every row leaves mean / biased var unchanged; only the unbiased
+                # running_var factor sees the reference's row count ndir*T*B
+                pscale, pshift = bn_finalize(mean, var, gamma, beta, eps, running_mean, running_var, momentum, ndir * TB)
+            else:
+                mean, var = running_mean, running_var
+                pscale, pshift = bn_finalize(mean, var, gamma, beta, eps)
+        else:
+            pscale = torch.ones(GH, device=x.device)
+            pshift = bcat.contiguous() if bcat is not None else torch.zeros(GH, device=x.device)
+        Y = _new(T, B, ndir * H, like=x2)
+        S = _new(ndir, TB, NS * H, like=x2)
+        work = _new(int(lib.pk_rec_work_floats(CELL[cell], T, B, int(bidir), H)), like=x2)
+        algo = choose_rec_algo(cell, H, False)
+        prec = PREC[settings.precision]
+        if algo == REC_PERSISTENT:
+            _lib.raise_if_persist_failed()
+        rc = lib.pk_rec_fwd(_stream(), algo, prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
+                            _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), None, None, _p(Y), _p(S), None, _p(work))
+        _lib.check(rc, "pk_rec_fwd")
+        ctx.save_for_backward(x2, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, pscale)
+        ctx.cfg = cfg
+        ctx.algo, ctx.prec = algo, prec
+        ctx.in_shape = x.shape
+        ctx.has_bias = bcat is not None
+        if use_bn and training:
+            ctx.mark_non_differentiable(mean, var)
+            return Y, mean, var
+        return Y, None, None
+
+    @staticmethod
+    def backward(ctx, dY, _dm, _dv):
+        lib = _lib.load()
+        x2, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, pscale = ctx.saved_tensors
+        cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar = ctx.cfg
+        T, B, D = ctx.in_shape
+        G = lib.pk_rec_num_gates(CELL[cell])
+        ndir = 2 if bidir else 1
+        TB, GH = T * B, G * H
+        dY = dY.contiguous()
+        dP2 = _new(ndir, TB, GH, like=dY)
+        dU = _new(GH, H, like=dY)
+        work = _new(int(lib.pk_rec_work_floats(CELL[cell], T, B, int(bidir), H)), like=dY)
+        rc = lib.pk_rec_bwd(_stream(), ctx.algo, ctx.prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
+                            float(mask_scalar), None, _p(Y), _p(S), None, _p(dY), _p(dP2), _p(dU), None, None, _p(work))
+        _lib.check(rc, "pk_rec_bwd")
+        g1 = dP2[0]
+        g2 = dP2[1] if bidir else None
+        dgamma = dbeta = dbias = None
+        dPraw = _new(TB, GH, like=dY)
+        if use_bn:
+            part = _new(int(lib.pk_bn_partial_floats(TB, GH)), like=dY)
+            sum_g, sum_gx = _new(GH, like=dY), _new(GH, like=dY)
+            _lib.check(lib.pk_bn_bwd_reduce(_stream(), _p(g1), _p(g2), GH, _p(P), GH, TB, GH, _p(mean), _p(var), eps,
+                                            _p(part), _p(sum_g), _p(sum_gx)), "pk_bn_bwd_reduce")
+            dgamma, dbeta = sum_gx, sum_g
+            if training:
+                _lib.check(lib.pk_bn_bwd_apply(_stream(), _p(g1), _p(g2), GH, _p(P), GH, TB, GH, _p(mean), _p(var), eps,
+                                               _p(gamma), _p(sum_g), _p(sum_gx), float(TB), _p(dPraw), GH),
+                           "pk_bn_bwd_apply")
+            else:
+                gs = g1
+                if g2 is not None:
+                    gs = _new(TB, GH, like=dY)
+                    _lib.check(lib.pk_add(_stream(), _p(g1), _p(g2), TB * GH, _p(gs)), "pk_add")
+                zero = torch.zeros_like(pscale)
+                _lib.check(lib.pk_affine_act_fwd(_stream(), _p(gs), GH, TB, GH, _p(pscale), _p(zero), 0, None,
+                                                 _p(dPraw), GH), "pk_affine_act_fwd")
+        else:
+            if g2 is not None:
+                _lib.check(lib.pk_add(_stream(), _p(g1), _p(g2), TB * GH, _p(dPraw)), "pk_add")
+            else:
+                dPraw = g1
+            if ctx.has_bias:
+                dbias = colsum(dPraw)
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            dx = _new(TB, D, like=dY)
+            gemm(TB, D, GH, dPraw, GH, 1, Wcat, D, 1, dx, D)
+            dx = dx.view(T, B, D)
+        dW = _new(GH, D, like=dY)
+        gemm(GH, D, TB, dPraw, 1, GH, x2, x2.stride(0), 1, dW, D, splitk=_splitk(_tiles(GH, D), TB))
+        return dx, dW, dbias, dU, dgamma, dbeta, None, None, None, None
+
+
+# ----------------------------------------------------------------------------
+# conv1d + max_pool1d (neural_networks.py:1546-1552, 1655-1661, 1805-1813)
+# ----------------------------------------------------------------------------
+class ConvPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, pool):
+        _need_gpu(x, w, bias)
+        lib = _lib.load()
+        x = x.contiguous()
+        w = w.contiguous()
+        B, Cin, L = x.shape
+        Cout, _, K = w.shape
+        Lp = (L - K + 1) // pool
+        y = _new(B, Cout, Lp, like=x)
+        arg = torch.empty(B, Cout, Lp, device=x.device, dtype=torch.int32)
+        _lib.check(lib.pk_conv1d_pool_fwd(_stream(), _p(x), _p(w), _p(bias), B, Cin, L, Cout, K, pool, _p(y),
+                                          ctypes.c_void_p(arg.data_ptr())), "pk_conv1d_pool_fwd")
+        ctx.save_for_backward(x, w, arg)
+        ctx.pool = pool
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, arg = ctx.saved_tensors
+        B, Cin, L = x.shape
+        Cout, _, K = w.shape
+        pool = ctx.pool
+        dy = dy.contiguous()
+        dw = torch.empty_like(w)
+        db = _new(Cout, like=x) if ctx.has_bias else None
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        part = None
+        if dx is not None:
+            part = _new(int(lib.pk_conv_partial_floats(B, Cin, L, Cout, K, pool)), like=x)
+        _lib.check(lib.pk_conv1d_pool_bwd(_stream(), _p(x), _p(w), _p(dy), ctypes.c_void_p(arg.data_ptr()), B, Cin, L,
+                                          Cout, K, pool, _p(dw), _p(db), _p(dx), _p(part)), "pk_conv1d_pool_bwd")
+        return dx, dw, db, None
+
+
+def conv1d_pool(x, w, bias, pool):
+    return ConvPoolFn.apply(x, w, bias, pool)

@@ -1,0 +1,463 @@
+"""Drop-in ``arch_library`` for PyTorch-Kaldi recipes: the acoustic-model classes of
+the reference's ``neural_networks.py`` re-built on the MI355X engine.
+
+Use it by changing one cfg line per architecture::
+
+    arch_library = pytorch-kaldi_amd.nn        # was: neural_networks
+    arch_class   = liGRU                       # unchanged
+
+Contract kept from the reference:
+  * ``Class(options, inp_dim)`` where ``options`` is the cfg section (all values are
+    strings, keys may be lower-cased by configparser) with the injected ``use_cuda``
+    and ``to_do`` fields (utils.py:2051-2057); ``.out_dim``; ``forward(x)`` with
+    ``x`` = (T, B, F) for sequence models and (N, F) otherwise;
+  * parameter / buffer names and shapes identical to the reference, so ``.pkl``
+    checkpoints interoperate (core.py:523-535, 710-722), including the unused
+    ``ln``/``bn`` sub-modules the reference always creates;
+  * sub-modules are created in the reference's order with the same torch
+    initialisers, so the same seed gives the same initial weights;
+  * recurrent drop masks are sampled per layer per forward call on the CPU RNG,
+    unscaled and constant over time, exactly like the reference
+    (e.g. neural_networks.py:1102-1107), then moved to the GPU.
+
+The nn.Linear / nn.BatchNorm1d / nn.Conv1d sub-modules are parameter containers
+only: ``forward`` never calls them, it hands their tensors to the HIP kernels
+through ``functional``.  There is no CPU path: ``use_cuda`` must be True.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from ._lib import PkError
+
+
+def strtobool(s):
+    s = str(s).strip().lower()
+    if s in ("y", "yes", "t", "true", "on", "1"):
+        return 1
+    if s in ("n", "no", "f", "false", "off", "0"):
+        return 0
+    raise ValueError("invalid truth value %r" % (s,))
+
+
+def _opt(options, key):
+    try:
+        return options[key]
+    except KeyError:
+        return options[key.lower()]
+
+
+def _ints(s):
+    return list(map(int, str(s).split(",")))
+
+
+def _floats(s):
+    return list(map(float, str(s).split(",")))
+
+
+def _bools(s):
+    return list(map(strtobool, str(s).split(",")))
+
+
+class LayerNorm(nn.Module):
+    """gamma*(x-mean)/(std_unbiased+eps)+beta over the last dim (neural_networks.py:23-33)."""
+
+    def __init__(self, features, eps=1e-6):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(features))
+        self.beta = nn.Parameter(torch.zeros(features))
+        self.eps = eps
+
+    def forward(self, x):
+        if self.gamma.dim() == 1:
+            return F_.layer_norm(x, self.gamma, self.beta, self.eps)
+        return F_.layer_norm_last(x, self.gamma, self.beta, self.eps)
+
+
+class _Act(nn.Module):
+    """Placeholder kept so that ``self.act`` exists like in the reference (no parameters)."""
+
+    def __init__(self, name):
+        super().__init__()
+        self.name = name
+
+
+def act_fun(act_type):
+    """neural_networks.py:36-57; returns a parameter-free marker module."""
+    if act_type not in ("relu", "tanh", "sigmoid", "leaky_relu", "elu", "softmax", "linear"):
+        raise ValueError("unknown activation %r" % (act_type,))
+    return _Act(act_type)
+
+
+def flip(x, dim):
+    """Time reversal (neural_networks.py:1962-1970); the engine folds it into kernel indexing,
+    this helper exists for API parity."""
+    return torch.flip(x, dims=[dim])
+
+
+def _apply_act_drop(x2, bn, use_bn, training, act, drop_p, eps=None):
+    """drop(act(bn(x))) on a 2-D tensor; 'softmax' is LogSoftmax(dim=1)."""
+    mask = None
+    if training and drop_p > 0.0:
+        mask = torch.empty_like(x2).bernoulli_(1.0 - drop_p).div_(1.0 - drop_p)
+    if act == "softmax":
+        y = F_.norm_act_drop(x2, bn, use_bn, training, "linear", None, eps) if use_bn else x2
+        y = F_.log_softmax(y)
+        return y * mask if mask is not None else y
+    return F_.norm_act_drop(x2, bn, use_bn, training, act, mask, eps)
+
+
+class MLP(nn.Module):
+    """neural_networks.py:60-150."""
+
+    def __init__(self, options, inp_dim):
+        super().__init__()
+        self.input_dim = inp_dim
+        self.dnn_lay = _ints(_opt(options, "dnn_lay"))
+        self.dnn_drop = _floats(_opt(options, "dnn_drop"))
+        self.dnn_use_batchnorm = _bools(_opt(options, "dnn_use_batchnorm"))
+        self.dnn_use_laynorm = _bools(_opt(options, "dnn_use_laynorm"))
+        self.dnn_use_laynorm_inp = strtobool(_opt(options, "dnn_use_laynorm_inp"))
+        self.dnn_use_batchnorm_inp = strtobool(_opt(options, "dnn_use_batchnorm_inp"))
+        self.dnn_act = str(_opt(options, "dnn_act")).split(",")
+        self.wx = nn.ModuleList([])
+        self.bn = nn.ModuleList([])
+        self.ln = nn.ModuleList([])
+        self.act = nn.ModuleList([])
+        self.drop = nn.ModuleList([])
+        if self.dnn_use_laynorm_inp:
+            self.ln0 = LayerNorm(self.input_dim)
+        if self.dnn_use_batchnorm_inp:
+            self.bn0 = nn.BatchNorm1d(self.input_dim, momentum=0.05)
+        self.N_dnn_lay = len(self.dnn_lay)
+        cur = self.input_dim
+        for i in range(self.N_dnn_lay):
+            self.drop.append(nn.Dropout(p=self.dnn_drop[i]))
+            self.act.append(act_fun(self.dnn_act[i]))
+            self.ln.append(LayerNorm(self.dnn_lay[i]))
+            self.bn.append(nn.BatchNorm1d(self.dnn_lay[i], momentum=0.05))
+            add_bias = not (self.dnn_use_laynorm[i] or self.dnn_use_batchnorm[i])
+            self.wx.append(nn.Linear(cur, self.dnn_lay[i], bias=add_bias))
+            bound = np.sqrt(0.01 / (cur + self.dnn_lay[i]))
+            self.wx[i].weight = nn.Parameter(torch.Tensor(self.dnn_lay[i], cur).uniform_(-bound, bound))
+            self.wx[i].bias = nn.Parameter(torch.zeros(self.dnn_lay[i]))  # the reference always re-creates it (:120)
+            cur = self.dnn_lay[i]
+        self.out_dim = cur
+
+    def forward(self, x):
+        if self.dnn_use_laynorm_inp:
+            x = self.ln0(x)
+        if self.dnn_use_batchnorm_inp:
+            x = F_.norm_act_drop(x, self.bn0, True, self.training, "linear")
+        for i in range(self.N_dnn_lay):
+            z = F_.linear(x, self.wx[i].weight, self.wx[i].bias)
+            if self.dnn_use_laynorm[i]:
+                z = self.ln[i](z)
+            x = _apply_act_drop(z, self.bn[i], bool(self.dnn_use_batchnorm[i]), self.training, self.dnn_act[i],
+                                self.dnn_drop[i])
+        return x
+
+
+# gate order of the concatenated projections (matches PK_CELL_* in include/pk_amd.h)
+_REC_SPEC = {
+    "liGRU": ("ligru", [("wz", "uz", "bn_wz"), ("wh", "uh", "bn_wh")], ["wh", "wz"], ["uh", "uz"], ["bn_wh", "bn_wz"]),
+    "minimalGRU": ("minimalgru", [("wz", "uz", "bn_wz"), ("wh", "uh", "bn_wh")], ["wh", "wz"], ["uh", "uz"],
+                   ["bn_wh", "bn_wz"]),
+    "GRU": ("gru", [("wz", "uz", "bn_wz"), ("wr", "ur", "bn_wr"), ("wh", "uh", "bn_wh")], ["wh", "wz", "wr"],
+            ["uh", "uz", "ur"], ["bn_wh", "bn_wz", "bn_wr"]),
+    "LSTM": ("lstm", [("wfx", "ufh", "bn_wfx"), ("wix", "uih", "bn_wix"), ("wox", "uoh", "bn_wox"),
+                      ("wcx", "uch", "bn_wcx")], ["wfx", "wix", "wox", "wcx"], ["ufh", "uih", "uoh", "uch"],
+             ["bn_wfx", "bn_wix", "bn_wox", "bn_wcx"]),
+    "RNN": ("rnn", [("wh", "uh", "bn_wh")], ["wh"], ["uh"], ["bn_wh"]),
+}
+
+
+class _Recurrent(nn.Module):
+    """Shared body of LSTM / GRU / liGRU / minimalGRU / RNN (neural_networks.py:300-655, 997-1461)."""
+
+    KIND = None
+
+    def __init__(self, options, inp_dim):
+        super().__init__()
+        pre, gates, w_order, u_order, bn_order = _REC_SPEC[self.KIND]
+        self._pre, self._gates = pre, gates
+        self.input_dim = inp_dim
+        lay = _ints(_opt(options, pre + "_lay"))
+        setattr(self, pre + "_lay", lay)
+        self._lay = lay
+        self._drop = _floats(_opt(options, pre + "_drop"))
+        self._use_bn = _bools(_opt(options, pre + "_use_batchnorm"))
+        self._use_ln = _bools(_opt(options, pre + "_use_laynorm"))
+        self._use_ln_inp = strtobool(_opt(options, pre + "_use_laynorm_inp"))
+        self._use_bn_inp = strtobool(_opt(options, pre + "_use_batchnorm_inp"))
+        self._orthinit = strtobool(_opt(options, pre + "_orthinit"))
+        self._act = str(_opt(options, pre + "_act")).split(",")
+        self.bidir = strtobool(_opt(options, pre + "_bidir"))
+        self.use_cuda = strtobool(_opt(options, "use_cuda"))
+        self.to_do = _opt(options, "to_do")
+        self.test_flag = self.to_do != "train"
+        for a in self._act:
+            if a not in F_.ACT:
+                raise PkError("%s: activation %r is not supported inside the recurrence" % (self.KIND, a))
+        for name in w_order + u_order + ["ln"] + bn_order + ["act"]:
+            setattr(self, name, nn.ModuleList([]))
+        if self._use_ln_inp:
+            self.ln0 = LayerNorm(self.input_dim)
+        if self._use_bn_inp:
+            self.bn0 = nn.BatchNorm1d(self.input_dim, momentum=0.05)
+        self._n_lay = len(lay)
+        cur = self.input_dim
+        for i in range(self._n_lay):
+            self.act.append(act_fun(self._act[i]))
+            add_bias = not (self._use_ln[i] or self._use_bn[i])
+            for name in w_order:  # feed-forward connections, reference order
+                getattr(self, name).append(nn.Linear(cur, lay[i], bias=add_bias))
+            for name in u_order:  # recurrent connections
+                getattr(self, name).append(nn.Linear(lay[i], lay[i], bias=False))
+            if self._orthinit:
+                for name in u_order:
+                    nn.init.orthogonal_(getattr(self, name)[i].weight)
+            for name in bn_order:
+                getattr(self, name).append(nn.BatchNorm1d(lay[i], momentum=0.05))
+            self.ln.append(LayerNorm(lay[i]))
+            cur = 2 * lay[i] if self.bidir else lay[i]
+        self.out_dim = lay[-1] + self.bidir * lay[-1]
+
+    def _drop_masks(self, batch, device):
+        """One Bernoulli(1-p) mask (rows, H) per layer on the CPU RNG, in layer order."""
+        rows = 2 * batch if self.bidir else batch
+        if self.test_flag:
+            return [None] * self._n_lay, [1.0 - p for p in self._drop]
+        cpu = [torch.bernoulli(torch.Tensor(rows, h).fill_(1 - p)) for h, p in zip(self._lay, self._drop)]
+        return [m.pin_memory().to(device, non_blocking=True) if device.type == "cuda" else m for m in cpu], \
+               [1.0] * self._n_lay
+
+    def forward(self, x, drop_masks=None):
+        if not x.is_cuda:
+            raise PkError("pytorch-kaldi_amd.nn.%s runs on the GPU only: set use_cuda=True" % self.KIND)
+        if self._use_ln_inp:
+            x = self.ln0(x)
+        if self._use_bn_inp:
+            T, B, D = x.shape
+            x = F_.norm_act_drop(x.reshape(T * B, D), self.bn0, True, self.training, "linear").view(T, B, D)
+        if drop_masks is None:
+            masks, scalars = self._drop_masks(x.shape[1], x.device)
+        else:  # injected (parity tests): tensors (rows,H) in train mode, 1-element tensors in test mode
+            masks = [m if m.numel() > 1 else None for m in drop_masks]
+            scalars = [1.0 if m.numel() > 1 else float(m) for m in drop_masks]
+            masks = [m.to(x.device).float().contiguous() if m is not None else None for m in masks]
+        for i in range(self._n_lay):
+            if self._use_ln[i]:
+                raise PkError("%s: per-step LayerNorm (%s_use_laynorm) is not available in this build of the engine"
+                              % (self.KIND, self._pre))
+            H = self._lay[i]
+            Ws = [getattr(self, w)[i] for (w, _, _) in self._gates]
+            Us = [getattr(self, u)[i] for (_, u, _) in self._gates]
+            Wcat = torch.cat([m.weight for m in Ws], 0) if len(Ws) > 1 else Ws[0].weight
+            Ucat = torch.cat([m.weight for m in Us], 0) if len(Us) > 1 else Us[0].weight
+            bcat = None
+            if Ws[0].bias is not None:
+                bcat = torch.cat([m.bias for m in Ws], 0) if len(Ws) > 1 else Ws[0].bias
+            gamma = beta = rmean = rvar = None
+            use_bn = bool(self._use_bn[i])
+            bns = [getattr(self, b)[i] for (_, _, b) in self._gates]
+            if use_bn:
+                gamma = torch.cat([b.weight for b in bns], 0)
+                beta = torch.cat([b.bias for b in bns], 0)
+                if not self.training:
+                    rmean = torch.cat([b.running_mean for b in bns], 0)
+                    rvar = torch.cat([b.running_var for b in bns], 0)
+            cfg = (self.KIND, self._act[i], H, bool(self.bidir), use_bn, self.training, 1e-5, 0.05, scalars[i])
+            y, bmean, bvar = F_.RecLayerFn.apply(x, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, masks[i], cfg)
+            if use_bn and self.training:
+                n = x.shape[0] * x.shape[1] * (2 if self.bidir else 1)
+                with torch.no_grad():  # BatchNorm1d(momentum=0.05) running statistics, per gate
+                    for k, b in enumerate(bns):
+                        b.running_mean.mul_(0.95).add_(bmean[k * H:(k + 1) * H], alpha=0.05)
+                        b.running_var.mul_(0.95).add_(bvar[k * H:(k + 1) * H], alpha=0.05 * n / (n - 1))
+                        b.num_batches_tracked += 1
+            x = y
+        return x
+
+
+class liGRU(_Recurrent):
+    """neural_networks.py:997-1155."""
+    KIND = "liGRU"
+
+
+class minimalGRU(_Recurrent):
+    """neural_networks.py:1158-1316."""
+    KIND = "minimalGRU"
+
+
+class GRU(_Recurrent):
+    """neural_networks.py:486-655."""
+    KIND = "GRU"
+
+
+class LSTM(_Recurrent):
+    """neural_networks.py:300-483."""
+    KIND = "LSTM"
+
+
+class RNN(_Recurrent):
+    """neural_networks.py:1319-1461."""
+    KIND = "RNN"
+
+
+class SincConv(nn.Module):
+    """Sinc band-pass bank (neural_networks.py:1668-1813).  The 2x128 parameters ->
+    128x129 filter synthesis stays in torch autograd (tiny); the
+    convolution itself runs in the fused HIP conv+pool kernel of the caller."""
+
+    @staticmethod
+    def to_mel(hz):
+        return 2595 * np.log10(1 + hz / 700)
+
+    @staticmethod
+    def to_hz(mel):
+        return 700 * (10 ** (mel / 2595) - 1)
+
+    def __init__(self, in_channels, out_channels, kernel_size, sample_rate=16000, min_low_hz=50, min_band_hz=50):
+        super().__init__()
+        if in_channels != 1:
+            raise ValueError("SincConv only support one input channel (here, in_channels = {%i})" % (in_channels))
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size + 1 if kernel_size % 2 == 0 else kernel_size
+        self.sample_rate, self.min_low_hz, self.min_band_hz = sample_rate, min_low_hz, min_band_hz
+        low_hz = 30
+        high_hz = self.sample_rate / 2 - (self.min_low_hz + self.min_band_hz)
+        mel = np.linspace(self.to_mel(low_hz), self.to_mel(high_hz), self.out_channels + 1)
+        hz = self.to_hz(mel) / self.sample_rate
+        self.low_hz_ = nn.Parameter(torch.Tensor(hz[:-1]).view(-1, 1))
+        self.band_hz_ = nn.Parameter(torch.Tensor(np.diff(hz)).view(-1, 1))
+        n_lin = torch.linspace(0, self.kernel_size, steps=self.kernel_size)
+        self.window_ = 0.54 - 0.46 * torch.cos(2 * math.pi * n_lin / self.kernel_size)
+        n = (self.kernel_size - 1) / 2
+        self.n_ = torch.arange(-n, n + 1).view(1, -1) / self.sample_rate
+
+    def _sinc(self, v):
+        left = v[:, 0:int((v.shape[1] - 1) / 2)]
+        yl = torch.sin(left) / left
+        return torch.cat([yl, torch.ones([v.shape[0], 1], device=v.device), torch.flip(yl, dims=[1])], dim=1)
+
+    def filters(self):
+        dev = self.low_hz_.device
+        self.n_ = self.n_.to(dev)
+        self.window_ = self.window_.to(dev)
+        low = self.min_low_hz / self.sample_rate + torch.abs(self.low_hz_)
+        high = low + self.min_band_hz / self.sample_rate + torch.abs(self.band_hz_)
+        lp1 = 2 * low * self._sinc(2 * math.pi * torch.matmul(low, self.n_) * self.sample_rate)
+        lp2 = 2 * high * self._sinc(2 * math.pi * torch.matmul(high, self.n_) * self.sample_rate)
+        bp = lp2 - lp1
+        mx, _ = torch.max(bp, dim=1, keepdim=True)
+        bp = bp / mx
+        return (bp * self.window_).view(self.out_channels, 1, self.kernel_size)
+
+
+class _ConvStack(nn.Module):
+    """Shared body of CNN (:1464-1556) and SincNet (:1559-1665)."""
+
+    PRE = None
+
+    def __init__(self, options, inp_dim):
+        super().__init__()
+        p = self.PRE
+        self.input_dim = inp_dim
+        self._n_filt = _ints(_opt(options, p + "_N_filt"))
+        self._len_filt = _ints(_opt(options, p + "_len_filt"))
+        self._pool = _ints(_opt(options, p + "_max_pool_len"))
+        self._act = str(_opt(options, p + "_act")).split(",")
+        self._drop = _floats(_opt(options, p + "_drop"))
+        self._use_ln = _bools(_opt(options, p + "_use_laynorm"))
+        self._use_bn = _bools(_opt(options, p + "_use_batchnorm"))
+        self._use_ln_inp = strtobool(_opt(options, p + "_use_laynorm_inp"))
+        self._use_bn_inp = strtobool(_opt(options, p + "_use_batchnorm_inp"))
+        self._n_lay = len(self._n_filt)
+        if p == "sinc":
+            self.sinc_sample_rate = int(_opt(options, "sinc_sample_rate"))
+            self.sinc_min_low_hz = int(_opt(options, "sinc_min_low_hz"))
+            self.sinc_min_band_hz = int(_opt(options, "sinc_min_band_hz"))
+        self.conv = nn.ModuleList([])
+        self.bn = nn.ModuleList([])
+        self.ln = nn.ModuleList([])
+        self.act = nn.ModuleList([])
+        self.drop = nn.ModuleList([])
+        if self._use_ln_inp:
+            self.ln0 = LayerNorm(self.input_dim)
+        if self._use_bn_inp:
+            self.bn0 = nn.BatchNorm1d([self.input_dim], momentum=0.05)
+        cur = self.input_dim
+        for i in range(self._n_lay):
+            n_filt, len_filt = self._n_filt[i], self._len_filt[i]
+            self.drop.append(nn.Dropout(p=self._drop[i]))
+            self.act.append(act_fun(self._act[i]))
+            pooled = int((cur - len_filt + 1) / self._pool[i])
+            self.ln.append(LayerNorm([n_filt, pooled]))
+            # the reference passes the pooled length positionally, i.e. as eps (:1515-1517 / :1615-1617)
+            self.bn.append(nn.BatchNorm1d(n_filt, pooled, momentum=0.05))
+            if i == 0:
+                if p == "sinc":
+                    self.conv.append(SincConv(1, n_filt, len_filt, sample_rate=self.sinc_sample_rate,
+                                              min_low_hz=self.sinc_min_low_hz, min_band_hz=self.sinc_min_band_hz))
+                else:
+                    self.conv.append(nn.Conv1d(1, n_filt, len_filt))
+            else:
+                self.conv.append(nn.Conv1d(self._n_filt[i - 1], n_filt, len_filt))
+            cur = pooled
+        self.out_dim = cur * self._n_filt[-1]
+
+    def _conv_pool(self, i, x):
+        c = self.conv[i]
+        if isinstance(c, SincConv):
+            return F_.conv1d_pool(x, c.filters(), None, self._pool[i])
+        return F_.conv1d_pool(x, c.weight, c.bias, self._pool[i])
+
+    def _post(self, i, z, use_bn):
+        B, C, L = z.shape
+        mask = None
+        if self.training and self._drop[i] > 0.0:
+            mask = torch.empty_like(z).bernoulli_(1.0 - self._drop[i]).div_(1.0 - self._drop[i])
+        act = self._act[i]
+        if act == "softmax":
+            raise PkError("softmax activation inside a conv stack is not supported")
+        if use_bn:
+            # BatchNorm1d over (B, L) per channel: put channels last for the column kernels
+            zt = z.permute(0, 2, 1).reshape(B * L, C)
+            mt = None if mask is None else mask.permute(0, 2, 1).reshape(B * L, C)
+            y = F_.norm_act_drop(zt, self.bn[i], True, self.training, act, mt)
+            return y.view(B, L, C).permute(0, 2, 1).contiguous()
+        m2 = None if mask is None else mask.reshape(B * C, L)
+        return F_.norm_act_drop(z.reshape(B * C, L), None, False, self.training, act, m2).view(B, C, L)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise PkError("pytorch-kaldi_amd.nn conv stacks run on the GPU only: set use_cuda=True")
+        batch, seq_len = x.shape[0], x.shape[1]
+        if self._use_ln_inp:
+            x = self.ln0(x)
+        if self._use_bn_inp:
+            x = F_.norm_act_drop(x, self.bn0, True, self.training, "linear")
+        x = x.reshape(batch, 1, seq_len)
+        for i in range(self._n_lay):
+            x_in = x
+            if self._use_ln[i]:
+                x = self._post(i, self.ln[i](self._conv_pool(i, x_in)), False)
+            if self._use_bn[i]:
+                x = self._post(i, self._conv_pool(i, x), True)
+            if not self._use_bn[i] and not self._use_ln[i]:
+                x = self._post(i, self._conv_pool(i, x_in), False)
+        return x.reshape(batch, -1)
+
+
+class CNN(_ConvStack):
+    """neural_networks.py:1464-1556."""
+    PRE = "cnn"
+
+
+class SincNet(_ConvStack):
+    """neural_networks.py:1559-1665."""
+    PRE = "sinc"

@@ -1,0 +1,280 @@
+#!/usr/bin/env python
+"""Training-throughput bench of the hot path (frames/sec), BASELINE.json contract.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch: forward_model
+(Li-GRU 5x550 bidirectional + the 1938- and 48-way heads, the [model] section of
+cfg/TIMIT_baselines/TIMIT_liGRU_fmllr.cfg), loss_final.backward(), gradient
+all-reduce (N > 1) and the optimizer step - what run_nn times as
+elapsed_time_chunk (core.py:567-701).  Inputs are resident in HBM before the
+timed region.  N > 1: one process per GPU under torch.distributed.run, the batch
+axis is sharded (weak scaling: B per GPU fixed), gradients all-reduced over RCCL.
+
+Prints ONE JSON line on rank 0 (metric, roofline of the dominant kernel measured
+live with HIP events, CPU baseline = the oracle timed on this host's cores).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+HBM_PEAK = 8000.0                      # GB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--recipe", default="timit_ligru")
+    ap.add_argument("--T", type=int, default=500)
+    ap.add_argument("--B", type=int, default=128, help="sequences per GPU (weak scaling)")
+    ap.add_argument("--prec", default=os.environ.get("PK_PRECISION", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "persistent"])
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--torch-optim", action="store_true", help="torch.optim instead of the fused flat optimizers")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    return ap.parse_args()
+
+
+class Trainer:
+    """The run_nn inner loop (core.py:616-642) on the engine."""
+
+    def __init__(self, args, rank, world):
+        self.U = importlib.import_module("pytorch-kaldi_amd.utils")
+        self.R = importlib.import_module("pytorch-kaldi_amd.recipes")
+        self.DP = importlib.import_module("pytorch-kaldi_amd.dp")
+        self.OPT = importlib.import_module("pytorch-kaldi_amd.optim")
+        F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+        F_.set_precision(args.prec)
+        F_.set_rec_algo(args.algo)
+        self.args, self.rank, self.world = args, rank, world
+        self.rcp = rcp = self.R.recipe(args.recipe, n_lay=args.layers)
+        self.inp_out_dict = {"fea": rcp["fea_dict"]["fea"][5:]}
+        torch.manual_seed(2234)
+        self.nns, self.costs = self.U.model_init(self.inp_out_dict, rcp["model"], rcp["cfg"], rcp["arch_dict"], True,
+                                                 False, "train")
+        if args.torch_optim:
+            self.opts = self.U.optimizer_init(self.nns, rcp["cfg"], rcp["arch_dict"])
+            flats = None
+        else:
+            self.opts = self.OPT.fused_optimizer_init(self.nns, rcp["cfg"], rcp["arch_dict"])
+            flats = {k: o.flat for k, o in self.opts.items()}
+        self.reducer = self.DP.GradReducer(self.nns, flats=flats)
+        # one resident synthetic batch per rank (different seeds per rank = different shards)
+        self.T, self.B = (args.T, args.B) if rcp["seq"] else (1, args.B)
+        self.batches = [self.R.synthetic_batch(rcp, self.T, self.B, 4234 + 17 * rank + i, "cuda") for i in range(2)]
+        self.n_params = sum(p.numel() for n in self.nns.values() for p in n.parameters())
+
+    def step(self, i):
+        rcp = self.rcp
+        inp = self.batches[i % len(self.batches)]
+        outs = self.U.forward_model(rcp["fea_dict"], rcp["lab_dict"], rcp["arch_dict"], rcp["model"], self.nns,
+                                    self.costs, inp, self.inp_out_dict, self.T, self.B, "train", [])
+        for o in self.opts.values():
+            o.zero_grad()
+        outs["loss_final"].backward()
+        self.reducer.finish()
+        for o in self.opts.values():
+            o.step()
+        return outs["loss_final"].detach()
+
+
+def algorithmic_flops(rcp, T, B):
+    """fwd+bwd FLOPs per step from the layer shapes: fwd + dX + dW for every
+    GEMM, no dX for the first layer's input projection."""
+    cfg = rcp["cfg"]
+    a1 = cfg["architecture1"]
+    frames = T * B
+    total = 0.0
+    rec_flops = 0.0
+    if rcp["seq"]:
+        pre = {"liGRU": "ligru", "LSTM": "lstm", "GRU": "gru"}[a1["arch_class"]]
+        G = {"liGRU": 2, "LSTM": 4, "GRU": 3}[a1["arch_class"]]
+        lay = [int(v) for v in a1[pre + "_lay"].split(",")]
+        din = rcp["nfea"]
+        for i, H in enumerate(lay):
+            proj = 2.0 * frames * din * G * H            # x2 directions share weights: rows are not duplicated
+            rec = 2.0 * (2 * frames) * H * G * H         # both directions
+            total += proj * (2 if i == 0 else 3) + rec * 3
+            rec_flops += rec * 3
+            din = 2 * H
+        feat = din
+    else:
+        lay = [int(v) for v in a1["dnn_lay"].split(",")]
+        din = rcp["nfea"]
+        for i, H in enumerate(lay):
+            total += 2.0 * frames * din * H * (2 if i == 0 else 3)
+            din = H
+        feat = din
+    heads = rcp["n_cd"] + rcp["n_mono"]
+    total += 2.0 * frames * feat * heads * 3
+    return total, rec_flops
+
+
+def profile_entry_points(tr, steps=2):
+    """HIP-event timing of every C-ABI call of a few steps (events recorded on the stream the
+    kernels are launched on = torch's current stream)."""
+    _lib = importlib.import_module("pytorch-kaldi_amd._lib")
+    prof = _lib.Profiler()
+    with prof:
+        for i in range(steps):
+            tr.step(i)
+        torch.cuda.synchronize()
+    return prof.summary(steps)
+
+
+def cpu_baseline(args, rcp_name):
+    """The CPU oracle (a torch-CPU port of the reference path; kind = "port") timed on this host's
+    cores on a bounded sample of the same workload: same network, shorter/narrower batch."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pk_oracle as O
+
+    R = importlib.import_module("pytorch-kaldi_amd.recipes")
+    rcp = R.recipe(rcp_name, n_lay=args.layers)
+    cfg = rcp["cfg"]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    a1 = cfg["architecture1"]
+    kind = a1["arch_class"]
+    nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
+    torch.manual_seed(2234)
+    nets = {"architecture1": getattr(nn_amd, kind)(dict(a1, use_cuda="False", to_do="train"), rcp["nfea"])}
+    nets["architecture2"] = nn_amd.MLP(dict(cfg["architecture2"]), nets["architecture1"].out_dim)
+    if rcp["n_mono"]:
+        nets["architecture3"] = nn_amd.MLP(dict(cfg["architecture3"]), nets["architecture1"].out_dim)
+    sds = {k: {n: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in n)
+               for n, v in net.state_dict().items()} for k, net in nets.items()}
+    leaves = [v for sd in sds.values() for v in sd.values() if v.requires_grad]
+    opt = torch.optim.RMSprop(leaves, lr=4e-4, alpha=0.95, eps=1e-8)
+    T, B = (50, 8) if rcp["seq"] else (1, 128)
+
+    def one_step(seed):
+        inp = R.synthetic_batch(rcp, T, B, seed)
+        x = inp[..., :rcp["nfea"]]
+        lab_cd = inp[..., rcp["nfea"]].reshape(-1).long()
+        if rcp["seq"]:
+            h = O.recurrent_forward(kind, dict(a1), sds["architecture1"], x)
+            h = h.reshape(T * B, -1)
+        else:
+            h = O.mlp_forward(dict(a1), sds["architecture1"], x)
+        loss = torch.nn.functional.nll_loss(O.mlp_forward(dict(cfg["architecture2"]), sds["architecture2"], h), lab_cd)
+        if rcp["n_mono"]:
+            lab_m = inp[..., rcp["nfea"] + 1].reshape(-1).long()
+            loss = loss + torch.nn.functional.nll_loss(
+                O.mlp_forward(dict(cfg["architecture3"]), sds["architecture3"], h), lab_m)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    one_step(1)  # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        one_step(2 + n)
+        n += 1
+        if time.time() - t0 > args.cpu_budget_s or n >= 50:
+            break
+    dt = time.time() - t0
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(n * T * B / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of the same network (fwd+bwd+RMSprop) at T=%d, B=%d on %s, torch-CPU oracle fp32" %
+                      (n, T, B, model or "host CPU")}
+
+
+def main():
+    args = parse()
+    DP = importlib.import_module("pytorch-kaldi_amd.dp")
+    rank, world, _ = DP.init_from_env()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    tr = Trainer(args, rank, world)
+    import torch.distributed as dist
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        tr.step(i)
+    barrier()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(args.steps):
+        loss = tr.step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    _lib = importlib.import_module("pytorch-kaldi_amd._lib")
+    _lib.raise_if_persist_failed()
+    frames = args.steps * tr.T * tr.B * world
+    ms_per_step = 1e3 * dt / args.steps
+    out = {
+        "metric": "train_frames_per_sec", "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+        "config": {"workload": "%s: %s, T=%d, B=%d per GPU, 40-dim fMLLR, %d+%d senone/phone heads, fwd+bwd+optimizer"
+                               % (args.recipe, tr.rcp["cfg"]["architecture1"]["arch_class"], tr.T, tr.B,
+                                  tr.rcp["n_cd"], tr.rcp["n_mono"]),
+                   "global_batch": tr.B * world, "seq_len": tr.T, "parallelism": "dp%d" % world,
+                   "rec_algo": args.algo, "optimizer": "torch" if args.torch_optim else "fused-flat",
+                   "params": tr.n_params},
+        "loss_final": round(float(loss), 5),
+    }
+    if rank == 0:
+        # roofline of the dominant kernel class, measured live with HIP events
+        summ = profile_entry_points(tr)
+        total_flops, rec_flops = algorithmic_flops(tr.rcp, tr.T, tr.B)
+        dom = max(summ, key=lambda k: summ[k]["ms_per_step"]) if summ else None
+        roof = {"bound": "mfma", "achieved": None, "peak": PEAK[args.prec], "unit": "TFLOP/s", "frac": None,
+                "traffic": None}
+        if dom is not None:
+            d = summ[dom]
+            if dom in ("pk_rec_fwd", "pk_rec_bwd"):
+                # the recurrent launches: fwd = 1/3, bwd (carry GEMM + deferred dU) = 2/3 of rec_flops
+                share = (1.0 if dom == "pk_rec_fwd" else 2.0) / 3.0
+                fl = rec_flops * share / d["calls_per_step"]
+            elif dom == "pk_gemm":
+                fl = (total_flops - rec_flops) / d["calls_per_step"]
+            else:
+                fl = 0.0
+            ach = fl / (d["avg_ms"] * 1e-3) / 1e12 if d["avg_ms"] > 0 else 0.0
+            roof.update({"kernel": dom, "achieved": round(ach, 3), "frac": round(ach / PEAK[args.prec], 5),
+                         "avg_launch_ms": round(d["avg_ms"], 4), "launches_per_step": d["calls_per_step"],
+                         "flops_per_launch": fl})
+        out["roofline"] = roof
+        out["entry_points_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in
+                                           sorted(summ.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+        out["whole_step_tflops"] = round(total_flops / (ms_per_step * 1e-3) / 1e12, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.recipe)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,3 +109,71 @@ def raise_if_persist_failed():
         lib.pk_persist_error_reset()
         raise PkError("persistent recurrent kernel: %d wave(s) timed out waiting for a peer workgroup "
                       "(results of that launch are invalid)" % n)
+
+
+# ----------------------------------------------------------------------------
+# measurement: HIP-event timing of every C-ABI call (bench.py's roofline leg)
+# ----------------------------------------------------------------------------
+_profiler = None
+_raw_load = load
+
+
+class _TimedLib:
+    """Proxy that brackets each entry point that takes a stream with two events recorded on
+    torch's current stream - the stream the kernels are launched on."""
+
+    def __init__(self, lib, prof):
+        self._lib, self._prof = lib, prof
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        sig = SIGNATURES.get(name)
+        if sig is None or not sig[1] or sig[1][0] is not P or name in ("pk_selftest_mfma",):
+            return fn
+        prof = self._prof
+
+        def timed(*a):
+            import torch
+
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            prof.events.append((name, e0, e1))
+            return rc
+
+        return timed
+
+
+class Profiler:
+    def __init__(self):
+        self.events = []
+
+    def __enter__(self):
+        global _profiler
+        _profiler = self
+        return self
+
+    def __exit__(self, *exc):
+        global _profiler
+        _profiler = None
+
+    def summary(self, steps):
+        import torch
+
+        torch.cuda.synchronize()
+        acc = {}
+        for name, e0, e1 in self.events:
+            d = acc.setdefault(name, [0.0, 0])
+            d[0] += e0.elapsed_time(e1)
+            d[1] += 1
+        return {k: {"ms_per_step": v[0] / steps, "calls_per_step": v[1] / steps, "avg_ms": v[0] / max(1, v[1])}
+                for k, v in acc.items()}
+
+
+def load():  # noqa: F811 - same name on purpose: every caller goes through the switch
+    lib = _raw_load()
+    if _profiler is not None:
+        return _TimedLib(lib, _profiler)
+    return lib

@@ -1,0 +1,143 @@
+"""Data parallelism for the chunk loop: one process per GPU, gradients all-reduced
+over RCCL/xGMI.
+
+The reference's only multi-GPU mechanism is ``torch.nn.DataParallel``
+(core.py:103-104, 537-538), which scatters dim 0 - the TIME axis of (T, B, F)
+sequence batches.  Here the batch (utterance) axis is sharded instead: rank r
+takes columns [r*B/N, (r+1)*B/N) of every (T, B, F) batch (rows for 2-D batches),
+BatchNorm statistics stay per replica (what DataParallel does too), and the only
+exchange is one gradient all-reduce per step, issued bucket by bucket while
+backward is still running so that it overlaps with the remaining BPTT kernels.
+
+``GradReducer`` works on plain modules (per-parameter grads are packed into a
+bucket) or on ``optim.FlatParams`` (buckets are slices of the flat gradient
+buffer: zero copies).  Backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU
+for the tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Rendezvous from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def shard_batch(inp, rank, world):
+    """Rank's share of one batch: columns of (T, B, F), rows of (N, F).  B must divide evenly
+    (the chunk planner pads the last batch like the reference drops it, core.py:552-556)."""
+    if world == 1:
+        return inp
+    dim = 1 if inp.dim() == 3 else 0
+    n = inp.shape[dim]
+    if n % world != 0:
+        raise ValueError("batch of %d does not shard over %d ranks" % (n, world))
+    per = n // world
+    return inp.narrow(dim, rank * per, per)
+
+
+class GradReducer:
+    """Average gradients across ranks, overlapping the all-reduce with backward.
+
+    Buckets are filled in REVERSE parameter order (the order backward produces
+    gradients).  A bucket is launched from the post-accumulate-grad hook of its
+    last parameter; ``finish()`` waits for all of them (and launches whatever did
+    not fire, e.g. parameters that received no gradient this step).
+    """
+
+    def __init__(self, modules, bucket_bytes=32 << 20, flats=None, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.flats = flats  # dict name -> FlatParams or None
+        self.buckets = []   # each: dict(params=[...], flat=tensor or None, pending=int)
+        self.handles = []
+        self._hooks = []
+        if self.world == 1:
+            return
+        for name, mod in modules.items():
+            flat = flats[name] if flats else None
+            params = [p for p in mod.parameters() if p.requires_grad]
+            if flat is not None:
+                order = sorted(zip(flat.offsets, flat.params), key=lambda t: -t[0])
+                cur, cur_hi = [], None
+                for off, p in order:
+                    if cur_hi is None:
+                        cur_hi = off + p.numel()
+                    cur.append(p)
+                    if (cur_hi - off) * 4 >= bucket_bytes:
+                        self._add_bucket(cur, flat.grad[off:cur_hi])
+                        cur, cur_hi = [], None
+                if cur:
+                    self._add_bucket(cur, flat.grad[0:cur_hi])
+            else:
+                cur, size = [], 0
+                for p in reversed(params):
+                    cur.append(p)
+                    size += p.numel() * 4
+                    if size >= bucket_bytes:
+                        self._add_bucket(cur, None)
+                        cur, size = [], 0
+                if cur:
+                    self._add_bucket(cur, None)
+
+    def _add_bucket(self, params, flat_slice):
+        b = {"params": list(params), "flat": flat_slice, "pending": len(params), "fired": False}
+        self.buckets.append(b)
+        for p in params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, b=b: self._ready(b)))
+
+    def _ready(self, b):
+        b["pending"] -= 1
+        if b["pending"] == 0 and not b["fired"]:
+            self._launch(b)
+
+    def _launch(self, b):
+        b["fired"] = True
+        if b["flat"] is not None:
+            buf = b["flat"]
+        else:
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b["params"]]
+            buf = torch.cat([g.reshape(-1) for g in grads])
+            b["packed"] = (buf, grads)
+        buf.div_(self.world)
+        self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), b))
+
+    def finish(self):
+        """Call after backward(): completes every bucket and re-arms for the next step."""
+        if self.world == 1:
+            return
+        for b in self.buckets:
+            if not b["fired"]:
+                self._launch(b)
+        for h, b in self.handles:
+            h.wait()
+            if b["flat"] is None:
+                buf, grads = b.pop("packed")
+                o = 0
+                for p, g in zip(b["params"], grads):
+                    n = g.numel()
+                    if p.grad is None:
+                        p.grad = buf[o:o + n].view_as(p).clone()
+                    else:
+                        p.grad.copy_(buf[o:o + n].view_as(p))
+                    o += n
+        self.handles = []
+        for b in self.buckets:
+            b["pending"] = len(b["params"])
+            b["fired"] = False

@@ -1,0 +1,104 @@
+"""In-memory versions of the reference recipes BASELINE.json names (section values are the
+strings of the shipped cfg files), plus the synthetic chunk generator of SURVEY.md 8(d).
+Used by bench.py, smoke() and the tests; real runs keep reading the .cfg files through the
+reference's own run_exp.py."""
+import configparser
+
+import torch
+
+_RMS = {"arch_lr": "0.0004", "arch_halving_factor": "0.5", "arch_improvement_threshold": "0.001",
+        "arch_opt": "rmsprop", "opt_momentum": "0.0", "opt_alpha": "0.95", "opt_eps": "1e-8",
+        "opt_centered": "False", "opt_weight_decay": "0.0", "arch_freeze": "False",
+        "arch_library": "pytorch-kaldi_amd.nn", "arch_pretrain_file": "none"}
+
+
+def _rep(v, n):
+    return ",".join([str(v)] * n)
+
+
+def _head(n_out):
+    d = {"arch_class": "MLP", "arch_seq_model": "False", "dnn_lay": str(n_out), "dnn_drop": "0.0",
+         "dnn_use_laynorm_inp": "False", "dnn_use_batchnorm_inp": "False", "dnn_use_batchnorm": "False",
+         "dnn_use_laynorm": "False", "dnn_act": "softmax"}
+    d.update(_RMS)
+    return d
+
+
+def _rec(kind, pre, n_lay, H, act, lr):
+    d = {"arch_class": kind, "arch_seq_model": "True", pre + "_lay": _rep(H, n_lay), pre + "_drop": _rep(0.2, n_lay),
+         pre + "_use_laynorm_inp": "False", pre + "_use_batchnorm_inp": "False",
+         pre + "_use_laynorm": _rep(False, n_lay), pre + "_use_batchnorm": _rep(True, n_lay), pre + "_bidir": "True",
+         pre + "_act": _rep(act, n_lay), pre + "_orthinit": "True"}
+    d.update(_RMS)
+    d["arch_lr"] = str(lr)
+    return d
+
+
+TWO_HEAD_MODEL = ["out_dnn1=compute(%s,fea)", "out_dnn2=compute(MLP_layers,out_dnn1)",
+                  "out_dnn3=compute(MLP_layers2,out_dnn1)", "loss_mono=cost_nll(out_dnn3,lab_mono)",
+                  "loss_mono_w=mult_constant(loss_mono,1.0)", "loss_cd=cost_nll(out_dnn2,lab_cd)",
+                  "loss_final=sum(loss_cd,loss_mono_w)", "err_final=cost_err(out_dnn2,lab_cd)"]
+ONE_HEAD_MODEL = ["out_dnn1=compute(%s,fea)", "out_dnn2=compute(MLP_layers,out_dnn1)",
+                  "loss_final=cost_nll(out_dnn2,lab_cd)", "err_final=cost_err(out_dnn2,lab_cd)"]
+
+
+def recipe(name, n_lay=None, H=550):
+    """Returns dict(cfg, model, fea_dict, lab_dict, arch_dict, nfea, n_cd, n_mono, seq).
+
+    timit_ligru  cfg/TIMIT_baselines/TIMIT_liGRU_fmllr.cfg:131-217   (BASELINE configs[1])
+    timit_lstm   cfg/TIMIT_baselines/TIMIT_LSTM_fmllr.cfg:131-217    (configs[2])
+    libri_gru    cfg/Librispeech_baselines/libri_GRU_fmllr.cfg:76-146 (configs[3])
+    timit_mlp    cfg/TIMIT_baselines/TIMIT_MLP_fmllr.cfg:131-214     (configs[0])
+    """
+    cfg = configparser.ConfigParser()
+    cfg["exp"] = {"to_do": "train", "use_cuda": "True"}
+    nfea, n_cd, n_mono, seq = 40, 1938, 48, True
+    if name == "timit_ligru":
+        first = "liGRU_layers"
+        cfg["architecture1"] = _rec("liGRU", "ligru", n_lay or 5, H, "relu", 0.0004)
+        model = TWO_HEAD_MODEL
+    elif name == "timit_lstm":
+        first = "LSTM_layers"
+        cfg["architecture1"] = _rec("LSTM", "lstm", n_lay or 4, H, "tanh", 0.0016)
+        model = TWO_HEAD_MODEL
+    elif name == "libri_gru":
+        first = "GRU_layers"
+        cfg["architecture1"] = _rec("GRU", "gru", n_lay or 5, H, "tanh", 0.0004)
+        model, n_cd, n_mono = ONE_HEAD_MODEL, 3400, 0
+    elif name == "timit_mlp":
+        first, nfea, seq = "MLP_layers1", 440, False
+        n = n_lay or 5
+        d = {"arch_class": "MLP", "arch_seq_model": "False", "dnn_lay": _rep(1024, n), "dnn_drop": _rep(0.15, n),
+             "dnn_use_laynorm_inp": "False", "dnn_use_batchnorm_inp": "False", "dnn_use_batchnorm": _rep(True, n),
+             "dnn_use_laynorm": _rep(False, n), "dnn_act": _rep("relu", n)}
+        d.update(_RMS)
+        d.update({"arch_lr": "0.08", "arch_opt": "sgd", "opt_momentum": "0.0", "opt_weight_decay": "0.0",
+                  "opt_dampening": "0.0", "opt_nesterov": "False"})
+        cfg["architecture1"] = d
+        model = TWO_HEAD_MODEL
+    else:
+        raise ValueError("unknown recipe " + name)
+    cfg["architecture2"] = _head(n_cd)
+    arch_dict = {first: ["architecture1", first, seq], "MLP_layers": ["architecture2", "MLP_layers", False]}
+    lab_dict = {"lab_cd": ["lab_cd", "f", "o", nfea]}
+    if n_mono:
+        cfg["architecture3"] = _head(n_mono)
+        arch_dict["MLP_layers2"] = ["architecture3", "MLP_layers2", False]
+        lab_dict["lab_mono"] = ["lab_mono", "f", "o", nfea + 1]
+    model = [m % first if "%s" in m else m for m in model]
+    fea_dict = {"fea": ["fea", "lst", "opts", "0", "0", 0, nfea, nfea]}
+    return {"cfg": cfg, "model": model, "fea_dict": fea_dict, "lab_dict": lab_dict, "arch_dict": arch_dict,
+            "nfea": nfea, "n_cd": n_cd, "n_mono": n_mono, "seq": seq, "first": first}
+
+
+def synthetic_batch(rcp, T, B, seed, device="cpu"):
+    """One (T, B, nfea + n_lab) batch [(N, .) for non-sequence recipes]: N(0,1) features (chunks are
+    mean/var normalised, data_io.py:263) and uniform integer labels stored as float columns."""
+    g = torch.Generator().manual_seed(seed)
+    nlab = 2 if rcp["n_mono"] else 1
+    shape = (T, B, rcp["nfea"] + nlab) if rcp["seq"] else (B, rcp["nfea"] + nlab)
+    inp = torch.randn(*shape, generator=g)
+    inp[..., rcp["nfea"]] = torch.randint(0, rcp["n_cd"], shape[:-1], generator=g).float()
+    if rcp["n_mono"]:
+        inp[..., rcp["nfea"] + 1] = torch.randint(0, rcp["n_mono"], shape[:-1], generator=g).float()
+    return inp.to(device)

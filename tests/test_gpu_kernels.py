@@ -1,0 +1,213 @@
+"""Kernel-level numerics of libpk_amd.so on the GPU, each against a plain fp64/fp32
+torch-CPU evaluation of the same op (a torch reference is appropriate here: these
+are floating-point kernels; the model-level parity lives in test_gpu_parity.py)."""
+import ctypes
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+_lib = importlib.import_module("pytorch-kaldi_amd._lib")
+
+
+def test_mfma_fragment_layouts():
+    lib = _lib.load()
+    bad = ctypes.c_int(-1)
+    rc = lib.pk_selftest_mfma(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(bad))
+    _lib.check(rc, "pk_selftest_mfma")
+    assert bad.value == 0
+
+
+def test_single_hip_runtime():
+    """libpk_amd.so must bind to the HIP runtime torch already mapped (one runtime per
+    process): exactly one libamdhip64 in /proc/self/maps."""
+    _lib.load()
+    torch.zeros(1).cuda()
+    libs = set()
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            libs.add(line.split()[-1])
+    assert len(libs) == 1, libs
+
+
+GEMM_SHAPES = [
+    # M, N, K, a_kc, b_kc, splitk
+    (1, 1, 1, True, True, 1),
+    (37, 53, 29, True, True, 1),
+    (128, 128, 64, True, False, 1),
+    (300, 130, 550, False, True, 1),
+    (257, 1100, 40, True, True, 1),
+    (130, 70, 5000, False, False, 8),
+    (1100, 40, 6000, False, False, 16),
+    (512, 1938, 1100, True, True, 1),
+]
+
+
+@pytest.mark.parametrize("M,N,K,a_kc,b_kc,splitk", GEMM_SHAPES)
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_gemm(M, N, K, a_kc, b_kc, splitk, prec):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    Ad = (A if a_kc else A.t().contiguous()).cuda()   # storage [M,K] or [K,M]
+    Bd = (B.t().contiguous() if b_kc else B).cuda()   # storage [N,K] or [K,N]
+    a_rs, a_cs = (K, 1) if a_kc else (1, M)
+    b_rs, b_cs = (1, K) if b_kc else (N, 1)
+    C = C0.clone().cuda()
+    F_.gemm(M, N, K, Ad, a_rs, a_cs, Bd, b_rs, b_cs, C, N, alpha=0.5, beta=2.0, bias=bias.cuda(), splitk=splitk, prec=prec)
+    torch.cuda.synchronize()
+    ref = 0.5 * (A.double() @ B.double()) + 2.0 * C0.double() + bias.double()
+    tol = 2e-6 if prec == "fp32" else 1e-2
+    assert rel_err(C, ref) < tol
+
+
+def test_gemm_strided_rows_and_unaligned():
+    """forward_model hands column slices (row stride = feat + labels, utils.py:2321)."""
+    g = torch.Generator().manual_seed(1)
+    wide = torch.randn(100, 43, generator=g).cuda()
+    A = wide[:, 1:41]  # unaligned base, ld 43
+    W = torch.randn(64, 40, generator=g).cuda()
+    C = torch.empty(100, 64).cuda()
+    F_.gemm(100, 64, 40, A, 43, 1, W, 1, 40, C, 64, prec="fp32")
+    assert rel_err(C, A.cpu().double() @ W.cpu().double().t()) < 2e-6
+
+
+def test_linear_autograd():
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(50, 33, generator=g)
+    w = torch.randn(21, 33, generator=g)
+    b = torch.randn(21, generator=g)
+    cot = torch.randn(50, 21, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    (TF.linear(xr, wr, br) * cot.double()).sum().backward()
+    xe, we, be = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+    (F_.linear(xe, we, be) * cot.cuda()).sum().backward()
+    for a, r in ((xe, xr), (we, wr), (be, br)):
+        assert rel_err(a.grad, r.grad) < 2e-6
+
+
+@pytest.mark.parametrize("M,N", [(7, 5), (1000, 70), (128000 // 8, 1100)])
+def test_batchnorm_act_drop(M, N):
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, N, generator=g) * 2 + 0.5
+    bn = torch.nn.BatchNorm1d(N, momentum=0.05)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(N, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(N, generator=g))
+    mask = torch.bernoulli(torch.full((M, N), 0.85), generator=g) / 0.85
+    cot = torch.randn(M, N, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.relu(bn(xr)) * mask
+    (yr * cot).sum().backward()
+    bn2 = torch.nn.BatchNorm1d(N, momentum=0.05)
+    bn2.load_state_dict({k: v for k, v in bn.state_dict().items()})
+    with torch.no_grad():
+        bn2.running_mean.zero_(); bn2.running_var.fill_(1.0); bn2.num_batches_tracked.zero_()
+    bn2.cuda()
+    xe = x.clone().cuda().requires_grad_(True)
+    ye = F_.norm_act_drop(xe, bn2, True, True, "relu", mask.cuda())
+    (ye * cot.cuda()).sum().backward()
+    assert rel_err(ye, yr) < 1e-5
+    assert rel_err(xe.grad, xr.grad) < 1e-4
+    assert rel_err(bn2.weight.grad, bn.weight.grad) < 1e-4
+    assert rel_err(bn2.bias.grad, bn.bias.grad) < 1e-4
+    assert rel_err(bn2.running_mean, bn.running_mean) < 1e-5
+    assert rel_err(bn2.running_var, bn.running_var) < 1e-5
+
+
+@pytest.mark.parametrize("rows,F", [(3, 7), (64, 550), (16, 3200)])
+def test_layernorm(rows, F):
+    import pk_oracle as O
+
+    g = torch.Generator().manual_seed(rows + F)
+    x = torch.randn(rows, F, generator=g)
+    gamma = torch.rand(F, generator=g) + 0.5
+    beta = torch.randn(F, generator=g)
+    cot = torch.randn(rows, F, generator=g)
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    (O.layer_norm(xr, gr, br) * cot.double()).sum().backward()
+    xe, ge, be = (t.clone().cuda().requires_grad_(True) for t in (x, gamma, beta))
+    y = F_.layer_norm(xe, ge, be, 1e-6)
+    (y * cot.cuda()).sum().backward()
+    assert rel_err(y, O.layer_norm(x.double(), gamma.double(), beta.double())) < 1e-5
+    for a, r in ((xe, xr), (ge, gr), (be, br)):
+        assert rel_err(a.grad, r.grad) < 1e-5
+
+
+@pytest.mark.parametrize("rows,N", [(1, 1), (5, 48), (300, 1938)])
+def test_logsoftmax(rows, N):
+    g = torch.Generator().manual_seed(rows + N)
+    x = torch.randn(rows, N, generator=g) * 4
+    cot = torch.randn(rows, N, generator=g)
+    xr = x.double().requires_grad_(True)
+    (TF.log_softmax(xr, 1) * cot.double()).sum().backward()
+    xe = x.clone().cuda().requires_grad_(True)
+    y = F_.log_softmax(xe)
+    (y * cot.cuda()).sum().backward()
+    assert rel_err(y, TF.log_softmax(x.double(), 1)) < 1e-6
+    assert rel_err(xe.grad, xr.grad) < 1e-5
+
+
+CONV_SHAPES = [
+    # B, Cin, L, Cout, K, pool
+    (2, 1, 200, 8, 33, 3),
+    (3, 8, 56, 6, 5, 2),
+    (2, 6, 26, 5, 3, 2),
+    (4, 1, 3200, 128, 129, 3),
+    (4, 60, 340, 60, 5, 3),
+    (2, 3, 50, 17, 7, 1),
+]
+
+
+@pytest.mark.parametrize("B,Cin,L,Cout,K,pool", CONV_SHAPES)
+def test_conv_pool(B, Cin, L, Cout, K, pool):
+    g = torch.Generator().manual_seed(B + Cin + L)
+    x = torch.randn(B, Cin, L, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / (Cin * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    Lp = (L - K + 1) // pool
+    cot = torch.randn(B, Cout, Lp, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = TF.max_pool1d(TF.conv1d(xr, wr, br), pool)
+    (yr * cot.double()).sum().backward()
+    xe, we, be = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+    ye = F_.conv1d_pool(xe, we, be, pool)
+    (ye * cot.cuda()).sum().backward()
+    assert rel_err(ye, yr) < 1e-5
+    assert rel_err(xe.grad, xr.grad) < 1e-5
+    assert rel_err(we.grad, wr.grad) < 1e-5
+    assert rel_err(be.grad, br.grad) < 1e-5
+
+
+def test_optimizers_match_torch():
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(4)
+    p0 = torch.randn(10007, generator=g)
+    grads = [torch.randn(10007, generator=g) for _ in range(3)]
+    # RMSprop as utils.optimizer_init builds it (lr 4e-4, alpha .95, eps 1e-8)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.RMSprop([pr], lr=4e-4, alpha=0.95, eps=1e-8)
+    pe, sq = p0.clone().cuda(), torch.zeros(10007).cuda()
+    for gr in grads:
+        pr.grad = gr.clone()
+        opt.step()
+        ge = gr.cuda()
+        _lib.check(lib.pk_rmsprop_step(st, pe.data_ptr(), ge.data_ptr(), sq.data_ptr(), 10007, 4e-4, 0.95, 1e-8, 0.0), "rms")
+    assert rel_err(pe, pr) < 1e-6
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.08, momentum=0.9, weight_decay=1e-4)
+    pe, buf = p0.clone().cuda(), torch.zeros(10007).cuda()
+    for i, gr in enumerate(grads):
+        pr.grad = gr.clone()
+        opt.step()
+        ge = gr.cuda()
+        _lib.check(lib.pk_sgd_step(st, pe.data_ptr(), ge.data_ptr(), buf.data_ptr(), 10007, 0.08, 0.9, 1e-4, int(i == 0)), "sgd")
+    assert rel_err(pe, pr) < 1e-6

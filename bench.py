@@ -135,6 +135,26 @@ def profile_entry_points(tr, steps=2):
     return prof.summary(steps)
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def log(msg):
+    if os.environ.get("PK_BENCH_VERBOSE"):
+        print("[bench %.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.time()
+
+
 def cpu_baseline(args, rcp_name):
     """The CPU oracle (a torch-CPU port of the reference path; kind = "port") timed on this host's
     cores on a bounded sample of the same workload: same network, shorter/narrower batch."""
@@ -144,7 +164,7 @@ def cpu_baseline(args, rcp_name):
     R = importlib.import_module("pytorch-kaldi_amd.recipes")
     rcp = R.recipe(rcp_name, n_lay=args.layers)
     cfg = rcp["cfg"]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     a1 = cfg["architecture1"]
     kind = a1["arch_class"]
@@ -214,8 +234,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    log("model built")
     for i in range(args.warmup):
         tr.step(i)
+        torch.cuda.synchronize()
+        log("warmup step %d done" % i)
     barrier()
     t0 = time.perf_counter()
     loss = None
@@ -223,6 +246,7 @@ def main():
         loss = tr.step(i)
     barrier()
     dt = time.perf_counter() - t0
+    log("timed region done: %.3f s" % dt)
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -268,6 +292,7 @@ def main():
         out["entry_points_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in
                                            sorted(summ.items(), key=lambda kv: -kv[1]["ms_per_step"])}
         out["whole_step_tflops"] = round(total_flops / (ms_per_step * 1e-3) / 1e12, 3)
+        log("roofline leg done")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.recipe)
         print(json.dumps(out), flush=True)

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void step_bwd_kernel(StepGeom g, int t, int ac
                                                         const float* __restrict__ mask, float mask_scalar,
                                                         const float* __restrict__ carry_h,  // [R,H] or null (t == T-1)
                                                         const float* __restrict__ carry_c,
+                                                        const float* __restrict__ dh_in,  // LayerNorm: dL/d(pre-LN h_t), replaces dY + carry_h
                                                         float* __restrict__ dG,      // [R, G*H] contiguous copy
                                                         float* __restrict__ dP2,     // [ndir][T*B][G*H]
                                                         float* __restrict__ next_h,  // direct part of dL/dh_{t-1}
@@ -172,10 +173,10 @@ __global__ __launch_bounds__(256) void step_bwd_kernel(StepGeom g, int t, int ac
             cp = S[((long)dir * g.T * g.B + (long)tsp * g.B + b) * (NS * g.H) + 4 * g.H + j];
         }
         const float m = mask ? mask[idx] : mask_scalar;
-        float dh = dY[prow * g.YH + dir * g.H + j];
+        float dh = dh_in ? dh_in[idx] : dY[prow * g.YH + dir * g.H + j];
         float dc = 0.f;
         if (carry_h) {
-            dh += carry_h[idx];
+            if (!dh_in) dh += carry_h[idx];
             if (CELL == PK_CELL_LSTM) dc = carry_c[idx];
         }
         float dg[G], dh_direct, dc_prev;
@@ -195,7 +196,8 @@ template <int CELL>
 __global__ __launch_bounds__(256) void step_bwd_pa_kernel(StepGeom g, int t, int act, const float* __restrict__ Y,
                                                            const float* __restrict__ S, const float* __restrict__ dY,
                                                            const float* __restrict__ mask, float mask_scalar,
-                                                           const float* __restrict__ carry_h, float* __restrict__ dA,
+                                                           const float* __restrict__ carry_h,
+                                                           const float* __restrict__ dh_in, float* __restrict__ dA,
                                                            float* __restrict__ dzp, float* __restrict__ next_h) {
     constexpr int NS = pk_cell_saved(CELL);
     const long total = (long)g.R * g.H;
@@ -210,8 +212,8 @@ __global__ __launch_bounds__(256) void step_bwd_pa_kernel(StepGeom g, int t, int
         for (int k = 0; k < NS; ++k) s[k] = S[srow * (NS * g.H) + k * g.H + j];
         const float hp = load_hprev(g, Y, t, dir, b, ts, j);
         const float m = mask ? mask[idx] : mask_scalar;
-        float dh = dY[prow * g.YH + dir * g.H + j];
-        if (carry_h) dh += carry_h[idx];
+        float dh = dh_in ? dh_in[idx] : dY[prow * g.YH + dir * g.H + j];
+        if (carry_h && !dh_in) dh += carry_h[idx];
         float dz_part, dh_direct;
         dA[idx] = pk_cell_bwd_pa<CELL>(act, s, hp, m, dh, dz_part, dh_direct);
         dzp[idx] = dz_part;
@@ -248,6 +250,93 @@ __global__ __launch_bounds__(256) void step_bwd_pb_kernel(StepGeom g, int t, con
     }
 }
 
+
+// ---- per-step LayerNorm of h_t (neural_networks.py:466-467, :638-639, :1138-1139, :1299-1300,
+// :1444-1445): the normalised value is both stored and fed to step t+1.  One block per row.
+// LNS row (t, n): [mean, 1/(std+eps), pre-LN h[0..H)].
+__device__ __forceinline__ float rec_block_sum(float v, float* sh) {
+    v = pk_wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    const int nw = blockDim.x >> 6;
+    for (int k = 0; k < nw; ++k) t += sh[k];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void step_ln_fwd_kernel(StepGeom g, int t, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           float* __restrict__ h, float* __restrict__ Y,
+                                                           float* __restrict__ LNS) {
+    __shared__ float sh[8];
+    const int n = blockIdx.x, H = g.H;
+    int dir, b, ts;
+    row_index(g, t, n, dir, b, ts);
+    float* hr = h + (long)n * H;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) s += hr[j];
+    const float mu = rec_block_sum(s, sh) / (float)H;
+    float q = 0.f;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        const float d = hr[j] - mu;
+        q += d * d;
+    }
+    const float var = rec_block_sum(q, sh) / (float)(H - 1);
+    const float rinv = 1.0f / (sqrtf(var) + eps);
+    float* l = LNS + ((long)t * g.R + n) * (H + 2);
+    float* yr = Y + ((long)ts * g.B + b) * g.YH + dir * H;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        const float x = hr[j];
+        l[2 + j] = x;
+        const float y = gamma[j] * ((x - mu) * rinv) + beta[j];
+        hr[j] = y;
+        yr[j] = y;
+    }
+    if (threadIdx.x == 0) {
+        l[0] = mu;
+        l[1] = rinv;
+    }
+}
+
+// dh (w.r.t. the normalised h_t) = dY + carry  ->  dhpre (w.r.t. the pre-LN h_t); accumulates the
+// per-(row, unit) gamma/beta gradient terms (each element is owned by one thread: deterministic).
+__global__ __launch_bounds__(256) void step_ln_bwd_kernel(StepGeom g, int t, const float* __restrict__ gamma,
+                                                           float eps, const float* __restrict__ dY,
+                                                           const float* __restrict__ carry_h,
+                                                           const float* __restrict__ LNS, float* __restrict__ dhpre,
+                                                           float* __restrict__ accg, float* __restrict__ accb) {
+    __shared__ float sh[8];
+    const int n = blockIdx.x, H = g.H;
+    int dir, b, ts;
+    row_index(g, t, n, dir, b, ts);
+    const float* l = LNS + ((long)t * g.R + n) * (H + 2);
+    const float* dyr = dY + ((long)ts * g.B + b) * g.YH + dir * H;
+    const float mu = l[0], rinv = l[1];
+    const float stdv = 1.0f / rinv - eps;
+    float sg = 0.f, sgd = 0.f;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        float dh = dyr[j];
+        if (carry_h) dh += carry_h[(long)n * H + j];
+        const float gq = dh * gamma[j];
+        sg += gq;
+        sgd += gq * (l[2 + j] - mu);
+    }
+    sg = rec_block_sum(sg, sh);
+    sgd = rec_block_sum(sgd, sh);
+    const float mg = sg / (float)H;
+    const float k2 = rinv * rinv * sgd / ((float)(H - 1) * stdv);
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        float dh = dyr[j];
+        if (carry_h) dh += carry_h[(long)n * H + j];
+        const float d = l[2 + j] - mu;
+        dhpre[(long)n * H + j] = rinv * (dh * gamma[j] - mg) - k2 * d;
+        accg[(long)n * H + j] += dh * (d * rinv);
+        accb[(long)n * H + j] += dh;
+    }
+}
+
 inline int ew_blocks(long n) {
     long b = (n + 255) / 256;
     if (b > 2048) b = 2048;
@@ -257,7 +346,9 @@ inline int ew_blocks(long n) {
 
 struct Work {
     float *h0, *h1, *c0, *c1, *urec, *gh, *ua, *dg, *ws;
+    float *ln_dh, *ln_accg, *ln_accb, *ln_part;  // per-step LayerNorm backward scratch
 };
+constexpr int DU_SPLITK = 16;
 inline Work carve(float* w, long R, long H, long G) {
     Work k;
     long o = 0;
@@ -275,9 +366,13 @@ inline Work carve(float* w, long R, long H, long G) {
     k.ua = take(R * H);
     k.dg = take(R * G * H);
     k.ws = w + o;
+    o += (long)DU_SPLITK * G * H * H + 64;
+    k.ln_dh = take(R * H);
+    k.ln_accg = take(R * H);
+    k.ln_accb = take(R * H);
+    k.ln_part = w + o;
     return k;
 }
-constexpr int DU_SPLITK = 16;
 
 #define PK_TRY(expr)          \
     do {                      \
@@ -287,8 +382,8 @@ constexpr int DU_SPLITK = 16;
 
 template <int CELL>
 int fwd_stepwise(hipStream_t st, int prec, int act, StepGeom g, const float* P, const float* pscale,
-                 const float* pshift, const float* U, const float* mask, float mask_scalar, float* Y, float* S,
-                 float* work) {
+                 const float* pshift, const float* U, const float* mask, float mask_scalar, const float* ln_gamma,
+                 const float* ln_beta, float* Y, float* S, float* LNS, float* work) {
     constexpr int G = pk_cell_gates(CELL);
     constexpr bool TWO = pk_cell_two_phase(CELL);
     Work w = carve(work, g.R, g.H, G);
@@ -317,6 +412,11 @@ int fwd_stepwise(hipStream_t st, int prec, int act, StepGeom g, const float* P, 
                                first ? (const float*)nullptr : w.ua, hcur, mask, mask_scalar, hnext, Y, S);
             PK_LAUNCH_CHECK();
         }
+        if (ln_gamma) {
+            hipLaunchKernelGGL(step_ln_fwd_kernel, dim3(g.R), dim3(256), 0, st, g, t, ln_gamma, ln_beta, 1e-6f, hnext, Y,
+                               LNS);
+            PK_LAUNCH_CHECK();
+        }
         float* tmp = hcur; hcur = hnext; hnext = tmp;
         tmp = ccur; ccur = cnext; cnext = tmp;
     }
@@ -325,25 +425,33 @@ int fwd_stepwise(hipStream_t st, int prec, int act, StepGeom g, const float* P, 
 
 template <int CELL>
 int bwd_stepwise(hipStream_t st, int prec, int act, StepGeom g, const float* U, const float* mask, float mask_scalar,
-                 const float* Y, const float* S, const float* dY, float* dP2, float* work) {
+                 const float* ln_gamma, const float* Y, const float* S, const float* LNS, const float* dY, float* dP2,
+                 float* dln_gamma, float* dln_beta, float* work) {
     constexpr int G = pk_cell_gates(CELL);
     constexpr bool TWO = pk_cell_two_phase(CELL);
     Work w = carve(work, g.R, g.H, G);
     float *ch = w.h0, *nh = w.h1, *cc = w.c0, *nc = w.c1;
     const int blocks = ew_blocks((long)g.R * g.H);
     const int H = g.H;
+    if (ln_gamma) PK_CHECK_HIP(hipMemsetAsync(w.ln_accg, 0, sizeof(float) * 2 * (((size_t)g.R * H + 63) / 64 * 64), st));
+    const float* dh_in = ln_gamma ? w.ln_dh : nullptr;
     for (int t = g.T - 1; t >= 0; --t) {
         const bool last = (t == g.T - 1);
+        if (ln_gamma) {
+            hipLaunchKernelGGL(step_ln_bwd_kernel, dim3(g.R), dim3(256), 0, st, g, t, ln_gamma, 1e-6f, dY,
+                               last ? (const float*)nullptr : ch, LNS, w.ln_dh, w.ln_accg, w.ln_accb);
+            PK_LAUNCH_CHECK();
+        }
         if constexpr (!TWO) {
             hipLaunchKernelGGL((step_bwd_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, act, Y, S, dY, mask,
-                               mask_scalar, last ? (const float*)nullptr : ch, cc, w.dg, dP2, nh, nc);
+                               mask_scalar, last ? (const float*)nullptr : ch, cc, dh_in, w.dg, dP2, nh, nc);
             PK_LAUNCH_CHECK();
             if (t > 0)  // nh[R,H] += dG[R,G*H] . U[G*H,H]
                 PK_TRY(pk_gemm(st, prec, g.R, H, G * H, 1.f, w.dg, G * H, 1, U, H, 1, 1.f, nh, H, nullptr, 1, nullptr));
         } else {
             constexpr int G1 = G - 1;
             hipLaunchKernelGGL((step_bwd_pa_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, act, Y, S, dY, mask,
-                               mask_scalar, last ? (const float*)nullptr : ch, w.gh, w.ua, nh);
+                               mask_scalar, last ? (const float*)nullptr : ch, dh_in, w.gh, w.ua, nh);
             PK_LAUNCH_CHECK();
             // q[R,H] = dA[R,H] . U_h[H,H]
             PK_TRY(pk_gemm(st, prec, g.R, H, H, 1.f, w.gh, H, 1, U + (long)G1 * H * H, H, 1, 0.f, w.urec, H, nullptr, 1,
@@ -356,6 +464,10 @@ int bwd_stepwise(hipStream_t st, int prec, int act, StepGeom g, const float* U, 
         }
         float* tmp = ch; ch = nh; nh = tmp;
         tmp = cc; cc = nc; nc = tmp;
+    }
+    if (ln_gamma) {
+        PK_TRY(pk_colsum(st, w.ln_accg, nullptr, H, g.R, H, w.ln_part, dln_gamma));
+        PK_TRY(pk_colsum(st, w.ln_accb, nullptr, H, g.R, H, w.ln_part, dln_beta));
     }
     return 0;
 }
@@ -411,7 +523,9 @@ extern "C" int64_t pk_rec_work_floats(int cell, int T, int B, int bidir, int H) 
     (void)T;
     long n = 6 * ((R * H + 63) / 64 * 64) + 2 * ((R * G * H + 63) / 64 * 64);
     n += (long)DU_SPLITK * G * H * H + 64;
-    // persistent algorithm: error/timeout words + slack
+    // per-step LayerNorm backward: dh, two accumulators, column-sum partials
+    n += 3 * ((R * H + 63) / 64 * 64) + pk_bn_partial_floats(R, H);
+    // slack
     n += 4096;
     return n;
 }
@@ -421,8 +535,11 @@ extern "C" int pk_rec_fwd(void* stream, int algo, int prec, int cell, int act, i
                           float mask_scalar, const float* ln_gamma, const float* ln_beta, float* Y, float* S, float* LNS,
                           float* work) {
     PK_TRY(check_common("pk_rec_fwd", algo, prec, cell, act, T, B, bidir, H));
-    PK_REQUIRE(ln_gamma == nullptr && ln_beta == nullptr && LNS == nullptr,
-               "pk_rec_fwd: per-step LayerNorm is not implemented in this build");
+    PK_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr) && (ln_gamma == nullptr) == (LNS == nullptr),
+               "pk_rec_fwd: ln_gamma, ln_beta and LNS go together");
+    PK_REQUIRE(ln_gamma == nullptr || algo == PK_REC_STEPWISE,
+               "pk_rec_fwd: per-step LayerNorm runs in the step-wise algorithm only");
+    PK_REQUIRE(ln_gamma == nullptr || H > 1, "pk_rec_fwd: LayerNorm needs H > 1");
     hipStream_t st = pk_stream(stream);
     StepGeom g;
     g.T = T; g.B = B; g.R = B * (1 + bidir); g.H = H;
@@ -431,11 +548,11 @@ extern "C" int pk_rec_fwd(void* stream, int algo, int prec, int cell, int act, i
         return pk_rec_fwd_persistent(st, prec, cell, act, T, B, bidir, H, P, pscale, pshift, U, mask, mask_scalar, Y, S,
                                      work);
     switch (cell) {
-        case PK_CELL_LIGRU: return fwd_stepwise<PK_CELL_LIGRU>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, Y, S, work);
-        case PK_CELL_RNN: return fwd_stepwise<PK_CELL_RNN>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, Y, S, work);
-        case PK_CELL_LSTM: return fwd_stepwise<PK_CELL_LSTM>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, Y, S, work);
-        case PK_CELL_GRU: return fwd_stepwise<PK_CELL_GRU>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, Y, S, work);
-        default: return fwd_stepwise<PK_CELL_MINGRU>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, Y, S, work);
+        case PK_CELL_LIGRU: return fwd_stepwise<PK_CELL_LIGRU>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, ln_gamma, ln_beta, Y, S, LNS, work);
+        case PK_CELL_RNN: return fwd_stepwise<PK_CELL_RNN>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, ln_gamma, ln_beta, Y, S, LNS, work);
+        case PK_CELL_LSTM: return fwd_stepwise<PK_CELL_LSTM>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, ln_gamma, ln_beta, Y, S, LNS, work);
+        case PK_CELL_GRU: return fwd_stepwise<PK_CELL_GRU>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, ln_gamma, ln_beta, Y, S, LNS, work);
+        default: return fwd_stepwise<PK_CELL_MINGRU>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, ln_gamma, ln_beta, Y, S, LNS, work);
     }
 }
 
@@ -444,8 +561,11 @@ extern "C" int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, i
                           const float* S, const float* LNS, const float* dY, float* dP2, float* dU, float* dln_gamma,
                           float* dln_beta, float* work) {
     PK_TRY(check_common("pk_rec_bwd", algo, prec, cell, act, T, B, bidir, H));
-    PK_REQUIRE(ln_gamma == nullptr && LNS == nullptr && dln_gamma == nullptr && dln_beta == nullptr,
-               "pk_rec_bwd: per-step LayerNorm is not implemented in this build");
+    PK_REQUIRE((ln_gamma == nullptr) == (LNS == nullptr) && (ln_gamma == nullptr) == (dln_gamma == nullptr) &&
+                   (ln_gamma == nullptr) == (dln_beta == nullptr),
+               "pk_rec_bwd: ln_gamma, LNS, dln_gamma and dln_beta go together");
+    PK_REQUIRE(ln_gamma == nullptr || algo == PK_REC_STEPWISE,
+               "pk_rec_bwd: per-step LayerNorm runs in the step-wise algorithm only");
     hipStream_t st = pk_stream(stream);
     StepGeom g;
     g.T = T; g.B = B; g.R = B * (1 + bidir); g.H = H;
@@ -455,11 +575,11 @@ extern "C" int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, i
         rc = pk_rec_bwd_persistent(st, prec, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dP2, work);
     } else {
         switch (cell) {
-            case PK_CELL_LIGRU: rc = bwd_stepwise<PK_CELL_LIGRU>(st, prec, act, g, U, mask, mask_scalar, Y, S, dY, dP2, work); break;
-            case PK_CELL_RNN: rc = bwd_stepwise<PK_CELL_RNN>(st, prec, act, g, U, mask, mask_scalar, Y, S, dY, dP2, work); break;
-            case PK_CELL_LSTM: rc = bwd_stepwise<PK_CELL_LSTM>(st, prec, act, g, U, mask, mask_scalar, Y, S, dY, dP2, work); break;
-            case PK_CELL_GRU: rc = bwd_stepwise<PK_CELL_GRU>(st, prec, act, g, U, mask, mask_scalar, Y, S, dY, dP2, work); break;
-            default: rc = bwd_stepwise<PK_CELL_MINGRU>(st, prec, act, g, U, mask, mask_scalar, Y, S, dY, dP2, work); break;
+            case PK_CELL_LIGRU: rc = bwd_stepwise<PK_CELL_LIGRU>(st, prec, act, g, U, mask, mask_scalar, ln_gamma, Y, S, LNS, dY, dP2, dln_gamma, dln_beta, work); break;
+            case PK_CELL_RNN: rc = bwd_stepwise<PK_CELL_RNN>(st, prec, act, g, U, mask, mask_scalar, ln_gamma, Y, S, LNS, dY, dP2, dln_gamma, dln_beta, work); break;
+            case PK_CELL_LSTM: rc = bwd_stepwise<PK_CELL_LSTM>(st, prec, act, g, U, mask, mask_scalar, ln_gamma, Y, S, LNS, dY, dP2, dln_gamma, dln_beta, work); break;
+            case PK_CELL_GRU: rc = bwd_stepwise<PK_CELL_GRU>(st, prec, act, g, U, mask, mask_scalar, ln_gamma, Y, S, LNS, dY, dP2, dln_gamma, dln_beta, work); break;
+            default: rc = bwd_stepwise<PK_CELL_MINGRU>(st, prec, act, g, U, mask, mask_scalar, ln_gamma, Y, S, LNS, dY, dP2, dln_gamma, dln_beta, work); break;
         }
     }
     if (rc) return rc;

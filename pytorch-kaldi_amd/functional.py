@@ -351,8 +351,8 @@ class RecLayerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, Wcat, bcat, Ucat, gamma, beta, running_mean, running_var, mask, cfg):
-        _need_gpu(x, Wcat, bcat, Ucat, gamma, beta, mask)
+    def forward(ctx, x, Wcat, bcat, Ucat, gamma, beta, running_mean, running_var, mask, ln_gamma, ln_beta, cfg):
+        _need_gpu(x, Wcat, bcat, Ucat, gamma, beta, mask, ln_gamma, ln_beta)
         lib = _lib.load()
         cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar = cfg
         T, B, D = x.shape
@@ -383,14 +383,20 @@ class RecLayerFn(torch.autograd.Function):
         Y = _new(T, B, ndir * H, like=x2)
         S = _new(ndir, TB, NS * H, like=x2)
         work = _new(int(lib.pk_rec_work_floats(CELL[cell], T, B, int(bidir), H)), like=x2)
-        algo = choose_rec_algo(cell, H, False)
+        use_ln = ln_gamma is not None
+        algo = choose_rec_algo(cell, H, use_ln)
         prec = PREC[settings.precision]
         if algo == REC_PERSISTENT:
             _lib.raise_if_persist_failed()
+        LNS = None
+        if use_ln:  # per-step LayerNorm of h_t: saved [mean, 1/(std+eps), pre-LN h] per (step, row)
+            ln_gamma, ln_beta = ln_gamma.contiguous(), ln_beta.contiguous()
+            LNS = _new(T, ndir * B, H + 2, like=x2)
         rc = lib.pk_rec_fwd(_stream(), algo, prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
-                            _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), None, None, _p(Y), _p(S), None, _p(work))
+                            _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(ln_gamma), _p(ln_beta), _p(Y), _p(S),
+                            _p(LNS), _p(work))
         _lib.check(rc, "pk_rec_fwd")
-        ctx.save_for_backward(x2, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, pscale)
+        ctx.save_for_backward(x2, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, pscale, ln_gamma, LNS)
         ctx.cfg = cfg
         ctx.algo, ctx.prec = algo, prec
         ctx.in_shape = x.shape
@@ -403,7 +409,7 @@ class RecLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY, _dm, _dv):
         lib = _lib.load()
-        x2, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, pscale = ctx.saved_tensors
+        x2, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, pscale, ln_gamma, LNS = ctx.saved_tensors
         cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar = ctx.cfg
         T, B, D = ctx.in_shape
         G = lib.pk_rec_num_gates(CELL[cell])
@@ -413,8 +419,12 @@ class RecLayerFn(torch.autograd.Function):
         dP2 = _new(ndir, TB, GH, like=dY)
         dU = _new(GH, H, like=dY)
         work = _new(int(lib.pk_rec_work_floats(CELL[cell], T, B, int(bidir), H)), like=dY)
+        dlg = dlb = None
+        if ln_gamma is not None:
+            dlg, dlb = _new(H, like=dY), _new(H, like=dY)
         rc = lib.pk_rec_bwd(_stream(), ctx.algo, ctx.prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
-                            float(mask_scalar), None, _p(Y), _p(S), None, _p(dY), _p(dP2), _p(dU), None, None, _p(work))
+                            float(mask_scalar), _p(ln_gamma), _p(Y), _p(S), _p(LNS), _p(dY), _p(dP2), _p(dU), _p(dlg),
+                            _p(dlb), _p(work))
         _lib.check(rc, "pk_rec_bwd")
         g1 = dP2[0]
         g2 = dP2[1] if bidir else None
@@ -452,7 +462,7 @@ class RecLayerFn(torch.autograd.Function):
             dx = dx.view(T, B, D)
         dW = _new(GH, D, like=dY)
         gemm(GH, D, TB, dPraw, 1, GH, x2, x2.stride(0), 1, dW, D, splitk=_splitk(_tiles(GH, D), TB))
-        return dx, dW, dbias, dU, dgamma, dbeta, None, None, None, None
+        return dx, dW, dbias, dU, dgamma, dbeta, None, None, None, dlg, dlb, None
 
 
 # ----------------------------------------------------------------------------

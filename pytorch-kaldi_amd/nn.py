@@ -250,9 +250,6 @@ class _Recurrent(nn.Module):
             scalars = [1.0 if m.numel() > 1 else float(m) for m in drop_masks]
             masks = [m.to(x.device).float().contiguous() if m is not None else None for m in masks]
         for i in range(self._n_lay):
-            if self._use_ln[i]:
-                raise PkError("%s: per-step LayerNorm (%s_use_laynorm) is not available in this build of the engine"
-                              % (self.KIND, self._pre))
             H = self._lay[i]
             Ws = [getattr(self, w)[i] for (w, _, _) in self._gates]
             Us = [getattr(self, u)[i] for (_, u, _) in self._gates]
@@ -271,7 +268,9 @@ class _Recurrent(nn.Module):
                     rmean = torch.cat([b.running_mean for b in bns], 0)
                     rvar = torch.cat([b.running_var for b in bns], 0)
             cfg = (self.KIND, self._act[i], H, bool(self.bidir), use_bn, self.training, 1e-5, 0.05, scalars[i])
-            y, bmean, bvar = F_.RecLayerFn.apply(x, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, masks[i], cfg)
+            lng = self.ln[i].gamma if self._use_ln[i] else None
+            lnb = self.ln[i].beta if self._use_ln[i] else None
+            y, bmean, bvar = F_.RecLayerFn.apply(x, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, masks[i], lng, lnb, cfg)
             if use_bn and self.training:
                 n = x.shape[0] * x.shape[1] * (2 if self.bidir else 1)
                 with torch.no_grad():  # BatchNorm1d(momentum=0.05) running statistics, per gate

@@ -29,9 +29,7 @@ class FlatParams:
     def __init__(self, module, align=64):
         self.module = module
         self.params = [p for p in module.parameters()]
-        dev = self.params[0].device
-        if dev.type != "cuda":
-            raise _lib.PkError("FlatParams needs the module on the GPU")
+        dev = self.params[0].device  # the flat layout itself is device-agnostic (CPU in the gloo tests)
         self.offsets = []
         off = 0
         for p in self.params:
@@ -75,6 +73,8 @@ class FusedOptimizer:
         self.flat.zero_grad()
 
     def step(self):
+        if not self.flat.flat.is_cuda:
+            raise _lib.PkError("fused optimizer step runs on the GPU only (no CPU fallback)")
         lib = _lib.load()
         lr = float(self.param_groups[0]["lr"])
         f = self.flat

@@ -1,0 +1,86 @@
+"""Data-parallel gradient exchange (pytorch-kaldi_amd/dp.py) on CPU: world_size 2, gloo.
+N-rank result must equal the per-shard gradients averaged (SURVEY.md 8e parity definition)."""
+import importlib
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.Tanh(), torch.nn.Linear(9, 5), torch.nn.Tanh(),
+                               torch.nn.Linear(5, 3))
+
+
+def _batch():
+    g = torch.Generator().manual_seed(3)
+    return torch.randn(7, 8, 6, generator=g), torch.randn(7, 8, 3, generator=g)
+
+
+def _worker(rank, world, port, use_flat, bucket_bytes, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    DP = importlib.import_module("pytorch-kaldi_amd.dp")
+    OPT = importlib.import_module("pytorch-kaldi_amd.optim")
+    r, w, _ = DP.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    net = _model(0)
+    # an unused parameter, like the reference's never-called ln/bn sub-modules (grad stays None / zero)
+    net.unused = torch.nn.Parameter(torch.ones(4))
+    flats = {"net": OPT.FlatParams(net)} if use_flat else None
+    red = DP.GradReducer({"net": net}, bucket_bytes=bucket_bytes, flats=flats)
+    x, y = _batch()
+    for step in range(2):  # two steps: buckets must re-arm
+        if flats:
+            flats["net"].zero_grad()
+        else:
+            net.zero_grad()
+        xs, ys = DP.shard_batch(x, rank, world), DP.shard_batch(y, rank, world)
+        ((net(xs) - ys) ** 2).mean().backward()
+        red.finish()
+    grads = {k: (p.grad.clone() if p.grad is not None else None) for k, p in net.named_parameters()}
+    if rank == 0:
+        torch.save(grads, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_flat,bucket_bytes", [(False, 1 << 20), (False, 64), (True, 1 << 20), (True, 128)])
+def test_two_rank_allreduce_equals_shard_average(tmp_path, use_flat, bucket_bytes):
+    world = 2
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_worker, args=(world, _free_port(), use_flat, bucket_bytes, out), nprocs=world, join=True)
+    got = torch.load(out)
+    x, y = _batch()
+    ref = None
+    for r in range(world):
+        net = _model(0)
+        xs, ys = x[:, r * 4:(r + 1) * 4], y[:, r * 4:(r + 1) * 4]
+        ((net(xs) - ys) ** 2).mean().backward()
+        g = {k: p.grad for k, p in net.named_parameters()}
+        ref = g if ref is None else {k: ref[k] + g[k] for k in g}
+    for k, v in ref.items():
+        assert torch.allclose(got[k], v / world, rtol=1e-6, atol=1e-7), k
+    assert got["unused"] is None or float(got["unused"].abs().max()) == 0.0
+
+
+def test_shard_batch_shapes():
+    DP = importlib.import_module("pytorch-kaldi_amd.dp")
+    x = torch.arange(2 * 8 * 3).reshape(2, 8, 3)
+    assert torch.equal(DP.shard_batch(x, 1, 4), x[:, 2:4])
+    y = torch.arange(8 * 3).reshape(8, 3)
+    assert torch.equal(DP.shard_batch(y, 3, 4), y[6:8])
+    with pytest.raises(ValueError):
+        DP.shard_batch(x, 0, 3)

@@ -66,6 +66,20 @@ int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha, const floa
             int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
             const float* bias, int splitk, float* workspace);
 
+/* ---- perf-mode GEMM on bf16 operands resident in HBM (fp32 accumulate and output); same reference
+ * call sites as pk_gemm.  a_kc != 0: A is stored [M][lda] (k contiguous), else [K][lda] (m
+ * contiguous - the dW / dU shapes whose reduction runs over the T*B rows); likewise B with N / ldb.
+ * Bases 16-byte aligned, pitches multiples of 8 elements; elements between K and the next multiple of
+ * 8 inside a k-contiguous row must be zero (pk_cvt_bf16 writes them so).  splitk as pk_gemm. */
+int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
+                 const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc, const float* bias,
+                 int splitk, float* workspace);
+/* fp32 [rows][ld_src] -> bf16 [rows][ld_dst].  The source columns are nseg segments of seglen values;
+ * segment s lands at destination column s*segpad (e.g. the two direction halves of a layer output,
+ * 550 -> 576, so that each half starts 16-byte aligned); all other destination elements are zero. */
+int pk_cvt_bf16(void* stream, const float* src, int64_t ld_src, int64_t rows, int nseg, int seglen, int segpad,
+                uint16_t* dst, int64_t ld_dst);
+
 /* ---- column statistics / BatchNorm: replaces nn.BatchNorm1d(momentum=0.05)
  * at neural_networks.py:85,105,142-145 (MLP) and :438-450, :614-623,
  * :1118-1124 (per-gate BN over the T*rows projection rows).
@@ -152,13 +166,29 @@ int pk_rec_fwd(void* stream, int algo, int prec, int cell, int act, int T, int B
 /* Backward through time.  dY [T,B,(1+bidir)*H] is the gradient of Y.
  * Outputs: dP2 [1+bidir][T*B][G*H]: gradient w.r.t. the (scaled+shifted)
  * projections, one slab per direction, both indexed by ORIGINAL time; the
- * caller adds the slabs (pk_bn_bwd_* take g and g2).  dU [G*H, H] (overwritten).
+ * caller adds the slabs (pk_bn_bwd_* take g and g2).  dU [G*H, H] (overwritten; NULL = skip the deferred
+ * dU GEMMs, the caller forms dU = sum_t dgate_t^T . h_{t-1} itself, e.g. with pk_gemm_bf16).
  * dln_gamma/dln_beta [H] (overwritten) when LayerNorm is on.
  * Hprev for dU and the carry come from Y / LNS. */
 int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, int T, int B, int bidir, int H,
                const float* U, const float* mask, float mask_scalar, const float* ln_gamma, const float* Y,
                const float* S, const float* LNS, const float* dY, float* dP2, float* dU, float* dln_gamma,
                float* dln_beta, float* work);
+
+/* ---- perf-mode persistent recurrences (liGRU / RNN / LSTM; same reference loops as pk_rec_fwd/bwd):
+ * bf16 MFMA operands, fp32 gate math / state / outputs.  The in-kernel exchange buffers are also
+ * outputs: Yb [T*B][y_pitch] bf16 copy of Y (direction d at column d*Hp, Hp = H rounded up to 8, zero
+ * padded) and dGb [ndir*T*B][g_pitch] bf16 gate gradients (gate g at column g*Hp) are laid out as the
+ * k-major operands pk_gemm_bf16 needs for dU / dW.  Columns beyond ndir*Hp (G*Hp) of a row are left
+ * undefined.  Pitches are multiples of 8 elements; H <= 576. */
+int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
+                    const float* pscale, const float* pshift, const float* U, const float* mask, float mask_scalar,
+                    float* Y, float* S, uint16_t* Yb, int64_t y_pitch);
+int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
+                    float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, uint16_t* dGb,
+                    int64_t g_pitch);
+unsigned pk_persist2_error_count(void);
+void pk_persist2_error_reset(void);
 
 /* ---- conv1d (valid, stride 1) fused with max_pool1d(kernel=stride=pool):
  * replaces F.conv1d + F.max_pool1d at neural_networks.py:1546-1552,

@@ -27,6 +27,9 @@ SIGNATURES = {
     "pk_num_cu": (c_int, []),
     "pk_gemm": (c_int, [P, c_int, c_int, c_int, c_int, c_float, P, c_int64, c_int64, P, c_int64, c_int64, c_float, P,
                         c_int64, P, c_int, P]),
+    "pk_gemm_bf16": (c_int, [P, c_int, c_int, c_int, c_float, P, c_int64, c_int, P, c_int64, c_int, c_float, P, c_int64, P,
+                             c_int, P]),
+    "pk_cvt_bf16": (c_int, [P, P, c_int64, c_int64, c_int, c_int, c_int, P, c_int64]),
     "pk_bn_partial_floats": (c_int64, [c_int64, c_int64]),
     "pk_bn_stats": (c_int, [P, P, c_int64, c_int64, c_int64, P, P, P]),
     "pk_bn_finalize": (c_int, [P, c_int64, P, P, P, P, c_float, P, P, P, P, c_float, c_double]),
@@ -48,6 +51,10 @@ SIGNATURES = {
                            P, P, P]),
     "pk_rec_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P,
                            P, P, P, P]),
+    "pk_rec_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, P, c_int64]),
+    "pk_rec_bwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int64]),
+    "pk_persist2_error_count": (ctypes.c_uint, []),
+    "pk_persist2_error_reset": (None, []),
     "pk_conv1d_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "pk_conv_partial_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "pk_conv1d_pool_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
@@ -104,9 +111,10 @@ def check(rc, what):
 def raise_if_persist_failed():
     """Spin time-outs of the persistent recurrence land in a host-mapped counter."""
     lib = load()
-    n = lib.pk_persist_error_count()
+    n = lib.pk_persist_error_count() + lib.pk_persist2_error_count()
     if n:
         lib.pk_persist_error_reset()
+        lib.pk_persist2_error_reset()
         raise PkError("persistent recurrent kernel: %d wave(s) timed out waiting for a peer workgroup "
                       "(results of that launch are invalid)" % n)
 

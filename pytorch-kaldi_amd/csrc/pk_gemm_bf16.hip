@@ -1,0 +1,317 @@
+// pk_gemm_bf16.hip - perf-mode GEMM for gfx950: bf16 operands resident in HBM,
+// fp32 accumulate / output.  Replaces the same reference call sites as pk_gemm
+// (nn.Linear forward/backward, neural_networks.py:111/139-148, :432-435,
+// :609-611, :1114-1115, and the deferred dU = sum_t dgate_t^T . h_{t-1}).
+//
+//   C[M,N] = alpha * sum_k A(m,k) * B(k,n) + beta*C + bias
+//
+// Each operand is either "k-contiguous" (KC: A stored [M][lda], B stored
+// [N][ldb] - activations x weights^T) or "k-major" (A stored [K][lda] with m
+// contiguous, B stored [K][ldb] - the dW / dU shapes whose reduction runs over
+// the T*B rows).  No operand is ever transposed in HBM:
+//   * tiles go HBM -> LDS with the LDS-DMA (global_load_lds_dwordx4, 16 B per
+//     lane, no VGPR round trip); the LDS image is lane-linear, so the bank
+//     swizzle is applied to the per-lane SOURCE address and again on the read;
+//   * KC fragments are one ds_read_b128; k-major fragments are two
+//     ds_read_b64_tr_b16 (the gfx950 LDS transpose read) - the MFMA operand
+//     wants 8 consecutive k per lane, the image has k as the row index.
+// Block tile 128 x 128 x 64, 4 waves (2 x 2), wave tile 64 x 64 = 4 x 4
+// v_mfma_f32_16x16x32_bf16, LDS double buffer (64 KB), one barrier per k-tile.
+// blockIdx -> tile mapping is XCD-aware: the n-tiles of one 128-row A panel run
+// back to back on ONE XCD so the panel is read from HBM once and re-read from
+// that XCD's L2.
+//
+// Edges: rows beyond M / N are clamped (their results are never stored);
+// 16-byte k-chunks beyond K come from a zero page, so K needs no padding
+// beyond a multiple of 8 elements (producers zero-fill inside the last chunk).
+#include "pk_common.h"
+
+namespace {
+
+constexpr int TM = 128, TN = 128, TK = 64;
+typedef short s4v __attribute__((ext_vector_type(4)));
+
+struct BArgs {
+    int M, N, K;
+    float alpha, beta;
+    const unsigned short* A;
+    long lda;
+    const unsigned short* B;
+    long ldb;
+    float* C;
+    long ldc;
+    const float* bias;
+    float* ws;  // split-K slabs [splits][M][N] or null
+    int k_per_split;
+    int tiles_m, tiles_n;
+    const unsigned short* zeros;  // >= 16 bytes of zeros
+};
+
+__device__ unsigned short g_zero_page[64];
+
+// swizzles (same involution on the staging source and on the fragment read)
+__device__ __forceinline__ int swz_kc(int row) { return (row >> 1) & 7; }                  // 8 x 16-B slots per row
+__device__ __forceinline__ int swz_km(int kr) { return 2 * ((kr & 3) | ((kr >> 1) & 4)); }  // 16 x 16-B slots per row
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// branch-free address select (a pointer ?: makes hipcc emit two exec-masked LDS-DMA loads)
+__device__ __forceinline__ unsigned long long sel_addr(bool ok, const void* a, const void* z) {
+    const unsigned long long m = 0ull - (unsigned long long)ok;
+    return ((unsigned long long)a & m) | ((unsigned long long)z & ~m);
+}
+
+// Stage one 128 x 64 operand tile (16 KB) into `buf`.  KC image: [128 rows][8 slots]; k-major image: [64 k][16 slots].
+template <bool KC>
+__device__ __forceinline__ void stage(const unsigned short* __restrict__ base, long ld, int r0, int rmax, int k0, int kmax,
+                                      const unsigned short* zeros, unsigned char* buf, int tid, int wave) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = j * 256 + tid;
+        unsigned long long src;  // selected as an integer so that it stays ONE load (no exec-masked pair)
+        if (KC) {
+            const int row = q >> 3, ps = q & 7;
+            const int ks = ps ^ swz_kc(row);
+            int gr = r0 + row;
+            gr = gr < rmax ? gr : rmax - 1;
+            const int gk = k0 + ks * 8;
+            src = sel_addr(gk < kmax, base + (long)gr * ld + gk, zeros);
+        } else {
+            const int kr = q >> 4, ps = q & 15;
+            const int cs = ps ^ swz_km(kr);
+            int gc = r0 + cs * 8;
+            if (gc >= rmax) gc = (rmax - 1) & ~7;  // chunk entirely out of range: any in-range chunk (never stored)
+            const int gk = k0 + kr;
+            src = sel_addr(gk < kmax, base + (long)gk * ld + gc, zeros);
+        }
+        glds16(reinterpret_cast<const void*>(src), buf + (j * 256 + wave * 64) * 16);
+    }
+}
+
+// MFMA 16x16x32 operand fragment for the 16 rows starting at `sub` (tile-local), k-step kk (0/1) of the 64-deep tile.
+template <bool KC>
+__device__ __forceinline__ bf16x8 frag(const unsigned char* buf, int sub, int kk, int lane) {
+    if (KC) {
+        const int row = sub + (lane & 15);
+        const int ks = kk * 4 + (lane >> 4);
+        const int ps = ks ^ swz_kc(row);
+        return *reinterpret_cast<const bf16x8*>(buf + row * 128 + ps * 16);
+    } else {
+        const int g = lane >> 4, i = lane & 15;
+        const int col = sub + (i & 3) * 4;  // tile-local m (or n) of this lane's 8-byte piece
+        bf16x8 out;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kr = kk * 32 + g * 8 + h * 4 + (i >> 2);
+            const int ps = (col >> 3) ^ swz_km(kr);
+            const unsigned char* a = buf + kr * 256 + ps * 16 + (col & 7) * 2;
+            const s4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)a);
+            out[4 * h + 0] = v[0];
+            out[4 * h + 1] = v[1];
+            out[4 * h + 2] = v[2];
+            out[4 * h + 3] = v[3];
+        }
+        return out;
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x_kernel(BArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [2][A 16 KB | B 16 KB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile mapping: id%8 = XCD (observed round-robin dispatch; speed only)
+    const int id = blockIdx.x;
+    const int xcd = id & 7, local = id >> 3;
+    const int tn = local % p.tiles_n;
+    const int tm = (local / p.tiles_n) * 8 + xcd;
+    if (tm >= p.tiles_m) return;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int split = blockIdx.y;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + TK - 1) / TK;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+        stage<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, p.zeros, smem, tid, wave);
+        stage<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, p.zeros, smem + 16384, tid, wave);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        unsigned char* cur = smem + (kt & 1) * 32768;
+        unsigned char* nxt = smem + ((kt + 1) & 1) * 32768;
+        if (kt + 1 < nk) {
+            const int k0 = kbeg + (kt + 1) * TK;
+            stage<A_KC>(p.A, p.lda, m0, p.M, k0, kend, p.zeros, nxt, tid, wave);
+            stage<B_KC>(p.B, p.ldb, n0, p.N, k0, kend, p.zeros, nxt + 16384, tid, wave);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag<A_KC>(cur, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = frag<B_KC>(cur + 16384, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // epilogue: C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+            if (col >= p.N) continue;
+            const float bv = (p.bias != nullptr && p.ws == nullptr) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (row >= p.M) continue;
+                const float v = acc[i][j][r];
+                if (p.ws != nullptr) {
+                    p.ws[((long)split * p.M + row) * p.N + col] = v;
+                } else {
+                    float* c = p.C + (long)row * p.ldc + col;
+                    float o = p.alpha * v + bv;
+                    if (p.beta != 0.f) o += p.beta * (*c);
+                    *c = o;
+                }
+            }
+        }
+}
+
+__global__ void splitk_reduce_bf_kernel(const float* __restrict__ ws, int splitk, int M, int N, float alpha, float beta,
+                                        const float* __restrict__ bias, float* __restrict__ C, long ldc) {
+    const long total = (long)M * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / N), col = (int)(i % N);
+        float s = 0.f;
+        for (int k = 0; k < splitk; ++k) s += ws[(long)k * total + i];
+        float o = alpha * s + (bias ? bias[col] : 0.f);
+        float* c = C + (long)row * ldc + col;
+        if (beta != 0.f) o += beta * (*c);
+        *c = o;
+    }
+}
+
+// fp32 [rows][lds] -> bf16 [rows][ldd]; source columns are `nseg` segments of `seglen`, each placed at
+// a pitch of `segpad` in the destination; every other destination element of the row is zero.
+__global__ void cvt_bf16_kernel(const float* __restrict__ src, long lds, long rows, int nseg, int seglen, int segpad,
+                                unsigned short* __restrict__ dst, long ldd) {
+    const long chunks_per_row = ldd >> 3;  // 8 bf16 = 16 B per thread
+    const long total = rows * chunks_per_row;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / chunks_per_row;
+        const int c0 = (int)(i - r * chunks_per_row) * 8;
+        const float* s = src + r * lds;
+        unsigned pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = c0 + 2 * e + h;
+                const int sg = c / segpad, off = c - sg * segpad;
+                v[h] = (sg < nseg && off < seglen) ? s[sg * seglen + off] : 0.f;
+            }
+            pk[e] = pk_pack_bf2(v[0], v[1]);
+        }
+        *reinterpret_cast<uint4*>(dst + r * ldd + c0) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+}
+
+}  // namespace
+
+extern "C" int pk_cvt_bf16(void* stream, const float* src, int64_t ld_src, int64_t rows, int nseg, int seglen, int segpad,
+                           uint16_t* dst, int64_t ld_dst) {
+    if (rows <= 0) return 0;
+    PK_REQUIRE(nseg >= 1 && seglen >= 1 && segpad >= seglen, "pk_cvt_bf16: bad segments");
+    PK_REQUIRE((ld_dst % 8) == 0 && ld_dst >= (int64_t)nseg * segpad - (segpad - seglen) && ((uintptr_t)dst & 15) == 0,
+               "pk_cvt_bf16: destination pitch must be a multiple of 8 elements and hold every segment");
+    const long total = rows * (ld_dst >> 3);
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, pk_stream(stream), src, (long)ld_src,
+                       (long)rows, nseg, seglen, segpad, (unsigned short*)dst, (long)ld_dst);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
+                            const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc,
+                            const float* bias, int splitk, float* workspace) {
+    if (M <= 0 || N <= 0) return 0;
+    PK_REQUIRE(K >= 0, "pk_gemm_bf16: negative K");
+    PK_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
+               "pk_gemm_bf16: operands need 16-byte aligned bases and pitches that are multiples of 8 elements");
+    PK_REQUIRE(!a_kc || (K % 8) == 0 || lda >= ((K + 7) & ~7), "pk_gemm_bf16: A pitch shorter than K rounded up to 8");
+    PK_REQUIRE(!b_kc || (K % 8) == 0 || ldb >= ((K + 7) & ~7), "pk_gemm_bf16: B pitch shorter than K rounded up to 8");
+    PK_REQUIRE(a_kc || lda >= ((M + 7) & ~7), "pk_gemm_bf16: k-major A needs a pitch of at least M rounded up to 8");
+    PK_REQUIRE(b_kc || ldb >= ((N + 7) & ~7), "pk_gemm_bf16: k-major B needs a pitch of at least N rounded up to 8");
+    hipStream_t st = pk_stream(stream);
+    BArgs p;
+    p.M = M; p.N = N; p.K = K;
+    p.alpha = alpha; p.beta = beta;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
+    p.C = C; p.ldc = ldc; p.bias = bias;
+    p.tiles_m = (M + TM - 1) / TM;
+    p.tiles_n = (N + TN - 1) / TN;
+    void* zp = nullptr;
+    PK_CHECK_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)));
+    p.zeros = (const unsigned short*)zp;
+    if (splitk < 1) splitk = 1;
+    if (splitk > 1) {
+        PK_REQUIRE(workspace != nullptr, "pk_gemm_bf16: split-K needs a workspace");
+        int kps = (K + splitk - 1) / splitk;
+        kps = ((kps + TK - 1) / TK) * TK;
+        splitk = kps > 0 ? (K + kps - 1) / kps : 1;
+        p.k_per_split = kps;
+    }
+    if (splitk <= 1) {
+        splitk = 1;
+        p.k_per_split = ((K + TK - 1) / TK) * TK;
+        if (p.k_per_split == 0) p.k_per_split = TK;
+    }
+    p.ws = splitk > 1 ? workspace : nullptr;
+    const int mgroups = (p.tiles_m + 7) / 8;
+    dim3 grid((unsigned)(mgroups * 8 * p.tiles_n), (unsigned)splitk), block(256);
+    const size_t lds = 65536;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x_kernel<true, true>), grid, block, lds, st, p);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16x_kernel<true, false>), grid, block, lds, st, p);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x_kernel<false, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((gemm_bf16x_kernel<false, false>), grid, block, lds, st, p);
+    PK_LAUNCH_CHECK();
+    if (splitk > 1) {
+        const long total = (long)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_bf_kernel, dim3(blocks), dim3(256), 0, st, workspace, splitk, M, N, alpha, beta,
+                           bias, C, (long)ldc);
+        PK_LAUNCH_CHECK();
+    }
+    return 0;
+}

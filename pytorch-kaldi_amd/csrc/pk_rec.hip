@@ -583,6 +583,7 @@ extern "C" int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, i
         }
     }
     if (rc) return rc;
+    if (dU == nullptr) return 0;  // the caller computes dU itself (bf16 perf mode: pk_gemm_bf16 on bf16 copies)
     Work w = carve(work, g.R, g.H, g.G);
     return deferred_dU(st, prec, cell, g, Y, S, dP2, dU, w.ws);
 }

@@ -103,6 +103,59 @@ def _tiles(M, N):
     return ((M + 127) // 128) * ((N + 127) // 128)
 
 
+def _up(n, m):
+    return (n + m - 1) // m * m
+
+
+def cvt_bf16(x2, nseg=1, seglen=None, segpad=None):
+    """fp32 [rows, cols] (unit column stride) -> bf16 [rows, pitch]; the columns are `nseg` segments of
+    `seglen`, each placed at a pitch of `segpad` (multiple of 8 so that every segment starts 16-byte
+    aligned); padding is zero.  pitch = nseg*segpad rounded up to 64."""
+    lib = _lib.load()
+    rows, cols = x2.shape
+    if seglen is None:
+        nseg, seglen = 1, cols
+    if segpad is None:
+        segpad = _up(seglen, 8)
+    assert nseg * seglen == cols and x2.stride(1) == 1
+    pitch = _up(nseg * segpad, 64)
+    out = torch.empty(rows, pitch, device=x2.device, dtype=torch.bfloat16)
+    _lib.check(lib.pk_cvt_bf16(_stream(), _p(x2), x2.stride(0), rows, nseg, seglen, segpad, _p(out), pitch),
+               "pk_cvt_bf16")
+    return out
+
+
+def gemm_bf16(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, alpha=1.0, beta=0.0, bias=None, splitk=1):
+    """C[M,N] fp32 = alpha * A.B + beta*C + bias on bf16 operands (see include/pk_amd.h: pk_gemm_bf16).
+    A / B may be tensors or (tensor, element_offset) pairs."""
+    lib = _lib.load()
+    ws = None
+    if splitk > 1:
+        ws = torch.empty(splitk * M * N, device=C.device, dtype=torch.float32)
+
+    def ptr(t):
+        if isinstance(t, tuple):
+            return ctypes.c_void_p(t[0].data_ptr() + 2 * t[1])
+        return ctypes.c_void_p(t.data_ptr())
+
+    rc = lib.pk_gemm_bf16(_stream(), M, N, K, alpha, ptr(A), lda, int(a_kc), ptr(B), ldb, int(b_kc), beta, _p(C), ldc,
+                          _p(bias), splitk, _p(ws))
+    _lib.check(rc, "pk_gemm_bf16")
+    return C
+
+
+def _splitk_bf(out_tiles, K):
+    """Split the reduction of the dW / dU shapes (few output tiles, K = T*B rows) over the chip."""
+    if K < 2048:
+        return 1
+    s = max(1, (2 * 256) // max(1, out_tiles))
+    return int(min(32, s, max(1, K // 512)))
+
+
+def bf16_mode():
+    return settings.precision == "bf16"
+
+
 # ----------------------------------------------------------------------------
 # Linear:  y = x W^T + b        (nn.Linear; neural_networks.py:111, 139-148)
 # ----------------------------------------------------------------------------
@@ -115,8 +168,15 @@ class LinearFn(torch.autograd.Function):
         M, K = x2.shape
         N = weight.shape[0]
         y = _new(M, N, like=x2)
-        gemm(M, N, K, x2, x2.stride(0), 1, weight, 1, K, y, N, bias=bias)
-        ctx.save_for_backward(x2, weight)
+        ctx.bf = bf16_mode()
+        if ctx.bf:  # perf mode: operands rounded to bf16 once, saved in bf16 for backward
+            xb, wb = cvt_bf16(x2), cvt_bf16(weight)
+            gemm_bf16(M, N, K, xb, xb.shape[1], 1, wb, wb.shape[1], 1, y, N, bias=bias)
+            ctx.save_for_backward(xb, wb)
+        else:
+            gemm(M, N, K, x2, x2.stride(0), 1, weight, 1, K, y, N, bias=bias)
+            ctx.save_for_backward(x2, weight)
+        ctx.dims = (M, N, K)
         ctx.has_bias = bias is not None
         ctx.in_shape = x.shape
         return y.view(*x.shape[:-1], N)
@@ -124,10 +184,22 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, weight = ctx.saved_tensors
-        M, K = x2.shape
-        N = weight.shape[0]
+        M, N, K = ctx.dims
         dy2 = _rows2d(dy.contiguous())
         dx = dw = db = None
+        if ctx.bf:
+            xb, wb = x2, weight
+            dyb = cvt_bf16(dy2)
+            if ctx.needs_input_grad[0]:  # dx[m,k] = sum_n dy[m,n] W[n,k]: A k-contiguous, B = W is k-major
+                dx = _new(M, K, like=dy2)
+                gemm_bf16(M, K, N, dyb, dyb.shape[1], 1, wb, wb.shape[1], 0, dx, K)
+                dx = dx.view(ctx.in_shape)
+            if ctx.needs_input_grad[1]:  # dw[n,k] = sum_m dy[m,n] x[m,k]: both operands k-major
+                dw = _new(N, K, like=dy2)
+                gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K, splitk=_splitk_bf(_tiles(N, K), M))
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum(dy2)
+            return dx, dw, db
         if ctx.needs_input_grad[0]:
             dx = _new(M, K, like=dy2)
             gemm(M, K, N, dy2, N, 1, weight, K, 1, dx, K)
@@ -333,7 +405,9 @@ def log_softmax(x):
 # ----------------------------------------------------------------------------
 def choose_rec_algo(cell, H, use_ln):
     want = settings.rec_algo
-    ok = cell in ("liGRU", "RNN", "LSTM") and H % 2 == 0 and H <= 576 and not use_ln
+    ok = cell in ("liGRU", "RNN", "LSTM") and H <= 576 and not use_ln
+    if not bf16_mode():  # the exact-fp32 persistent kernels exchange pairs of fp32 values
+        ok = ok and H % 2 == 0
     if want == "persistent":
         if not ok:
             raise _lib.PkError("persistent recurrence does not cover cell=%s H=%d laynorm=%s" % (cell, H, use_ln))
@@ -341,6 +415,43 @@ def choose_rec_algo(cell, H, use_ln):
     if want == "stepwise":
         return REC_STEPWISE
     return REC_PERSISTENT if ok else REC_STEPWISE
+
+
+def _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, Yb=None, dGb=None):
+    """dU[G*H, H] = sum over directions and steps of dgate_t^T . (vector that fed U_g at step t), as
+    k-major x k-major bf16 GEMMs over the (T-1)*B rows (Appendix C of SURVEY.md; pk_rec.hip deferred_dU
+    is the fp32 twin).  Y's two direction halves are re-pitched to a multiple of 8 so that the reversed
+    half starts 16-byte aligned."""
+    TB, GH = T * B, G * H
+    two_phase = cell in ("GRU", "minimalGRU")
+    Gh = G - 1 if two_phase else G
+    Kh = (T - 1) * B
+    Hp = _up(H, 8)
+    if Yb is None:  # (the persistent bf16 kernels hand both buffers over in exactly this layout)
+        Yb = cvt_bf16(Y.view(TB, ndir * H), ndir, H, Hp)
+    Yp = Yb.shape[1]
+    if dGb is None:
+        dGb = cvt_bf16(dP2.view(ndir * TB, GH), G, H, Hp)  # gate g of a row starts at column g*Hp (16-byte aligned)
+    Gp = dGb.shape[1]
+    # one GEMM per (direction, gate) unless the gates are already contiguous (H % 8 == 0)
+    groups = [(0, Gh)] if Hp == H else [(g, 1) for g in range(Gh)]
+    for (g0, ng) in groups:
+        rows = dU[g0 * H:(g0 + ng) * H]
+        if Kh == 0:
+            rows.zero_()
+            continue
+        for d in range(ndir):
+            # rows whose previous state exists: dir 0 -> ts >= 1 (h at ts-1); dir 1 -> ts <= T-2 (h at ts+1)
+            a_off = (d * TB + (0 if d else B)) * Gp + g0 * Hp
+            b_off = (B if d else 0) * Yp + d * Hp
+            gemm_bf16(ng * H, H, Kh, (dGb, a_off), Gp, 0, (Yb, b_off), Yp, 0, rows, H, beta=0.0 if d == 0 else 1.0,
+                      splitk=_splitk_bf(_tiles(ng * H, H), Kh))
+    if two_phase:  # candidate gate: dU_h = sum dA^T . (r*h) or (z*h), saved in S
+        slot = 3 if cell == "GRU" else 2
+        for d in range(ndir):
+            gh = cvt_bf16(S[d][:, slot * H:(slot + 1) * H])
+            gemm_bf16(H, H, TB, (dGb, d * TB * Gp + Gh * Hp), Gp, 0, gh, gh.shape[1], 0, dU[Gh * H:], H,
+                      beta=0.0 if d == 0 else 1.0, splitk=_splitk_bf(_tiles(H, H), TB))
 
 
 class RecLayerFn(torch.autograd.Function):
@@ -366,7 +477,13 @@ class RecLayerFn(torch.autograd.Function):
         # K1: input projections for all steps at once, on the NON-duplicated batch (the reversed
         # half of the reference's cat([x, flip(x)]) is the same rows read backwards in time)
         P = _new(TB, GH, like=x2)
-        gemm(TB, GH, D, x2, x2.stride(0), 1, Wcat, 1, D, P, GH)
+        bf = bf16_mode()
+        xb = Wb = None
+        if bf:  # perf mode: bf16 operands (rounded once, kept for backward), fp32 accumulate / P
+            xb, Wb = cvt_bf16(x2), cvt_bf16(Wcat)
+            gemm_bf16(TB, GH, D, xb, xb.shape[1], 1, Wb, Wb.shape[1], 1, P, GH)
+        else:
+            gemm(TB, GH, D, x2, x2.stride(0), 1, Wcat, 1, D, P, GH)
         mean = var = None
         if use_bn:
             if training:
@@ -392,11 +509,26 @@ class RecLayerFn(torch.autograd.Function):
         if use_ln:  # per-step LayerNorm of h_t: saved [mean, 1/(std+eps), pre-LN h] per (step, row)
             ln_gamma, ln_beta = ln_gamma.contiguous(), ln_beta.contiguous()
             LNS = _new(T, ndir * B, H + 2, like=x2)
-        rc = lib.pk_rec_fwd(_stream(), algo, prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
-                            _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(ln_gamma), _p(ln_beta), _p(Y), _p(S),
-                            _p(LNS), _p(work))
-        _lib.check(rc, "pk_rec_fwd")
-        ctx.save_for_backward(x2, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, pscale, ln_gamma, LNS)
+        Yb = None
+        if bf and algo == REC_PERSISTENT:
+            # perf mode: second-generation persistent kernel; its bf16 exchange buffer Yb is also the
+            # k-major operand of the dU GEMM in backward (nothing is converted afterwards)
+            Hp = _up(H, 8)
+            Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
+            rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
+                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1])
+            _lib.check(rc, "pk_rec_fwd_bf16")
+        else:
+            rc = lib.pk_rec_fwd(_stream(), algo, prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
+                                _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(ln_gamma), _p(ln_beta), _p(Y),
+                                _p(S), _p(LNS), _p(work))
+            _lib.check(rc, "pk_rec_fwd")
+        ctx.bf = bf
+        ctx.Yb = Yb
+        if bf:
+            ctx.save_for_backward(xb, Wb, Ucat, P, mean, var, gamma, mask, Y, S, pscale, ln_gamma, LNS)
+        else:
+            ctx.save_for_backward(x2, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, pscale, ln_gamma, LNS)
         ctx.cfg = cfg
         ctx.algo, ctx.prec = algo, prec
         ctx.in_shape = x.shape
@@ -422,10 +554,22 @@ class RecLayerFn(torch.autograd.Function):
         dlg = dlb = None
         if ln_gamma is not None:
             dlg, dlb = _new(H, like=dY), _new(H, like=dY)
-        rc = lib.pk_rec_bwd(_stream(), ctx.algo, ctx.prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
-                            float(mask_scalar), _p(ln_gamma), _p(Y), _p(S), _p(LNS), _p(dY), _p(dP2), _p(dU), _p(dlg),
-                            _p(dlb), _p(work))
-        _lib.check(rc, "pk_rec_bwd")
+        bf = ctx.bf
+        dGb = None
+        if ctx.Yb is not None:
+            Hp = _up(H, 8)
+            dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16)
+            rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
+                                     float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dP2), _p(dGb), dGb.shape[1])
+            _lib.check(rc, "pk_rec_bwd_bf16")
+        else:
+            rc = lib.pk_rec_bwd(_stream(), ctx.algo, ctx.prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat),
+                                _p(mask), float(mask_scalar), _p(ln_gamma), _p(Y), _p(S), _p(LNS), _p(dY), _p(dP2),
+                                None if bf else _p(dU), _p(dlg), _p(dlb), _p(work))
+            _lib.check(rc, "pk_rec_bwd")
+        if bf:
+            _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, ctx.Yb, dGb)
+            ctx.Yb = None
         g1 = dP2[0]
         g2 = dP2[1] if bidir else None
         dgamma = dbeta = dbias = None
@@ -456,11 +600,20 @@ class RecLayerFn(torch.autograd.Function):
             if ctx.has_bias:
                 dbias = colsum(dPraw)
         dx = dW = None
+        dW = _new(GH, D, like=dY)
+        if bf:
+            xb, Wb = x2, Wcat
+            dPb = cvt_bf16(dPraw)
+            if ctx.needs_input_grad[0]:
+                dx = _new(TB, D, like=dY)
+                gemm_bf16(TB, D, GH, dPb, dPb.shape[1], 1, Wb, Wb.shape[1], 0, dx, D)
+                dx = dx.view(T, B, D)
+            gemm_bf16(GH, D, TB, dPb, dPb.shape[1], 0, xb, xb.shape[1], 0, dW, D, splitk=_splitk_bf(_tiles(GH, D), TB))
+            return dx, dW, dbias, dU, dgamma, dbeta, None, None, None, dlg, dlb, None
         if ctx.needs_input_grad[0]:
             dx = _new(TB, D, like=dY)
             gemm(TB, D, GH, dPraw, GH, 1, Wcat, D, 1, dx, D)
             dx = dx.view(T, B, D)
-        dW = _new(GH, D, like=dY)
         gemm(GH, D, TB, dPraw, 1, GH, x2, x2.stride(0), 1, dW, D, splitk=_splitk(_tiles(GH, D), TB))
         return dx, dW, dbias, dU, dgamma, dbeta, None, None, None, dlg, dlb, None
 

@@ -211,3 +211,92 @@ def test_optimizers_match_torch():
         ge = gr.cuda()
         _lib.check(lib.pk_sgd_step(st, pe.data_ptr(), ge.data_ptr(), buf.data_ptr(), 10007, 0.08, 0.9, 1e-4, int(i == 0)), "sgd")
     assert rel_err(pe, pr) < 1e-6
+
+
+# ---- perf-mode GEMM on bf16 operands (LDS-DMA staging, transpose reads for k-major operands) --------
+def _bf_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def test_cvt_bf16_segments():
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(37, 2 * 550, generator=g).cuda()
+    out = F_.cvt_bf16(x, 2, 550, 552)
+    assert out.shape == (37, 1152) and out.dtype == torch.bfloat16
+    ref = torch.zeros(37, 1152, dtype=torch.bfloat16)
+    ref[:, :550] = x[:, :550].cpu().to(torch.bfloat16)
+    ref[:, 552:1102] = x[:, 550:].cpu().to(torch.bfloat16)
+    assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+    wide = torch.randn(9, 45, generator=g).cuda()
+    out = F_.cvt_bf16(wide[:, 1:41])  # strided, unaligned source
+    assert torch.equal(out.cpu()[:, :40].view(torch.int16), wide[:, 1:41].cpu().to(torch.bfloat16).view(torch.int16))
+    assert float(out[:, 40:].float().abs().max()) == 0.0
+
+
+BF_GEMM_SHAPES = [
+    # M, N, K, a_kc, b_kc, splitk
+    (16, 16, 64, 1, 1, 1),
+    (128, 128, 64, 1, 1, 1),
+    (128, 128, 64, 0, 0, 1),
+    (128, 128, 64, 1, 0, 1),
+    (128, 128, 64, 0, 1, 1),
+    (37, 53, 40, 1, 1, 1),
+    (300, 1100, 1100, 1, 1, 1),
+    (2050, 130, 552, 1, 0, 1),
+    (1100, 40, 3000, 0, 0, 8),
+    (550, 550, 2111, 0, 0, 5),
+    (1100, 1100, 6400, 0, 0, 16),
+    (1, 1, 8, 1, 1, 1),
+    (5, 1938, 1100, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("M,N,K,a_kc,b_kc,splitk", BF_GEMM_SHAPES)
+def test_gemm_bf16_operands(M, N, K, a_kc, b_kc, splitk):
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + a_kc + 2 * b_kc)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    Ab = F_.cvt_bf16((A if a_kc else A.t().contiguous()).cuda())   # [M][Kp] or [K][Mp]
+    Bb = F_.cvt_bf16((B.t().contiguous() if b_kc else B).cuda())   # [N][Kp] or [K][Np]
+    C = C0.clone().cuda()
+    F_.gemm_bf16(M, N, K, Ab, Ab.shape[1], a_kc, Bb, Bb.shape[1], b_kc, C, N, alpha=0.5, beta=2.0, bias=bias.cuda(),
+                 splitk=splitk)
+    torch.cuda.synchronize()
+    ref = 0.5 * (_bf_round(A) @ _bf_round(B)) + 2.0 * C0.double() + bias.double()
+    assert rel_err(C, ref) < 2e-5  # operands are exactly the bf16-rounded values; only fp32 accumulation differs
+
+
+def test_gemm_bf16_offset_operands():
+    """The dU shape: sub-matrices addressed by element offsets into larger bf16 buffers."""
+    g = torch.Generator().manual_seed(77)
+    T, Bn, H, GH = 6, 8, 24, 48
+    dG = torch.randn(T * Bn, GH, generator=g)
+    Y = torch.randn(T * Bn, 2 * H, generator=g)
+    dGb, Yb = F_.cvt_bf16(dG.cuda()), F_.cvt_bf16(Y.cuda(), 2, H, H)
+    K = (T - 1) * Bn
+    C = torch.empty(GH, H).cuda()
+    F_.gemm_bf16(GH, H, K, (dGb, Bn * dGb.shape[1]), dGb.shape[1], 0, (Yb, H), Yb.shape[1], 0, C, H)
+    ref = _bf_round(dG[Bn:]).t() @ _bf_round(Y[:K, H:])
+    assert rel_err(C, ref) < 2e-5
+
+
+def test_linear_autograd_bf16_mode():
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(700, 330, generator=g)
+    w = torch.randn(210, 330, generator=g) / 18
+    b = torch.randn(210, generator=g)
+    cot = torch.randn(700, 210, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    (TF.linear(xr, wr, br) * cot.double()).sum().backward()
+    F_.set_precision("bf16")
+    try:
+        xe, we, be = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+        y = F_.linear(xe, we, be)
+        (y * cot.cuda()).sum().backward()
+    finally:
+        F_.set_precision("fp32")
+    assert rel_err(y, TF.linear(x.double(), w.double(), b.double())) < 1e-2
+    for a, r in ((xe, xr), (we, wr), (be, br)):
+        assert rel_err(a.grad, r.grad) < 1e-2

@@ -205,17 +205,21 @@ def test_persistent_matches_stepwise_full_width():
     assert rel_err(torch.flip(yf[:, :, :H], dims=[0]), y[:, :, H:]) < 1e-5
 
 
-def test_bf16_mode_is_close():
-    """Perf mode: bf16 MFMA operands, fp32 accumulate/state.  Not the graded parity mode;
-    documented tolerance 3e-2 norm-relative on a 2-layer Li-GRU."""
+@pytest.mark.parametrize("kind,pre,act,H", [("liGRU", "ligru", "relu", 550), ("LSTM", "lstm", "tanh", 550),
+                                             ("GRU", "gru", "tanh", 550), ("minimalGRU", "minimalgru", "relu", 64),
+                                             ("RNN", "rnn", "tanh", 128)])
+def test_bf16_mode_is_close(kind, pre, act, H):
+    """Perf mode: bf16 MFMA operands (bf16 copies of activations / gradients / weights in HBM,
+    pk_gemm_bf16), fp32 accumulate / state / master weights.  Not the graded parity mode;
+    documented tolerance: 3e-2 norm-relative on outputs, 1e-1 on gradients of a 2-layer net."""
     from engine_util import F_amd, nn_amd
 
-    opts = _rec_opts("ligru", [550, 550], "relu")
+    opts = _rec_opts(pre, [H, H], act)
     torch.manual_seed(11)
-    net = nn_amd.liGRU(opts, 40).cuda().train()
+    net = getattr(nn_amd, kind)(opts, 40).cuda().train()
     g = torch.Generator().manual_seed(3)
     x = torch.randn(20, 8, 40, generator=g).cuda()
-    masks = O.make_drop_masks("liGRU", opts, 8, "train", generator=g)
+    masks = O.make_drop_masks(kind, opts, 8, "train", generator=g)
     res = {}
     for prec in ("fp32", "bf16"):
         F_amd.set_precision(prec)
@@ -223,6 +227,42 @@ def test_bf16_mode_is_close():
         xe = x.clone().requires_grad_(True)
         y = net(xe, drop_masks=masks)
         y.square().sum().backward()
-        res[prec] = (y.detach().cpu(), xe.grad.cpu())
+        grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
+        res[prec] = (y.detach().cpu(), xe.grad.cpu(), grads)
     assert rel_err(res["bf16"][0], res["fp32"][0]) < 3e-2
     assert rel_err(res["bf16"][1], res["fp32"][1]) < 1e-1
+    for k, v in res["fp32"][2].items():
+        assert rel_err(res["bf16"][2][k], v) < 1e-1, k
+
+
+@pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("LSTM", "lstm", "tanh"), ("RNN", "rnn", "tanh")])
+@pytest.mark.parametrize("H,T,B,bidir", [(550, 12, 5, True), (40, 9, 3, True), (20, 7, 4, False), (14, 5, 33, True),
+                                         (129, 6, 2, True)])
+def test_bf16_persistent_matches_bf16_stepwise(kind, pre, act, H, T, B, bidir):
+    """The perf-mode persistent kernels (bf16 exchange through L2, MFMA B fragments in registers) and the
+    step-wise algorithm in bf16 mode round the same operands (h_{t-1}, dgates_{t+1}, U) to bf16 and
+    accumulate in fp32: they must agree far more tightly (5e-3) than bf16 vs fp32 does (3e-2)."""
+    from engine_util import F_amd, nn_amd
+
+    opts = _rec_opts(pre, [H, H], act, bidir=bidir)
+    torch.manual_seed(21)
+    net = getattr(nn_amd, kind)(opts, 23).cuda().train()
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(T, B, 23, generator=g).cuda()
+    masks = O.make_drop_masks(kind, opts, B, "train", generator=g)
+    cot = torch.randn(T, B, net.out_dim, generator=g).cuda()
+    F_amd.set_precision("bf16")
+    res = {}
+    for algo in ("stepwise", "persistent"):
+        F_amd.set_rec_algo(algo)
+        net.zero_grad()
+        xe = x.clone().requires_grad_(True)
+        y = net(xe, drop_masks=masks)
+        (y * cot).sum().backward()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
+        res[algo] = (y.detach().cpu(), xe.grad.cpu(), grads)
+    assert rel_err(res["persistent"][0], res["stepwise"][0]) < 5e-3
+    assert rel_err(res["persistent"][1], res["stepwise"][1]) < 2e-2
+    for k, v in res["stepwise"][2].items():
+        assert rel_err(res["persistent"][2][k], v) < 2e-2, k

@@ -187,6 +187,12 @@ int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, in
 int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
                     float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, uint16_t* dGb,
                     int64_t g_pitch);
+/* diagnostics: when non-NULL, cluster 0 / member 0 / wave 0 of every following launch writes
+ * T x 8 shader-clock stamps (phase boundaries of each step) to this device buffer. */
+void pk_persist2_set_trace(void* dev_buf);
+/* 0 (default): clusters whose workgroups all run on one XCD exchange through that XCD's L2 (plain
+ * stores + nt loads), others use write-through stores + agent-scope loads; 1: always the latter. */
+void pk_persist2_set_mode(int force_safe);
 unsigned pk_persist2_error_count(void);
 void pk_persist2_error_reset(void);
 

@@ -53,6 +53,8 @@ SIGNATURES = {
                            P, P, P, P]),
     "pk_rec_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, P, c_int64]),
     "pk_rec_bwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int64]),
+    "pk_persist2_set_trace": (None, [P]),
+    "pk_persist2_set_mode": (None, [c_int]),
     "pk_persist2_error_count": (ctypes.c_uint, []),
     "pk_persist2_error_reset": (None, []),
     "pk_conv1d_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),

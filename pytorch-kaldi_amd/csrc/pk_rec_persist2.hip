@@ -49,7 +49,16 @@ struct R2Args {
     int Gpitch;  // elements per row of dGb; gate g starts at g*Hp
     unsigned* err;
     int spin_limit;
+    float* trash;               // >= 64 bytes per lane-group of write-only scratch for masked-off stores
+    int force_safe;             // 1 = always use the placement-independent write-through exchange
+    unsigned* xcd_tab;          // [C][16] placement handshake words (0xFFFFFFFF before the launch)
+    unsigned long long* trace;  // optional [T][8] phase time stamps of (cluster 0, member 0, wave 0); null = off
 };
+
+#define PK_TRACE(slot)                                                                      \
+    do {                                                                                    \
+        if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 
 __device__ __forceinline__ bool has_sent16(const u32x4 v) {
     bool s = false;
@@ -78,27 +87,52 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 }
 
 // Poll NCH 16-byte chunks per lane (write-through loads) until none holds the sentinel, then store them to LDS.
-template <int NCH>
-__device__ __forceinline__ bool poll_to_lds(__amdgpu_buffer_rsrc_t rs, const unsigned (&goff)[NCH], const bool (&cv)[NCH],
-                                            const int (&loff)[NCH], unsigned char* tile, unsigned* err, int spin_limit,
-                                            int lane, bool dead) {
+// FAST (every member of the cluster sits on one XCD, decided by the start-up handshake): the
+// exchange stays inside that XCD's L2 - producers use plain stores (the line stays in L2), consumers
+// poll with nt loads (bypass the per-CU L1, served by L2).  Otherwise: write-through (sc1) stores
+// and agent-scope (sc1) loads, correct for any placement.  Placement only ever changes the speed.
+//
+// vmcnt is ONE counter for loads and stores on gfx9-class hardware and the two kinds retire out of order
+// with respect to each other, so a counted wait cannot tell a landed poll from an acknowledged store:
+// the poll data is only safe behind s_waitcnt vmcnt(0).  The step is therefore ordered so that everything
+// still in flight at that point is old: the fp32 output stores of step t-1 and the prefetch loads of
+// step t+1 are issued right AFTER the poll of step t has landed (a whole MFMA + gate phase before the
+// next poll); only the 16-byte publish store is young.
+template <bool FAST>
+__device__ __forceinline__ u32x4 poll_load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return FAST ? __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 2) : __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+}
+template <bool FAST>
+__device__ __forceinline__ void pub_store(__amdgpu_buffer_rsrc_t rs, unsigned off, u32x4 v) {
+    if (FAST) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
+}
+
+// Poll NCH 16-byte chunks per lane until none holds the sentinel, then store them to the LDS tile.
+// Chunk slots a lane does not own alias one of the cluster's real chunks (harmless duplicate read) and
+// land in an LDS trash slot, which keeps the code branch-free.  (The loads are compiler-visible on
+// purpose: with inline-asm loads nothing stops the register allocator from copying a destination register
+// before the s_waitcnt that makes it valid.)
+template <int NCH, bool FAST>
+__device__ __forceinline__ bool poll_to_lds(__amdgpu_buffer_rsrc_t rs, const unsigned (&goff)[NCH], const int (&loff)[NCH],
+                                            unsigned char* tile, unsigned* err, int spin_limit, int lane, bool dead,
+                                            int& retries) {
     u32x4 v[NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        v[i] = u32x4{0u, 0u, 0u, 0u};
-        if (cv[i]) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i], 0, 16);
-    }
-    if (!dead) {
+    for (int i = 0; i < NCH; ++i) v[i] = poll_load<FAST>(rs, goff[i]);
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) bad = bad | has_sent16(v[i]);
+    if (__any(bad) && !dead) {
         int spins = 0;
         while (true) {
-            bool bad = false;
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                if (cv[i] && has_sent16(v[i])) {
-                    v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[i], 0, 16);
-                    bad = bad || has_sent16(v[i]);
-                }
-            }
+            for (int i = 0; i < NCH; ++i)
+                if (has_sent16(v[i])) v[i] = poll_load<FAST>(rs, goff[i]);
+            bad = false;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) bad = bad | has_sent16(v[i]);
+            ++retries;
             if (!__any(bad)) break;
             if (spin_check2(spins, spin_limit, err, lane)) {
                 dead = true;
@@ -107,10 +141,99 @@ __device__ __forceinline__ bool poll_to_lds(__amdgpu_buffer_rsrc_t rs, const uns
         }
     }
 #pragma unroll
-    for (int i = 0; i < NCH; ++i)
-        if (cv[i]) *reinterpret_cast<u32x4*>(tile + loff[i]) = v[i];
+    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(tile + loff[i]) = v[i];
     return dead;
 }
+
+// One-time placement handshake: every member publishes the XCD it runs on (write-through) and
+// reads all members' words (agent scope); all members see the same words, hence take the same
+// decision.  Returns true when the whole cluster shares one XCD.
+__device__ __forceinline__ bool cluster_on_one_xcd(const R2Args& a, int c, int p, int tid, bool& dead) {
+    const unsigned my = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;  // HW_REG_XCC_ID
+    unsigned* tab = a.xcd_tab + c * 16;
+    if (tid == 0) __hip_atomic_store(tab + p, my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int same = 1;
+    if (tid < a.Pn) {
+        unsigned v = 0xFFFFFFFFu;
+        for (int spins = 0; spins < a.spin_limit; ++spins) {
+            v = __hip_atomic_load(tab + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 0xFFFFFFFFu) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (v == 0xFFFFFFFFu) {
+            atomicAdd_system(a.err, 1u);
+            same = 0;
+            dead = true;
+        } else {
+            same = (v == my) ? 1 : 0;
+        }
+    }
+    return __syncthreads_and(same) != 0;
+}
+
+// workgroup barrier that orders LDS only: __syncthreads() also drains vmcnt, i.e. it would wait for
+// the prefetch loads issued just before it (HBM latency on the dependency chain)
+#define PK_BARRIER_LDS()                               \
+    do {                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                  \
+        asm volatile("" ::: "memory");                 \
+    } while (0)
+
+// ---- wave-private fp32 patches [16 rows][16 units] in LDS: the transposer between the MFMA C/D
+// layout (lane -> rows kq*4+r, unit lane&15: what the gate math works in) and the "vector" layout
+// (lane -> row lane>>2, 4 consecutive units: one 16-byte global access per lane, 1 KB per wave
+// instruction).  4-byte-per-lane global accesses cost the same issue slot as 16-byte ones and were
+// 60 % of a step; LDS round trips are an order of magnitude cheaper.
+__device__ __forceinline__ void patch_put_cd(float* patch, int kq, int lane, const float (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) patch[(kq * 4 + r) * 16 + (lane & 15)] = v[r];
+}
+__device__ __forceinline__ void patch_get_cd(const float* patch, int kq, int lane, float (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = patch[(kq * 4 + r) * 16 + (lane & 15)];
+}
+__device__ __forceinline__ f32x4 patch_get_vec(const float* patch, int lane) {
+    return *reinterpret_cast<const f32x4*>(patch + (lane >> 2) * 16 + (lane & 3) * 4);
+}
+__device__ __forceinline__ void patch_put_vec(float* patch, int lane, f32x4 v) {
+    *reinterpret_cast<f32x4*>(patch + (lane >> 2) * 16 + (lane & 3) * 4) = v;
+}
+#define PK_LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// 16-byte (4 unit) global access of the vector layout; nv = number of valid units (edge of H).
+// Straight-line code: invalid lanes / elements are redirected (loads: to the tensor base, result
+// unused; stores: to a library-owned trash page) instead of being branched around, so that the compiler
+// can count the outstanding operations exactly - a divergent store makes it fall back to
+// s_waitcnt vmcnt(0), which would put the store acknowledgements back on the dependency chain.
+// Plain 64-bit addressing (no buffer descriptors: four of them per kernel exhaust the SGPRs and the
+// compiler then wraps every access in a waterfall loop).
+// EDGE is wave-uniform: true only for the one wave whose 16 units straddle H when H % 4 != 0; it uses
+// four 4-byte accesses per lane, every other wave a single 16-byte access.
+template <bool EDGE>
+__device__ __forceinline__ f32x4 ld4(const float* base, unsigned off, int nv) {
+    if (!EDGE) {
+        return *reinterpret_cast<const f32x4*>(base + (nv == 4 ? off : 0u));
+    } else {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = base[e < nv ? off + e : 0u];
+        return v;
+    }
+}
+template <bool EDGE>
+__device__ __forceinline__ void st4(float* base, unsigned off, int nv, float* trash, f32x4 v) {
+    if (!EDGE) {
+        *reinterpret_cast<f32x4*>(nv == 4 ? base + off : trash) = v;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *(e < nv ? base + off + e : trash + e) = v[e];
+    }
+}
+template <bool B>
+struct BoolC {
+    static constexpr bool value = B;
+};
 
 // ============================================================================
 // forward
@@ -121,7 +244,9 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     constexpr int LDA = KPAD + 8;                 // bf16 elements per A-tile row (1168 B: odd multiple of 16 B)
     constexpr int ATILE = RMAX * LDA * 2;         // bytes
     constexpr int NCH = (RMAX * (KPAD / 8) + 255) / 256;  // 16-byte chunks polled per lane (5)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][ATILE] | pack [4][16][16] bf16
+    constexpr int WAVE_LDS = (G + 1 + NS) * 1024 + 512;   // P stage | Y | S slots | bf16 publish patch
+    constexpr int LDS_TRASH = 2 * ATILE + 4 * WAVE_LDS;   // 16-byte dump slot for chunks a lane does not own
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][ATILE] | 4 x WAVE_LDS | trash
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x % a.C, p = blockIdx.x / a.C;
@@ -130,85 +255,129 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     int nrows = a.R - n_base;
     nrows = nrows < a.rpc ? nrows : a.rpc;
     if (nrows <= 0) return;  // whole workgroup (uniform): this cluster has no rows
-    const int unit = p * 64 + wave * 16 + (lane & 15);
+    const int ubase = p * 64 + wave * 16;
+    const int unit = ubase + (lane & 15);
     const bool unit_ok = unit < H;
     const int kq = lane >> 4;
 
     // ---- recurrent weights of my 16 units -> registers (once): B[k][n] = U_g[unit n][k]
     bf16x8 Bf[G][KSTEPS];
+    {
+        const unsigned szU = (unsigned)((size_t)G * H * H * 4);
+        const __amdgpu_buffer_rsrc_t rsU = make_rsrc(a.U, szU);
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+        for (int g = 0; g < G; ++g) {
+            u32x4 raw[KSTEPS][2];
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            bf16x8 f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = kk * 32 + kq * 8 + e;
-                const float w = (unit_ok && k < H) ? a.U[((long)(g * H + unit)) * H + k] : 0.f;
-                f[e] = (short)pk_f2bf(w);
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const int k0 = kk * 32 + kq * 8;
+                const unsigned off = (unsigned)(((g * H + unit) * H + k0) * 4);
+                raw[kk][0] = __builtin_amdgcn_raw_buffer_load_b128(rsU, (unit_ok && k0 < H) ? off : szU, 0, 0);
+                raw[kk][1] = __builtin_amdgcn_raw_buffer_load_b128(rsU, (unit_ok && k0 + 4 < H) ? off + 16 : szU, 0, 0);
             }
-            Bf[g][kk] = f;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                bf16x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = kk * 32 + kq * 8 + e;
+                    const float w = (k < H) ? __uint_as_float(raw[kk][e >> 2][e & 3]) : 0.f;  // beyond H: the next row's data
+                    f[e] = (short)pk_f2bf(w);
+                }
+                Bf[g][kk] = f;
+            }
         }
+    }
     float psc[G], psh[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         psc[g] = unit_ok ? a.pscale[g * H + unit] : 0.f;
         psh[g] = unit_ok ? a.pshift[g * H + unit] : 0.f;
     }
-    for (int i = tid; i < (2 * ATILE + 4 * 512) / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+    for (int i = tid; i < (LDS_TRASH + 16) / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;
 
     // ---- poll descriptors: chunk ci = (row, col) of the cluster's [nrows][Hp/8] block of h_{t-1}
     const int CPR = Hp >> 3;
     const unsigned TS = (unsigned)B * a.Ypitch * 2u;  // bytes per time slab of Yb
-    unsigned cbase[NCH];
-    int cdir[NCH], clds[NCH];
-    bool cv[NCH];
+    const unsigned szYb = (unsigned)T * TS;
+    unsigned cbase[NCH], cstep[NCH];  // byte offset at step 1 and its increment per step (out of range: not my chunk)
+    int clds[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ci = tid + 256 * i;
-        cv[i] = ci < nrows * CPR;
-        const int row = cv[i] ? ci / CPR : 0, col = cv[i] ? ci - row * CPR : 0;
+        const int ci = tid + 256 * i, nck = nrows * CPR;
+        const bool ok = ci < nck;
+        const int cj = ok ? ci : ci % nck;  // not my chunk: alias a real one (duplicate read, dumped in LDS)
+        const int row = cj / CPR, col = cj - row * CPR;
         const int n = n_base + row;
         const int dir = n >= B ? 1 : 0, b = n - dir * B;
-        cdir[i] = dir;
-        cbase[i] = ((unsigned)b * a.Ypitch + dir * Hp + col * 8) * 2u;
-        clds[i] = row * (LDA * 2) + col * 16;
+        // step t reads storage time (dir ? T-t : t-1)
+        cbase[i] = ((unsigned)b * a.Ypitch + dir * Hp + col * 8) * 2u + (unsigned)(dir ? (T - 1) : 0) * TS;
+        cstep[i] = dir ? 0u - TS : TS;
+        clds[i] = ok ? row * (LDA * 2) + col * 16 : LDS_TRASH;
     }
-    // ---- my (row, unit) pairs of the gate math: C/D layout row = kq*4 + r, col = lane&15
-    bool rv[4];
-    int rdir[4], rb[4];
-    float msk[4], hprev[4], cprev[4];
+    // ---- gate-math (C/D) layout: rows kq*4 + r, unit lane&15
+    float rvf[4], msk[4], hprev[4], cprev[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = kq * 4 + r, n = n_base + row;
-        rv[r] = row < nrows && unit_ok;
-        rdir[r] = n >= B ? 1 : 0;
-        rb[r] = n - rdir[r] * B;
-        msk[r] = (a.mask != nullptr && rv[r]) ? a.mask[(long)n * H + unit] : a.mask_scalar;
+        const bool ok = row < nrows && unit_ok;
+        rvf[r] = ok ? 1.f : 0.f;
+        msk[r] = (a.mask != nullptr && ok) ? a.mask[(long)n * H + unit] : a.mask_scalar;
         hprev[r] = 0.f;
         cprev[r] = 0.f;
     }
-    // ---- publish descriptors: lanes 0..31 store one 16-byte piece (row, 8 units) of the wave's patch
+    // ---- vector layout: row lane>>2, units ubase + (lane&3)*4 .. +3
+    const int vrow = lane >> 2, vu0 = ubase + (lane & 3) * 4;
+    const int vn = n_base + (vrow < nrows ? vrow : 0);
+    const int vdir = vn >= B ? 1 : 0, vb = vn - vdir * B;
+    int vnv = H - vu0;
+    vnv = vnv > 4 ? 4 : (vnv < 0 ? 0 : vnv);
+    const bool edge = __any(vnv > 0 && vnv < 4) != 0;  // wave-uniform: my 16 units straddle H
+    vnv = vrow < nrows ? vnv : 0;
+    // element offsets of my 4 units at storage time 0 / per unit of storage time, for P, Y and S
+    const unsigned vP0 = ((unsigned)vb * GH + vu0), vPs = (unsigned)B * GH;
+    const unsigned vY0 = ((unsigned)vb * a.YH + vdir * H + vu0), vYs = (unsigned)B * a.YH;
+    const unsigned vS0 = (((unsigned)vdir * T * B + vb) * (NS * H) + vu0), vSs = (unsigned)B * NS * H;
+    // ---- publish descriptors: lanes 0..31 store one 16-byte piece (row, 8 units) of the wave's bf16 patch
     const int prow = lane >> 1, phalf = lane & 1;
-    const int pu0 = p * 64 + wave * 16 + phalf * 8;
+    const int pu0 = ubase + phalf * 8;
     const bool pk_ok = lane < 32 && prow < nrows && pu0 < Hp;
     const int pn = n_base + (prow < nrows ? prow : 0);
     const int pdir = pn >= B ? 1 : 0, pb = pn - pdir * B;
-    const unsigned pbase = ((unsigned)pb * a.Ypitch + pdir * Hp + pu0) * 2u;
-    unsigned short* patch = reinterpret_cast<unsigned short*>(smem + 2 * ATILE + wave * 512);
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.Yb, (unsigned)T * TS);
+    const unsigned pbase = pk_ok ? ((unsigned)pb * a.Ypitch + pdir * Hp + pu0) * 2u : szYb;  // out of range: dropped
 
-    float pre[4][G];
+    unsigned char* wl = smem + 2 * ATILE + wave * WAVE_LDS;
+    float* patchP = reinterpret_cast<float*>(wl);                     // [G][256]
+    float* patchY = reinterpret_cast<float*>(wl + G * 1024);          // [256]
+    float* patchS = reinterpret_cast<float*>(wl + (G + 1) * 1024);    // [NS][256]
+    unsigned short* patchB = reinterpret_cast<unsigned short*>(wl + (G + 1 + NS) * 1024);  // [16][16] bf16
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.Yb, szYb);
+    float* trash = a.trash + (tid & 63) * 4;
+
+    // projections of step tt (vector layout; staged to the gate-math layout at the top of that step)
+    f32x4 pv[G];
+    auto load_proj = [&](int tt, auto E) {
+        const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const long pr0 = (long)(rdir[r] ? (T - 1) : 0) * B + rb[r];
+        for (int g = 0; g < G; ++g) pv[g] = ld4<decltype(E)::value>(a.P, vP0 + ts * vPs + g * H, vnv);
+    };
+    // layer output and saved gates of step tt: wave patches -> HBM, 16 bytes per lane
+    auto flush_outputs = [&](int tt, auto E) {
+        constexpr bool EE = decltype(E)::value;
+        const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
+        st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchY, lane));
 #pragma unroll
-        for (int g = 0; g < G; ++g) pre[r][g] = rv[r] ? a.P[pr0 * GH + g * H + unit] : 0.f;
-    }
+        for (int k = 0; k < NS; ++k) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, patch_get_vec(patchS + k * 256, lane));
+    };
+    if (edge) load_proj(0, BoolC<true>());
+    else load_proj(0, BoolC<false>());
     __syncthreads();
 
     bool dead = false;
+    const bool fast = cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0;
     for (int t = 0; t < T; ++t) {
+        const int step_idx = t;
+        PK_TRACE(0);
         f32x4 acc[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -216,21 +385,27 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
         if (t > 0) {
             unsigned goff[NCH];
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) goff[i] = cbase[i] + (unsigned)(cdir[i] ? (T - t) : (t - 1)) * TS;
-            dead = poll_to_lds<NCH>(rs, goff, cv, clds, At, a.err, a.spin_limit, lane, dead);
+            for (int i = 0; i < NCH; ++i) goff[i] = cbase[i] + (unsigned)(t - 1) * cstep[i];
+            int retries = 0;
+            dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries)
+                        : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries);
+            if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
+            // fp32 outputs of the previous step: issued now, they have a whole step to drain before the next poll
+            if (edge) flush_outputs(t - 1, BoolC<true>());
+            else flush_outputs(t - 1, BoolC<false>());
         }
-        // projections of step t+1: issued now, consumed after the next poll
-        float pnx[4][G];
+        PK_TRACE(1);
+        // stage this step's projections (loaded one step ago) into the gate-math layout ...
+#pragma unroll
+        for (int g = 0; g < G; ++g) patch_put_vec(patchP + g * 256, lane, pv[g]);
+        // ... and issue the loads of step t+1 now: they are consumed after the next poll
         if (t + 1 < T) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long pr1 = (long)(rdir[r] ? (T - 2 - t) : (t + 1)) * B + rb[r];
-#pragma unroll
-                for (int g = 0; g < G; ++g) pnx[r][g] = rv[r] ? a.P[pr1 * GH + g * H + unit] : 0.f;
-            }
+            if (edge) load_proj(t + 1, BoolC<true>());
+            else load_proj(t + 1, BoolC<false>());
         }
         if (t > 0) {
-            __syncthreads();
+            PK_BARRIER_LDS();
+            PK_TRACE(2);
             const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -238,42 +413,50 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, Bf[g][kk], acc[g], 0, 0, 0);
             }
+        } else {
+            PK_LDS_ORDER();
         }
+        PK_TRACE(3);
         // ---- gate math for my (row, unit) pairs
+        float pre[G][4];
+#pragma unroll
+        for (int g = 0; g < G; ++g) patch_get_cd(patchP + g * 256, kq, lane, pre[g]);
+        float hv[4], sv[NS][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float pr[G];
 #pragma unroll
-            for (int g = 0; g < G; ++g) pr[g] = pre[r][g] * psc[g] + psh[g] + acc[g][r];
+            for (int g = 0; g < G; ++g) pr[g] = pre[g][r] * psc[g] + psh[g] + acc[g][r];
             float h, cc, s[NS];
             pk_cell_fwd<CELL>(a.act, pr, hprev[r], cprev[r], msk[r], h, cc, s);
-            unsigned short hb = 0;
-            if (rv[r]) {
-                hprev[r] = h;
-                cprev[r] = cc;
-                hb = to_bf_pub(h);
-                const long prw = (long)(rdir[r] ? (T - 1 - t) : t) * B + rb[r];
-                a.Y[prw * a.YH + rdir[r] * H + unit] = h;
-                float* sp = a.S + ((long)rdir[r] * T * B + prw) * (NS * H) + unit;
+            h = rvf[r] != 0.f ? h : 0.f;  // rows / units outside the layer carry exact zeros (published as padding)
+            cc = rvf[r] != 0.f ? cc : 0.f;
+            hprev[r] = h;
+            cprev[r] = cc;
+            hv[r] = h;
 #pragma unroll
-                for (int k = 0; k < NS; ++k) sp[k * H] = s[k];
-            }
-            patch[(kq * 4 + r) * 16 + (lane & 15)] = hb;
+            for (int k = 0; k < NS; ++k) sv[k][r] = s[k];
+            patchB[(kq * 4 + r) * 16 + (lane & 15)] = to_bf_pub(h);
         }
-        // ---- publish h_t: 8 units per lane, one write-through 16-byte store
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (pk_ok) {
-            const u32x4 o = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(patch) + prow * 32 + phalf * 16);
-            const unsigned off = pbase + (unsigned)(pdir ? (T - 1 - t) : t) * TS;
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs, off, 0, 16);
+        PK_TRACE(4);
+        // ---- publish h_t first: it is what the other workgroups of the cluster wait for
+        PK_LDS_ORDER();
+        {
+            const u32x4 o = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(patchB) + (prow & 15) * 32 + phalf * 16);
+            const unsigned off = pbase + (pk_ok ? (unsigned)(pdir ? (T - 1 - t) : t) * TS : 0u);
+            if (fast) pub_store<true>(rs, off, o);
+            else pub_store<false>(rs, off, o);
         }
-        if (t + 1 < T) {
+        // ---- the fp32 outputs (layer output, gates saved for backward) go to the wave patches; they are
+        // written to HBM at the top of the next step, behind its poll loads
+        patch_put_cd(patchY, kq, lane, hv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int g = 0; g < G; ++g) pre[r][g] = pnx[r][g];
-        }
+        for (int k = 0; k < NS; ++k) patch_put_cd(patchS + k * 256, kq, lane, sv[k]);
+        PK_LDS_ORDER();
+        PK_TRACE(5);
     }
+    if (edge) flush_outputs(T - 1, BoolC<true>());
+    else flush_outputs(T - 1, BoolC<false>());
 }
 
 // ============================================================================
@@ -282,115 +465,168 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
 template <int CELL>
 __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
+    constexpr bool LSTM = (CELL == PK_CELL_LSTM);
     constexpr int LDA = G * KPAD + 8;
     constexpr int ATILE = RMAX * LDA * 2;
+    constexpr int NBUF = (2 * ATILE > 96 * 1024) ? 1 : 2;  // LSTM: one A tile (74 KB) + an extra barrier per step
     constexpr int NCH = (RMAX * G * (KPAD / 8) + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][ATILE] | pack [4][G][16][16] bf16
+    constexpr int NIN = NS + 2 + (LSTM ? 1 : 0);            // saved gates, h_{t-1}, dY (, c_{t-1})
+    constexpr int WAVE_LDS = (NIN + G) * 1024 + G * 512;    // input patches | dgate fp32 patches | dgate bf16 patches
+    constexpr int LDS_TRASH = NBUF * ATILE + 4 * WAVE_LDS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x % a.C, p = blockIdx.x / a.C;
     const int H = a.H, Hp = a.Hp, B = a.B, T = a.T, GH = G * H;
-    const long TB = (long)T * B;
+    const unsigned TB = (unsigned)T * B;
     const int n_base = a.row0 + c * a.rpc;
     int nrows = a.R - n_base;
     nrows = nrows < a.rpc ? nrows : a.rpc;
     if (nrows <= 0) return;
-    const int unit = p * 64 + wave * 16 + (lane & 15);
+    const int ubase = p * 64 + wave * 16;
+    const int unit = ubase + (lane & 15);
     const bool unit_ok = unit < H;
     const int kq = lane >> 4;
 
     // B[kidx = (g, j)][n = unit] = U_g[j][unit]
     bf16x8 Bf[G][KSTEPS];
+    {
+        const unsigned szU = (unsigned)((size_t)G * H * H * 4);
+        const __amdgpu_buffer_rsrc_t rsU = make_rsrc(a.U, szU);
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+        for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            bf16x8 f;
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                unsigned raw[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int j = kk * 32 + kq * 8 + e;
-                const float w = (unit_ok && j < H) ? a.U[((long)(g * H + j)) * H + unit] : 0.f;
-                f[e] = (short)pk_f2bf(w);
+                for (int e = 0; e < 8; ++e) {
+                    const int j = kk * 32 + kq * 8 + e;
+                    raw[e] = __builtin_amdgcn_raw_buffer_load_b32(rsU, (unit_ok && j < H) ? (unsigned)(((g * H + j) * H + unit) * 4) : szU, 0, 0);
+                }
+                bf16x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (short)pk_f2bf(__uint_as_float(raw[e]));
+                Bf[g][kk] = f;
             }
-            Bf[g][kk] = f;
-        }
-    for (int i = tid; i < (2 * ATILE + 4 * G * 512) / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+    }
+    for (int i = tid; i < (LDS_TRASH + 16) / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;
 
     // ---- poll descriptors: chunk ci = (row, gate, col) of the cluster's dgates_{t+1} block
     const int CPR = Hp >> 3;
     const unsigned TS = (unsigned)B * a.Gpitch * 2u;  // bytes per time slab of dGb
-    unsigned cbase[NCH];
-    int cdir[NCH], clds[NCH];
-    bool cv[NCH];
+    const unsigned ndir = (unsigned)(a.R / B);
+    const unsigned szGb = ndir * (unsigned)T * TS;
+    unsigned cbase[NCH], cstep[NCH];  // byte offset of the first polled step and its increment per iteration
+    int clds[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ci = tid + 256 * i;
-        cv[i] = ci < nrows * G * CPR;
-        const int row = cv[i] ? ci / (G * CPR) : 0;
-        const int rem = cv[i] ? ci - row * (G * CPR) : 0;
+        const int ci = tid + 256 * i, nck = nrows * G * CPR;
+        const bool ok = ci < nck;
+        const int cj = ok ? ci : ci % nck;  // not my chunk: alias a real one (duplicate read, dumped in LDS)
+        const int row = cj / (G * CPR);
+        const int rem = cj - row * (G * CPR);
         const int g = rem / CPR, col = rem - g * CPR;
         const int n = n_base + row;
         const int dir = n >= B ? 1 : 0, b = n - dir * B;
-        cdir[i] = dir;
-        cbase[i] = (unsigned)dir * (unsigned)T * TS + ((unsigned)b * a.Gpitch + g * Hp + col * 8) * 2u;
-        clds[i] = row * (LDA * 2) + (g * KPAD + col * 8) * 2;
+        // iteration it (t = T-1-it, it >= 1) reads storage time (dir ? T-2-t : t+1) = (dir ? it-1 : T-it)
+        cbase[i] = (unsigned)dir * (unsigned)T * TS + ((unsigned)b * a.Gpitch + g * Hp + col * 8) * 2u +
+                   (unsigned)(dir ? 0 : (T - 1)) * TS;
+        cstep[i] = dir ? TS : 0u - TS;
+        clds[i] = ok ? row * (LDA * 2) + (g * KPAD + col * 8) * 2 : LDS_TRASH;
     }
-    bool rv[4];
-    int rdir[4], rb[4];
-    float msk[4], dh_dir[4], dc_car[4];
+    float rvf[4], msk[4], dh_dir[4], dc_car[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = kq * 4 + r, n = n_base + row;
-        rv[r] = row < nrows && unit_ok;
-        rdir[r] = n >= B ? 1 : 0;
-        rb[r] = n - rdir[r] * B;
-        msk[r] = (a.mask != nullptr && rv[r]) ? a.mask[(long)n * H + unit] : a.mask_scalar;
+        const bool ok = row < nrows && unit_ok;
+        rvf[r] = ok ? 1.f : 0.f;
+        msk[r] = (a.mask != nullptr && ok) ? a.mask[(long)n * H + unit] : a.mask_scalar;
         dh_dir[r] = 0.f;
         dc_car[r] = 0.f;
     }
+    const int vrow = lane >> 2, vu0 = ubase + (lane & 3) * 4;
+    const int vn = n_base + (vrow < nrows ? vrow : 0);
+    const int vdir = vn >= B ? 1 : 0, vb = vn - vdir * B;
+    int vnv = H - vu0;
+    vnv = vnv > 4 ? 4 : (vnv < 0 ? 0 : vnv);
+    const bool edge = __any(vnv > 0 && vnv < 4) != 0;  // wave-uniform: my 16 units straddle H
+    vnv = vrow < nrows ? vnv : 0;
+    const unsigned vY0 = ((unsigned)vb * a.YH + vdir * H + vu0), vYs = (unsigned)B * a.YH;
+    const unsigned vS0 = (((unsigned)vdir * TB + vb) * (NS * H) + vu0), vSs = (unsigned)B * NS * H;
+    const unsigned vG0 = (((unsigned)vdir * TB + vb) * GH + vu0), vGs = (unsigned)B * GH;
     const int prow = lane >> 1, phalf = lane & 1;
-    const int pu0 = p * 64 + wave * 16 + phalf * 8;
+    const int pu0 = ubase + phalf * 8;
     const bool pk_ok = lane < 32 && prow < nrows && pu0 < Hp;
     const int pn = n_base + (prow < nrows ? prow : 0);
     const int pdir = pn >= B ? 1 : 0, pb = pn - pdir * B;
-    const unsigned pbase = (unsigned)pdir * (unsigned)T * TS + ((unsigned)pb * a.Gpitch + pu0) * 2u;
-    unsigned short* patch = reinterpret_cast<unsigned short*>(smem + 2 * ATILE + wave * (G * 512));
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dGb, (unsigned)(a.R / B) * (unsigned)T * TS);
+    const unsigned pbase = pk_ok ? (unsigned)pdir * (unsigned)T * TS + ((unsigned)pb * a.Gpitch + pu0) * 2u : szGb;
 
-    // saved tensors of one step for my (row, unit) pairs
-    float sv[4][NS], hp[4], cp[4], dy[4];
-    auto load_step = [&](int t, float (&sv_)[4][NS], float (&hp_)[4], float (&cp_)[4], float (&dy_)[4]) {
+    unsigned char* wl = smem + NBUF * ATILE + wave * WAVE_LDS;
+    float* patchI = reinterpret_cast<float*>(wl);                       // [NIN][256]: S slots, hp, dY (, cp)
+    float* patchG = reinterpret_cast<float*>(wl + NIN * 1024);          // [G][256] fp32 gate gradients
+    unsigned short* patchB = reinterpret_cast<unsigned short*>(wl + (NIN + G) * 1024);  // [G][16][16] bf16
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dGb, szGb);
+    float* trash = a.trash + (tid & 63) * 4;
+
+    // saved tensors of one step in the vector layout: [0..NS) gates, NS = h_{t-1}, NS+1 = dY, NS+2 = c_{t-1}
+    f32x4 iv[NIN];
+    auto load_step_e = [&](int t, auto E) {
+        constexpr bool EE = decltype(E)::value;
+        const unsigned ts = (unsigned)(vdir ? (T - 1 - t) : t);
+        const unsigned tp = t > 0 ? (vdir ? ts + 1 : ts - 1) : ts;  // storage time of step t-1 (any valid row when t == 0)
+        const int nvp = t > 0 ? vnv : 0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ts = rdir[r] ? (T - 1 - t) : t;
-            const long prw = (long)ts * B + rb[r];
-            const long srow = (long)rdir[r] * TB + prw;
-            const long prev = (long)(rdir[r] ? ts + 1 : ts - 1) * B + rb[r];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) sv_[r][k] = rv[r] ? a.S[srow * (NS * H) + k * H + unit] : 0.f;
-            hp_[r] = (rv[r] && t > 0) ? a.Y[prev * a.YH + rdir[r] * H + unit] : 0.f;
-            cp_[r] = (CELL == PK_CELL_LSTM && rv[r] && t > 0) ? a.S[((long)rdir[r] * TB + prev) * (NS * H) + 4 * H + unit] : 0.f;
-            dy_[r] = rv[r] ? a.dY[prw * a.YH + rdir[r] * H + unit] : 0.f;
+        for (int k = 0; k < NS; ++k) iv[k] = ld4<EE>(a.S, vS0 + ts * vSs + k * H, vnv);
+        iv[NS] = ld4<EE>(a.Y, vY0 + tp * vYs, nvp);
+        iv[NS + 1] = ld4<EE>(a.dY, vY0 + ts * vYs, vnv);
+        if (LSTM) iv[NIN - 1] = ld4<EE>(a.S, vS0 + tp * vSs + 4 * H, nvp);
+        if (t == 0) {  // h_{-1} = c_{-1} = 0
+            iv[NS] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (LSTM) iv[NIN - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    load_step(T - 1, sv, hp, cp, dy);
+    auto load_step = [&](int t) {
+        if (edge) load_step_e(t, BoolC<true>());
+        else load_step_e(t, BoolC<false>());
+    };
+    auto flush_outputs_e = [&](int tt, auto E) {
+        const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            st4<decltype(E)::value>(a.dP2, vG0 + ts * vGs + g * H, vnv, trash, patch_get_vec(patchG + g * 256, lane));
+    };
+    auto flush_outputs = [&](int tt) {
+        if (edge) flush_outputs_e(tt, BoolC<true>());
+        else flush_outputs_e(tt, BoolC<false>());
+    };
+    load_step(T - 1);
     __syncthreads();
 
     bool dead = false;
+    const bool fast = cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0;
     int it = 0;
     for (int t = T - 1; t >= 0; --t, ++it) {
+        const int step_idx = it;
+        PK_TRACE(0);
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        unsigned char* At = smem + (it & 1) * ATILE;
+        unsigned char* At = smem + (NBUF == 2 ? (it & 1) * ATILE : 0);
         if (t < T - 1) {
             unsigned goff[NCH];
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) goff[i] = cbase[i] + (unsigned)(cdir[i] ? (T - 2 - t) : (t + 1)) * TS;
-            dead = poll_to_lds<NCH>(rs, goff, cv, clds, At, a.err, a.spin_limit, lane, dead);
+            for (int i = 0; i < NCH; ++i) goff[i] = cbase[i] + (unsigned)(it - 1) * cstep[i];
+            int retries = 0;
+            dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries)
+                        : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries);
+            if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
+            flush_outputs(t + 1);  // fp32 gate gradients of the previous step: a whole step to drain
         }
-        float svn[4][NS], hpn[4], cpn[4], dyn[4];
-        if (t > 0) load_step(t - 1, svn, hpn, cpn, dyn);
+        PK_TRACE(1);
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) patch_put_vec(patchI + k * 256, lane, iv[k]);
+        if (t > 0) load_step(t - 1);
         if (t < T - 1) {
-            __syncthreads();
+            PK_BARRIER_LDS();
+            PK_TRACE(2);
             const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
 #pragma unroll
             for (int g = 0; g < G; ++g)
@@ -400,49 +636,66 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
                     if ((kk & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, Bf[g][kk], acc0, 0, 0, 0);
                     else acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, Bf[g][kk], acc1, 0, 0, 0);
                 }
+            if (NBUF == 1) PK_BARRIER_LDS();  // single A tile: everyone is done reading before the next poll refills it
+        } else {
+            PK_LDS_ORDER();
         }
+        PK_TRACE(3);
+        float sin[NIN][4];
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) patch_get_cd(patchI + k * 256, kq, lane, sin[k]);
+        float dgv[G][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float dh = dy[r] + dh_dir[r] + acc0[r] + acc1[r];
+            float s[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) s[k] = sin[k][r];
+            const float hp = sin[NS][r], dy = sin[NS + 1][r];
+            const float cp = LSTM ? sin[NIN - 1][r] : 0.f;
+            const float dh = dy + dh_dir[r] + acc0[r] + acc1[r];
             float dg[G], dhd, dcp;
-            pk_cell_bwd<CELL>(a.act, sv[r], hp[r], cp[r], msk[r], dh, dc_car[r], dg, dhd, dcp);
-            if (rv[r]) {
-                dh_dir[r] = dhd;
-                dc_car[r] = dcp;
-                const long prw = (long)(rdir[r] ? (T - 1 - t) : t) * B + rb[r];
-                float* o = a.dP2 + ((long)rdir[r] * TB + prw) * GH + unit;
-#pragma unroll
-                for (int g = 0; g < G; ++g) o[g * H] = dg[g];
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) patch[g * 256 + (kq * 4 + r) * 16 + (lane & 15)] = rv[r] ? to_bf_pub(dg[g]) : (unsigned short)0;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (pk_ok) {
-            const unsigned off = pbase + (unsigned)(pdir ? (T - 1 - t) : t) * TS;
+            pk_cell_bwd<CELL>(a.act, s, hp, cp, msk[r], dh, dc_car[r], dg, dhd, dcp);
+            // rows / units outside the layer: exact zeros (select, not multiply: their inputs are arbitrary)
+            dh_dir[r] = rvf[r] != 0.f ? dhd : 0.f;
+            dc_car[r] = rvf[r] != 0.f ? dcp : 0.f;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const u32x4 o = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(patch) + g * 512 + prow * 32 + phalf * 16);
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs, off + (unsigned)(g * Hp) * 2u, 0, 16);
+                const float d = rvf[r] != 0.f ? dg[g] : 0.f;
+                dgv[g][r] = d;
+                patchB[g * 256 + (kq * 4 + r) * 16 + (lane & 15)] = to_bf_pub(d);
             }
         }
-        if (t > 0) {
+        PK_TRACE(4);
+        PK_LDS_ORDER();
+        {
+            const unsigned off = pbase + (pk_ok ? (unsigned)(pdir ? (T - 1 - t) : t) * TS : 0u);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) sv[r][k] = svn[r][k];
-                hp[r] = hpn[r];
-                cp[r] = cpn[r];
-                dy[r] = dyn[r];
+            for (int g = 0; g < G; ++g) {
+                const u32x4 o = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(patchB) + g * 512 + (prow & 15) * 32 + phalf * 16);
+                const unsigned og = off + (pk_ok ? (unsigned)(g * Hp) * 2u : 0u);
+                if (fast) pub_store<true>(rs, og, o);
+                else pub_store<false>(rs, og, o);
             }
         }
+#pragma unroll
+        for (int g = 0; g < G; ++g) patch_put_cd(patchG + g * 256, kq, lane, dgv[g]);
+        PK_LDS_ORDER();
+        PK_TRACE(5);
     }
+    flush_outputs(0);
 }
 
+unsigned long long* g2_trace = nullptr;  // set by pk_persist2_set_trace (diagnostics only)
 unsigned* g2_err_host = nullptr;
 unsigned* g2_err_dev = nullptr;
+int g2_force_safe = 0;
+unsigned* g2_xcd_tab = nullptr;  // [256][16] handshake words (library-owned scratch, one launch at a time)
+float* g2_trash = nullptr;        // write-only dump page for masked-off vector stores
+constexpr size_t XCD_TAB_BYTES = 256 * 16 * sizeof(unsigned);
 int ensure_err2() {
     if (g2_err_host) return 0;
+    PK_CHECK_HIP(hipMalloc((void**)&g2_xcd_tab, XCD_TAB_BYTES));
+    PK_CHECK_HIP(hipMalloc((void**)&g2_trash, 4096));
     PK_CHECK_HIP(hipHostMalloc((void**)&g2_err_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
     *g2_err_host = 0;
     PK_CHECK_HIP(hipHostGetDevicePointer((void**)&g2_err_dev, g2_err_host, 0));
@@ -458,6 +711,7 @@ int make_plan2(int R, int H, Plan2& pl) {
     int C = ncu / pl.Pn;
     PK_REQUIRE(C >= 1, "persistent recurrence: H=%d needs %d workgroups per cluster but the device has %d CUs", H, pl.Pn,
                ncu);
+    if (C > 256) C = 256;
     if (C >= 8) C -= C % 8;  // members of one cluster congruent mod 8: one XCD under round-robin dispatch (speed only)
     int rpc = (R + C - 1) / C;
     if (rpc > RMAX) rpc = RMAX;
@@ -480,6 +734,8 @@ int check2(const char* who, int cell, int T, int B, int bidir, int H) {
 
 }  // namespace
 
+extern "C" void pk_persist2_set_mode(int force_safe) { g2_force_safe = force_safe ? 1 : 0; }
+extern "C" void pk_persist2_set_trace(void* dev_buf) { g2_trace = (unsigned long long*)dev_buf; }
 extern "C" unsigned pk_persist2_error_count(void) { return g2_err_host ? *g2_err_host : 0u; }
 extern "C" void pk_persist2_error_reset(void) {
     if (g2_err_host) *g2_err_host = 0u;
@@ -506,21 +762,25 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.P = P; a.pscale = pscale; a.pshift = pshift; a.U = U; a.mask = mask; a.mask_scalar = mask_scalar;
     a.Y = Y; a.S = S; a.Yb = (unsigned short*)Yb; a.Ypitch = (int)y_pitch;
     a.dY = nullptr; a.dP2 = nullptr; a.dGb = nullptr; a.Gpitch = 0;
-    a.err = g2_err_dev; a.spin_limit = 400000;
+    a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe; a.trash = g2_trash;
     // the bf16 layer output is the mailbox: poison it with the sentinel
     PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     const int G = pk_cell_gates(cell);
-    (void)G;
-    const size_t lds = 2 * (size_t)RMAX * (KPAD + 8) * 2 + 4 * 512;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PK_CHECK_HIP(hipFuncSetAttribute((const void*)rec2_fwd_kernel<PK_CELL_LIGRU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PK_CHECK_HIP(hipFuncSetAttribute((const void*)rec2_fwd_kernel<PK_CELL_RNN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PK_CHECK_HIP(hipFuncSetAttribute((const void*)rec2_fwd_kernel<PK_CELL_LSTM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
+    const size_t lds = 2 * (size_t)RMAX * (KPAD + 8) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024 + 512) + 16;
+    {   // dynamic LDS above the 64 KB default needs the opt-in (exact size: the kernels also hold a little static LDS)
+        const void* fn = cell == PK_CELL_LIGRU ? (const void*)rec2_fwd_kernel<PK_CELL_LIGRU>
+                         : cell == PK_CELL_RNN ? (const void*)rec2_fwd_kernel<PK_CELL_RNN>
+                                               : (const void*)rec2_fwd_kernel<PK_CELL_LSTM>;
+        static size_t granted[3] = {0, 0, 0};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
+        const int slot = cell == PK_CELL_LIGRU ? 0 : cell == PK_CELL_RNN ? 1 : 2;
+        if (granted[slot] < lds) {
+            PK_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            granted[slot] = lds;
+        }
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
+        PK_CHECK_HIP(hipMemsetAsync(g2_xcd_tab, 0xFF, XCD_TAB_BYTES, st));
         dim3 grid(pl.C * pl.Pn), block(256);
         if (cell == PK_CELL_LIGRU) hipLaunchKernelGGL((rec2_fwd_kernel<PK_CELL_LIGRU>), grid, block, lds, st, a);
         else if (cell == PK_CELL_RNN) hipLaunchKernelGGL((rec2_fwd_kernel<PK_CELL_RNN>), grid, block, lds, st, a);
@@ -551,18 +811,25 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.P = nullptr; a.pscale = nullptr; a.pshift = nullptr; a.U = U; a.mask = mask; a.mask_scalar = mask_scalar;
     a.Y = const_cast<float*>(Y); a.S = const_cast<float*>(S); a.Yb = nullptr; a.Ypitch = 0;
     a.dY = dY; a.dP2 = dP2; a.dGb = (unsigned short*)dGb; a.Gpitch = (int)g_pitch;
-    a.err = g2_err_dev; a.spin_limit = 400000;
+    a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe; a.trash = g2_trash;
     PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
-    const size_t lds = 2 * (size_t)RMAX * (G * KPAD + 8) * 2 + 4 * (size_t)G * 512;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PK_CHECK_HIP(hipFuncSetAttribute((const void*)rec2_bwd_kernel<PK_CELL_LIGRU>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PK_CHECK_HIP(hipFuncSetAttribute((const void*)rec2_bwd_kernel<PK_CELL_RNN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PK_CHECK_HIP(hipFuncSetAttribute((const void*)rec2_bwd_kernel<PK_CELL_LSTM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
+    const size_t atile = (size_t)RMAX * (G * KPAD + 8) * 2;
+    const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0);
+    const size_t lds = (2 * atile > 96 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(nin + G) * 1024 + (size_t)G * 512) + 16;
+    {
+        const void* fn = cell == PK_CELL_LIGRU ? (const void*)rec2_bwd_kernel<PK_CELL_LIGRU>
+                         : cell == PK_CELL_RNN ? (const void*)rec2_bwd_kernel<PK_CELL_RNN>
+                                               : (const void*)rec2_bwd_kernel<PK_CELL_LSTM>;
+        static size_t granted[3] = {0, 0, 0};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
+        const int slot = cell == PK_CELL_LIGRU ? 0 : cell == PK_CELL_RNN ? 1 : 2;
+        if (granted[slot] < lds) {
+            PK_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            granted[slot] = lds;
+        }
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
+        PK_CHECK_HIP(hipMemsetAsync(g2_xcd_tab, 0xFF, XCD_TAB_BYTES, st));
         dim3 grid(pl.C * pl.Pn), block(256);
         if (cell == PK_CELL_LIGRU) hipLaunchKernelGGL((rec2_bwd_kernel<PK_CELL_LIGRU>), grid, block, lds, st, a);
         else if (cell == PK_CELL_RNN) hipLaunchKernelGGL((rec2_bwd_kernel<PK_CELL_RNN>), grid, block, lds, st, a);

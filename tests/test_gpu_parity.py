@@ -238,7 +238,8 @@ def test_bf16_mode_is_close(kind, pre, act, H):
 @pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("LSTM", "lstm", "tanh"), ("RNN", "rnn", "tanh")])
 @pytest.mark.parametrize("H,T,B,bidir", [(550, 12, 5, True), (40, 9, 3, True), (20, 7, 4, False), (14, 5, 33, True),
                                          (129, 6, 2, True)])
-def test_bf16_persistent_matches_bf16_stepwise(kind, pre, act, H, T, B, bidir):
+@pytest.mark.parametrize("safe", [0, 1])
+def test_bf16_persistent_matches_bf16_stepwise(kind, pre, act, H, T, B, bidir, safe):
     """The perf-mode persistent kernels (bf16 exchange through L2, MFMA B fragments in registers) and the
     step-wise algorithm in bf16 mode round the same operands (h_{t-1}, dgates_{t+1}, U) to bf16 and
     accumulate in fp32: they must agree far more tightly (5e-3) than bf16 vs fp32 does (3e-2)."""
@@ -252,6 +253,8 @@ def test_bf16_persistent_matches_bf16_stepwise(kind, pre, act, H, T, B, bidir):
     masks = O.make_drop_masks(kind, opts, B, "train", generator=g)
     cot = torch.randn(T, B, net.out_dim, generator=g).cuda()
     F_amd.set_precision("bf16")
+    lib = importlib.import_module("pytorch-kaldi_amd._lib").load()
+    lib.pk_persist2_set_mode(safe)  # 1: placement-independent write-through exchange; 0: XCD-local fast path when possible
     res = {}
     for algo in ("stepwise", "persistent"):
         F_amd.set_rec_algo(algo)
@@ -262,6 +265,7 @@ def test_bf16_persistent_matches_bf16_stepwise(kind, pre, act, H, T, B, bidir):
         torch.cuda.synchronize()
         grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if p.grad is not None}
         res[algo] = (y.detach().cpu(), xe.grad.cpu(), grads)
+    lib.pk_persist2_set_mode(0)
     assert rel_err(res["persistent"][0], res["stepwise"][0]) < 5e-3
     assert rel_err(res["persistent"][1], res["stepwise"][1]) < 2e-2
     for k, v in res["stepwise"][2].items():

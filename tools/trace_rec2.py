@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Phase timing of the persistent bf16 recurrences (diagnostics): runs one Li-GRU layer fwd+bwd at
+the BASELINE geometry with pk_persist2_set_trace and prints the mean shader-clock cycles per phase."""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+_lib = importlib.import_module("pytorch-kaldi_amd._lib")
+nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
+
+T, B, H = int(os.environ.get("T", 500)), int(os.environ.get("B", 128)), 550
+kind = os.environ.get("KIND", "liGRU")
+pre = {"liGRU": "ligru", "LSTM": "lstm", "RNN": "rnn"}[kind]
+opts = {pre + "_lay": str(H), pre + "_drop": "0.2", pre + "_use_laynorm_inp": "False", pre + "_use_batchnorm_inp": "False",
+        pre + "_use_laynorm": "False", pre + "_use_batchnorm": "True", pre + "_bidir": "True",
+        pre + "_act": "relu" if kind != "LSTM" else "tanh", pre + "_orthinit": "True", "use_cuda": "True", "to_do": "train"}
+F_.set_precision("bf16")
+net = getattr(nn_amd, kind)(opts, 40).cuda().train()
+x = torch.randn(T, B, 40, device="cuda", requires_grad=True)
+lib = _lib.load()
+lib.pk_persist2_set_mode(int(os.environ.get("SAFE", "0")))
+names = ["poll", "prefetch-issue+barrier", "mfma", "gate math", "publish", "loop tail"]
+for rep in range(2):
+    tr_f = torch.zeros(T, 8, dtype=torch.int64, device="cuda")
+    lib.pk_persist2_set_trace(tr_f.data_ptr())
+    y = net(x)
+    torch.cuda.synchronize()
+    tr_b = torch.zeros(T, 8, dtype=torch.int64, device="cuda")
+    lib.pk_persist2_set_trace(tr_b.data_ptr())
+    y.sum().backward()
+    torch.cuda.synchronize()
+    lib.pk_persist2_set_trace(None)
+for tag, tr in (("fwd", tr_f.cpu()), ("bwd", tr_b.cpu())):
+    tr = tr[5:-5].double()
+    d = tr[:, 1:6] - tr[:, 0:5]
+    step = tr[1:, 0] - tr[:-1, 0]
+    print("%s: cycles/step mean %.0f median %.0f p90 %.0f (s_memtime ticks)" % (tag, step.mean(), step.median(), step.quantile(0.9)))
+    for i, n in enumerate(names[:5]):
+        print("   %-24s mean %8.0f  median %8.0f" % (n, d[:, i].mean(), d[:, i].median()))
+    print("   poll retries per step: mean %.2f  max %d" % (tr[:, 6].mean(), int(tr[:, 6].max())))
+    tail = tr[1:, 0] - tr[:-1, 5]
+    print("   %-24s mean %8.0f  median %8.0f" % (names[5], tail.mean(), tail.median()))

@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--prec", default=os.environ.get("PK_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "persistent"])
     ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--mask-rng", default="device", choices=["device", "reference"],
+                    help="recurrent drop masks: GPU RNG (default) or the reference's CPU torch.bernoulli stream")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim instead of the fused flat optimizers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
@@ -59,6 +61,7 @@ class Trainer:
         F_ = importlib.import_module("pytorch-kaldi_amd.functional")
         F_.set_precision(args.prec)
         F_.set_rec_algo(args.algo)
+        F_.set_mask_rng(args.mask_rng)
         self.args, self.rank, self.world = args, rank, world
         self.rcp = rcp = self.R.recipe(args.recipe, n_lay=args.layers)
         self.inp_out_dict = {"fea": rcp["fea_dict"]["fea"][5:]}
@@ -263,7 +266,7 @@ def main():
                                % (args.recipe, tr.rcp["cfg"]["architecture1"]["arch_class"], tr.T, tr.B,
                                   tr.rcp["n_cd"], tr.rcp["n_mono"]),
                    "global_batch": tr.B * world, "seq_len": tr.T, "parallelism": "dp%d" % world,
-                   "rec_algo": args.algo, "optimizer": "torch" if args.torch_optim else "fused-flat",
+                   "rec_algo": args.algo, "mask_rng": args.mask_rng, "optimizer": "torch" if args.torch_optim else "fused-flat",
                    "params": tr.n_params},
         "loss_final": round(float(loss), 5),
     }

@@ -113,6 +113,15 @@ int pk_bn_bwd_reduce(void* stream, const float* g, const float* g2, int64_t ldg,
 int pk_bn_bwd_apply(void* stream, const float* g, const float* g2, int64_t ldg, const float* x, int64_t ldx,
                     int64_t M, int64_t N, const float* mean, const float* var, float eps, const float* gamma,
                     const float* sum_g, const float* sum_gx, double count, float* dx, int64_t lddx);
+/* Perf mode: the whole BatchNorm backward of a recurrent layer's projections from the bf16 gate
+ * gradients pk_rec_bwd_bf16 publishes (g0 / g1: one slab per direction, [M][g_pitch], gate g at
+ * column g*Hp; g1 may be NULL).  Writes sum_g / sum_gx [G*H] (= dbeta / dgamma; sum_g = the bias
+ * gradient when mean == NULL, i.e. no BatchNorm: then dx = g0 + g1) and the projection gradient as
+ * bf16 in the plain layout out[M][out_pitch] (column g*H + j, pad columns zeroed) that the dX / dW
+ * GEMMs (pk_gemm_bf16) read.  partial: >= pk_bn_partial_floats(M, G*H) floats. */
+int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* g1, int64_t g_pitch, int G, int H, const float* x,
+                   int64_t ldx, int64_t M, const float* mean, const float* var, float eps, const float* gamma,
+                   double count, float* partial, float* sum_g, float* sum_gx, uint16_t* out, int64_t out_pitch);
 /* column sums of g (+g2): bias gradient when there is no BatchNorm. */
 int pk_colsum(void* stream, const float* g, const float* g2, int64_t ldg, int64_t M, int64_t N, float* partial,
               float* out);
@@ -180,7 +189,8 @@ int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, int T, int B
  * outputs: Yb [T*B][y_pitch] bf16 copy of Y (direction d at column d*Hp, Hp = H rounded up to 8, zero
  * padded) and dGb [ndir*T*B][g_pitch] bf16 gate gradients (gate g at column g*Hp) are laid out as the
  * k-major operands pk_gemm_bf16 needs for dU / dW.  Columns beyond ndir*Hp (G*Hp) of a row are left
- * undefined.  Pitches are multiples of 8 elements; H <= 576. */
+ * undefined.  Pitches are multiples of 8 elements; H <= 576.  dP2 may be NULL (the fp32 gate-gradient
+ * slabs are then not written: pk_bn_bwd_bf16 works from dGb). */
 int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
                     const float* pscale, const float* pshift, const float* U, const float* mask, float mask_scalar,
                     float* Y, float* S, uint16_t* Yb, int64_t y_pitch);
@@ -193,6 +203,8 @@ void pk_persist2_set_trace(void* dev_buf);
 /* 0 (default): clusters whose workgroups all run on one XCD exchange through that XCD's L2 (plain
  * stores + nt loads), others use write-through stores + agent-scope loads; 1: always the latter. */
 void pk_persist2_set_mode(int force_safe);
+/* tuning: idle time (units of 64 clocks) between a workgroup's publish and its first poll of the next step */
+void pk_persist2_set_poll_delay(int units);
 unsigned pk_persist2_error_count(void);
 void pk_persist2_error_reset(void);
 

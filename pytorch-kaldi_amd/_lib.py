@@ -38,6 +38,8 @@ SIGNATURES = {
     "pk_bn_bwd_reduce": (c_int, [P, P, P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_float, P, P, P]),
     "pk_bn_bwd_apply": (c_int, [P, P, P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_float, P, P, P, c_double, P,
                                 c_int64]),
+    "pk_bn_bwd_bf16": (c_int, [P, P, P, c_int64, c_int, c_int, P, c_int64, c_int64, P, P, c_float, P, c_double, P, P, P, P,
+                               c_int64]),
     "pk_colsum": (c_int, [P, P, P, c_int64, c_int64, c_int64, P, P]),
     "pk_add": (c_int, [P, P, P, c_int64, P]),
     "pk_layernorm_fwd": (c_int, [P, P, c_int64, c_int64, P, P, c_float, P, P, P]),
@@ -55,6 +57,7 @@ SIGNATURES = {
     "pk_rec_bwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int64]),
     "pk_persist2_set_trace": (None, [P]),
     "pk_persist2_set_mode": (None, [c_int]),
+    "pk_persist2_set_poll_delay": (None, [c_int]),
     "pk_persist2_error_count": (ctypes.c_uint, []),
     "pk_persist2_error_reset": (None, []),
     "pk_conv1d_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -27,7 +27,11 @@ __host__ __device__ constexpr int pk_cell_saved(int cell) {
 // cells whose candidate GEMM depends on a gate of the same step (two GEMM phases per step)
 __host__ __device__ constexpr bool pk_cell_two_phase(int cell) { return cell == PK_CELL_GRU || cell == PK_CELL_MINGRU; }
 
+#ifdef PK_CELL_FAST_MATH
+__device__ __forceinline__ float pk_sig(float x) { return pk_fast_sigmoid(x); }
+#else
 __device__ __forceinline__ float pk_sig(float x) { return 1.0f / (1.0f + expf(-x)); }
+#endif
 
 // ---------------------------------------------------------------- forward ----
 // single-phase cells.  pre[g] = p[g] + u[g].  Writes h (and c), fills s[0..NS).

@@ -56,12 +56,25 @@ __device__ __forceinline__ float pk_tanh(float x) {
     return 1.0f - 2.0f / (e + 1.0f);
 }
 
-// act_fun of the reference, neural_networks.py:36-57
+// act_fun of the reference, neural_networks.py:36-57.  A translation unit that defines PK_CELL_FAST_MATH
+// (the bf16 perf-mode kernels) gets hardware-rate exp / reciprocal (1-2 ulp) instead of the precise forms.
+#ifdef PK_CELL_FAST_MATH
+__device__ __forceinline__ float pk_fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float pk_fast_tanh(float x) {
+    const float e = __expf(2.0f * fminf(x, 15.0f));  // tanh(15) == 1 in fp32; keeps exp finite
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+#endif
 __device__ __forceinline__ float pk_act(int act, float x) {
     switch (act) {
         case PK_ACT_RELU: return x > 0.f ? x : 0.f;
+#ifdef PK_CELL_FAST_MATH
+        case PK_ACT_TANH: return pk_fast_tanh(x);
+        case PK_ACT_SIGMOID: return pk_fast_sigmoid(x);
+#else
         case PK_ACT_TANH: return tanhf(x);
         case PK_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+#endif
         case PK_ACT_LEAKY_RELU: return x > 0.f ? x : 0.2f * x;
         case PK_ACT_ELU: return x > 0.f ? x : (expf(x) - 1.0f);
         default: return x;

@@ -456,3 +456,196 @@ extern "C" int pk_logsoftmax_bwd(void* stream, const float* dy, const float* y, 
     PK_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Perf mode: BatchNorm backward straight from the bf16 gate gradients the persistent recurrence
+// publishes (dGb: [ndir][M][g_pitch], gate g at column g*Hp, both directions summed here), writing
+// the projection gradient as bf16 in the plain [M][G*H (+pad)] layout the dX / dW GEMMs read.
+// The fp32 gate-gradient slabs are never materialised in this mode (563 MB per layer at the
+// BASELINE shape).  One thread owns a 16-byte chunk (8 units of one gate) for a strip of rows.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int BC_COLS = 16;  // chunks (of 8 columns) per block
+constexpr int BC_ROWL = 16;  // row lanes per block
+
+__device__ __forceinline__ void bf8_to_f32(uint4 v, float (&f)[8]) {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[2 * e] = __uint_as_float(w[e] << 16);
+        f[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+    }
+}
+
+// MODE 0: per-column sums of g and g*xhat (BatchNorm); MODE 1: sum of g only (bias gradient, no BatchNorm)
+template <int MODE>
+__global__ __launch_bounds__(256) void bnb_reduce_kernel(const unsigned short* __restrict__ g0,
+                                                          const unsigned short* __restrict__ g1, long gpitch, int G, int H,
+                                                          int Hp, const float* __restrict__ x, long ldx, long M,
+                                                          const float* __restrict__ mean, const float* __restrict__ var,
+                                                          float eps, float* __restrict__ partial) {
+    const int cl = threadIdx.x & (BC_COLS - 1), rl = threadIdx.x / BC_COLS;
+    const int chunk = blockIdx.x * BC_COLS + cl;  // chunk index in the padded layout
+    const int cpg = Hp >> 3;
+    const int g = chunk / cpg, j0 = (chunk - g * cpg) * 8;
+    const bool cok = g < G;
+    const int rb = gridDim.y;
+    const long rows_per = (M + rb - 1) / rb;
+    const long r0 = (long)blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float s0[8], s1[8], mu[8], inv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s0[e] = s1[e] = 0.f;
+        const int j = j0 + e;
+        const bool ok = cok && j < H;
+        mu[e] = (MODE == 0 && ok) ? mean[g * H + j] : 0.f;
+        inv[e] = (MODE == 0 && ok) ? 1.0f / sqrtf(var[g * H + j] + eps) : 0.f;
+    }
+    if (cok) {
+        const long goff = (long)g * Hp + j0;
+        for (long r = r0 + rl; r < r1; r += BC_ROWL) {
+            float a[8], b[8];
+            bf8_to_f32(*reinterpret_cast<const uint4*>(g0 + r * gpitch + goff), a);
+            if (g1) {
+                bf8_to_f32(*reinterpret_cast<const uint4*>(g1 + r * gpitch + goff), b);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += b[e];
+            }
+            const float* xr = x + r * ldx + (long)g * H + j0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s0[e] += a[e];
+                if (MODE == 0 && j0 + e < H) s1[e] += a[e] * ((xr[e] - mu[e]) * inv[e]);
+            }
+        }
+    }
+    __shared__ float sh[BC_ROWL][BC_COLS][16];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sh[rl][cl][e] = s0[e];
+        sh[rl][cl][8 + e] = s1[e];
+    }
+    __syncthreads();
+    // 256 threads: one (chunk, element, kind) each
+    const int oc = threadIdx.x >> 4, oe = threadIdx.x & 15;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < BC_ROWL; ++k) t += sh[k][oc][oe];
+    const int ochunk = blockIdx.x * BC_COLS + oc;
+    const int og = ochunk / cpg, oj = (ochunk - og * cpg) * 8 + (oe & 7);
+    if (og < G && oj < H) partial[((long)blockIdx.y * ((long)G * H) + (long)og * H + oj) * 2 + (oe >> 3)] = t;
+}
+
+// dx = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count) as bf16 (MODE 0), or dx = g (MODE 1)
+template <int MODE>
+__global__ __launch_bounds__(256) void bnb_apply_kernel(const unsigned short* __restrict__ g0,
+                                                         const unsigned short* __restrict__ g1, long gpitch, int G, int H,
+                                                         int Hp, const float* __restrict__ x, long ldx, long M,
+                                                         const float* __restrict__ mean, const float* __restrict__ var,
+                                                         float eps, const float* __restrict__ gamma,
+                                                         const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
+                                                         float inv_count, unsigned short* __restrict__ out, long opitch) {
+    const int cl = threadIdx.x & (BC_COLS - 1), rl = threadIdx.x / BC_COLS;
+    const int chunk = blockIdx.x * BC_COLS + cl;
+    const int cpg = Hp >> 3;
+    const int g = chunk / cpg, j0 = (chunk - g * cpg) * 8;
+    if (g >= G) return;
+    const int rb = gridDim.y;
+    const long rows_per = (M + rb - 1) / rb;
+    const long r0 = (long)blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float mu[8], sc[8], c0[8], c1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int n = g * H + j0 + e;
+        const bool ok = j0 + e < H;
+        if (MODE == 0 && ok) {
+            const float inv = 1.0f / sqrtf(var[n] + eps);
+            mu[e] = mean[n];
+            sc[e] = (gamma ? gamma[n] : 1.f) * inv;
+            c0[e] = sum_g[n] * inv_count;
+            c1[e] = sum_gx[n] * inv_count * inv;  // xhat*c1' with xhat = (x-mu)*inv folded: (x-mu)*inv*sum_gx/count
+        } else {
+            mu[e] = 0.f; sc[e] = ok ? 1.f : 0.f; c0[e] = 0.f; c1[e] = 0.f;
+        }
+    }
+    const long goff = (long)g * Hp + j0;
+    const int nvalid = (H - j0) < 8 ? (H - j0) : 8;
+    for (long r = r0 + rl; r < r1; r += BC_ROWL) {
+        float a[8], b[8];
+        bf8_to_f32(*reinterpret_cast<const uint4*>(g0 + r * gpitch + goff), a);
+        if (g1) {
+            bf8_to_f32(*reinterpret_cast<const uint4*>(g1 + r * gpitch + goff), b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += b[e];
+        }
+        float o[8];
+        if (MODE == 0) {
+            const float* xr = x + r * ldx + (long)g * H + j0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (e < nvalid) ? sc[e] * (a[e] - c0[e] - (xr[e] - mu[e]) * c1[e]) : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (e < nvalid) ? a[e] : 0.f;
+        }
+        // plain layout: column g*H + j0 (+e); 4-byte aligned pairs (H even) or single elements
+        unsigned short* op = out + r * opitch + (long)g * H + j0;
+        if ((((long)g * H + j0) & 1) == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                if (e + 1 < nvalid) *reinterpret_cast<unsigned*>(op + e) = pk_pack_bf2(o[e], o[e + 1]);
+                else if (e < nvalid) op[e] = pk_f2bf(o[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < nvalid) op[e] = pk_f2bf(o[e]);
+        }
+    }
+}
+
+// zero the pad columns [n0, pitch) of every row of a bf16 matrix
+__global__ void bf16_zero_pad_kernel(unsigned short* __restrict__ out, long pitch, long M, int n0) {
+    const int w = (int)pitch - n0;
+    const long total = M * w;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / w;
+        out[r * pitch + n0 + (i - r * w)] = 0;
+    }
+}
+
+}  // namespace
+
+extern "C" int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* g1, int64_t g_pitch, int G, int H,
+                              const float* x, int64_t ldx, int64_t M, const float* mean, const float* var, float eps,
+                              const float* gamma, double count, float* partial, float* sum_g, float* sum_gx,
+                              uint16_t* out, int64_t out_pitch) {
+    PK_REQUIRE(M > 0 && G > 0 && H > 0, "pk_bn_bwd_bf16: empty input");
+    PK_REQUIRE((g_pitch % 8) == 0 && ((uintptr_t)g0 & 15) == 0 && (g1 == nullptr || ((uintptr_t)g1 & 15) == 0),
+               "pk_bn_bwd_bf16: gate gradients must be 16-byte aligned with a pitch that is a multiple of 8");
+    PK_REQUIRE(out_pitch >= (int64_t)G * H, "pk_bn_bwd_bf16: output pitch shorter than G*H");
+    hipStream_t st = pk_stream(stream);
+    const int Hp = (H + 7) & ~7;
+    const int chunks = G * (Hp >> 3);
+    const int rb = row_blocks(M);
+    dim3 grid((chunks + BC_COLS - 1) / BC_COLS, rb);
+    const long N = (long)G * H;
+    const bool use_bn = mean != nullptr;
+    if (use_bn) hipLaunchKernelGGL((bnb_reduce_kernel<0>), grid, dim3(256), 0, st, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x, (long)ldx, (long)M, mean, var, eps, partial);
+    else hipLaunchKernelGGL((bnb_reduce_kernel<1>), grid, dim3(256), 0, st, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x, (long)ldx, (long)M, mean, var, eps, partial);
+    PK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partial, rb, N, sum_g,
+                       use_bn ? sum_gx : (float*)nullptr);
+    PK_LAUNCH_CHECK();
+    if (use_bn) hipLaunchKernelGGL((bnb_apply_kernel<0>), grid, dim3(256), 0, st, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x, (long)ldx, (long)M, mean, var, eps, gamma, sum_g, sum_gx, (float)(1.0 / count), (unsigned short*)out, (long)out_pitch);
+    else hipLaunchKernelGGL((bnb_apply_kernel<1>), grid, dim3(256), 0, st, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x, (long)ldx, (long)M, mean, var, eps, gamma, sum_g, sum_gx, 0.f, (unsigned short*)out, (long)out_pitch);
+    PK_LAUNCH_CHECK();
+    if (out_pitch > N) {
+        const long total = M * (out_pitch - N);
+        long blocks = (total + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(bf16_zero_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned short*)out, (long)out_pitch, (long)M, (int)N);
+        PK_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -24,6 +24,7 @@
 //    barrier per step); projections / saved gates of step t+1 are prefetched
 //    right after the poll of step t returns, so HBM latency is off the
 //    dependency chain; every spin is bounded (host-visible error word).
+#define PK_CELL_FAST_MATH 1  // perf mode: hardware-rate exp / reciprocal in the gate math
 #include "pk_cell.h"
 
 namespace {
@@ -50,6 +51,7 @@ struct R2Args {
     unsigned* err;
     int spin_limit;
     float* trash;               // >= 64 bytes per lane-group of write-only scratch for masked-off stores
+    int poll_delay;             // s_sleep units (64 clocks) between the publish and the first poll of the next step
     int force_safe;             // 1 = always use the placement-independent write-through exchange
     unsigned* xcd_tab;          // [C][16] placement handshake words (0xFFFFFFFF before the launch)
     unsigned long long* trace;  // optional [T][8] phase time stamps of (cluster 0, member 0, wave 0); null = off
@@ -210,10 +212,15 @@ __device__ __forceinline__ void patch_put_vec(float* patch, int lane, f32x4 v) {
 // compiler then wraps every access in a waterfall loop).
 // EDGE is wave-uniform: true only for the one wave whose 16 units straddle H when H % 4 != 0; it uses
 // four 4-byte accesses per lane, every other wave a single 16-byte access.
-template <bool EDGE>
+template <int EDGE>
 __device__ __forceinline__ f32x4 ld4(const float* base, unsigned off, int nv) {
-    if (!EDGE) {
+    if (EDGE == 0) {
         return *reinterpret_cast<const f32x4*>(base + (nv == 4 ? off : 0u));
+    } else if (EDGE == 1) {  // even H: nv is 0, 2 or 4 - two 8-byte halves
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 lo = *reinterpret_cast<const f32x2*>(base + (nv >= 2 ? off : 0u));
+        const f32x2 hi = *reinterpret_cast<const f32x2*>(base + (nv == 4 ? off + 2 : 0u));
+        return f32x4{lo[0], lo[1], hi[0], hi[1]};
     } else {
         f32x4 v;
 #pragma unroll
@@ -221,18 +228,22 @@ __device__ __forceinline__ f32x4 ld4(const float* base, unsigned off, int nv) {
         return v;
     }
 }
-template <bool EDGE>
+template <int EDGE>
 __device__ __forceinline__ void st4(float* base, unsigned off, int nv, float* trash, f32x4 v) {
-    if (!EDGE) {
+    if (EDGE == 0) {
         *reinterpret_cast<f32x4*>(nv == 4 ? base + off : trash) = v;
+    } else if (EDGE == 1) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f32x2*>(nv >= 2 ? base + off : trash) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2*>(nv == 4 ? base + off + 2 : trash + 2) = f32x2{v[2], v[3]};
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) *(e < nv ? base + off + e : trash + e) = v[e];
     }
 }
-template <bool B>
-struct BoolC {
-    static constexpr bool value = B;
+template <int B>
+struct BoolC {  // (an int: 0 = no edge, 1 = even-H edge in 8-byte halves, 2 = odd-H edge element by element)
+    static constexpr int value = B;
 };
 
 // ============================================================================
@@ -332,7 +343,8 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     const int vdir = vn >= B ? 1 : 0, vb = vn - vdir * B;
     int vnv = H - vu0;
     vnv = vnv > 4 ? 4 : (vnv < 0 ? 0 : vnv);
-    const bool edge = __any(vnv > 0 && vnv < 4) != 0;  // wave-uniform: my 16 units straddle H
+    // wave-uniform: 0 = my 16 units do not straddle H, 1 = they do and H is even, 2 = H is odd
+    const int edge = __any(vnv > 0 && vnv < 4) != 0 ? ((H & 1) ? 2 : 1) : 0;
     vnv = vrow < nrows ? vnv : 0;
     // element offsets of my 4 units at storage time 0 / per unit of storage time, for P, Y and S
     const unsigned vP0 = ((unsigned)vb * GH + vu0), vPs = (unsigned)B * GH;
@@ -363,14 +375,20 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     };
     // layer output and saved gates of step tt: wave patches -> HBM, 16 bytes per lane
     auto flush_outputs = [&](int tt, auto E) {
-        constexpr bool EE = decltype(E)::value;
+        constexpr int EE = decltype(E)::value;
         const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
         st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchY, lane));
 #pragma unroll
         for (int k = 0; k < NS; ++k) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, patch_get_vec(patchS + k * 256, lane));
     };
-    if (edge) load_proj(0, BoolC<true>());
-    else load_proj(0, BoolC<false>());
+#define PK_EDGE_DISPATCH(CALL)                 \
+    do {                                        \
+        if (edge == 0) CALL(BoolC<0>());        \
+        else if (edge == 1) CALL(BoolC<1>());   \
+        else CALL(BoolC<2>());                  \
+    } while (0)
+#define PK_LP0(E) load_proj(0, E)
+    PK_EDGE_DISPATCH(PK_LP0);
     __syncthreads();
 
     bool dead = false;
@@ -386,13 +404,15 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
             unsigned goff[NCH];
 #pragma unroll
             for (int i = 0; i < NCH; ++i) goff[i] = cbase[i] + (unsigned)(t - 1) * cstep[i];
+            // a poll that arrives before the other members' stores costs a whole extra round trip
+            for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             int retries = 0;
             dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries)
                         : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries);
             if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
             // fp32 outputs of the previous step: issued now, they have a whole step to drain before the next poll
-            if (edge) flush_outputs(t - 1, BoolC<true>());
-            else flush_outputs(t - 1, BoolC<false>());
+#define PK_FO(E) flush_outputs(t - 1, E)
+            PK_EDGE_DISPATCH(PK_FO);
         }
         PK_TRACE(1);
         // stage this step's projections (loaded one step ago) into the gate-math layout ...
@@ -400,8 +420,8 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
         for (int g = 0; g < G; ++g) patch_put_vec(patchP + g * 256, lane, pv[g]);
         // ... and issue the loads of step t+1 now: they are consumed after the next poll
         if (t + 1 < T) {
-            if (edge) load_proj(t + 1, BoolC<true>());
-            else load_proj(t + 1, BoolC<false>());
+#define PK_LP1(E) load_proj(t + 1, E)
+            PK_EDGE_DISPATCH(PK_LP1);
         }
         if (t > 0) {
             PK_BARRIER_LDS();
@@ -455,8 +475,8 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
         PK_LDS_ORDER();
         PK_TRACE(5);
     }
-    if (edge) flush_outputs(T - 1, BoolC<true>());
-    else flush_outputs(T - 1, BoolC<false>());
+#define PK_FOL(E) flush_outputs(T - 1, E)
+    PK_EDGE_DISPATCH(PK_FOL);
 }
 
 // ============================================================================
@@ -549,7 +569,8 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
     const int vdir = vn >= B ? 1 : 0, vb = vn - vdir * B;
     int vnv = H - vu0;
     vnv = vnv > 4 ? 4 : (vnv < 0 ? 0 : vnv);
-    const bool edge = __any(vnv > 0 && vnv < 4) != 0;  // wave-uniform: my 16 units straddle H
+    // wave-uniform: 0 = my 16 units do not straddle H, 1 = they do and H is even, 2 = H is odd
+    const int edge = __any(vnv > 0 && vnv < 4) != 0 ? ((H & 1) ? 2 : 1) : 0;
     vnv = vrow < nrows ? vnv : 0;
     const unsigned vY0 = ((unsigned)vb * a.YH + vdir * H + vu0), vYs = (unsigned)B * a.YH;
     const unsigned vS0 = (((unsigned)vdir * TB + vb) * (NS * H) + vu0), vSs = (unsigned)B * NS * H;
@@ -571,7 +592,7 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
     // saved tensors of one step in the vector layout: [0..NS) gates, NS = h_{t-1}, NS+1 = dY, NS+2 = c_{t-1}
     f32x4 iv[NIN];
     auto load_step_e = [&](int t, auto E) {
-        constexpr bool EE = decltype(E)::value;
+        constexpr int EE = decltype(E)::value;
         const unsigned ts = (unsigned)(vdir ? (T - 1 - t) : t);
         const unsigned tp = t > 0 ? (vdir ? ts + 1 : ts - 1) : ts;  // storage time of step t-1 (any valid row when t == 0)
         const int nvp = t > 0 ? vnv : 0;
@@ -586,8 +607,8 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
         }
     };
     auto load_step = [&](int t) {
-        if (edge) load_step_e(t, BoolC<true>());
-        else load_step_e(t, BoolC<false>());
+#define PK_LS(E) load_step_e(t, E)
+        PK_EDGE_DISPATCH(PK_LS);
     };
     auto flush_outputs_e = [&](int tt, auto E) {
         const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
@@ -596,8 +617,9 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
             st4<decltype(E)::value>(a.dP2, vG0 + ts * vGs + g * H, vnv, trash, patch_get_vec(patchG + g * 256, lane));
     };
     auto flush_outputs = [&](int tt) {
-        if (edge) flush_outputs_e(tt, BoolC<true>());
-        else flush_outputs_e(tt, BoolC<false>());
+        if (a.dP2 == nullptr) return;  // perf mode: BatchNorm backward works from the bf16 copy
+#define PK_FOB(E) flush_outputs_e(tt, E)
+        PK_EDGE_DISPATCH(PK_FOB);
     };
     load_step(T - 1);
     __syncthreads();
@@ -614,6 +636,7 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
             unsigned goff[NCH];
 #pragma unroll
             for (int i = 0; i < NCH; ++i) goff[i] = cbase[i] + (unsigned)(it - 1) * cstep[i];
+            for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             int retries = 0;
             dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries)
                         : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries);
@@ -677,9 +700,11 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
                 else pub_store<false>(rs, og, o);
             }
         }
+        if (a.dP2 != nullptr) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) patch_put_cd(patchG + g * 256, kq, lane, dgv[g]);
-        PK_LDS_ORDER();
+            for (int g = 0; g < G; ++g) patch_put_cd(patchG + g * 256, kq, lane, dgv[g]);
+            PK_LDS_ORDER();
+        }
         PK_TRACE(5);
     }
     flush_outputs(0);
@@ -689,6 +714,7 @@ unsigned long long* g2_trace = nullptr;  // set by pk_persist2_set_trace (diagno
 unsigned* g2_err_host = nullptr;
 unsigned* g2_err_dev = nullptr;
 int g2_force_safe = 0;
+int g2_poll_delay = 0;
 unsigned* g2_xcd_tab = nullptr;  // [256][16] handshake words (library-owned scratch, one launch at a time)
 float* g2_trash = nullptr;        // write-only dump page for masked-off vector stores
 constexpr size_t XCD_TAB_BYTES = 256 * 16 * sizeof(unsigned);
@@ -735,6 +761,7 @@ int check2(const char* who, int cell, int T, int B, int bidir, int H) {
 }  // namespace
 
 extern "C" void pk_persist2_set_mode(int force_safe) { g2_force_safe = force_safe ? 1 : 0; }
+extern "C" void pk_persist2_set_poll_delay(int units) { g2_poll_delay = units < 0 ? 0 : units; }
 extern "C" void pk_persist2_set_trace(void* dev_buf) { g2_trace = (unsigned long long*)dev_buf; }
 extern "C" unsigned pk_persist2_error_count(void) { return g2_err_host ? *g2_err_host : 0u; }
 extern "C" void pk_persist2_error_reset(void) {
@@ -762,7 +789,7 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.P = P; a.pscale = pscale; a.pshift = pshift; a.U = U; a.mask = mask; a.mask_scalar = mask_scalar;
     a.Y = Y; a.S = S; a.Yb = (unsigned short*)Yb; a.Ypitch = (int)y_pitch;
     a.dY = nullptr; a.dP2 = nullptr; a.dGb = nullptr; a.Gpitch = 0;
-    a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe; a.trash = g2_trash;
+    a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe; a.trash = g2_trash; a.poll_delay = g2_poll_delay;
     // the bf16 layer output is the mailbox: poison it with the sentinel
     PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     const int G = pk_cell_gates(cell);
@@ -811,7 +838,7 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.P = nullptr; a.pscale = nullptr; a.pshift = nullptr; a.U = U; a.mask = mask; a.mask_scalar = mask_scalar;
     a.Y = const_cast<float*>(Y); a.S = const_cast<float*>(S); a.Yb = nullptr; a.Ypitch = 0;
     a.dY = dY; a.dP2 = dP2; a.dGb = (unsigned short*)dGb; a.Gpitch = (int)g_pitch;
-    a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe; a.trash = g2_trash;
+    a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe; a.trash = g2_trash; a.poll_delay = g2_poll_delay;
     PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
     const size_t atile = (size_t)RMAX * (G * KPAD + 8) * 2;
     const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0);

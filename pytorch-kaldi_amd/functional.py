@@ -29,6 +29,10 @@ class _Settings:
     def __init__(self):
         self.precision = os.environ.get("PK_PRECISION", "fp32")
         self.rec_algo = os.environ.get("PK_REC_ALGO", "auto")
+        # recurrent drop masks: "reference" = the reference's torch.bernoulli call on the CPU RNG (same seed ->
+        # same masks as the reference), "device" = drawn on the GPU RNG (no host work in the step)
+        self.mask_rng = os.environ.get("PK_MASK_RNG", "reference")
+        assert self.mask_rng in ("reference", "device"), self.mask_rng
         assert self.precision in PREC, self.precision
         assert self.rec_algo in ("auto", "stepwise", "persistent"), self.rec_algo
 
@@ -39,6 +43,11 @@ settings = _Settings()
 def set_precision(p):
     assert p in PREC, p
     settings.precision = p
+
+
+def set_mask_rng(m):
+    assert m in ("reference", "device"), m
+    settings.mask_rng = m
 
 
 def set_rec_algo(a):
@@ -616,6 +625,134 @@ class RecLayerFn(torch.autograd.Function):
             dx = dx.view(T, B, D)
         gemm(GH, D, TB, dPraw, 1, GH, x2, x2.stride(0), 1, dW, D, splitk=_splitk(_tiles(GH, D), TB))
         return dx, dW, dbias, dU, dgamma, dbeta, None, None, None, dlg, dlb, None
+
+
+def perf_path_ok(cell, H, use_ln, use_bn, training):
+    """The bf16 pipeline below covers liGRU / RNN / LSTM layers without per-step LayerNorm; BatchNorm
+    backward through frozen statistics (eval-mode module with autograd on) stays on the general path."""
+    if not bf16_mode() or settings.rec_algo == "stepwise":
+        return False
+    if cell not in ("liGRU", "RNN", "LSTM") or H > 576 or use_ln:
+        return False
+    return training or not use_bn or not torch.is_grad_enabled()
+
+
+class RecLayerPerfFn(torch.autograd.Function):
+    """Perf-mode (bf16 MFMA operands) recurrent layer: same math as RecLayerFn, but every GEMM operand
+    lives in HBM as bf16 and nothing is converted twice:
+
+      xb   bf16 layer input - either converted here (first layer) or the previous layer's Yb, the bf16
+           copy of its output that the persistent kernel publishes anyway (direction halves at a pitch
+           of Hp = H rounded up to 8; the weight copy Wb is re-pitched the same way);
+      Yb / dGb  the kernels' exchange buffers, reused as the k-major operands of the dU GEMMs;
+      dPb  BatchNorm backward (pk_bn_bwd_bf16) reads dGb and writes the projection gradient as bf16:
+           the fp32 gate-gradient slabs and dP never exist.
+
+    y, bn_mean, bn_var, Yb = f(x, xb_in, Wcat, bcat, Ucat, gamma, beta, running_mean, running_var, mask)
+    """
+
+    @staticmethod
+    def forward(ctx, x, xb_in, Wcat, bcat, Ucat, gamma, beta, running_mean, running_var, mask, cfg):
+        _need_gpu(x, Wcat, bcat, Ucat, gamma, beta, mask)
+        lib = _lib.load()
+        cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar, xseg = cfg
+        T, B, D = x.shape
+        G = lib.pk_rec_num_gates(CELL[cell])
+        NS = lib.pk_rec_num_saved(CELL[cell])
+        ndir = 2 if bidir else 1
+        TB, GH = T * B, G * H
+        Wcat = Wcat.contiguous()
+        Ucat = Ucat.contiguous()
+        if xb_in is None:
+            xseg = None
+            xb, Wb, K = cvt_bf16(_rows2d(x)), cvt_bf16(Wcat), D
+        else:
+            nseg, seglen, segpad = xseg
+            assert nseg * seglen == D and xb_in.shape[0] == TB
+            xb, Wb, K = xb_in, cvt_bf16(Wcat, nseg, seglen, segpad), nseg * segpad
+            assert Wb.shape[1] == xb.shape[1]
+        P = _new(TB, GH, like=Wcat)
+        gemm_bf16(TB, GH, K, xb, xb.shape[1], 1, Wb, Wb.shape[1], 1, P, GH)
+        mean = var = None
+        if use_bn:
+            if training:
+                mean, var = bn_stats(P)
+                pscale, pshift = bn_finalize(mean, var, gamma, beta, eps, running_mean, running_var, momentum, ndir * TB)
+            else:
+                mean, var = running_mean, running_var
+                pscale, pshift = bn_finalize(mean, var, gamma, beta, eps)
+        else:
+            pscale = torch.ones(GH, device=x.device)
+            pshift = bcat.contiguous() if bcat is not None else torch.zeros(GH, device=x.device)
+        Y = _new(T, B, ndir * H, like=Wcat)
+        S = _new(ndir, TB, NS * H, like=Wcat)
+        Hp = _up(H, 8)
+        Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
+        _lib.raise_if_persist_failed()
+        rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
+                                 _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1])
+        _lib.check(rc, "pk_rec_fwd_bf16")
+        ctx.save_for_backward(xb, Wb, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, Yb)
+        ctx.cfg = cfg[:-1] + (xseg,)
+        ctx.in_shape = x.shape
+        ctx.has_bias = bcat is not None
+        if use_bn and training:
+            ctx.mark_non_differentiable(mean, var, Yb)
+            return Y, mean, var, Yb
+        ctx.mark_non_differentiable(Yb)
+        return Y, None, None, Yb
+
+    @staticmethod
+    def backward(ctx, dY, _dm, _dv, _dyb):
+        lib = _lib.load()
+        xb, Wb, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, Yb = ctx.saved_tensors
+        cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar, xseg = ctx.cfg
+        if use_bn and not training:
+            raise _lib.PkError("perf-mode recurrent layer: backward through frozen BatchNorm statistics is not covered")
+        T, B, D = ctx.in_shape
+        G = lib.pk_rec_num_gates(CELL[cell])
+        ndir = 2 if bidir else 1
+        TB, GH = T * B, G * H
+        Hp = _up(H, 8)
+        dY = dY.contiguous()
+        dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16)
+        Gp = dGb.shape[1]
+        rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
+                                 float(mask_scalar), _p(Y), _p(S), _p(dY), None, _p(dGb), Gp)
+        _lib.check(rc, "pk_rec_bwd_bf16")
+        dU = _new(GH, H, like=dY)
+        _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, None, dU, Yb, dGb)
+        # BatchNorm backward (or plain sum of the two directions) straight from dGb -> bf16 projection gradient
+        dPb = torch.empty(TB, _up(GH, 64), device=dY.device, dtype=torch.bfloat16)
+        part = _new(int(lib.pk_bn_partial_floats(TB, GH)), like=dY)
+        sum_g = _new(GH, like=dY)
+        sum_gx = _new(GH, like=dY) if use_bn else None
+        g1 = ctypes.c_void_p(dGb.data_ptr() + 2 * TB * Gp) if bidir else None
+        rc = lib.pk_bn_bwd_bf16(_stream(), _p(dGb), g1, Gp, G, H, _p(P), GH, TB, _p(mean) if use_bn else None,
+                                _p(var) if use_bn else None, eps, _p(gamma) if use_bn else None, float(TB), _p(part),
+                                _p(sum_g), _p(sum_gx), _p(dPb), dPb.shape[1])
+        _lib.check(rc, "pk_bn_bwd_bf16")
+        dgamma = dbeta = dbias = None
+        if use_bn:
+            dgamma, dbeta = sum_gx, sum_g
+        elif ctx.has_bias:
+            dbias = sum_g
+        dx = None
+        if ctx.needs_input_grad[0]:  # dx[m,d] = sum_n dP[m,n] W[n,d]: A k-contiguous, B = W (plain pitch) k-major
+            Wb2 = Wb if xseg is None else cvt_bf16(Wcat)
+            dx = _new(TB, D, like=dY)
+            gemm_bf16(TB, D, GH, dPb, dPb.shape[1], 1, Wb2, Wb2.shape[1], 0, dx, D)
+            dx = dx.view(T, B, D)
+        # dW[n,d] = sum_m dP[m,n] x[m,d]: both operands k-major; with a re-pitched input the columns come out re-pitched
+        Kx = D if xseg is None else xseg[0] * xseg[2]
+        dWp = _new(GH, Kx, like=dY)
+        gemm_bf16(GH, Kx, TB, dPb, dPb.shape[1], 0, xb, xb.shape[1], 0, dWp, Kx, splitk=_splitk_bf(_tiles(GH, Kx), TB))
+        if xseg is None:
+            dW = dWp
+        else:
+            nseg, seglen, segpad = xseg
+            dW = torch.cat([dWp[:, s_ * segpad:s_ * segpad + seglen] for s_ in range(nseg)], 1)
+        return dx, None, dW, dbias, dU, dgamma, dbeta, None, None, None, None
 
 
 # ----------------------------------------------------------------------------

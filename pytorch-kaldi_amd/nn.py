@@ -226,14 +226,19 @@ class _Recurrent(nn.Module):
             cur = 2 * lay[i] if self.bidir else lay[i]
         self.out_dim = lay[-1] + self.bidir * lay[-1]
 
-    def _drop_masks(self, batch, device):
-        """One Bernoulli(1-p) mask (rows, H) per layer on the CPU RNG, in layer order."""
-        rows = 2 * batch if self.bidir else batch
+    def _drop_mask(self, i, batch, device):
+        """Bernoulli(1-p) mask (rows, H) of layer i, unscaled and constant over time (:1102-1107), or
+        (None, 1-p) in test mode.  Drawn lazily, layer by layer in layer order like the reference does,
+        so that the host-side draw of layer i+1 overlaps the GPU work of layer i.
+        settings.mask_rng = "reference": the reference's own call on the CPU RNG (same seed -> same
+        masks), then copied to the GPU; "device": drawn on the GPU RNG (no host work, no H2D copy)."""
+        p = self._drop[i]
         if self.test_flag:
-            return [None] * self._n_lay, [1.0 - p for p in self._drop]
-        cpu = [torch.bernoulli(torch.Tensor(rows, h).fill_(1 - p)) for h, p in zip(self._lay, self._drop)]
-        return [m.pin_memory().to(device, non_blocking=True) if device.type == "cuda" else m for m in cpu], \
-               [1.0] * self._n_lay
+            return None, 1.0 - p
+        rows = 2 * batch if self.bidir else batch
+        if F_.settings.mask_rng == "device":
+            return torch.empty(rows, self._lay[i], device=device).bernoulli_(1 - p), 1.0
+        return torch.bernoulli(torch.Tensor(rows, self._lay[i]).fill_(1 - p)).to(device), 1.0
 
     def forward(self, x, drop_masks=None):
         if not x.is_cuda:
@@ -243,13 +248,15 @@ class _Recurrent(nn.Module):
         if self._use_bn_inp:
             T, B, D = x.shape
             x = F_.norm_act_drop(x.reshape(T * B, D), self.bn0, True, self.training, "linear").view(T, B, D)
-        if drop_masks is None:
-            masks, scalars = self._drop_masks(x.shape[1], x.device)
-        else:  # injected (parity tests): tensors (rows,H) in train mode, 1-element tensors in test mode
+        masks = scalars = None
+        if drop_masks is not None:  # injected (parity tests): tensors (rows,H) in train mode, 1-element tensors in test mode
             masks = [m if m.numel() > 1 else None for m in drop_masks]
             scalars = [1.0 if m.numel() > 1 else float(m) for m in drop_masks]
             masks = [m.to(x.device).float().contiguous() if m is not None else None for m in masks]
+        batch = x.shape[1]
+        xb = xseg = None  # perf mode: bf16 copy of the running activation, handed from layer to layer
         for i in range(self._n_lay):
+            mask_i, scalar_i = (masks[i], scalars[i]) if masks is not None else self._drop_mask(i, batch, x.device)
             H = self._lay[i]
             Ws = [getattr(self, w)[i] for (w, _, _) in self._gates]
             Us = [getattr(self, u)[i] for (_, u, _) in self._gates]
@@ -267,10 +274,16 @@ class _Recurrent(nn.Module):
                 if not self.training:
                     rmean = torch.cat([b.running_mean for b in bns], 0)
                     rvar = torch.cat([b.running_var for b in bns], 0)
-            cfg = (self.KIND, self._act[i], H, bool(self.bidir), use_bn, self.training, 1e-5, 0.05, scalars[i])
-            lng = self.ln[i].gamma if self._use_ln[i] else None
-            lnb = self.ln[i].beta if self._use_ln[i] else None
-            y, bmean, bvar = F_.RecLayerFn.apply(x, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, masks[i], lng, lnb, cfg)
+            cfg = (self.KIND, self._act[i], H, bool(self.bidir), use_bn, self.training, 1e-5, 0.05, scalar_i)
+            if F_.perf_path_ok(self.KIND, H, bool(self._use_ln[i]), use_bn, self.training):
+                y, bmean, bvar, xb = F_.RecLayerPerfFn.apply(x, xb, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, mask_i,
+                                                           cfg + (xseg,))
+                xseg = (2 if self.bidir else 1, H, (H + 7) // 8 * 8)
+            else:
+                lng = self.ln[i].gamma if self._use_ln[i] else None
+                lnb = self.ln[i].beta if self._use_ln[i] else None
+                y, bmean, bvar = F_.RecLayerFn.apply(x, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, mask_i, lng, lnb, cfg)
+                xb = xseg = None
             if use_bn and self.training:
                 n = x.shape[0] * x.shape[1] * (2 if self.bidir else 1)
                 with torch.no_grad():  # BatchNorm1d(momentum=0.05) running statistics, per gate

@@ -32,5 +32,34 @@ def main():
     w.writerows(out)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 2 and sys.argv[2] == "--gaps"):
     main()
+
+
+def gaps(db_path, top=25, tail_frac=1.0):
+    """Idle time on the device between consecutive kernels, grouped by (previous, next) kernel names.
+    tail_frac < 1 restricts the analysis to the last part of the trace (steady state, no warm-up)."""
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select name, start, end from kernels order by start").fetchall()
+    if tail_frac < 1.0:
+        t0 = rows[0][1] + (rows[-1][2] - rows[0][1]) * (1.0 - tail_frac)
+        rows = [r for r in rows if r[1] >= t0]
+    acc = {}
+    busy = 0
+    for (n0, s0, e0), (n1, s1, e1) in zip(rows[:-1], rows[1:]):
+        busy += e0 - s0
+        g = s1 - e0
+        if g <= 0:
+            continue
+        k = (short(n0)[:50], short(n1)[:50])
+        d = acc.setdefault(k, [0, 0])
+        d[0] += g
+        d[1] += 1
+    span = rows[-1][2] - rows[0][1]
+    print("span %.3f ms, busy %.3f ms, idle %.3f ms" % (span / 1e6, busy / 1e6, (span - busy) / 1e6))
+    for k, v in sorted(acc.items(), key=lambda kv: -kv[1][0])[:top]:
+        print("%9.3f ms %6d x  %s  ->  %s" % (v[0] / 1e6, v[1], k[0], k[1]))
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "--gaps":
+    gaps(sys.argv[1], tail_frac=float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)

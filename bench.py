@@ -279,10 +279,11 @@ def main():
                 "traffic": None}
         if dom is not None:
             d = summ[dom]
-            if dom in ("pk_rec_fwd", "pk_rec_bwd"):
-                # the recurrent launches: fwd = 1/3, bwd (carry GEMM + deferred dU) = 2/3 of rec_flops
-                share = (1.0 if dom == "pk_rec_fwd" else 2.0) / 3.0
-                fl = rec_flops * share / d["calls_per_step"]
+            if dom in ("pk_rec_fwd", "pk_rec_bwd", "pk_rec_fwd_bf16", "pk_rec_bwd_bf16"):
+                # recurrent launches: fwd step GEMM = 1/3 of rec_flops, bwd carry GEMM = 1/3, deferred dU = 1/3
+                # (inside pk_rec_bwd in the fp32 library path, a separate pk_gemm_bf16 in the perf pipeline)
+                share = 2.0 if dom == "pk_rec_bwd" else 1.0
+                fl = rec_flops * share / 3.0 / d["calls_per_step"]
             elif dom == "pk_gemm":
                 fl = (total_flops - rec_flops) / d["calls_per_step"]
             else:

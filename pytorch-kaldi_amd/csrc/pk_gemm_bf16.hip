@@ -24,6 +24,8 @@
 // Edges: rows beyond M / N are clamped (their results are never stored);
 // 16-byte k-chunks beyond K come from a zero page, so K needs no padding
 // beyond a multiple of 8 elements (producers zero-fill inside the last chunk).
+#include <stdlib.h>
+
 #include "pk_common.h"
 
 namespace {
@@ -118,9 +120,12 @@ __device__ __forceinline__ bf16x8 frag(const unsigned char* buf, int sub, int kk
     }
 }
 
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 2) void gemm_bf16x_kernel(BArgs p) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [2][A 16 KB | B 16 KB]
+// STAGES = 2: LDS double buffer, one barrier per k-tile, 2 workgroups per CU (64 KB each).
+// STAGES = 1: single buffer, two barriers per k-tile, 3-4 workgroups per CU (32 KB each): the overlap of
+//             loads and MFMA comes from the co-resident workgroups instead of from the software pipeline.
+template <bool A_KC, bool B_KC, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16x_kernel(BArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [STAGES][A 16 KB | B 16 KB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // XCD-aware tile mapping: id%8 = XCD (observed round-robin dispatch; speed only)
@@ -141,19 +146,31 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x_kernel(BArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (nk > 0) {
-        stage<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, p.zeros, smem, tid, wave);
-        stage<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, p.zeros, smem + 16384, tid, wave);
+    // operands are swapped in the MFMA (D' = B.A^T): a lane then holds 4 consecutive COLUMNS n of one row m,
+    // so the epilogue stores 16 bytes per lane instead of four scattered dwords
+    if (STAGES == 2) {
+        if (nk > 0) {
+            stage<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, p.zeros, smem, tid, wave);
+            stage<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, p.zeros, smem + 16384, tid, wave);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        unsigned char* cur = smem + (kt & 1) * 32768;
-        unsigned char* nxt = smem + ((kt + 1) & 1) * 32768;
-        if (kt + 1 < nk) {
-            const int k0 = kbeg + (kt + 1) * TK;
-            stage<A_KC>(p.A, p.lda, m0, p.M, k0, kend, p.zeros, nxt, tid, wave);
-            stage<B_KC>(p.B, p.ldb, n0, p.N, k0, kend, p.zeros, nxt + 16384, tid, wave);
+        unsigned char* cur = smem + (STAGES == 2 ? (kt & 1) * 32768 : 0);
+        if (STAGES == 2) {
+            unsigned char* nxt = smem + ((kt + 1) & 1) * 32768;
+            if (kt + 1 < nk) {
+                const int k0 = kbeg + (kt + 1) * TK;
+                stage<A_KC>(p.A, p.lda, m0, p.M, k0, kend, p.zeros, nxt, tid, wave);
+                stage<B_KC>(p.B, p.ldb, n0, p.N, k0, kend, p.zeros, nxt + 16384, tid, wave);
+            }
+        } else {
+            const int k0 = kbeg + kt * TK;
+            stage<A_KC>(p.A, p.lda, m0, p.M, k0, kend, p.zeros, cur, tid, wave);
+            stage<B_KC>(p.B, p.ldb, n0, p.N, k0, kend, p.zeros, cur + 16384, tid, wave);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -166,31 +183,44 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x_kernel(BArgs p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    // epilogue: C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + r
+    // epilogue.  D' layout: row (lane>>4)*4 + r is the COLUMN offset, lane&15 the ROW offset of C
+    const bool vec_ok = (((uintptr_t)(p.ws ? p.ws : p.C) & 15) == 0) && (((p.ws ? (long)p.N : p.ldc) & 3) == 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wn * 64 + j * 16 + (lane & 15);
-            if (col >= p.N) continue;
-            const float bv = (p.bias != nullptr && p.ws == nullptr) ? p.bias[col] : 0.f;
+            const int row = m0 + wm * 64 + i * 16 + (lane & 15);
+            const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (row >= p.M || col >= p.N) continue;
+            const f32x4 v = acc[i][j];
+            float* dst = p.ws ? p.ws + ((long)split * p.M + row) * p.N + col : p.C + (long)row * p.ldc + col;
+            if (vec_ok && col + 3 < p.N) {
+                f32x4 o = v;
+                if (p.ws == nullptr) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-                if (row >= p.M) continue;
-                const float v = acc[i][j][r];
-                if (p.ws != nullptr) {
-                    p.ws[((long)split * p.M + row) * p.N + col] = v;
-                } else {
-                    float* c = p.C + (long)row * p.ldc + col;
-                    float o = p.alpha * v + bv;
-                    if (p.beta != 0.f) o += p.beta * (*c);
-                    *c = o;
+                    for (int r = 0; r < 4; ++r) o[r] = p.alpha * v[r] + (p.bias ? p.bias[col + r] : 0.f);
+                    if (p.beta != 0.f) {
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] += p.beta * c[r];
+                    }
+                }
+                *reinterpret_cast<f32x4*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (col + r >= p.N) continue;
+                    float o = v[r];
+                    if (p.ws == nullptr) {
+                        o = p.alpha * o + (p.bias ? p.bias[col + r] : 0.f);
+                        if (p.beta != 0.f) o += p.beta * dst[r];
+                    }
+                    dst[r] = o;
                 }
             }
         }
@@ -291,19 +321,30 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
     p.ws = splitk > 1 ? workspace : nullptr;
     const int mgroups = (p.tiles_m + 7) / 8;
     dim3 grid((unsigned)(mgroups * 8 * p.tiles_n), (unsigned)splitk), block(256);
-    const size_t lds = 65536;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+    // measured on MI355X (tools/bench_gemm.py): the single-buffer / 3-4 workgroups per CU variant wins on the
+    // row-streaming shapes (A k-contiguous: 630-644 vs 534-552 TFLOP/s at M = 64000), the double-buffered one on
+    // the split-K k-major shapes (357 vs 331).  PK_GEMM_STAGES=1|2 forces one of them.
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("PK_GEMM_STAGES");
+        forced = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 0;
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     }
-    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x_kernel<true, true>), grid, block, lds, st, p);
-    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16x_kernel<true, false>), grid, block, lds, st, p);
-    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x_kernel<false, true>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((gemm_bf16x_kernel<false, false>), grid, block, lds, st, p);
+    const int stages = forced ? forced : (a_kc ? 1 : 2);
+    const size_t lds = stages == 2 ? 65536 : 32768;
+#define PK_LAUNCH_BF(ST)                                                                                     \
+    do {                                                                                                     \
+        if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x_kernel<true, true, ST>), grid, block, lds, st, p);    \
+        else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16x_kernel<true, false, ST>), grid, block, lds, st, p); \
+        else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16x_kernel<false, true, ST>), grid, block, lds, st, p); \
+        else hipLaunchKernelGGL((gemm_bf16x_kernel<false, false, ST>), grid, block, lds, st, p);              \
+    } while (0)
+    if (stages == 2) PK_LAUNCH_BF(2);
+    else PK_LAUNCH_BF(1);
+#undef PK_LAUNCH_BF
     PK_LAUNCH_CHECK();
     if (splitk > 1) {
         const long total = (long)M * N;

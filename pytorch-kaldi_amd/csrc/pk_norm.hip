@@ -469,6 +469,12 @@ namespace {
 constexpr int BC_COLS = 16;  // chunks (of 8 columns) per block
 constexpr int BC_ROWL = 16;  // row lanes per block
 
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte access
+__device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
+    const f32x4u a = *reinterpret_cast<const f32x4u*>(p), b = *reinterpret_cast<const f32x4u*>(p + 4);
+    f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3];
+    f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
 __device__ __forceinline__ void bf8_to_f32(uint4 v, float (&f)[8]) {
     const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -504,19 +510,29 @@ __global__ __launch_bounds__(256) void bnb_reduce_kernel(const unsigned short* _
     }
     if (cok) {
         const long goff = (long)g * Hp + j0;
+        const bool full = j0 + 8 <= H;  // (the last chunk of a gate may hang over H: element-wise there)
+#pragma unroll 2
         for (long r = r0 + rl; r < r1; r += BC_ROWL) {
-            float a[8], b[8];
+            float a[8], b[8], xv[8];
             bf8_to_f32(*reinterpret_cast<const uint4*>(g0 + r * gpitch + goff), a);
             if (g1) {
                 bf8_to_f32(*reinterpret_cast<const uint4*>(g1 + r * gpitch + goff), b);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a[e] += b[e];
             }
-            const float* xr = x + r * ldx + (long)g * H + j0;
+            if (MODE == 0) {
+                const float* xr = x + r * ldx + (long)g * H + j0;
+                if (full) {
+                    ld8f(xr, xv);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[e] = (j0 + e < H) ? xr[e] : 0.f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 s0[e] += a[e];
-                if (MODE == 0 && j0 + e < H) s1[e] += a[e] * ((xr[e] - mu[e]) * inv[e]);
+                if (MODE == 0) s1[e] += a[e] * ((xv[e] - mu[e]) * inv[e]);  // inv = 0 beyond H
             }
         }
     }
@@ -571,6 +587,7 @@ __global__ __launch_bounds__(256) void bnb_apply_kernel(const unsigned short* __
     }
     const long goff = (long)g * Hp + j0;
     const int nvalid = (H - j0) < 8 ? (H - j0) : 8;
+#pragma unroll 2
     for (long r = r0 + rl; r < r1; r += BC_ROWL) {
         float a[8], b[8];
         bf8_to_f32(*reinterpret_cast<const uint4*>(g0 + r * gpitch + goff), a);
@@ -582,8 +599,15 @@ __global__ __launch_bounds__(256) void bnb_apply_kernel(const unsigned short* __
         float o[8];
         if (MODE == 0) {
             const float* xr = x + r * ldx + (long)g * H + j0;
+            float xv[8];
+            if (nvalid == 8) {
+                ld8f(xr, xv);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (e < nvalid) ? sc[e] * (a[e] - c0[e] - (xr[e] - mu[e]) * c1[e]) : 0.f;
+                for (int e = 0; e < 8; ++e) xv[e] = (e < nvalid) ? xr[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (e < nvalid) ? sc[e] * (a[e] - c0[e] - (xv[e] - mu[e]) * c1[e]) : 0.f;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (e < nvalid) ? a[e] : 0.f;

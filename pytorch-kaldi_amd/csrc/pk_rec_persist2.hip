@@ -118,10 +118,14 @@ __device__ __forceinline__ void pub_store(__amdgpu_buffer_rsrc_t rs, unsigned of
 template <int NCH, bool FAST>
 __device__ __forceinline__ bool poll_to_lds(__amdgpu_buffer_rsrc_t rs, const unsigned (&goff)[NCH], const int (&loff)[NCH],
                                             unsigned char* tile, unsigned* err, int spin_limit, int lane, bool dead,
-                                            int& retries) {
+                                            int& retries, int nch) {
+    // nch (workgroup-uniform) = chunk slots actually in use: NCH is sized for 16 rows, a cluster usually owns fewer
     u32x4 v[NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) v[i] = poll_load<FAST>(rs, goff[i]);
+    for (int i = 0; i < NCH; ++i) {
+        v[i] = u32x4{0u, 0u, 0u, 0u};
+        if (i < nch) v[i] = poll_load<FAST>(rs, goff[i]);
+    }
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) bad = bad | has_sent16(v[i]);
@@ -143,7 +147,8 @@ __device__ __forceinline__ bool poll_to_lds(__amdgpu_buffer_rsrc_t rs, const uns
         }
     }
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(tile + loff[i]) = v[i];
+    for (int i = 0; i < NCH; ++i)
+        if (i < nch) *reinterpret_cast<u32x4*>(tile + loff[i]) = v[i];
     return dead;
 }
 
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
 
     // ---- poll descriptors: chunk ci = (row, col) of the cluster's [nrows][Hp/8] block of h_{t-1}
     const int CPR = Hp >> 3;
+    const int nch = (nrows * CPR + 255) >> 8;         // chunk slots per lane in use (workgroup-uniform)
     const unsigned TS = (unsigned)B * a.Ypitch * 2u;  // bytes per time slab of Yb
     const unsigned szYb = (unsigned)T * TS;
     unsigned cbase[NCH], cstep[NCH];  // byte offset at step 1 and its increment per step (out of range: not my chunk)
@@ -407,25 +413,28 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
             // a poll that arrives before the other members' stores costs a whole extra round trip
             for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             int retries = 0;
-            dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries)
-                        : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries);
+            dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries, nch)
+                        : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries, nch);
             if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
-            // fp32 outputs of the previous step: issued now, they have a whole step to drain before the next poll
+        }
+        PK_TRACE(1);
+        // stage this step's projections (loaded one step ago) into the gate-math layout
+#pragma unroll
+        for (int g = 0; g < G; ++g) patch_put_vec(patchP + g * 256, lane, pv[g]);
+        if (t > 0) PK_BARRIER_LDS();
+        else PK_LDS_ORDER();
+        PK_TRACE(2);
+        // off the dependency chain, behind the barrier (they overlap the MFMA phase and have the rest of the step
+        // to drain before the next poll): fp32 outputs of the previous step, projections of the next one
+        if (t > 0) {
 #define PK_FO(E) flush_outputs(t - 1, E)
             PK_EDGE_DISPATCH(PK_FO);
         }
-        PK_TRACE(1);
-        // stage this step's projections (loaded one step ago) into the gate-math layout ...
-#pragma unroll
-        for (int g = 0; g < G; ++g) patch_put_vec(patchP + g * 256, lane, pv[g]);
-        // ... and issue the loads of step t+1 now: they are consumed after the next poll
         if (t + 1 < T) {
 #define PK_LP1(E) load_proj(t + 1, E)
             PK_EDGE_DISPATCH(PK_LP1);
         }
         if (t > 0) {
-            PK_BARRIER_LDS();
-            PK_TRACE(2);
             const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -433,8 +442,6 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, Bf[g][kk], acc[g], 0, 0, 0);
             }
-        } else {
-            PK_LDS_ORDER();
         }
         PK_TRACE(3);
         // ---- gate math for my (row, unit) pairs
@@ -533,6 +540,7 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
 
     // ---- poll descriptors: chunk ci = (row, gate, col) of the cluster's dgates_{t+1} block
     const int CPR = Hp >> 3;
+    const int nch = (nrows * G * CPR + 255) >> 8;     // chunk slots per lane in use (workgroup-uniform)
     const unsigned TS = (unsigned)B * a.Gpitch * 2u;  // bytes per time slab of dGb
     const unsigned ndir = (unsigned)(a.R / B);
     const unsigned szGb = ndir * (unsigned)T * TS;
@@ -638,18 +646,21 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
             for (int i = 0; i < NCH; ++i) goff[i] = cbase[i] + (unsigned)(it - 1) * cstep[i];
             for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             int retries = 0;
-            dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries)
-                        : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries);
+            dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries, nch)
+                        : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries, nch);
             if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
-            flush_outputs(t + 1);  // fp32 gate gradients of the previous step: a whole step to drain
         }
         PK_TRACE(1);
 #pragma unroll
         for (int k = 0; k < NIN; ++k) patch_put_vec(patchI + k * 256, lane, iv[k]);
+        if (t < T - 1) PK_BARRIER_LDS();
+        else PK_LDS_ORDER();
+        PK_TRACE(2);
+        // off the dependency chain, behind the barrier: fp32 gate gradients of the previous step (if wanted) and
+        // the saved tensors of the next one
+        if (t < T - 1) flush_outputs(t + 1);
         if (t > 0) load_step(t - 1);
         if (t < T - 1) {
-            PK_BARRIER_LDS();
-            PK_TRACE(2);
             const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
 #pragma unroll
             for (int g = 0; g < G; ++g)
@@ -660,8 +671,6 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
                     else acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, Bf[g][kk], acc1, 0, 0, 0);
                 }
             if (NBUF == 1) PK_BARRIER_LDS();  // single A tile: everyone is done reading before the next poll refills it
-        } else {
-            PK_LDS_ORDER();
         }
         PK_TRACE(3);
         float sin[NIN][4];

@@ -442,19 +442,22 @@ def _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, Yb=None, dGb=N
     if dGb is None:
         dGb = cvt_bf16(dP2.view(ndir * TB, GH), G, H, Hp)  # gate g of a row starts at column g*Hp (16-byte aligned)
     Gp = dGb.shape[1]
-    # one GEMM per (direction, gate) unless the gates are already contiguous (H % 8 == 0)
-    groups = [(0, Gh)] if Hp == H else [(g, 1) for g in range(Gh)]
-    for (g0, ng) in groups:
-        rows = dU[g0 * H:(g0 + ng) * H]
-        if Kh == 0:
-            rows.zero_()
-            continue
+    # one GEMM per direction over all gates fed by h_{t-1}: with the gates re-pitched to Hp the output has
+    # Hp - H dead rows per gate (zero gate gradients), dropped when the rows are copied into dU
+    Mp = Gh * H if Hp == H else Gh * Hp
+    out = dU[:Gh * H] if Hp == H else _new(Mp, H, like=dU)
+    if Kh == 0:
+        dU[:Gh * H].zero_()
+    else:
         for d in range(ndir):
             # rows whose previous state exists: dir 0 -> ts >= 1 (h at ts-1); dir 1 -> ts <= T-2 (h at ts+1)
-            a_off = (d * TB + (0 if d else B)) * Gp + g0 * Hp
+            a_off = (d * TB + (0 if d else B)) * Gp
             b_off = (B if d else 0) * Yp + d * Hp
-            gemm_bf16(ng * H, H, Kh, (dGb, a_off), Gp, 0, (Yb, b_off), Yp, 0, rows, H, beta=0.0 if d == 0 else 1.0,
-                      splitk=_splitk_bf(_tiles(ng * H, H), Kh))
+            gemm_bf16(Mp, H, Kh, (dGb, a_off), Gp, 0, (Yb, b_off), Yp, 0, out, H, beta=0.0 if d == 0 else 1.0,
+                      splitk=_splitk_bf(_tiles(Mp, H), Kh))
+        if Hp != H:
+            for g in range(Gh):
+                dU[g * H:(g + 1) * H].copy_(out[g * Hp:g * Hp + H])
     if two_phase:  # candidate gate: dU_h = sum dA^T . (r*h) or (z*h), saved in S
         slot = 3 if cell == "GRU" else 2
         for d in range(ndir):

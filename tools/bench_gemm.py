@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Micro-benchmark of pk_gemm_bf16 on the BASELINE shapes (T*B = 64000 rows, H = 550):
+forward projection (NT), dX (A k-contiguous, B k-major), dW / dU (both k-major, split-K)."""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+
+TB = 64000
+SHAPES = [
+    # name, M, N, K, a_kc, b_kc
+    ("fwd proj  x.W^T", TB, 1100, 1104, 1, 1),
+    ("head 1938 x.W^T", TB, 1938, 1100, 1, 1),
+    ("dX        dP.W ", TB, 1100, 1100, 1, 0),
+    ("dW     dP^T.x  ", 1100, 1104, TB, 0, 0),
+    ("dU     dG^T.h  ", 550, 550, TB - 128, 0, 0),
+    ("dWhead dy^T.x  ", 1938, 1100, TB, 0, 0),
+]
+
+
+def up(n, m):
+    return (n + m - 1) // m * m
+
+
+for name, M, N, K, akc, bkc in SHAPES:
+    A = torch.randn((M, up(K, 64)) if akc else (K, up(M, 64)), device="cuda").to(torch.bfloat16)
+    B = torch.randn((N, up(K, 64)) if bkc else (K, up(N, 64)), device="cuda").to(torch.bfloat16)
+    C = torch.empty(M, N, device="cuda")
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    sk = F_._splitk_bf(tiles, K) if not akc else 1
+
+    def run():
+        F_.gemm_bf16(M, N, K, A, A.shape[1], akc, B, B.shape[1], bkc, C, N, splitk=sk)
+
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 10
+    for _ in range(n):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    print("%s  M=%6d N=%5d K=%6d splitk=%2d  %.3f ms  %.0f TFLOP/s" % (name, M, N, K, sk, ms, 2.0 * M * N * K / ms / 1e9))

@@ -208,7 +208,13 @@ extern "C" int pk_conv1d_pool_bwd(void* stream, const float* x, const float* w, 
         hipLaunchKernelGGL(unpool_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, argmax, n, Lp, Lc, partial);
         PK_LAUNCH_CHECK();
         const size_t lds = sizeof(float) * (size_t)Cout * K;
-        PK_REQUIRE(lds <= 64 * 1024, "pk_conv1d_pool_bwd: Cout*K too large for the weight tile");
+        PK_REQUIRE(lds <= 160 * 1024, "pk_conv1d_pool_bwd: Cout*K too large for the weight tile");
+        static bool attr_bwd = false;
+        if (!attr_bwd) {
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)conv_bwd_data_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             160 * 1024));
+            attr_bwd = true;
+        }
         dim3 grid((L + 255) / 256, Cin, B);
         hipLaunchKernelGGL(conv_bwd_data_kernel, grid, dim3(256), lds, st, partial, w, B, Cin, L, Cout, K, Lc, dx);
         PK_LAUNCH_CHECK();

@@ -66,6 +66,69 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
+// 16-byte variant: a thread owns 4 consecutive columns (1 KB per wave and row); needs N % 4 == 0, ldx % 4 == 0
+// and a 16-byte aligned base.  Same shifted-sum / Chan-merge arithmetic per column as the scalar kernel.
+__global__ __launch_bounds__(256) void bn_stats_partial_v4_kernel(const float* __restrict__ x, long ldx, long M, long N,
+                                                                   float* __restrict__ partial) {
+    const int cx = threadIdx.x & (COLS - 1), ry = threadIdx.x >> 6;
+    const long c = ((long)blockIdx.x * COLS + cx) * 4;
+    const int rb = gridDim.y;
+    const long rows_per = (M + rb - 1) / rb;
+    const long r0 = (long)blockIdx.y * rows_per;
+    const long r1 = min(M, r0 + rows_per);
+    float n = 0.f, shift[4] = {0.f, 0.f, 0.f, 0.f}, s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+#pragma unroll 4
+        for (long r = r0 + ry; r < r1; r += RLANES) {
+            const float4 v4 = *reinterpret_cast<const float4*>(x + r * ldx + c);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            if (n == 0.f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) shift[e] = v[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[e] - shift[e];
+                s[e] += d;
+                ss[e] += d * d;
+            }
+            n += 1.f;
+        }
+    }
+    __shared__ float sh[RLANES][COLS][4][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float mean = 0.f, m2 = 0.f;
+        if (n > 0.f) {
+            mean = shift[e] + s[e] / n;
+            m2 = fmaxf(ss[e] - s[e] * s[e] / n, 0.f);
+        }
+        sh[ry][cx][e][0] = n;
+        sh[ry][cx][e][1] = mean;
+        sh[ry][cx][e][2] = m2;
+    }
+    __syncthreads();
+    // 256 threads: (column group 0..63, element 0..3)
+    const int oc = threadIdx.x >> 2, oe = threadIdx.x & 3;
+    const long ocol = ((long)blockIdx.x * COLS + oc) * 4 + oe;
+    if (ocol < N) {
+        float na = sh[0][oc][oe][0], ma = sh[0][oc][oe][1], qa = sh[0][oc][oe][2];
+        for (int k = 1; k < RLANES; ++k) {
+            const float nb = sh[k][oc][oe][0], mb = sh[k][oc][oe][1], qb = sh[k][oc][oe][2];
+            if (nb > 0.f) {
+                const float nt = na + nb, d = mb - ma;
+                ma += d * (nb / nt);
+                qa += qb + d * d * (na * nb / nt);
+                na = nt;
+            }
+        }
+        float* o = partial + ((long)blockIdx.y * N + ocol) * 3;
+        o[0] = na;
+        o[1] = ma;
+        o[2] = qa;
+    }
+}
+
 __global__ void bn_stats_final_kernel(const float* __restrict__ partial, int rb, long N, float* __restrict__ mean,
                                       float* __restrict__ var) {
     const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,8 +398,13 @@ extern "C" int pk_bn_stats(void* stream, const float* x, int64_t ldx, int64_t M,
     PK_REQUIRE(M > 0 && N > 0, "pk_bn_stats: empty input");
     hipStream_t st = pk_stream(stream);
     const int rb = row_blocks(M);
-    dim3 grid((unsigned)((N + COLS - 1) / COLS), rb);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, grid, dim3(256), 0, st, x, (long)ldx, (long)M, (long)N, partial);
+    if ((N & 3) == 0 && (ldx & 3) == 0 && ((uintptr_t)x & 15) == 0) {
+        dim3 grid4((unsigned)((N / 4 + COLS - 1) / COLS), rb);
+        hipLaunchKernelGGL(bn_stats_partial_v4_kernel, grid4, dim3(256), 0, st, x, (long)ldx, (long)M, (long)N, partial);
+    } else {
+        dim3 grid((unsigned)((N + COLS - 1) / COLS), rb);
+        hipLaunchKernelGGL(bn_stats_partial_kernel, grid, dim3(256), 0, st, x, (long)ldx, (long)M, (long)N, partial);
+    }
     PK_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partial, rb, (long)N,
                        mean, var);

@@ -118,14 +118,13 @@ __device__ __forceinline__ void pub_store(__amdgpu_buffer_rsrc_t rs, unsigned of
 template <int NCH, bool FAST>
 __device__ __forceinline__ bool poll_to_lds(__amdgpu_buffer_rsrc_t rs, const unsigned (&goff)[NCH], const int (&loff)[NCH],
                                             unsigned char* tile, unsigned* err, int spin_limit, int lane, bool dead,
-                                            int& retries, int nch) {
-    // nch (workgroup-uniform) = chunk slots actually in use: NCH is sized for 16 rows, a cluster usually owns fewer
+                                            int& retries) {
+    // straight-line on purpose (a branch per slot makes hipcc wait for every load separately).  Chunk slots a
+    // lane does not own carry an out-of-range offset: the bounds check answers with zeros without touching
+    // memory, zeros are never the sentinel, and the value lands in an LDS trash slot.
     u32x4 v[NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        v[i] = u32x4{0u, 0u, 0u, 0u};
-        if (i < nch) v[i] = poll_load<FAST>(rs, goff[i]);
-    }
+    for (int i = 0; i < NCH; ++i) v[i] = poll_load<FAST>(rs, goff[i]);
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) bad = bad | has_sent16(v[i]);
@@ -147,8 +146,7 @@ __device__ __forceinline__ bool poll_to_lds(__amdgpu_buffer_rsrc_t rs, const uns
         }
     }
 #pragma unroll
-    for (int i = 0; i < NCH; ++i)
-        if (i < nch) *reinterpret_cast<u32x4*>(tile + loff[i]) = v[i];
+    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(tile + loff[i]) = v[i];
     return dead;
 }
 
@@ -314,22 +312,20 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
 
     // ---- poll descriptors: chunk ci = (row, col) of the cluster's [nrows][Hp/8] block of h_{t-1}
     const int CPR = Hp >> 3;
-    const int nch = (nrows * CPR + 255) >> 8;         // chunk slots per lane in use (workgroup-uniform)
     const unsigned TS = (unsigned)B * a.Ypitch * 2u;  // bytes per time slab of Yb
     const unsigned szYb = (unsigned)T * TS;
     unsigned cbase[NCH], cstep[NCH];  // byte offset at step 1 and its increment per step (out of range: not my chunk)
     int clds[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ci = tid + 256 * i, nck = nrows * CPR;
-        const bool ok = ci < nck;
-        const int cj = ok ? ci : ci % nck;  // not my chunk: alias a real one (duplicate read, dumped in LDS)
-        const int row = cj / CPR, col = cj - row * CPR;
+        const int ci = tid + 256 * i;
+        const bool ok = ci < nrows * CPR;
+        const int row = ok ? ci / CPR : 0, col = ok ? ci - row * CPR : 0;
         const int n = n_base + row;
         const int dir = n >= B ? 1 : 0, b = n - dir * B;
-        // step t reads storage time (dir ? T-t : t-1)
-        cbase[i] = ((unsigned)b * a.Ypitch + dir * Hp + col * 8) * 2u + (unsigned)(dir ? (T - 1) : 0) * TS;
-        cstep[i] = dir ? 0u - TS : TS;
+        // step t reads storage time (dir ? T-t : t-1); a slot I do not own stays out of range
+        cbase[i] = ok ? ((unsigned)b * a.Ypitch + dir * Hp + col * 8) * 2u + (unsigned)(dir ? (T - 1) : 0) * TS : szYb;
+        cstep[i] = ok ? (dir ? 0u - TS : TS) : 0u;
         clds[i] = ok ? row * (LDA * 2) + col * 16 : LDS_TRASH;
     }
     // ---- gate-math (C/D) layout: rows kq*4 + r, unit lane&15
@@ -413,8 +409,8 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
             // a poll that arrives before the other members' stores costs a whole extra round trip
             for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             int retries = 0;
-            dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries, nch)
-                        : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries, nch);
+            dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries)
+                        : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries);
             if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
         }
         PK_TRACE(1);
@@ -540,7 +536,6 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
 
     // ---- poll descriptors: chunk ci = (row, gate, col) of the cluster's dgates_{t+1} block
     const int CPR = Hp >> 3;
-    const int nch = (nrows * G * CPR + 255) >> 8;     // chunk slots per lane in use (workgroup-uniform)
     const unsigned TS = (unsigned)B * a.Gpitch * 2u;  // bytes per time slab of dGb
     const unsigned ndir = (unsigned)(a.R / B);
     const unsigned szGb = ndir * (unsigned)T * TS;
@@ -548,18 +543,18 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
     int clds[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ci = tid + 256 * i, nck = nrows * G * CPR;
-        const bool ok = ci < nck;
-        const int cj = ok ? ci : ci % nck;  // not my chunk: alias a real one (duplicate read, dumped in LDS)
-        const int row = cj / (G * CPR);
-        const int rem = cj - row * (G * CPR);
+        const int ci = tid + 256 * i;
+        const bool ok = ci < nrows * G * CPR;
+        const int row = ok ? ci / (G * CPR) : 0;
+        const int rem = ok ? ci - row * (G * CPR) : 0;
         const int g = rem / CPR, col = rem - g * CPR;
         const int n = n_base + row;
         const int dir = n >= B ? 1 : 0, b = n - dir * B;
         // iteration it (t = T-1-it, it >= 1) reads storage time (dir ? T-2-t : t+1) = (dir ? it-1 : T-it)
-        cbase[i] = (unsigned)dir * (unsigned)T * TS + ((unsigned)b * a.Gpitch + g * Hp + col * 8) * 2u +
-                   (unsigned)(dir ? 0 : (T - 1)) * TS;
-        cstep[i] = dir ? TS : 0u - TS;
+        cbase[i] = ok ? (unsigned)dir * (unsigned)T * TS + ((unsigned)b * a.Gpitch + g * Hp + col * 8) * 2u +
+                            (unsigned)(dir ? 0 : (T - 1)) * TS
+                      : szGb;
+        cstep[i] = ok ? (dir ? TS : 0u - TS) : 0u;
         clds[i] = ok ? row * (LDA * 2) + (g * KPAD + col * 8) * 2 : LDS_TRASH;
     }
     float rvf[4], msk[4], dh_dir[4], dc_car[4];
@@ -646,8 +641,8 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
             for (int i = 0; i < NCH; ++i) goff[i] = cbase[i] + (unsigned)(it - 1) * cstep[i];
             for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             int retries = 0;
-            dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries, nch)
-                        : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries, nch);
+            dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries)
+                        : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries);
             if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
         }
         PK_TRACE(1);

@@ -126,6 +126,23 @@ def algorithmic_flops(rcp, T, B):
     return total, rec_flops
 
 
+def rec_launch_bytes(rcp, T, B, entry):
+    """Algorithmic HBM bytes of one persistent recurrent launch (bidirectional, fp32 tensors, bf16 exchange)."""
+    a1 = rcp["cfg"]["architecture1"]
+    kind = a1["arch_class"]
+    if kind not in ("liGRU", "LSTM", "RNN") or not entry.endswith("_bf16"):
+        return None
+    G = {"liGRU": 2, "LSTM": 4, "RNN": 1}[kind]
+    NS = {"liGRU": 2, "LSTM": 5, "RNN": 1}[kind]
+    H = int(a1[{"liGRU": "ligru", "LSTM": "lstm", "RNN": "rnn"}[kind] + "_lay"].split(",")[0])
+    Hp = (H + 7) // 8 * 8
+    rows = T * B
+    if "fwd" in entry:  # read P; write Y, S (both directions) and the bf16 copy Yb
+        return rows * G * H * 4 + rows * 2 * H * 4 + 2 * rows * NS * H * 4 + rows * 2 * Hp * 2
+    # read S, Y (h_{t-1}) and dY; write the bf16 gate gradients of both directions
+    return 2 * rows * NS * H * 4 + 2 * rows * 2 * H * 4 + 2 * rows * G * Hp * 2
+
+
 def profile_entry_points(tr, steps=2):
     """HIP-event timing of every C-ABI call of a few steps (events recorded on the stream the
     kernels are launched on = torch's current stream)."""
@@ -292,6 +309,20 @@ def main():
             roof.update({"kernel": dom, "achieved": round(ach, 3), "frac": round(ach / PEAK[args.prec], 5),
                          "avg_launch_ms": round(d["avg_ms"], 4), "launches_per_step": d["calls_per_step"],
                          "flops_per_launch": fl})
+            # algorithmic HBM bytes of one recurrent launch and the PMC-measured traffic
+            # of the same launch at this geometry (profiles/r01_pmc_traffic.json; null for any other geometry)
+            rb = rec_launch_bytes(tr.rcp, tr.T, tr.B, dom)
+            if rb:
+                roof["algorithmic_bytes_per_launch"] = rb
+                roof["hbm_gbps"] = round(rb / (d["avg_ms"] * 1e-3) / 1e9, 1)
+                roof["hbm_frac"] = round(rb / (d["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK, 5)
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                if dom in pm and args.recipe == "timit_ligru" and (tr.T, tr.B) == (500, 128) and args.layers is None:
+                    roof["traffic"] = pm[dom]["traffic_bytes"]
+                    roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            except (OSError, ValueError):
+                pass
         out["roofline"] = roof
         out["entry_points_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in
                                            sorted(summ.items(), key=lambda kv: -kv[1]["ms_per_step"])}

@@ -29,9 +29,11 @@ class _Settings:
     def __init__(self):
         self.precision = os.environ.get("PK_PRECISION", "fp32")
         self.rec_algo = os.environ.get("PK_REC_ALGO", "auto")
-        # recurrent drop masks: "reference" = the reference's torch.bernoulli call on the CPU RNG (same seed ->
-        # same masks as the reference), "device" = drawn on the GPU RNG (no host work in the step)
-        self.mask_rng = os.environ.get("PK_MASK_RNG", "reference")
+        # recurrent drop masks: "device" (default) = Bernoulli(1-p) drawn on the GPU RNG, no host work in the step;
+        # "reference" = the reference's own torch.bernoulli(torch.Tensor(rows,H).fill_(1-p)) call on the CPU RNG
+        # (same seed -> bit-identical masks to the reference; costs ~5.6 ms of host time per layer at 256x550 and
+        # makes the step host-bound: 109 vs 32 ms at BASELINE config 2)
+        self.mask_rng = os.environ.get("PK_MASK_RNG", "device")
         assert self.mask_rng in ("reference", "device"), self.mask_rng
         assert self.precision in PREC, self.precision
         assert self.rec_algo in ("auto", "stepwise", "persistent"), self.rec_algo

@@ -16,9 +16,10 @@ Contract kept from the reference:
     ``ln``/``bn`` sub-modules the reference always creates;
   * sub-modules are created in the reference's order with the same torch
     initialisers, so the same seed gives the same initial weights;
-  * recurrent drop masks are sampled per layer per forward call on the CPU RNG,
-    unscaled and constant over time, exactly like the reference
-    (e.g. neural_networks.py:1102-1107), then moved to the GPU.
+  * recurrent drop masks are Bernoulli(1-p), sampled per layer per forward call in layer
+    order, unscaled and constant over time like the reference's
+    (e.g. neural_networks.py:1102-1107); PK_MASK_RNG=reference draws them with the
+    reference's own CPU-RNG call (bit-identical stream), the default draws on the GPU.
 
 The nn.Linear / nn.BatchNorm1d / nn.Conv1d sub-modules are parameter containers
 only: ``forward`` never calls them, it hands their tensors to the HIP kernels
@@ -238,7 +239,31 @@ class _Recurrent(nn.Module):
         rows = 2 * batch if self.bidir else batch
         if F_.settings.mask_rng == "device":
             return torch.empty(rows, self._lay[i], device=device).bernoulli_(1 - p), 1.0
-        return torch.bernoulli(torch.Tensor(rows, self._lay[i]).fill_(1 - p)).to(device), 1.0
+        m = torch.bernoulli(torch.Tensor(rows, self._lay[i]).fill_(1 - p))  # the reference's own call
+        return self._to_device_async(i, m, device), 1.0
+
+    def _to_device_async(self, i, m, device):
+        """H2D copy of a freshly drawn mask that does not drain the GPU queue: a pageable .to(device) waits for
+        everything already enqueued.  Two pinned staging buffers per layer, each guarded by the event of its
+        last copy (a buffer is reused two forward calls later)."""
+        if device.type != "cuda":
+            return m.to(device)
+        if not hasattr(self, "_pin"):
+            self._pin, self._pin_ev, self._pin_k = {}, {}, {}
+        k = self._pin_k.get(i, 0)
+        key = (i, k, tuple(m.shape))
+        if key not in self._pin:
+            self._pin[key] = torch.empty(m.shape, dtype=m.dtype).pin_memory()
+            self._pin_ev[key] = None
+        if self._pin_ev[key] is not None:
+            self._pin_ev[key].synchronize()
+        self._pin[key].copy_(m)
+        d = self._pin[key].to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pin_ev[key] = ev
+        self._pin_k[i] = 1 - k
+        return d
 
     def forward(self, x, drop_masks=None):
         if not x.is_cuda:

@@ -205,6 +205,15 @@ void pk_persist2_set_trace(void* dev_buf);
 void pk_persist2_set_mode(int force_safe);
 /* tuning: idle time (units of 64 clocks) between a workgroup's publish and its first poll of the next step */
 void pk_persist2_set_poll_delay(int units);
+/* two-phase cells (GRU :629-641, minimalGRU :1291-1302): the candidate GEMM consumes a gate of the same
+ * step, so every step is two cluster-wide exchanges.  Xb [T*B][y_pitch] (bf16 r*h / z*h, laid out like Yb)
+ * is the second exchange buffer and the k-major operand of the dU_h GEMM; of S only the z(,r),a slots are
+ * written.  The backward leaves the fp32 gate gradients unwritten (dGb only, gates [z,(r,)a] at g*Hp). */
+int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
+                      const float* pscale, const float* pshift, const float* U, const float* mask, float mask_scalar,
+                      float* Y, float* S, uint16_t* Yb, uint16_t* Xb, int64_t y_pitch);
+int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
+                      float mask_scalar, const float* Y, const float* S, const float* dY, uint16_t* dGb, int64_t g_pitch);
 unsigned pk_persist2_error_count(void);
 void pk_persist2_error_reset(void);
 

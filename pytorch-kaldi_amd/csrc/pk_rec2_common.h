@@ -1,0 +1,250 @@
+// pk_rec2_common.h - shared device helpers of the perf-mode persistent recurrences
+// (pk_rec_persist2.hip: liGRU / RNN / LSTM; pk_rec_persist2_gru.hip: GRU / minimalGRU).
+// See pk_rec_persist2.hip for the design notes.
+#pragma once
+#define PK_CELL_FAST_MATH 1  // perf mode: hardware-rate exp / reciprocal in the gate math
+#include "pk_cell.h"
+
+struct R2Args {
+    int T, B, R, H, Hp, YH, act;
+    int C, Pn, rpc, row0;  // clusters, workgroups per cluster, rows per cluster, first row of this launch
+    const float *P, *pscale, *pshift, *U, *mask;
+    float mask_scalar;
+    float* Y;
+    float* S;
+    unsigned short* Yb;
+    unsigned short* Xb;  // two-phase cells: bf16 r*h (GRU) / z*h (minimalGRU), same layout as Yb
+    int Ypitch;  // elements per (t,b) row of Yb; direction d starts at d*Hp
+    const float* dY;
+    float* dP2;
+    unsigned short* dGb;
+    int Gpitch;  // elements per row of dGb; gate g starts at g*Hp
+    unsigned* err;
+    int spin_limit;
+    float* trash;               // >= 64 bytes per lane-group of write-only scratch for masked-off stores
+    int poll_delay;             // s_sleep units (64 clocks) between the publish and the first poll of the next step
+    int force_safe;             // 1 = always use the placement-independent write-through exchange
+    unsigned* xcd_tab;          // [C][16] placement handshake words (0xFFFFFFFF before the launch)
+    unsigned long long* trace;  // optional [T][8] phase time stamps of (cluster 0, member 0, wave 0); null = off
+};
+
+struct Plan2 {
+    int Pn, C, rpc, launches;
+};
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KPAD = 576;    // K (hidden units) padded to 18 MFMA k-steps of 32
+constexpr int KSTEPS = 18;
+constexpr int RMAX = 16;     // rows per cluster (one MFMA M tile)
+
+
+#define PK_TRACE(slot)                                                                      \
+    do {                                                                                    \
+        if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+__device__ __forceinline__ bool has_sent16(const u32x4 v) {
+    bool s = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s = s || ((v[e] & 0xFFFFu) == 0xFFFFu) || ((v[e] >> 16) == 0xFFFFu);
+    return s;
+}
+// bf16 with the sentinel pattern excluded (any NaN becomes the canonical quiet NaN 0x7FC0)
+__device__ __forceinline__ unsigned short to_bf_pub(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)0x7FC0;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ bool spin_check2(int& spins, int spin_limit, unsigned* err, int lane) {
+    if (++spins > spin_limit) {
+        if (lane == 0) atomicAdd_system(err, 1u);
+        return true;
+    }
+    if ((spins & 63) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return true;
+    __builtin_amdgcn_s_sleep(1);
+    return false;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// Poll NCH 16-byte chunks per lane (write-through loads) until none holds the sentinel, then store them to LDS.
+// FAST (every member of the cluster sits on one XCD, decided by the start-up handshake): the
+// exchange stays inside that XCD's L2 - producers use plain stores (the line stays in L2), consumers
+// poll with nt loads (bypass the per-CU L1, served by L2).  Otherwise: write-through (sc1) stores
+// and agent-scope (sc1) loads, correct for any placement.  Placement only ever changes the speed.
+//
+// vmcnt is ONE counter for loads and stores on gfx9-class hardware and the two kinds retire out of order
+// with respect to each other, so a counted wait cannot tell a landed poll from an acknowledged store:
+// the poll data is only safe behind s_waitcnt vmcnt(0).  The step is therefore ordered so that everything
+// still in flight at that point is old: the fp32 output stores of step t-1 and the prefetch loads of
+// step t+1 are issued right AFTER the poll of step t has landed (a whole MFMA + gate phase before the
+// next poll); only the 16-byte publish store is young.
+template <bool FAST>
+__device__ __forceinline__ u32x4 poll_load(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return FAST ? __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 2) : __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16);
+}
+template <bool FAST>
+__device__ __forceinline__ void pub_store(__amdgpu_buffer_rsrc_t rs, unsigned off, u32x4 v) {
+    if (FAST) __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
+}
+
+// Poll NCH 16-byte chunks per lane until none holds the sentinel, then store them to the LDS tile.
+// Chunk slots a lane does not own alias one of the cluster's real chunks (harmless duplicate read) and
+// land in an LDS trash slot, which keeps the code branch-free.  (The loads are compiler-visible on
+// purpose: with inline-asm loads nothing stops the register allocator from copying a destination register
+// before the s_waitcnt that makes it valid.)
+template <int NCH, bool FAST>
+__device__ __forceinline__ bool poll_to_lds(__amdgpu_buffer_rsrc_t rs, const unsigned (&goff)[NCH], const int (&loff)[NCH],
+                                            unsigned char* tile, unsigned* err, int spin_limit, int lane, bool dead,
+                                            int& retries) {
+    // straight-line on purpose (a branch per slot makes hipcc wait for every load separately).  Chunk slots a
+    // lane does not own carry an out-of-range offset: the bounds check answers with zeros without touching
+    // memory, zeros are never the sentinel, and the value lands in an LDS trash slot.
+    u32x4 v[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) v[i] = poll_load<FAST>(rs, goff[i]);
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) bad = bad | has_sent16(v[i]);
+    if (__any(bad) && !dead) {
+        int spins = 0;
+        while (true) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+                if (has_sent16(v[i])) v[i] = poll_load<FAST>(rs, goff[i]);
+            bad = false;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) bad = bad | has_sent16(v[i]);
+            ++retries;
+            if (!__any(bad)) break;
+            if (spin_check2(spins, spin_limit, err, lane)) {
+                dead = true;
+                break;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(tile + loff[i]) = v[i];
+    return dead;
+}
+
+// One-time placement handshake: every member publishes the XCD it runs on (write-through) and
+// reads all members' words (agent scope); all members see the same words, hence take the same
+// decision.  Returns true when the whole cluster shares one XCD.
+__device__ __forceinline__ bool cluster_on_one_xcd(const R2Args& a, int c, int p, int tid, bool& dead) {
+    const unsigned my = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;  // HW_REG_XCC_ID
+    unsigned* tab = a.xcd_tab + c * 16;
+    if (tid == 0) __hip_atomic_store(tab + p, my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int same = 1;
+    if (tid < a.Pn) {
+        unsigned v = 0xFFFFFFFFu;
+        for (int spins = 0; spins < a.spin_limit; ++spins) {
+            v = __hip_atomic_load(tab + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 0xFFFFFFFFu) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (v == 0xFFFFFFFFu) {
+            atomicAdd_system(a.err, 1u);
+            same = 0;
+            dead = true;
+        } else {
+            same = (v == my) ? 1 : 0;
+        }
+    }
+    return __syncthreads_and(same) != 0;
+}
+
+// workgroup barrier that orders LDS only: __syncthreads() also drains vmcnt, i.e. it would wait for
+// the prefetch loads issued just before it (HBM latency on the dependency chain)
+#define PK_BARRIER_LDS()                               \
+    do {                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_s_barrier();                  \
+        asm volatile("" ::: "memory");                 \
+    } while (0)
+
+// ---- wave-private fp32 patches [16 rows][16 units] in LDS: the transposer between the MFMA C/D
+// layout (lane -> rows kq*4+r, unit lane&15: what the gate math works in) and the "vector" layout
+// (lane -> row lane>>2, 4 consecutive units: one 16-byte global access per lane, 1 KB per wave
+// instruction).  4-byte-per-lane global accesses cost the same issue slot as 16-byte ones and were
+// 60 % of a step; LDS round trips are an order of magnitude cheaper.
+__device__ __forceinline__ void patch_put_cd(float* patch, int kq, int lane, const float (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) patch[(kq * 4 + r) * 16 + (lane & 15)] = v[r];
+}
+__device__ __forceinline__ void patch_get_cd(const float* patch, int kq, int lane, float (&v)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = patch[(kq * 4 + r) * 16 + (lane & 15)];
+}
+__device__ __forceinline__ f32x4 patch_get_vec(const float* patch, int lane) {
+    return *reinterpret_cast<const f32x4*>(patch + (lane >> 2) * 16 + (lane & 3) * 4);
+}
+__device__ __forceinline__ void patch_put_vec(float* patch, int lane, f32x4 v) {
+    *reinterpret_cast<f32x4*>(patch + (lane >> 2) * 16 + (lane & 3) * 4) = v;
+}
+#define PK_LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// 16-byte (4 unit) global access of the vector layout; nv = number of valid units (edge of H).
+// Straight-line code: invalid lanes / elements are redirected (loads: to the tensor base, result
+// unused; stores: to a library-owned trash page) instead of being branched around, so that the compiler
+// can count the outstanding operations exactly - a divergent store makes it fall back to
+// s_waitcnt vmcnt(0), which would put the store acknowledgements back on the dependency chain.
+// Plain 64-bit addressing (no buffer descriptors: four of them per kernel exhaust the SGPRs and the
+// compiler then wraps every access in a waterfall loop).
+// EDGE is wave-uniform: true only for the one wave whose 16 units straddle H when H % 4 != 0; it uses
+// four 4-byte accesses per lane, every other wave a single 16-byte access.
+template <int EDGE>
+__device__ __forceinline__ f32x4 ld4(const float* base, unsigned off, int nv) {
+    if (EDGE == 0) {
+        return *reinterpret_cast<const f32x4*>(base + (nv == 4 ? off : 0u));
+    } else if (EDGE == 1) {  // even H: nv is 0, 2 or 4 - two 8-byte halves
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 lo = *reinterpret_cast<const f32x2*>(base + (nv >= 2 ? off : 0u));
+        const f32x2 hi = *reinterpret_cast<const f32x2*>(base + (nv == 4 ? off + 2 : 0u));
+        return f32x4{lo[0], lo[1], hi[0], hi[1]};
+    } else {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = base[e < nv ? off + e : 0u];
+        return v;
+    }
+}
+template <int EDGE>
+__device__ __forceinline__ void st4(float* base, unsigned off, int nv, float* trash, f32x4 v) {
+    if (EDGE == 0) {
+        *reinterpret_cast<f32x4*>(nv == 4 ? base + off : trash) = v;
+    } else if (EDGE == 1) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f32x2*>(nv >= 2 ? base + off : trash) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2*>(nv == 4 ? base + off + 2 : trash + 2) = f32x2{v[2], v[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *(e < nv ? base + off + e : trash + e) = v[e];
+    }
+}
+template <int B>
+struct BoolC {  // (an int: 0 = no edge, 1 = even-H edge in 8-byte halves, 2 = odd-H edge element by element)
+    static constexpr int value = B;
+};
+
+
+#define PK_EDGE_DISPATCH(CALL)                 \
+    do {                                        \
+        if (edge == 0) CALL(BoolC<0>());        \
+        else if (edge == 1) CALL(BoolC<1>());   \
+        else CALL(BoolC<2>());                  \
+    } while (0)
+
+}  // namespace
+
+// host-side plumbing shared by both translation units (defined in pk_rec_persist2.hip)
+int pk_rec2_make_plan(int R, int H, Plan2& pl);
+int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidir, int H);
+int pk_rec2_host_setup(R2Args& a);                 // error word, trash page, handshake table, tuning knobs
+int pk_rec2_reset_handshake(hipStream_t st);       // before every launch

@@ -428,7 +428,7 @@ def choose_rec_algo(cell, H, use_ln):
     return REC_PERSISTENT if ok else REC_STEPWISE
 
 
-def _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, Yb=None, dGb=None):
+def _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, Yb=None, dGb=None, Xb=None):
     """dU[G*H, H] = sum over directions and steps of dgate_t^T . (vector that fed U_g at step t), as
     k-major x k-major bf16 GEMMs over the (T-1)*B rows (Appendix C of SURVEY.md; pk_rec.hip deferred_dU
     is the fp32 twin).  Y's two direction halves are re-pitched to a multiple of 8 so that the reversed
@@ -463,8 +463,12 @@ def _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, Yb=None, dGb=N
     if two_phase:  # candidate gate: dU_h = sum dA^T . (r*h) or (z*h), saved in S
         slot = 3 if cell == "GRU" else 2
         for d in range(ndir):
-            gh = cvt_bf16(S[d][:, slot * H:(slot + 1) * H])
-            gemm_bf16(H, H, TB, (dGb, d * TB * Gp + Gh * Hp), Gp, 0, gh, gh.shape[1], 0, dU[Gh * H:], H,
+            if Xb is not None:  # the persistent kernels publish r*h / z*h as bf16, direction d at column d*Hp
+                gh, gh_ld = (Xb, d * Hp), Xb.shape[1]
+            else:
+                gh = cvt_bf16(S[d][:, slot * H:(slot + 1) * H])
+                gh_ld = gh.shape[1]
+            gemm_bf16(H, H, TB, (dGb, d * TB * Gp + Gh * Hp), Gp, 0, gh, gh_ld, 0, dU[Gh * H:], H,
                       beta=0.0 if d == 0 else 1.0, splitk=_splitk_bf(_tiles(H, H), TB))
 
 
@@ -637,7 +641,7 @@ def perf_path_ok(cell, H, use_ln, use_bn, training):
     backward through frozen statistics (eval-mode module with autograd on) stays on the general path."""
     if not bf16_mode() or settings.rec_algo == "stepwise":
         return False
-    if cell not in ("liGRU", "RNN", "LSTM") or H > 576 or use_ln:
+    if cell not in ("liGRU", "RNN", "LSTM", "GRU", "minimalGRU") or H > 576 or use_ln:
         return False
     return training or not use_bn or not torch.is_grad_enabled()
 
@@ -694,9 +698,18 @@ class RecLayerPerfFn(torch.autograd.Function):
         Hp = _up(H, 8)
         Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
         _lib.raise_if_persist_failed()
-        rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
-                                 _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1])
-        _lib.check(rc, "pk_rec_fwd_bf16")
+        Xb = None
+        if cell in ("GRU", "minimalGRU"):  # two exchanges per step: h and r*h (z*h)
+            Xb = torch.empty_like(Yb)
+            rc = lib.pk_rec2p_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
+                                       _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), _p(Xb),
+                                       Yb.shape[1])
+            _lib.check(rc, "pk_rec2p_fwd_bf16")
+        else:
+            rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
+                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1])
+            _lib.check(rc, "pk_rec_fwd_bf16")
+        ctx.Xb = Xb
         ctx.save_for_backward(xb, Wb, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, Yb)
         ctx.cfg = cfg[:-1] + (xseg,)
         ctx.in_shape = x.shape
@@ -722,11 +735,17 @@ class RecLayerPerfFn(torch.autograd.Function):
         dY = dY.contiguous()
         dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16)
         Gp = dGb.shape[1]
-        rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
-                                 float(mask_scalar), _p(Y), _p(S), _p(dY), None, _p(dGb), Gp)
-        _lib.check(rc, "pk_rec_bwd_bf16")
+        if ctx.Xb is not None:
+            rc = lib.pk_rec2p_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
+                                       float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dGb), Gp)
+            _lib.check(rc, "pk_rec2p_bwd_bf16")
+        else:
+            rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
+                                     float(mask_scalar), _p(Y), _p(S), _p(dY), None, _p(dGb), Gp)
+            _lib.check(rc, "pk_rec_bwd_bf16")
         dU = _new(GH, H, like=dY)
-        _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, None, dU, Yb, dGb)
+        _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, None, dU, Yb, dGb, ctx.Xb)
+        ctx.Xb = None
         # BatchNorm backward (or plain sum of the two directions) straight from dGb -> bf16 projection gradient
         dPb = torch.empty(TB, _up(GH, 64), device=dY.device, dtype=torch.bfloat16)
         part = _new(int(lib.pk_bn_partial_floats(TB, GH)), like=dY)

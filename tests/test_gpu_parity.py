@@ -235,7 +235,8 @@ def test_bf16_mode_is_close(kind, pre, act, H):
         assert rel_err(res["bf16"][2][k], v) < 1e-1, k
 
 
-@pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("LSTM", "lstm", "tanh"), ("RNN", "rnn", "tanh")])
+@pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("LSTM", "lstm", "tanh"), ("RNN", "rnn", "tanh"),
+                                          ("GRU", "gru", "tanh"), ("minimalGRU", "minimalgru", "relu")])
 @pytest.mark.parametrize("H,T,B,bidir", [(550, 12, 5, True), (40, 9, 3, True), (20, 7, 4, False), (14, 5, 33, True),
                                          (129, 6, 2, True)])
 @pytest.mark.parametrize("safe", [0, 1])

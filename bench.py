@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--mask-rng", default="device", choices=["device", "reference"],
                     help="recurrent drop masks: GPU RNG (default) or the reference's CPU torch.bernoulli stream")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1: launch the gradient all-reduce bucket by bucket from backward hooks instead of after backward")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim instead of the fused flat optimizers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
@@ -75,7 +77,7 @@ class Trainer:
             self.opts = self.OPT.fused_optimizer_init(self.nns, rcp["cfg"], rcp["arch_dict"])
             flats = {k: o.flat for k, o in self.opts.items()}
         # 8 MB buckets: the recurrent stack's 31.7 MB of gradients leave in 4 pieces while BPTT of the lower layers runs
-        self.reducer = self.DP.GradReducer(self.nns, flats=flats, bucket_bytes=8 << 20)
+        self.reducer = self.DP.GradReducer(self.nns, flats=flats, bucket_bytes=8 << 20, overlap=args.overlap)
         # one resident synthetic batch per rank (different seeds per rank = different shards)
         self.T, self.B = (args.T, args.B) if rcp["seq"] else (1, args.B)
         self.batches = [self.R.synthetic_batch(rcp, self.T, self.B, 4234 + 17 * rank + i, "cuda") for i in range(2)]
@@ -114,6 +116,14 @@ def algorithmic_flops(rcp, T, B):
             total += proj * (2 if i == 0 else 3) + rec * 3
             rec_flops += rec * 3
             din = 2 * H
+        feat = din
+    elif a1["arch_class"] == "SincNet":
+        # conv FLOPs of the four blocks (194.26 MFLOP/frame fwd; conv1 has no dX) + the MLP trunk
+        total += frames * (101.45e6 * 2 + (78.34e6 + 12.10e6 + 2.38e6) * 3)
+        din = 3300
+        for H in [int(v) for v in rcp["cfg"]["architecture4"]["dnn_lay"].split(",")]:
+            total += 2.0 * frames * din * H * 3
+            din = H
         feat = din
     else:
         lay = [int(v) for v in a1["dnn_lay"].split(",")]
@@ -192,9 +202,13 @@ def cpu_baseline(args, rcp_name):
     nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
     torch.manual_seed(2234)
     nets = {"architecture1": getattr(nn_amd, kind)(dict(a1, use_cuda="False", to_do="train"), rcp["nfea"])}
-    nets["architecture2"] = nn_amd.MLP(dict(cfg["architecture2"]), nets["architecture1"].out_dim)
+    feat = nets["architecture1"].out_dim
+    if "architecture4" in cfg:  # SincNet recipe: an MLP trunk between the front-end and the heads
+        nets["architecture4"] = nn_amd.MLP(dict(cfg["architecture4"]), feat)
+        feat = nets["architecture4"].out_dim
+    nets["architecture2"] = nn_amd.MLP(dict(cfg["architecture2"]), feat)
     if rcp["n_mono"]:
-        nets["architecture3"] = nn_amd.MLP(dict(cfg["architecture3"]), nets["architecture1"].out_dim)
+        nets["architecture3"] = nn_amd.MLP(dict(cfg["architecture3"]), feat)
     sds = {k: {n: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in n)
                for n, v in net.state_dict().items()} for k, net in nets.items()}
     leaves = [v for sd in sds.values() for v in sd.values() if v.requires_grad]
@@ -209,7 +223,9 @@ def cpu_baseline(args, rcp_name):
             h = O.recurrent_forward(kind, dict(a1), sds["architecture1"], x)
             h = h.reshape(T * B, -1)
         else:
-            h = O.mlp_forward(dict(a1), sds["architecture1"], x)
+            h = O.arch_forward(kind, dict(a1), sds["architecture1"], x)
+            if "architecture4" in cfg:
+                h = O.mlp_forward(dict(cfg["architecture4"]), sds["architecture4"], h)
         loss = torch.nn.functional.nll_loss(O.mlp_forward(dict(cfg["architecture2"]), sds["architecture2"], h), lab_cd)
         if rcp["n_mono"]:
             lab_m = inp[..., rcp["nfea"] + 1].reshape(-1).long()
@@ -284,13 +300,14 @@ def main():
                                % (args.recipe, tr.rcp["cfg"]["architecture1"]["arch_class"], tr.T, tr.B,
                                   tr.rcp["n_cd"], tr.rcp["n_mono"]),
                    "global_batch": tr.B * world, "seq_len": tr.T, "parallelism": "dp%d" % world,
-                   "rec_algo": args.algo, "mask_rng": args.mask_rng, "optimizer": "torch" if args.torch_optim else "fused-flat",
+                   "rec_algo": args.algo, "mask_rng": args.mask_rng, "allreduce": "overlapped" if args.overlap else "after-backward", "optimizer": "torch" if args.torch_optim else "fused-flat",
                    "params": tr.n_params},
         "loss_final": round(float(loss), 5),
     }
+    # roofline of the dominant kernel class, measured live with HIP events (every rank runs the two extra steps:
+    # they contain the gradient all-reduce)
+    summ = profile_entry_points(tr)
     if rank == 0:
-        # roofline of the dominant kernel class, measured live with HIP events
-        summ = profile_entry_points(tr)
         total_flops, rec_flops = algorithmic_flops(tr.rcp, tr.T, tr.B)
         dom = max(summ, key=lambda k: summ[k]["ms_per_step"]) if summ else None
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK[args.prec], "unit": "TFLOP/s", "frac": None,

@@ -61,8 +61,13 @@ class GradReducer:
     not fire, e.g. parameters that received no gradient this step).
     """
 
-    def __init__(self, modules, bucket_bytes=32 << 20, flats=None, group=None):
+    def __init__(self, modules, bucket_bytes=32 << 20, flats=None, group=None, overlap=True):
+        """overlap=False: no hooks, every bucket is reduced in finish() (after backward).  At the recipes' sizes
+        (27-63 MB of gradients) the exchange is 1-2 % of a step either way; the serial form keeps
+        RCCL's kernels from competing for CUs with the persistent recurrent kernels, which want their whole
+        grid resident."""
         self.group = group
+        self.overlap = overlap
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.flats = flats  # dict name -> FlatParams or None
         self.buckets = []   # each: dict(params=[...], flat=tensor or None, pending=int)
@@ -103,8 +108,9 @@ class GradReducer:
         b = {"params": list(params), "flat": flat_slice, "pending": len(params), "fired": False, "seen": set(),
              "expect": None}
         self.buckets.append(b)
-        for p in params:
-            self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, b=b: self._ready(b, _p)))
+        if self.overlap:
+            for p in params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, b=b: self._ready(b, _p)))
 
     def _ready(self, b, p):
         if b["expect"] is None:

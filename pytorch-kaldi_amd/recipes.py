@@ -76,10 +76,34 @@ def recipe(name, n_lay=None, H=550):
                   "opt_dampening": "0.0", "opt_nesterov": "False"})
         cfg["architecture1"] = d
         model = TWO_HEAD_MODEL
+    elif name == "timit_sincnet":
+        # cfg/TIMIT_baselines/TIMIT_SincNet_raw.cfg:87-211: 200 ms raw-waveform frames (3200 samples) -> SincNet ->
+        # MLP 5x1024 -> heads.  Chained through a 4-architecture model section.
+        first, nfea, seq = "SincNet_layers", 3200, False
+        d = {"arch_class": "SincNet", "arch_seq_model": "False", "sinc_N_filt": "128,60,60,60", "sinc_len_filt": "129,5,5,3",
+             "sinc_max_pool_len": "3,3,3,2", "sinc_use_laynorm_inp": "True", "sinc_use_batchnorm_inp": "False",
+             "sinc_use_laynorm": "True,True,True,True", "sinc_use_batchnorm": "False,False,False,False",
+             "sinc_act": "relu,relu,relu,relu", "sinc_drop": "0.15,0.15,0.15,0.15", "sinc_sample_rate": "16000",
+             "sinc_min_low_hz": "50", "sinc_min_band_hz": "50"}
+        d.update(_RMS)
+        cfg["architecture1"] = d
+        n = n_lay or 5
+        m = {"arch_class": "MLP", "arch_seq_model": "False", "dnn_lay": _rep(1024, n), "dnn_drop": _rep(0.15, n),
+             "dnn_use_laynorm_inp": "False", "dnn_use_batchnorm_inp": "False", "dnn_use_batchnorm": _rep(True, n),
+             "dnn_use_laynorm": _rep(False, n), "dnn_act": _rep("relu", n)}
+        m.update(_RMS)
+        cfg["architecture4"] = m
+        model = ["out_dnn0=compute(SincNet_layers,fea)", "out_dnn1=compute(MLP_layers1,out_dnn0)",
+                 "out_dnn2=compute(MLP_layers,out_dnn1)", "out_dnn3=compute(MLP_layers2,out_dnn1)",
+                 "loss_mono=cost_nll(out_dnn3,lab_mono)", "loss_mono_w=mult_constant(loss_mono,1.0)",
+                 "loss_cd=cost_nll(out_dnn2,lab_cd)", "loss_final=sum(loss_cd,loss_mono_w)",
+                 "err_final=cost_err(out_dnn2,lab_cd)"]
     else:
         raise ValueError("unknown recipe " + name)
     cfg["architecture2"] = _head(n_cd)
     arch_dict = {first: ["architecture1", first, seq], "MLP_layers": ["architecture2", "MLP_layers", False]}
+    if name == "timit_sincnet":
+        arch_dict["MLP_layers1"] = ["architecture4", "MLP_layers1", False]
     lab_dict = {"lab_cd": ["lab_cd", "f", "o", nfea]}
     if n_mono:
         cfg["architecture3"] = _head(n_mono)

@@ -29,7 +29,7 @@ def _batch():
     return torch.randn(7, 8, 6, generator=g), torch.randn(7, 8, 3, generator=g)
 
 
-def _worker(rank, world, port, use_flat, bucket_bytes, out):
+def _worker(rank, world, port, use_flat, bucket_bytes, out, overlap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     DP = importlib.import_module("pytorch-kaldi_amd.dp")
@@ -40,7 +40,7 @@ def _worker(rank, world, port, use_flat, bucket_bytes, out):
     # an unused parameter, like the reference's never-called ln/bn sub-modules (grad stays None / zero)
     net.unused = torch.nn.Parameter(torch.ones(4))
     flats = {"net": OPT.FlatParams(net)} if use_flat else None
-    red = DP.GradReducer({"net": net}, bucket_bytes=bucket_bytes, flats=flats)
+    red = DP.GradReducer({"net": net}, bucket_bytes=bucket_bytes, flats=flats, overlap=overlap)
     x, y = _batch()
     for step in range(2):  # two steps: buckets must re-arm
         if flats:
@@ -57,11 +57,12 @@ def _worker(rank, world, port, use_flat, bucket_bytes, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_flat,bucket_bytes", [(False, 1 << 20), (False, 64), (True, 1 << 20), (True, 128)])
-def test_two_rank_allreduce_equals_shard_average(tmp_path, use_flat, bucket_bytes):
+@pytest.mark.parametrize("use_flat,bucket_bytes,overlap", [(False, 1 << 20, True), (False, 64, True), (True, 1 << 20, True),
+                                                           (True, 128, True), (True, 128, False)])
+def test_two_rank_allreduce_equals_shard_average(tmp_path, use_flat, bucket_bytes, overlap):
     world = 2
     out = str(tmp_path / "g.pt")
-    mp.spawn(_worker, args=(world, _free_port(), use_flat, bucket_bytes, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), use_flat, bucket_bytes, out, overlap), nprocs=world, join=True)
     got = torch.load(out)
     x, y = _batch()
     ref = None

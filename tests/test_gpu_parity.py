@@ -271,3 +271,82 @@ def test_bf16_persistent_matches_bf16_stepwise(kind, pre, act, H, T, B, bidir, s
     assert rel_err(res["persistent"][1], res["stepwise"][1]) < 2e-2
     for k, v in res["stepwise"][2].items():
         assert rel_err(res["persistent"][2][k], v) < 2e-2, k
+
+
+# --------------------------------------------------------------------------------
+# BASELINE configs[1] at FULL size (Li-GRU 5x550 bidirectional + 1938/48 heads, T=500, B=128):
+# the oracle needs ~400 s and 37 GB per step there, so parity is checked through
+# size-independent properties of the same computation.
+# --------------------------------------------------------------------------------
+def _full_trainer(prec):
+    from engine_util import F_amd
+
+    R = importlib.import_module("pytorch-kaldi_amd.recipes")
+    U = importlib.import_module("pytorch-kaldi_amd.utils")
+    F_amd.set_precision(prec)
+    F_amd.set_rec_algo("auto")
+    rcp = R.recipe("timit_ligru")
+    iod = {"fea": rcp["fea_dict"]["fea"][5:]}
+    torch.manual_seed(2234)
+    nns, costs = U.model_init(iod, rcp["model"], rcp["cfg"], rcp["arch_dict"], True, False, "train")
+    return R, U, rcp, iod, nns, costs
+
+
+def _fwd(U, rcp, iod, nns, costs, inp, T, B, masks):
+    rec = nns[rcp["first"]]
+    orig = rec.forward
+    rec.forward = lambda x: orig(x, drop_masks=masks)
+    try:
+        return U.forward_model(rcp["fea_dict"], rcp["lab_dict"], rcp["arch_dict"], rcp["model"], nns, costs, inp, iod,
+                               T, B, "train", [])
+    finally:
+        rec.forward = orig
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_full_size_properties(prec):
+    import math
+
+    T, B, H = 500, 128, 550
+    R, U, rcp, iod, nns, costs = _full_trainer(prec)
+    inp = R.synthetic_batch(rcp, T, B, 4234, "cuda")
+    g = torch.Generator().manual_seed(9)
+    masks = [torch.bernoulli(torch.full((2 * B, H), 0.8), generator=g).cuda() for _ in range(5)]
+    outs = _fwd(U, rcp, iod, nns, costs, inp, T, B, masks)
+    # (1) fresh network, uniform labels: loss_final = ln(1938) + ln(48) up to the spread of a random init
+    loss0 = float(outs["loss_final"])
+    assert abs(loss0 - (math.log(1938) + math.log(48))) < 0.05
+    # log-posteriors are normalised: sum(exp) == 1 for every frame
+    p = outs["out_dnn2"].exp().sum(1)
+    assert float((p - 1).abs().max()) < 1e-3
+    # (2) time-reversal symmetry of the bidirectional stack: flipping the input in time and swapping the mask
+    #     halves swaps the two direction halves of the output (exact identity of the reference's cat/flip)
+    y = outs["out_dnn1"].detach().view(T, B, 2 * H)
+    swapped = [torch.cat([m[B:], m[:B]], 0) for m in masks]
+    inp_f = torch.flip(inp, dims=[0])
+    with torch.no_grad():
+        yf = _fwd(U, rcp, iod, nns, costs, inp_f, T, B, swapped)["out_dnn1"].view(T, B, 2 * H)
+    tol = 1e-4 if prec == "fp32" else 3e-2
+    assert rel_err(torch.flip(yf[:, :, H:], dims=[0]), y[:, :, :H]) < tol
+    assert rel_err(torch.flip(yf[:, :, :H], dims=[0]), y[:, :, H:]) < tol
+    # (3) backward against a central finite difference of the loss along a random direction in the top
+    #     recurrent layer's input weights and the senone head (gradients are what training consumes)
+    outs["loss_final"].backward()
+    rec, head = nns[rcp["first"]], nns["MLP_layers"]
+    params = [rec.wh[4].weight, rec.wz[4].weight, rec.uh[4].weight, head.wx[0].weight]
+    dirs = [torch.randn(q.shape, generator=g).cuda() for q in params]
+    for d in dirs:
+        d /= d.norm()
+    analytic = sum(float((q.grad * d).sum()) for q, d in zip(params, dirs))
+    eps = 2e-2
+    vals = []
+    for sgn in (+1, -1):
+        with torch.no_grad():
+            for q, d in zip(params, dirs):
+                q.add_(d, alpha=sgn * eps)
+            vals.append(float(_fwd(U, rcp, iod, nns, costs, inp, T, B, masks)["loss_final"]))
+            for q, d in zip(params, dirs):
+                q.add_(d, alpha=-sgn * eps)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(numeric - analytic) < (2e-2 if prec == "fp32" else 1e-1) * max(abs(numeric), abs(analytic), 1e-3), (numeric, analytic)
+    importlib.import_module("pytorch-kaldi_amd.functional").set_precision("fp32")

@@ -223,7 +223,10 @@ void pk_persist2_error_reset(void);
  * y [B,Cout,Lp] with Lp = (L-K+1)/pool, argmax [B,Cout,Lp] (int32 position in
  * the un-pooled conv output) for backward. */
 int pk_conv1d_pool_fwd(void* stream, const float* x, const float* w, const float* bias, int B, int Cin, int L,
-                       int Cout, int K, int pool, float* y, int32_t* argmax);
+                       int Cout, int K, int pool, float* y, int32_t* argmax, float* work);
+/* work: scratch >= pk_conv_fwd_work_floats() floats (the weights re-packed per 16-channel tile so that the
+ * kernel reads them through the scalar cache). */
+int64_t pk_conv_fwd_work_floats(int Cin, int Cout, int K);
 /* dw [Cout,Cin,K], dbias [Cout] (may be NULL), dx [B,Cin,L] (may be NULL, e.g.
  * first layer).  partial: scratch >= pk_conv_partial_floats(). */
 int64_t pk_conv_partial_floats(int B, int Cin, int L, int Cout, int K, int pool);

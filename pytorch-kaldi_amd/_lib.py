@@ -62,7 +62,8 @@ SIGNATURES = {
     "pk_persist2_set_poll_delay": (None, [c_int]),
     "pk_persist2_error_count": (ctypes.c_uint, []),
     "pk_persist2_error_reset": (None, []),
-    "pk_conv1d_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "pk_conv1d_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "pk_conv_fwd_work_floats": (c_int64, [c_int, c_int, c_int]),
     "pk_conv_partial_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "pk_conv1d_pool_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "pk_rmsprop_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float]),

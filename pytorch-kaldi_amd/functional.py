@@ -794,8 +794,9 @@ class ConvPoolFn(torch.autograd.Function):
         Lp = (L - K + 1) // pool
         y = _new(B, Cout, Lp, like=x)
         arg = torch.empty(B, Cout, Lp, device=x.device, dtype=torch.int32)
+        work = _new(int(lib.pk_conv_fwd_work_floats(Cin, Cout, K)), like=x)
         _lib.check(lib.pk_conv1d_pool_fwd(_stream(), _p(x), _p(w), _p(bias), B, Cin, L, Cout, K, pool, _p(y),
-                                          ctypes.c_void_p(arg.data_ptr())), "pk_conv1d_pool_fwd")
+                                          ctypes.c_void_p(arg.data_ptr()), _p(work)), "pk_conv1d_pool_fwd")
         ctx.save_for_backward(x, w, arg)
         ctx.pool = pool
         ctx.has_bias = bias is not None
@@ -812,9 +813,7 @@ class ConvPoolFn(torch.autograd.Function):
         dw = torch.empty_like(w)
         db = _new(Cout, like=x) if ctx.has_bias else None
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        part = None
-        if dx is not None:
-            part = _new(int(lib.pk_conv_partial_floats(B, Cin, L, Cout, K, pool)), like=x)
+        part = _new(int(lib.pk_conv_partial_floats(B, Cin, L, Cout, K, pool)), like=x)
         _lib.check(lib.pk_conv1d_pool_bwd(_stream(), _p(x), _p(w), _p(dy), ctypes.c_void_p(arg.data_ptr()), B, Cin, L,
                                           Cout, K, pool, _p(dw), _p(db), _p(dx), _p(part)), "pk_conv1d_pool_bwd")
         return dx, dw, db, None

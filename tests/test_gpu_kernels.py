@@ -163,6 +163,12 @@ CONV_SHAPES = [
     (4, 1, 3200, 128, 129, 3),
     (4, 60, 340, 60, 5, 3),
     (2, 3, 50, 17, 7, 1),
+    (3, 40, 100, 80, 10, 3),     # cnn_len_filt = 10,3,3 / cnn_max_pool_len = 3,2,1 (TIMIT_CNN cfg)
+    (3, 80, 90, 60, 3, 2),
+    (3, 60, 43, 60, 3, 1),
+    (130, 20, 700, 33, 5, 3),    # more (batch, tile) pairs than reduction slices; ragged channel tiles
+    (2, 5, 2000, 20, 251, 3),    # long filters with several input channels
+    (2, 2, 64, 3, 4, 5),         # pool > 3: generic forward kernel
 ]
 
 

@@ -319,13 +319,19 @@ def test_full_size_properties(prec):
     # log-posteriors are normalised: sum(exp) == 1 for every frame
     p = outs["out_dnn2"].exp().sum(1)
     assert float((p - 1).abs().max()) < 1e-3
-    # (2) time-reversal symmetry of the bidirectional stack: flipping the input in time and swapping the mask
-    #     halves swaps the two direction halves of the output (exact identity of the reference's cat/flip)
-    y = outs["out_dnn1"].detach().view(T, B, 2 * H)
-    swapped = [torch.cat([m[B:], m[:B]], 0) for m in masks]
-    inp_f = torch.flip(inp, dims=[0])
-    with torch.no_grad():
-        yf = _fwd(U, rcp, iod, nns, costs, inp_f, T, B, swapped)["out_dnn1"].view(T, B, 2 * H)
+    # (2) time-reversal symmetry of a bidirectional layer at full T and B: flipping the input in time and swapping
+    #     the mask halves swaps the two direction halves of the output (the reference's cat/flip identity; it
+    #     holds per layer - the next layer sees the halves in swapped feature positions)
+    rec1 = nns[rcp["first"]]
+    x1 = inp[:, :, :rcp["nfea"]]
+    saved_lay = rec1._n_lay
+    rec1._n_lay = 1
+    try:
+        with torch.no_grad():
+            y = rec1(x1, drop_masks=masks[:1])
+            yf = rec1(torch.flip(x1, dims=[0]), drop_masks=[torch.cat([masks[0][B:], masks[0][:B]], 0)])
+    finally:
+        rec1._n_lay = saved_lay
     tol = 1e-4 if prec == "fp32" else 3e-2
     assert rel_err(torch.flip(yf[:, :, H:], dims=[0]), y[:, :, :H]) < tol
     assert rel_err(torch.flip(yf[:, :, :H], dims=[0]), y[:, :, H:]) < tol

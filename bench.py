@@ -296,9 +296,10 @@ def main():
         "metric": "train_frames_per_sec", "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
-        "config": {"workload": "%s: %s, T=%d, B=%d per GPU, 40-dim fMLLR, %d+%d senone/phone heads, fwd+bwd+optimizer"
+        "config": {"workload": "%s: %s, T=%d, B=%d per GPU, %s, %d+%d senone/phone heads, fwd+bwd+optimizer"
                                % (args.recipe, tr.rcp["cfg"]["architecture1"]["arch_class"], tr.T, tr.B,
-                                  tr.rcp["n_cd"], tr.rcp["n_mono"]),
+                                  "3200-sample raw waveform chunks" if tr.rcp["nfea"] == 3200
+                                  else "%d-dim features" % tr.rcp["nfea"], tr.rcp["n_cd"], tr.rcp["n_mono"]),
                    "global_batch": tr.B * world, "seq_len": tr.T, "parallelism": "dp%d" % world,
                    "rec_algo": args.algo, "mask_rng": args.mask_rng, "allreduce": "overlapped" if args.overlap else "after-backward", "optimizer": "torch" if args.torch_optim else "fused-flat",
                    "params": tr.n_params},
@@ -319,12 +320,19 @@ def main():
                 # (inside pk_rec_bwd in the fp32 library path, a separate pk_gemm_bf16 in the perf pipeline)
                 share = 2.0 if dom == "pk_rec_bwd" else 1.0
                 fl = rec_flops * share / 3.0 / d["calls_per_step"]
-            elif dom == "pk_gemm":
-                fl = (total_flops - rec_flops) / d["calls_per_step"]
+            elif dom in ("pk_gemm", "pk_gemm_bf16"):
+                conv = tr.T * tr.B * (101.45e6 * 2 + 92.82e6 * 3) if tr.rcp["nfea"] == 3200 else 0.0
+                dU = rec_flops / 3.0 if dom == "pk_gemm_bf16" else 0.0   # deferred dU GEMMs of the perf pipeline
+                fl = (total_flops - rec_flops - conv + dU) / d["calls_per_step"]
+            elif dom in ("pk_conv1d_pool_fwd", "pk_conv1d_pool_bwd"):
+                # fp32 direct convolution = packed-FMA VALU work (the fp32 MFMA rate is the same 157 TFLOP/s)
+                per_frame = 194.27e6 if dom.endswith("fwd") else 194.27e6 + 92.82e6 + 101.45e6
+                fl = tr.T * tr.B * per_frame / d["calls_per_step"]
+                roof.update({"bound": "valu-fp32", "peak": 157.3})
             else:
                 fl = 0.0
             ach = fl / (d["avg_ms"] * 1e-3) / 1e12 if d["avg_ms"] > 0 else 0.0
-            roof.update({"kernel": dom, "achieved": round(ach, 3), "frac": round(ach / PEAK[args.prec], 5),
+            roof.update({"kernel": dom, "achieved": round(ach, 3), "frac": round(ach / roof["peak"], 5),
                          "avg_launch_ms": round(d["avg_ms"], 4), "launches_per_step": d["calls_per_step"],
                          "flops_per_launch": fl})
             # algorithmic HBM bytes of one recurrent launch and the PMC-measured traffic

@@ -241,6 +241,9 @@ int pk_rmsprop_step(void* stream, float* p, const float* g, float* square_avg, i
                     float eps, float weight_decay);
 int pk_sgd_step(void* stream, float* p, const float* g, float* momentum_buf, int64_t n, float lr, float momentum,
                 float weight_decay, int first_step);
+/* torch.optim.Adam as utils.py:2130-2146 builds it; step counts from 1; max_exp_avg_sq NULL unless amsgrad. */
+int pk_adam_step(void* stream, float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                 int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step);
 
 /* persistent-recurrence health: number of spin time-outs since the last reset
  * (host-mapped counter, readable without a device sync). */

@@ -68,6 +68,7 @@ SIGNATURES = {
     "pk_conv1d_pool_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "pk_rmsprop_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float]),
     "pk_sgd_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_int]),
+    "pk_adam_step": (c_int, [P, P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int]),
     "pk_persist_error_count": (ctypes.c_uint, []),
     "pk_persist_error_reset": (None, []),
     "pk_selftest_mfma": (c_int, [P, ctypes.POINTER(c_int)]),

@@ -1,0 +1,292 @@
+"""Data-parallel chunk function: ``run_nn_dp`` has the signature and return value of the reference's
+``core.run_nn`` (core.py:439-753), so ``run_exp.py``, which resolves the chunk function by name from a module
+called ``core`` (run_exp.py:129-131), can use it with ``run_nn_script = run_nn_dp`` once this module is importable
+as ``core``.  What differs from the reference is everything SURVEY.md 8e / 8f-1..3 asks for:
+
+* one process per GPU (``torch.distributed.run``): every rank walks the same chunk with the same RNG stream, takes
+  its own columns of each batch (``dp.shard_batch``), and the gradient buckets are all-reduced over RCCL before the
+  fused optimizer step; ``nn.DataParallel`` (which would split the TIME axis, core.py:103-104) is never used;
+* batch assembly on the device: the reference copies sentence by sentence in a Python loop (core.py:581-598); here the
+  loop only draws the random left padding (same ``random.randint`` sequence) and ONE gather builds the padded
+  (T, B, D) batch from the resident chunk;
+* fused flat-bucket optimizers whose state dicts stay torch.optim-compatible, so ``.pkl`` checkpoints written here
+  load in the reference and vice versa;
+* rank 0 alone writes the ``.pkl`` / ``.info`` / ``.ark`` files.
+
+The chunk reader stays the reference's (Kaldi pipes, data_io.read_lab_fea): it is looked up as ``data_io.read_lab_fea``
+on ``sys.path`` unless a ``reader`` callable with the same signature is passed in.
+"""
+import configparser
+import os
+import random
+import struct
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+from . import dp as _dp
+from .optim import fused_optimizer_init
+from .utils import forward_model, model_init, strtobool
+
+
+def is_sequential_dict(config, arch_dict):
+    """utils.py:2006-2014."""
+    return any(strtobool(config[arch_dict[a][0]]["arch_seq_model"]) for a in arch_dict)
+
+
+def load_counts(class_counts_file):
+    """data_io.py:277-281 - one line ``[ c0 c1 ... ]``."""
+    with open(class_counts_file) as f:
+        row = next(f).strip().strip("[]").strip()
+    return np.array([np.float32(v) for v in row.split()])
+
+
+def write_mat(fd, m, key=""):
+    """Binary Kaldi matrix record, byte-for-byte what data_io.write_mat emits (data_io.py:1200-1239):
+    ``key SP \\0B (FM|DM) SP \\4 rows \\4 cols data``."""
+    m = np.ascontiguousarray(m)
+    if m.dtype == np.float32:
+        tag = b"FM "
+    elif m.dtype == np.float64:
+        tag = b"DM "
+    else:
+        raise TypeError("write_mat: '%s', please use 'float32' or 'float64'" % m.dtype)
+    if m.ndim != 2:
+        raise ValueError("write_mat: expected a matrix, got %d dims" % m.ndim)
+    if key != "":
+        fd.write((key + " ").encode("latin1"))
+    fd.write(b"\0B" + tag)
+    fd.write(b"\x04" + struct.pack("<I", m.shape[0]) + b"\x04" + struct.pack("<I", m.shape[1]))
+    fd.write(m.tobytes())
+
+
+def sentence_lengths(data_end_index):
+    """core.py:571-573: lengths from the cumulative end indices."""
+    end = np.asarray(data_end_index, dtype=np.int64)
+    return np.diff(end, prepend=0)
+
+
+class BatchAssembler:
+    """Zero-padded (max_len, B, D) batches with a random number of leading zeros per sentence
+    (core.py:581-598), built with one gather from the chunk instead of B slice copies.  The chunk gets one
+    extra all-zero row; the index map points padding at it."""
+
+    def __init__(self, data_set, data_end_index, device):
+        self.end = np.asarray(data_end_index, dtype=np.int64)
+        self.len = sentence_lengths(data_end_index)
+        self.beg = self.end - self.len
+        self.n_rows = data_set.shape[0]
+        pad = torch.zeros(1, data_set.shape[1], dtype=data_set.dtype, device=data_set.device)
+        self.src = torch.cat((data_set, pad), 0)
+        self.device = device
+        self._pinned = [None, None]
+        self._flip = 0
+
+    def index_map(self, snt_index, batch_size, cols=None):
+        """(max_len, len(cols)) source-row map of the batch starting at sentence ``snt_index``.  Draws one
+        ``random.randint`` per sentence of the WHOLE batch, in order, like the reference does, so that every
+        rank (and the oracle) sees the same padding whatever columns it keeps."""
+        lens = self.len[snt_index:snt_index + batch_size]
+        max_len = int(lens.max())
+        left = np.array([random.randint(0, int(max_len - n)) for n in lens], dtype=np.int64)
+        cols = np.arange(batch_size) if cols is None else np.asarray(cols)
+        t = np.arange(max_len, dtype=np.int64)[:, None]
+        rel = t - left[cols][None, :]
+        valid = (rel >= 0) & (rel < lens[cols][None, :])
+        idx = np.where(valid, self.beg[snt_index + cols][None, :] + rel, self.n_rows)
+        return max_len, idx
+
+    def batch(self, snt_index, batch_size, cols=None):
+        max_len, idx = self.index_map(snt_index, batch_size, cols)
+        it = torch.from_numpy(idx.reshape(-1))
+        if self.src.is_cuda:
+            buf = self._pinned[self._flip]
+            if buf is None or buf.numel() < it.numel():
+                buf = self._pinned[self._flip] = torch.empty(max(it.numel(), 1), dtype=torch.int64).pin_memory()
+            self._flip ^= 1
+            buf[:it.numel()].copy_(it)
+            it = buf[:it.numel()].to(self.src.device, non_blocking=True)
+        out = self.src.index_select(0, it).view(max_len, idx.shape[1], -1)
+        if out.device != self.device:
+            out = out.pin_memory().to(self.device, non_blocking=True) if self.device.type == "cuda" else out.to(self.device)
+        return max_len, out
+
+
+def _default_reader():
+    try:
+        import data_io  # the reference's, when running inside a PyTorch-Kaldi checkout
+    except ImportError as e:
+        raise RuntimeError("run_nn_dp needs a chunk reader: put PyTorch-Kaldi's data_io.py on sys.path or pass "
+                           "reader=callable(cfg_file, is_production, shared_list, output_folder)") from e
+    return data_io.read_lab_fea
+
+
+def _to_tensor(data_set, save_gpumem, use_cuda):
+    t = torch.from_numpy(data_set).float() if isinstance(data_set, np.ndarray) else data_set.float()
+    return t.cuda() if (use_cuda and not save_gpumem) else t
+
+
+def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict, cfg_file, processed_first,
+              next_config_file, reader=None):
+    """Process one chunk as ``[exp] to_do`` says (train / valid / forward) and return the next chunk's
+    ``[data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict]`` (core.py:753)."""
+    if not os.path.exists(cfg_file):
+        sys.stderr.write("ERROR: The config file %s does not exist!\n" % (cfg_file))
+        sys.exit(0)
+    config = configparser.ConfigParser()
+    config.read(cfg_file)
+    seed = int(config["exp"]["seed"])
+    torch.manual_seed(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+
+    exp = config["exp"]
+    output_folder = exp["out_folder"]
+    use_cuda = strtobool(exp["use_cuda"])
+    if not use_cuda:
+        raise RuntimeError("run_nn_dp drives the MI355X engine: it needs use_cuda=True (there is no CPU path)")
+    to_do = exp["to_do"]
+    info_file = exp["out_info"]
+    model = config["model"]["model"].split("\n")
+    forward_outs = config["forward"]["forward_out"].split(",")
+    forward_normalize_post = list(map(strtobool, config["forward"]["normalize_posteriors"].split(",")))
+    forward_count_files = config["forward"]["normalize_with_counts_from"].split(",")
+    require_decodings = list(map(strtobool, config["forward"]["require_decoding"].split(",")))
+    save_gpumem = strtobool(exp["save_gpumem"])
+    is_production = strtobool(exp["production"]) if "production" in exp else 0
+    batch_size = {"train": lambda: int(config["batches"]["batch_size_train"]),
+                  "valid": lambda: int(config["batches"]["batch_size_valid"]), "forward": lambda: 1}[to_do]()
+
+    rank, world, local_rank = _dp.init_from_env()
+    device = torch.device("cuda", torch.cuda.current_device())
+    if batch_size % world != 0 and to_do != "forward":
+        raise RuntimeError("batch size %d does not split over %d ranks" % (batch_size, world))
+    read = reader if reader is not None else _default_reader()
+
+    if processed_first:
+        shared_list = []
+        p = threading.Thread(target=read, args=(cfg_file, is_production, shared_list, output_folder))
+        p.start()
+        p.join()
+        data_name, data_end_index, fea_dict, lab_dict, arch_dict, data_set = shared_list[:6]
+        data_set = _to_tensor(data_set, save_gpumem, use_cuda)
+    shared_list = []
+    p = threading.Thread(target=read, args=(next_config_file, is_production, shared_list, output_folder))
+    p.start()
+
+    inp_out_dict = fea_dict
+    nns, costs = model_init(inp_out_dict, model, config, arch_dict, use_cuda, False, to_do)
+    optimizers = fused_optimizer_init(nns, config, arch_dict)
+    for net in nns.keys():
+        pt_file_arch = config[arch_dict[net][0]]["arch_pretrain_file"]
+        if pt_file_arch != "none":
+            checkpoint_load = torch.load(pt_file_arch, map_location=device)
+            nns[net].load_state_dict(checkpoint_load["model_par"])
+            optimizers[net].load_state_dict(checkpoint_load["optimizer_par"])
+            optimizers[net].param_groups[0]["lr"] = float(config[arch_dict[net][0]]["arch_lr"])
+    reducer = None
+    if to_do == "train" and world > 1:
+        reducer = _dp.GradReducer([nns[k] for k in nns], flats=[optimizers[k].flat for k in nns], overlap=False)
+
+    post_file = {}
+    if to_do == "forward" and rank == 0:
+        for out_id, name in enumerate(forward_outs):
+            suffix = "_to_decode.ark" if require_decodings[out_id] else ".ark"
+            post_file[name] = open(info_file.replace(".info", "_" + name + suffix), "wb")
+
+    seq_model = is_sequential_dict(config, arch_dict)
+    if seq_model or to_do == "forward":
+        N_batches = int(len(data_name) / batch_size)
+    else:
+        N_batches = int(data_set.shape[0] / batch_size)
+    end = np.asarray(data_end_index, dtype=np.int64)
+    assembler = BatchAssembler(data_set, data_end_index, device) if seq_model else None
+    local = batch_size // world if to_do != "forward" else 1
+    cols = np.arange(rank * local, (rank + 1) * local)
+    counts = {i: load_counts(forward_count_files[i]) for i in range(len(forward_outs))
+              if to_do == "forward" and forward_normalize_post[i]}
+
+    start_time = time.time()
+    loss_sum = torch.zeros((), device=device)
+    err_sum = torch.zeros((), device=device)
+    snt_index, beg_snt = 0, 0
+    for i in range(N_batches):
+        max_len = 0
+        if to_do == "forward":
+            if rank != 0:
+                continue
+            snt_len = int(end[snt_index]) - beg_snt
+            inp = data_set[beg_snt:beg_snt + snt_len, :].contiguous().to(device)
+            beg_snt = int(end[snt_index])
+            snt_index += 1
+            if seq_model:
+                max_len, inp = snt_len, inp.view(snt_len, 1, -1)
+        elif seq_model:
+            max_len, inp = assembler.batch(snt_index, batch_size, cols)
+            snt_index += batch_size
+        else:
+            b0 = i * batch_size + rank * local
+            inp = data_set[b0:b0 + local, :].contiguous().to(device, non_blocking=True)
+        nb = local if to_do != "forward" else 1
+        if to_do == "train":
+            outs_dict = forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out_dict, max_len, nb,
+                                      to_do, forward_outs)
+            for opt in optimizers.keys():
+                optimizers[opt].zero_grad()
+            outs_dict["loss_final"].backward()
+            if reducer is not None:
+                reducer.finish()
+            for opt in optimizers.keys():
+                if not strtobool(config[arch_dict[opt][0]]["arch_freeze"]):
+                    optimizers[opt].step()
+        else:
+            with torch.no_grad():
+                outs_dict = forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out_dict, max_len, nb,
+                                          to_do, forward_outs)
+        if to_do == "forward":
+            for out_id, name in enumerate(forward_outs):
+                out_save = outs_dict[name].detach().cpu().numpy()
+                if forward_normalize_post[out_id]:
+                    c = counts[out_id]
+                    out_save = out_save - np.log(c / np.sum(c))
+                write_mat(post_file[name], out_save, data_name[i])
+        else:
+            loss_sum += outs_dict["loss_final"].detach()
+            err_sum += outs_dict["err_final"].detach()
+    # the only host sync of the chunk (the reference syncs once per batch for its progress bar, core.py:689)
+    if to_do != "forward" and world > 1:
+        both = torch.stack((loss_sum, err_sum))
+        torch.distributed.all_reduce(both)
+        loss_sum, err_sum = both[0] / world, both[1] / world
+    torch.cuda.synchronize()
+    elapsed_time_chunk = time.time() - start_time
+    loss_tot = loss_sum / max(N_batches, 1)
+    err_tot = err_sum / max(N_batches, 1)
+
+    if to_do == "train" and rank == 0:
+        for net in nns.keys():
+            checkpoint = {"model_par": nns[net].state_dict(), "optimizer_par": optimizers[net].state_dict()}
+            torch.save(checkpoint, info_file.replace(".info", "_" + arch_dict[net][0] + ".pkl"))
+    for f in post_file.values():
+        f.close()
+    if rank == 0:
+        with open(info_file, "w") as text_file:
+            text_file.write("[results]\n")
+            if to_do != "forward":
+                text_file.write("loss=%s\n" % loss_tot.cpu().numpy())
+                text_file.write("err=%s\n" % err_tot.cpu().numpy())
+            text_file.write("elapsed_time_chunk=%f\n" % elapsed_time_chunk)
+    if world > 1:
+        torch.distributed.barrier()
+
+    p.join()
+    if len(shared_list) < 6:
+        return [None, None, None, None, None, None]
+    data_name, data_end_index, fea_dict, lab_dict, arch_dict, data_set = shared_list[:6]
+    return [data_name, _to_tensor(data_set, save_gpumem, use_cuda), data_end_index, fea_dict, lab_dict, arch_dict]
+
+
+run_nn = run_nn_dp  # so that cfgs with run_nn_script=run_nn pick the data-parallel loop up when this module is `core`

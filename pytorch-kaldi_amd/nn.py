@@ -203,7 +203,9 @@ class _Recurrent(nn.Module):
         for a in self._act:
             if a not in F_.ACT:
                 raise PkError("%s: activation %r is not supported inside the recurrence" % (self.KIND, a))
-        for name in w_order + u_order + ["ln"] + bn_order + ["act"]:
+        # registration order = the reference's (w, u pairs gate by gate, then ln, bn, act): parameters() order is
+        # what indexes torch optimizer state, so checkpoints' optimizer_par stay interchangeable
+        for name in [n for pair in zip(w_order, u_order) for n in pair] + ["ln"] + bn_order + ["act"]:
             setattr(self, name, nn.ModuleList([]))
         if self._use_ln_inp:
             self.ln0 = LayerNorm(self.input_dim)

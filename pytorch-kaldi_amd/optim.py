@@ -3,11 +3,11 @@
 ``FlatParams`` re-homes every parameter of a set of modules into ONE contiguous
 fp32 buffer (parameters become views) with a matching flat gradient buffer, so
 that (i) the optimizer step of an architecture is a single HIP kernel
-(``pk_rmsprop_step`` / ``pk_sgd_step``: 16 B read + 8 B written per parameter)
+(``pk_rmsprop_step`` / ``pk_sgd_step`` / ``pk_adam_step``: RMSprop reads 16 B and writes 8 B per parameter)
 and (ii) the data-parallel gradient exchange (dp.py) all-reduces slices of that
 same buffer with no packing copies.
 
-Semantics follow ``torch.optim.RMSprop`` / ``SGD`` exactly as
+Semantics follow ``torch.optim.RMSprop`` / ``SGD`` / ``Adam`` exactly as
 ``utils.optimizer_init`` configures them (utils.py:2106-2164).  Parameters the
 reference leaves without a gradient (its unused ``ln``/``bn`` sub-modules,
 SURVEY.md 7.2) keep a zero gradient here; for momentum-free RMSprop/SGD without
@@ -53,21 +53,42 @@ class FlatParams:
 
 
 class FusedOptimizer:
-    """One fused step per architecture.  kind: 'rmsprop' | 'sgd'."""
+    """One fused step per architecture.  kind: 'rmsprop' | 'sgd' | 'adam'.
+
+    ``state_dict()`` / ``load_state_dict()`` speak torch.optim's own format (per-parameter ``state`` entries,
+    ``param_groups`` with the torch hyper-parameter names), so the ``optimizer_par`` of a ``.pkl`` checkpoint
+    written by the reference loads here and vice versa (core.py:531-532, 708-722)."""
+
+    _STATE_KEYS = {"rmsprop": ("square_avg",), "sgd": ("momentum_buffer",),
+                   "adam": ("exp_avg", "exp_avg_sq", "max_exp_avg_sq")}
 
     def __init__(self, flat, kind, lr, alpha=0.99, eps=1e-8, momentum=0.0, weight_decay=0.0, centered=False,
-                 dampening=0.0, nesterov=False):
-        if kind not in ("rmsprop", "sgd"):
-            raise _lib.PkError("fused optimizer covers rmsprop and sgd (got %s); use torch.optim for the rest" % kind)
+                 dampening=0.0, nesterov=False, betas=(0.9, 0.999), amsgrad=False):
+        if kind not in ("rmsprop", "sgd", "adam"):
+            raise _lib.PkError("fused optimizer covers rmsprop, sgd and adam (got %s)" % kind)
         if kind == "rmsprop" and (momentum != 0.0 or centered):
             raise _lib.PkError("fused RMSprop is the momentum-free, non-centred form every shipped recipe uses")
         if kind == "sgd" and (dampening != 0.0 or nesterov):
             raise _lib.PkError("fused SGD does not implement dampening / nesterov")
         self.flat, self.kind, self.lr = flat, kind, lr
         self.alpha, self.eps, self.momentum, self.weight_decay = alpha, eps, momentum, weight_decay
-        self.state = torch.zeros_like(flat.flat) if (kind == "rmsprop" or momentum != 0.0) else None
+        self.betas, self.amsgrad = tuple(betas), bool(amsgrad)
+        z = lambda: torch.zeros_like(flat.flat)
+        self.bufs = {}
+        if kind == "rmsprop":
+            self.bufs["square_avg"] = z()
+        elif kind == "sgd" and momentum != 0.0:
+            self.bufs["momentum_buffer"] = z()
+        elif kind == "adam":
+            self.bufs["exp_avg"], self.bufs["exp_avg_sq"] = z(), z()
+            if self.amsgrad:
+                self.bufs["max_exp_avg_sq"] = z()
         self.steps = 0
         self.param_groups = [{"lr": lr}]  # run_nn overrides the LR through param_groups (core.py:533-535)
+
+    @property
+    def state(self):  # the (first) flat state buffer; kept for callers that only need "the" state
+        return next(iter(self.bufs.values()), None)
 
     def zero_grad(self):
         self.flat.zero_grad()
@@ -78,25 +99,72 @@ class FusedOptimizer:
         lib = _lib.load()
         lr = float(self.param_groups[0]["lr"])
         f = self.flat
+        ptr = lambda k: self.bufs[k].data_ptr() if k in self.bufs else None
         if self.kind == "rmsprop":
-            rc = lib.pk_rmsprop_step(_stream(), f.flat.data_ptr(), f.grad.data_ptr(), self.state.data_ptr(), f.numel, lr,
+            rc = lib.pk_rmsprop_step(_stream(), f.flat.data_ptr(), f.grad.data_ptr(), ptr("square_avg"), f.numel, lr,
                                      self.alpha, self.eps, self.weight_decay)
+        elif self.kind == "sgd":
+            rc = lib.pk_sgd_step(_stream(), f.flat.data_ptr(), f.grad.data_ptr(), ptr("momentum_buffer"), f.numel, lr,
+                                 self.momentum, self.weight_decay, int(self.steps == 0))
         else:
-            st = self.state.data_ptr() if self.state is not None else None
-            rc = lib.pk_sgd_step(_stream(), f.flat.data_ptr(), f.grad.data_ptr(), st, f.numel, lr, self.momentum,
-                                 self.weight_decay, int(self.steps == 0))
+            rc = lib.pk_adam_step(_stream(), f.flat.data_ptr(), f.grad.data_ptr(), ptr("exp_avg"), ptr("exp_avg_sq"),
+                                  ptr("max_exp_avg_sq"), f.numel, lr, self.betas[0], self.betas[1], self.eps,
+                                  self.weight_decay, self.steps + 1)
         _lib.check(rc, "fused optimizer step")
         self.steps += 1
 
+    def _torch_twin(self):
+        """The torch optimizer utils.optimizer_init would have built (never stepped): source of the
+        param_groups layout of the installed torch version."""
+        import torch.optim as optim
+        ps = self.flat.params
+        lr = float(self.param_groups[0]["lr"])
+        if self.kind == "rmsprop":
+            return optim.RMSprop(ps, lr=lr, alpha=self.alpha, eps=self.eps, weight_decay=self.weight_decay)
+        if self.kind == "sgd":
+            return optim.SGD(ps, lr=lr, momentum=self.momentum, weight_decay=self.weight_decay)
+        return optim.Adam(ps, lr=lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay, amsgrad=self.amsgrad)
+
     def state_dict(self):
-        return {"kind": self.kind, "steps": self.steps, "lr": self.param_groups[0]["lr"],
-                "state": None if self.state is None else self.state.clone()}
+        sd = self._torch_twin().state_dict()
+        state = {}
+        if self.steps > 0:
+            for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets)):
+                ent = {k: b[o:o + p.numel()].view(p.shape).clone() for k, b in self.bufs.items()}
+                if self.kind != "sgd":
+                    ent["step"] = torch.tensor(float(self.steps))
+                if ent:
+                    state[i] = ent
+        sd["state"] = state
+        return sd
 
     def load_state_dict(self, sd):
-        self.steps = sd["steps"]
-        self.param_groups[0]["lr"] = sd["lr"]
-        if sd["state"] is not None:
-            self.state.copy_(sd["state"])
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.flat.params):
+            raise _lib.PkError("optimizer state does not match this architecture's parameter list")
+        g = groups[0]
+        self.param_groups[0]["lr"] = g["lr"]
+        self.weight_decay = float(g.get("weight_decay", self.weight_decay))
+        if self.kind == "rmsprop":
+            self.alpha, self.eps = float(g.get("alpha", self.alpha)), float(g.get("eps", self.eps))
+        elif self.kind == "sgd":
+            self.momentum = float(g.get("momentum", self.momentum))
+        else:
+            self.betas, self.eps = tuple(g.get("betas", self.betas)), float(g.get("eps", self.eps))
+        steps = 0
+        for b in self.bufs.values():
+            b.zero_()
+        for i, ent in sd["state"].items():  # parameters torch never stepped (grad None) have no entry: zeros
+            i = int(i)
+            p, o = self.flat.params[i], self.flat.offsets[i]
+            for k, b in self.bufs.items():
+                if ent.get(k) is not None:
+                    b[o:o + p.numel()].copy_(ent[k].reshape(-1))
+            if "step" in ent:
+                steps = max(steps, int(float(ent["step"])))
+            elif ent.get("momentum_buffer") is not None:
+                steps = max(steps, 1)
+        self.steps = steps
 
 
 def fused_optimizer_init(nns, config, arch_dict):
@@ -121,6 +189,10 @@ def fused_optimizer_init(nns, config, arch_dict):
                                        weight_decay=float(sec["opt_weight_decay"]),
                                        dampening=float(sec["opt_dampening"]),
                                        nesterov=bool(strtobool(sec["opt_nesterov"])))
+        elif kind == "adam":
+            opts[net] = FusedOptimizer(flat, "adam", lr, betas=tuple(map(float, sec["opt_betas"].split(","))),
+                                       eps=float(sec["opt_eps"]), weight_decay=float(sec["opt_weight_decay"]),
+                                       amsgrad=bool(strtobool(sec["opt_amsgrad"])))
         else:
             raise _lib.PkError("fused optimizer: arch_opt=%s is not covered" % kind)
     return opts

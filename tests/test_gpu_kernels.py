@@ -217,6 +217,60 @@ def test_optimizers_match_torch():
         ge = gr.cuda()
         _lib.check(lib.pk_sgd_step(st, pe.data_ptr(), ge.data_ptr(), buf.data_ptr(), 10007, 0.08, 0.9, 1e-4, int(i == 0)), "sgd")
     assert rel_err(pe, pr) < 1e-6
+    # Adam as utils.py:2130-2146 builds it, with and without amsgrad
+    for ams in (False, True):
+        pr = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, amsgrad=ams)
+        pe = p0.clone().cuda()
+        m, v, vm = (torch.zeros(10007).cuda() for _ in range(3))
+        for i, gr in enumerate(grads):
+            pr.grad = gr.clone()
+            opt.step()
+            ge = gr.cuda()
+            _lib.check(lib.pk_adam_step(st, pe.data_ptr(), ge.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                        vm.data_ptr() if ams else None, 10007, 1e-3, 0.9, 0.999, 1e-8, 1e-4, i + 1), "adam")
+        assert rel_err(pe, pr) < 1e-6
+
+
+@pytest.mark.parametrize("kind", ["rmsprop", "sgd", "adam"])
+def test_fused_optimizer_continues_a_torch_checkpoint(kind):
+    """optimizer_par written by torch.optim (the reference, core.py:708-722) -> fused optimizer -> same next steps,
+    and the fused state_dict loads back into torch.optim."""
+    optim_ = importlib.import_module("pytorch-kaldi_amd.optim")
+    mk = {"rmsprop": lambda ps: torch.optim.RMSprop(ps, lr=4e-4, alpha=0.95, eps=1e-8),
+          "sgd": lambda ps: torch.optim.SGD(ps, lr=0.08, momentum=0.9),
+          "adam": lambda ps: torch.optim.Adam(ps, lr=1e-3)}[kind]
+    torch.manual_seed(3)
+    ref = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5)).cuda()
+    eng = torch.nn.Sequential(torch.nn.Linear(33, 17), torch.nn.Linear(17, 5)).cuda()
+    eng.load_state_dict(ref.state_dict())
+    x = torch.randn(64, 33).cuda()
+    ropt = mk(list(ref.parameters()))
+
+    def rstep(net, opt):
+        opt.zero_grad()
+        net(x).pow(2).mean().backward()
+        opt.step()
+
+    for _ in range(2):
+        rstep(ref, ropt)
+    eng.load_state_dict(ref.state_dict())
+    flat = optim_.FlatParams(eng)
+    kw = {"rmsprop": dict(alpha=0.95, eps=1e-8), "sgd": dict(momentum=0.9), "adam": dict()}[kind]
+    fopt = optim_.FusedOptimizer(flat, kind, {"rmsprop": 4e-4, "sgd": 0.08, "adam": 1e-3}[kind], **kw)
+    fopt.load_state_dict(ropt.state_dict())
+    for _ in range(2):
+        rstep(ref, ropt)
+        rstep(eng, fopt)
+    for a, b in zip(eng.parameters(), ref.parameters()):
+        assert rel_err(a, b) < 1e-5
+    # and back: torch continues from the fused optimizer's state
+    back = mk(list(ref.parameters()))
+    back.load_state_dict(fopt.state_dict())
+    rstep(ref, back)
+    rstep(eng, fopt)
+    for a, b in zip(eng.parameters(), ref.parameters()):
+        assert rel_err(a, b) < 1e-5
 
 
 # ---- perf-mode GEMM on bf16 operands (LDS-DMA staging, transpose reads for k-major operands) --------

@@ -46,6 +46,7 @@ struct BArgs {
     float* ws;  // split-K slabs [splits][M][N] or null
     int k_per_split;
     int tiles_m, tiles_n;
+    int items, per_xcd;  // work items = splits x tiles_m x tiles_n, and ceil(items / 8)
     const unsigned short* zeros;  // >= 16 bytes of zeros
 };
 
@@ -67,12 +68,12 @@ __device__ __forceinline__ unsigned long long sel_addr(bool ok, const void* a, c
 }
 
 // Stage one 128 x 64 operand tile (16 KB) into `buf`.  KC image: [128 rows][8 slots]; k-major image: [64 k][16 slots].
-template <bool KC>
+template <bool KC, int NT = 256>
 __device__ __forceinline__ void stage(const unsigned short* __restrict__ base, long ld, int r0, int rmax, int k0, int kmax,
                                       const unsigned short* zeros, unsigned char* buf, int tid, int wave) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = j * 256 + tid;
+    for (int j = 0; j < 1024 / NT; ++j) {
+        const int q = j * NT + tid;
         unsigned long long src;  // selected as an integer so that it stays ONE load (no exec-masked pair)
         if (KC) {
             const int row = q >> 3, ps = q & 7;
@@ -89,9 +90,46 @@ __device__ __forceinline__ void stage(const unsigned short* __restrict__ base, l
             const int gk = k0 + kr;
             src = sel_addr(gk < kmax, base + (long)gk * ld + gc, zeros);
         }
-        glds16(reinterpret_cast<const void*>(src), buf + (j * 256 + wave * 64) * 16);
+        glds16(reinterpret_cast<const void*>(src), buf + (j * NT + wave * 64) * 16);
     }
 }
+
+// The same tile image, fetched through per-thread source addresses that are computed ONCE and advanced by a
+// constant per k-tile: the address arithmetic of stage() (a 64-bit multiply per load for k-major operands) costs
+// more VALU cycles per k-tile than the tile's MFMAs take.  Valid for k-tiles that lie entirely below kmax; the
+// (single) ragged last tile of a split goes through stage().
+template <bool KC, int NT = 256>
+struct TileSrc {
+    unsigned long long a[1024 / NT];
+    unsigned long long step;
+    __device__ __forceinline__ void init(const unsigned short* __restrict__ base, long ld, int r0, int rmax, int k0, int tid) {
+#pragma unroll
+        for (int j = 0; j < 1024 / NT; ++j) {
+            const int q = j * NT + tid;
+            if (KC) {
+                const int row = q >> 3, ps = q & 7;
+                const int ks = ps ^ swz_kc(row);
+                int gr = r0 + row;
+                gr = gr < rmax ? gr : rmax - 1;
+                a[j] = (unsigned long long)(base + (long)gr * ld + k0 + ks * 8);
+            } else {
+                const int kr = q >> 4, ps = q & 15;
+                const int cs = ps ^ swz_km(kr);
+                int gc = r0 + cs * 8;
+                if (gc >= rmax) gc = (rmax - 1) & ~7;
+                a[j] = (unsigned long long)(base + (long)(k0 + kr) * ld + gc);
+            }
+        }
+        step = KC ? (unsigned long long)(TK * 2) : (unsigned long long)ld * (TK * 2);
+    }
+    __device__ __forceinline__ void issue(unsigned char* buf, int wave) {
+#pragma unroll
+        for (int j = 0; j < 1024 / NT; ++j) {
+            glds16(reinterpret_cast<const void*>(a[j]), buf + (j * NT + wave * 64) * 16);
+            a[j] += step;
+        }
+    }
+};
 
 // MFMA 16x16x32 operand fragment for the 16 rows starting at `sub` (tile-local), k-step kk (0/1) of the 64-deep tile.
 template <bool KC>
@@ -120,82 +158,15 @@ __device__ __forceinline__ bf16x8 frag(const unsigned char* buf, int sub, int kk
     }
 }
 
-// STAGES = 2: LDS double buffer, one barrier per k-tile, 2 workgroups per CU (64 KB each).
-// STAGES = 1: single buffer, two barriers per k-tile, 3-4 workgroups per CU (32 KB each): the overlap of
-//             loads and MFMA comes from the co-resident workgroups instead of from the software pipeline.
-template <bool A_KC, bool B_KC, int STAGES>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16x_kernel(BArgs p) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [STAGES][A 16 KB | B 16 KB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware tile mapping: id%8 = XCD (observed round-robin dispatch; speed only)
-    const int id = blockIdx.x;
-    const int xcd = id & 7, local = id >> 3;
-    const int tn = local % p.tiles_n;
-    const int tm = (local / p.tiles_n) * 8 + xcd;
-    if (tm >= p.tiles_m) return;
-    const int m0 = tm * TM, n0 = tn * TN;
-    const int split = blockIdx.y;
-    const int kbeg = split * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
-    const int nk = (kend - kbeg + TK - 1) / TK;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // operands are swapped in the MFMA (D' = B.A^T): a lane then holds 4 consecutive COLUMNS n of one row m,
-    // so the epilogue stores 16 bytes per lane instead of four scattered dwords
-    if (STAGES == 2) {
-        if (nk > 0) {
-            stage<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, p.zeros, smem, tid, wave);
-            stage<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, p.zeros, smem + 16384, tid, wave);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    for (int kt = 0; kt < nk; ++kt) {
-        unsigned char* cur = smem + (STAGES == 2 ? (kt & 1) * 32768 : 0);
-        if (STAGES == 2) {
-            unsigned char* nxt = smem + ((kt + 1) & 1) * 32768;
-            if (kt + 1 < nk) {
-                const int k0 = kbeg + (kt + 1) * TK;
-                stage<A_KC>(p.A, p.lda, m0, p.M, k0, kend, p.zeros, nxt, tid, wave);
-                stage<B_KC>(p.B, p.ldb, n0, p.N, k0, kend, p.zeros, nxt + 16384, tid, wave);
-            }
-        } else {
-            const int k0 = kbeg + kt * TK;
-            stage<A_KC>(p.A, p.lda, m0, p.M, k0, kend, p.zeros, cur, tid, wave);
-            stage<B_KC>(p.B, p.ldb, n0, p.N, k0, kend, p.zeros, cur + 16384, tid, wave);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = frag<A_KC>(cur, wm * 64 + i * 16, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = frag<B_KC>(cur + 16384, wn * 64 + j * 16, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-        }
-        if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    // epilogue.  D' layout: row (lane>>4)*4 + r is the COLUMN offset, lane&15 the ROW offset of C
+// D' layout of a wave's 64 x 64 tile at (mw, nw): row (lane>>4)*4 + r is the COLUMN offset, lane&15 the ROW offset of C
+__device__ __forceinline__ void epilogue(const BArgs& p, const f32x4 (&acc)[4][4], int mw, int nw, int split, int lane) {
     const bool vec_ok = (((uintptr_t)(p.ws ? p.ws : p.C) & 15) == 0) && (((p.ws ? (long)p.N : p.ldc) & 3) == 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int row = m0 + wm * 64 + i * 16 + (lane & 15);
-            const int col = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            const int row = mw + i * 16 + (lane & 15);
+            const int col = nw + j * 16 + (lane >> 4) * 4;
             if (row >= p.M || col >= p.N) continue;
             const f32x4 v = acc[i][j];
             float* dst = p.ws ? p.ws + ((long)split * p.M + row) * p.N + col : p.C + (long)row * p.ldc + col;
@@ -224,6 +195,155 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16x_kernel(BA
                 }
             }
         }
+}
+
+
+// STAGES = 2: LDS double buffer, one barrier per k-tile, 2 workgroups per CU (64 KB each).
+// STAGES = 1: single buffer, two barriers per k-tile, 3-4 workgroups per CU (32 KB each): the overlap of
+//             loads and MFMA comes from the co-resident workgroups instead of from the software pipeline.
+template <bool A_KC, bool B_KC, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16x_kernel(BArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [STAGES][A 16 KB | B 16 KB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware work mapping (block b runs on XCD b % 8 - observed round-robin dispatch; speed only): the
+    // (split, m-tile, n-tile) items, n fastest, are cut into 8 contiguous ranges, one per XCD.  Every XCD gets the
+    // same number of items whatever tiles_m is, and the items that share an A panel / a k-range sit on one L2.
+    const int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+    if (item >= p.items) return;
+    const int tn = item % p.tiles_n;
+    const int tm = (item / p.tiles_n) % p.tiles_m;
+    const int split = item / (p.tiles_n * p.tiles_m);
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + TK - 1) / TK;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // operands are swapped in the MFMA (D' = B.A^T): a lane then holds 4 consecutive COLUMNS n of one row m,
+    // so the epilogue stores 16 bytes per lane instead of four scattered dwords
+    TileSrc<A_KC> sa;
+    TileSrc<B_KC> sb;
+    sa.init(p.A, p.lda, m0, p.M, kbeg, tid);
+    sb.init(p.B, p.ldb, n0, p.N, kbeg, tid);
+    auto fetch = [&](int kt, unsigned char* buf) {
+        const int k0 = kbeg + kt * TK;
+        // incremental addresses pay for k-major operands only (their stage() address has a loop-variant 64-bit
+        // multiply); every k-tile but a ragged last one takes that path
+        const bool full = k0 + TK <= kend;
+        if (!A_KC && full) sa.issue(buf, wave);
+        else stage<A_KC>(p.A, p.lda, m0, p.M, k0, kend, p.zeros, buf, tid, wave);
+        if (!B_KC && full) sb.issue(buf + 16384, wave);
+        else stage<B_KC>(p.B, p.ldb, n0, p.N, k0, kend, p.zeros, buf + 16384, tid, wave);
+    };
+    if (STAGES == 2) {
+        if (nk > 0) fetch(0, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        unsigned char* cur = smem + (STAGES == 2 ? (kt & 1) * 32768 : 0);
+        if (STAGES == 2) {
+            if (kt + 1 < nk) fetch(kt + 1, smem + ((kt + 1) & 1) * 32768);
+        } else {
+            fetch(kt, cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag<A_KC>(cur, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = frag<B_KC>(cur + 16384, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, split, lane);
+}
+
+// Wide variant for the shapes with many rows: block tile 256 x 128 x 64, 8 waves (4 x 2, wave tile 64 x 64 as above),
+// THREE LDS stages of 48 KB (A rows 0-127 | A rows 128-255 | B) and a prefetch distance of two k-tiles.  The PMC
+// counters of the 128 x 128 kernel say why: its waves spend 55-65 % of their cycles in s_waitcnt (SQ_WAIT_ANY) with
+// the MFMA pipe 20-24 % busy and no LDS bank conflicts - one k-tile of prefetch does not cover the HBM/L2 latency.
+// Only loads are in flight in the main loop, so the counted s_waitcnt vmcnt(6) (the six LDS-DMA loads of the
+// newest stage) is exact: loads retire in order.
+constexpr int WIDE_STAGE = 49152;
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512) void gemm_bf16w_kernel(BArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [3][A0 16 KB | A1 16 KB | B 16 KB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
+    if (item >= p.items) return;
+    const int tn = item % p.tiles_n;
+    const int tm = (item / p.tiles_n) % p.tiles_m;
+    const int split = item / (p.tiles_n * p.tiles_m);
+    const int m0 = tm * 256, n0 = tn * TN;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + TK - 1) / TK;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    TileSrc<A_KC, 512> sa0, sa1;
+    TileSrc<B_KC, 512> sb;
+    sa0.init(p.A, p.lda, m0, p.M, kbeg, tid);
+    sa1.init(p.A, p.lda, m0 + 128, p.M, kbeg, tid);
+    sb.init(p.B, p.ldb, n0, p.N, kbeg, tid);
+    auto issue = [&](int kt) {
+        unsigned char* buf = smem + (kt % 3) * WIDE_STAGE;
+        const int k0 = kbeg + kt * TK;
+        if (k0 + TK <= kend) {
+            sa0.issue(buf, wave);
+            sa1.issue(buf + 16384, wave);
+            sb.issue(buf + 32768, wave);
+        } else {
+            stage<A_KC, 512>(p.A, p.lda, m0, p.M, k0, kend, p.zeros, buf, tid, wave);
+            stage<A_KC, 512>(p.A, p.lda, m0 + 128, p.M, k0, kend, p.zeros, buf + 16384, tid, wave);
+            stage<B_KC, 512>(p.B, p.ldb, n0, p.N, k0, kend, p.zeros, buf + 32768, tid, wave);
+        }
+    };
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // stage kt landed for every wave; everyone is done reading stage kt-1
+        if (kt + 2 < nk) issue(kt + 2);
+        const unsigned char* cur = smem + (kt % 3) * WIDE_STAGE;
+        const unsigned char* abuf = cur + (wm >> 1) * 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag<A_KC>(abuf, (wm & 1) * 64 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = frag<B_KC>(cur + 32768, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, split, lane);
 }
 
 __global__ void splitk_reduce_bf_kernel(const float* __restrict__ ws, int splitk, int M, int N, float alpha, float beta,
@@ -283,6 +403,22 @@ extern "C" int pk_cvt_bf16(void* stream, const float* src, int64_t ld_src, int64
     return 0;
 }
 
+// 256-row block tiles when that pads M by at most 15 % more than 128-row tiles would (PK_GEMM_WIDE=0|1 forces)
+static int wide_tile_rows(int M) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("PK_GEMM_WIDE");
+        forced = (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : 2;
+    }
+    if (forced == 0) return 128;
+    if (forced == 1) return M >= 256 ? 256 : 128;
+    if (forced == 2) return 128;  // measured slower than 3-4 co-resident 128-row workgroups (tools/bench_gemm.py)
+    const long pad128 = (long)((M + 127) / 128) * 128, pad256 = (long)((M + 255) / 256) * 256;
+    return (M >= 256 && pad256 * 100 <= pad128 * 115) ? 256 : 128;
+}
+
+extern "C" int pk_gemm_bf16_tile_m(int M) { return wide_tile_rows(M); }
+
 extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
                             const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc,
                             const float* bias, int splitk, float* workspace) {
@@ -300,7 +436,8 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
     p.alpha = alpha; p.beta = beta;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.bias = bias;
-    p.tiles_m = (M + TM - 1) / TM;
+    const int tile_m = wide_tile_rows(M);
+    p.tiles_m = (M + tile_m - 1) / tile_m;
     p.tiles_n = (N + TN - 1) / TN;
     void* zp = nullptr;
     PK_CHECK_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)));
@@ -319,8 +456,26 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
         if (p.k_per_split == 0) p.k_per_split = TK;
     }
     p.ws = splitk > 1 ? workspace : nullptr;
-    const int mgroups = (p.tiles_m + 7) / 8;
-    dim3 grid((unsigned)(mgroups * 8 * p.tiles_n), (unsigned)splitk), block(256);
+    p.items = splitk * p.tiles_m * p.tiles_n;
+    p.per_xcd = (p.items + 7) / 8;
+    dim3 grid((unsigned)(p.per_xcd * 8)), block(256);
+    if (tile_m == 256) {
+        static bool attr_w = false;
+        if (!attr_w) {
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WIDE_STAGE));
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WIDE_STAGE));
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WIDE_STAGE));
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WIDE_STAGE));
+            attr_w = true;
+        }
+        const dim3 wblock(512);
+        const size_t wlds = 3 * WIDE_STAGE;
+        if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16w_kernel<true, true>), grid, wblock, wlds, st, p);
+        else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16w_kernel<true, false>), grid, wblock, wlds, st, p);
+        else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16w_kernel<false, true>), grid, wblock, wlds, st, p);
+        else hipLaunchKernelGGL((gemm_bf16w_kernel<false, false>), grid, wblock, wlds, st, p);
+        PK_LAUNCH_CHECK();
+    } else {
     // measured on MI355X (tools/bench_gemm.py): the single-buffer / 3-4 workgroups per CU variant wins on the
     // row-streaming shapes (A k-contiguous: 630-644 vs 534-552 TFLOP/s at M = 64000), the double-buffered one on
     // the split-K k-major shapes (357 vs 331).  PK_GEMM_STAGES=1|2 forces one of them.
@@ -346,6 +501,7 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
     else PK_LAUNCH_BF(1);
 #undef PK_LAUNCH_BF
     PK_LAUNCH_CHECK();
+    }
     if (splitk > 1) {
         const long total = (long)M * N;
         int blocks = (int)((total + 255) / 256);

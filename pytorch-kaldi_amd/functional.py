@@ -114,6 +114,12 @@ def _tiles(M, N):
     return ((M + 127) // 128) * ((N + 127) // 128)
 
 
+def _tiles_bf(M, N):
+    """Output tiles of the bf16-operand GEMM: the library picks 128- or 256-row block tiles from M."""
+    tm = int(_lib.load().pk_gemm_bf16_tile_m(int(M)))
+    return ((M + tm - 1) // tm) * ((N + 127) // 128)
+
+
 def _up(n, m):
     return (n + m - 1) // m * m
 
@@ -207,7 +213,7 @@ class LinearFn(torch.autograd.Function):
                 dx = dx.view(ctx.in_shape)
             if ctx.needs_input_grad[1]:  # dw[n,k] = sum_m dy[m,n] x[m,k]: both operands k-major
                 dw = _new(N, K, like=dy2)
-                gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K, splitk=_splitk_bf(_tiles(N, K), M))
+                gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K, splitk=_splitk_bf(_tiles_bf(N, K), M))
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum(dy2)
             return dx, dw, db
@@ -456,7 +462,7 @@ def _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, Yb=None, dGb=N
             a_off = (d * TB + (0 if d else B)) * Gp
             b_off = (B if d else 0) * Yp + d * Hp
             gemm_bf16(Mp, H, Kh, (dGb, a_off), Gp, 0, (Yb, b_off), Yp, 0, out, H, beta=0.0 if d == 0 else 1.0,
-                      splitk=_splitk_bf(_tiles(Mp, H), Kh))
+                      splitk=_splitk_bf(_tiles_bf(Mp, H), Kh))
         if Hp != H:
             for g in range(Gh):
                 dU[g * H:(g + 1) * H].copy_(out[g * Hp:g * Hp + H])
@@ -469,7 +475,7 @@ def _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, Yb=None, dGb=N
                 gh = cvt_bf16(S[d][:, slot * H:(slot + 1) * H])
                 gh_ld = gh.shape[1]
             gemm_bf16(H, H, TB, (dGb, d * TB * Gp + Gh * Hp), Gp, 0, gh, gh_ld, 0, dU[Gh * H:], H,
-                      beta=0.0 if d == 0 else 1.0, splitk=_splitk_bf(_tiles(H, H), TB))
+                      beta=0.0 if d == 0 else 1.0, splitk=_splitk_bf(_tiles_bf(H, H), TB))
 
 
 class RecLayerFn(torch.autograd.Function):
@@ -626,7 +632,7 @@ class RecLayerFn(torch.autograd.Function):
                 dx = _new(TB, D, like=dY)
                 gemm_bf16(TB, D, GH, dPb, dPb.shape[1], 1, Wb, Wb.shape[1], 0, dx, D)
                 dx = dx.view(T, B, D)
-            gemm_bf16(GH, D, TB, dPb, dPb.shape[1], 0, xb, xb.shape[1], 0, dW, D, splitk=_splitk_bf(_tiles(GH, D), TB))
+            gemm_bf16(GH, D, TB, dPb, dPb.shape[1], 0, xb, xb.shape[1], 0, dW, D, splitk=_splitk_bf(_tiles_bf(GH, D), TB))
             return dx, dW, dbias, dU, dgamma, dbeta, None, None, None, dlg, dlb, None
         if ctx.needs_input_grad[0]:
             dx = _new(TB, D, like=dY)
@@ -770,7 +776,7 @@ class RecLayerPerfFn(torch.autograd.Function):
         # dW[n,d] = sum_m dP[m,n] x[m,d]: both operands k-major; with a re-pitched input the columns come out re-pitched
         Kx = D if xseg is None else xseg[0] * xseg[2]
         dWp = _new(GH, Kx, like=dY)
-        gemm_bf16(GH, Kx, TB, dPb, dPb.shape[1], 0, xb, xb.shape[1], 0, dWp, Kx, splitk=_splitk_bf(_tiles(GH, Kx), TB))
+        gemm_bf16(GH, Kx, TB, dPb, dPb.shape[1], 0, xb, xb.shape[1], 0, dWp, Kx, splitk=_splitk_bf(_tiles_bf(GH, Kx), TB))
         if xseg is None:
             dW = dWp
         else:

@@ -31,8 +31,7 @@ for name, M, N, K, akc, bkc in SHAPES:
     A = torch.randn((M, up(K, 64)) if akc else (K, up(M, 64)), device="cuda").to(torch.bfloat16)
     B = torch.randn((N, up(K, 64)) if bkc else (K, up(N, 64)), device="cuda").to(torch.bfloat16)
     C = torch.empty(M, N, device="cuda")
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    sk = F_._splitk_bf(tiles, K) if not akc else 1
+    sk = F_._splitk_bf(F_._tiles_bf(M, N), K) if not akc else 1
 
     def run():
         F_.gemm_bf16(M, N, K, A, A.shape[1], akc, B, B.shape[1], bkc, C, N, splitk=sk)

@@ -129,23 +129,51 @@ __global__ __launch_bounds__(256) void bn_stats_partial_v4_kernel(const float* _
     }
 }
 
-__global__ void bn_stats_final_kernel(const float* __restrict__ partial, int rb, long N, float* __restrict__ mean,
-                                      float* __restrict__ var) {
-    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+// Final merges: a block is 32 columns x 8 row-groups.  Group q folds partial rows q, q+8, ... (their loads are
+// independent of the running merge, so four are kept in flight), then thread (c, 0) folds the eight group results in
+// order - a fixed reduction tree, deterministic run to run.
+constexpr int FIN_COLS = 32, FIN_GROUPS = 8;
+
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+    if (nb > 0.f) {
+        const float nt = na + nb, d = mb - ma;
+        ma += d * (nb / nt);
+        qa += qb + d * d * (na * nb / nt);
+        na = nt;
+    }
+}
+
+__global__ __launch_bounds__(FIN_COLS* FIN_GROUPS) void bn_stats_final_kernel(const float* __restrict__ partial, int rb, long N,
+                                                                             float* __restrict__ mean,
+                                                                             float* __restrict__ var) {
+    __shared__ float sh[FIN_GROUPS][FIN_COLS][3];
+    const int cx = threadIdx.x & (FIN_COLS - 1), q = threadIdx.x / FIN_COLS;
+    const long c = (long)blockIdx.x * FIN_COLS + cx;
     float na = 0.f, ma = 0.f, qa = 0.f;
-    for (int k = 0; k < rb; ++k) {
-        const float* o = partial + ((long)k * N + c) * 3;
-        const float nb = o[0], mb = o[1], qb = o[2];
-        if (nb > 0.f) {
-            const float nt = na + nb, d = mb - ma;
-            ma += d * (nb / nt);
-            qa += qb + d * d * (na * nb / nt);
-            na = nt;
+    if (c < N) {
+        int k = q;
+        for (; k + 3 * FIN_GROUPS < rb; k += 4 * FIN_GROUPS) {
+            float v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* o = partial + ((long)(k + u * FIN_GROUPS) * N + c) * 3;
+                v[u][0] = o[0], v[u][1] = o[1], v[u][2] = o[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) chan_merge(na, ma, qa, v[u][0], v[u][1], v[u][2]);
+        }
+        for (; k < rb; k += FIN_GROUPS) {
+            const float* o = partial + ((long)k * N + c) * 3;
+            chan_merge(na, ma, qa, o[0], o[1], o[2]);
         }
     }
-    mean[c] = ma;
-    var[c] = na > 0.f ? qa / na : 0.f;  // biased, as BatchNorm normalises with
+    sh[q][cx][0] = na, sh[q][cx][1] = ma, sh[q][cx][2] = qa;
+    __syncthreads();
+    if (q == 0 && c < N) {
+        for (int g = 1; g < FIN_GROUPS; ++g) chan_merge(na, ma, qa, sh[g][cx][0], sh[g][cx][1], sh[g][cx][2]);
+        mean[c] = ma;
+        var[c] = na > 0.f ? qa / na : 0.f;  // biased, as BatchNorm normalises with
+    }
 }
 
 __global__ void bn_finalize_kernel(long N, const float* __restrict__ mean, const float* __restrict__ var,
@@ -236,18 +264,28 @@ __global__ __launch_bounds__(256) void col_reduce_partial_kernel(const float* __
     }
 }
 
-__global__ void col_reduce_final_kernel(const float* __restrict__ partial, int rb, long N, float* __restrict__ out0,
-                                        float* __restrict__ out1) {
-    const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
+__global__ __launch_bounds__(FIN_COLS* FIN_GROUPS) void col_reduce_final_kernel(const float* __restrict__ partial, int rb, long N,
+                                                                               float* __restrict__ out0,
+                                                                               float* __restrict__ out1) {
+    __shared__ float sh[FIN_GROUPS][FIN_COLS][2];
+    const int cx = threadIdx.x & (FIN_COLS - 1), q = threadIdx.x / FIN_COLS;
+    const long c = (long)blockIdx.x * FIN_COLS + cx;
     float a0 = 0.f, a1 = 0.f;
-    for (int k = 0; k < rb; ++k) {
-        const float* o = partial + ((long)k * N + c) * 2;
-        a0 += o[0];
-        a1 += o[1];
+    if (c < N) {
+#pragma unroll 4
+        for (int k = q; k < rb; k += FIN_GROUPS) {
+            const float* o = partial + ((long)k * N + c) * 2;
+            a0 += o[0];
+            a1 += o[1];
+        }
     }
-    out0[c] = a0;
-    if (out1) out1[c] = a1;
+    sh[q][cx][0] = a0, sh[q][cx][1] = a1;
+    __syncthreads();
+    if (q == 0 && c < N) {
+        for (int g = 1; g < FIN_GROUPS; ++g) a0 += sh[g][cx][0], a1 += sh[g][cx][1];
+        out0[c] = a0;
+        if (out1) out1[c] = a1;
+    }
 }
 
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ g2, long ldg,
@@ -382,6 +420,61 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __rest
     }
 }
 
+// Wave-per-row variants for rows of up to 64*NPL columns: the row lives in registers (every element is read from
+// HBM once, all loads of a lane in flight together) and the reductions are wave shuffles - no LDS, no barriers.
+template <int NPL>
+__global__ __launch_bounds__(256) void logsoftmax_fwd_wave_kernel(const float* __restrict__ x, long rows, long N,
+                                                                   float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+    for (long r = wid; r < rows; r += nw) {
+        const float* xr = x + r * N;
+        float v[NPL];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const long c = lane + 64 * i;
+            v[i] = c < N ? xr[c] : -INFINITY;
+            m = fmaxf(m, v[i]);
+        }
+        m = pk_wave_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) sum += expf(v[i] - m);  // exp(-inf) = 0 for the padding lanes
+        sum = pk_wave_sum(sum);
+        const float lse = m + logf(sum);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const long c = lane + 64 * i;
+            if (c < N) y[r * N + c] = v[i] - lse;
+        }
+    }
+}
+
+template <int NPL>
+__global__ __launch_bounds__(256) void logsoftmax_bwd_wave_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                   long rows, long N, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+    for (long r = wid; r < rows; r += nw) {
+        float g[NPL], e[NPL];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const long c = lane + 64 * i;
+            g[i] = c < N ? dy[r * N + c] : 0.f;
+            e[i] = c < N ? y[r * N + c] : -INFINITY;
+            sum += g[i];
+        }
+        sum = pk_wave_sum(sum);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const long c = lane + 64 * i;
+            if (c < N) dx[r * N + c] = g[i] - expf(e[i]) * sum;
+        }
+    }
+}
+
 inline int ew_blocks(long n) {
     long b = (n + 255) / 256;
     if (b > 4096) b = 4096;
@@ -406,7 +499,7 @@ extern "C" int pk_bn_stats(void* stream, const float* x, int64_t ldx, int64_t M,
         hipLaunchKernelGGL(bn_stats_partial_kernel, grid, dim3(256), 0, st, x, (long)ldx, (long)M, (long)N, partial);
     }
     PK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partial, rb, (long)N,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st, partial, rb, (long)N,
                        mean, var);
     PK_LAUNCH_CHECK();
     return 0;
@@ -449,7 +542,7 @@ extern "C" int pk_bn_bwd_reduce(void* stream, const float* g, const float* g2, i
     hipLaunchKernelGGL(col_reduce_partial_kernel<0>, grid, dim3(256), 0, st, g, g2, (long)ldg, x, (long)ldx, (long)M,
                        (long)N, mean, var, eps, partial);
     PK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partial, rb, (long)N,
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st, partial, rb, (long)N,
                        sum_g, sum_gx);
     PK_LAUNCH_CHECK();
     return 0;
@@ -473,7 +566,7 @@ extern "C" int pk_colsum(void* stream, const float* g, const float* g2, int64_t 
     hipLaunchKernelGGL(col_reduce_partial_kernel<1>, grid, dim3(256), 0, st, g, g2, (long)ldg, (const float*)nullptr, 0L,
                        (long)M, (long)N, (const float*)nullptr, (const float*)nullptr, 0.f, partial);
     PK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partial, rb, (long)N,
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st, partial, rb, (long)N,
                        out, (float*)nullptr);
     PK_LAUNCH_CHECK();
     return 0;
@@ -508,22 +601,42 @@ extern "C" int pk_layernorm_bwd(void* stream, const float* dy, const float* x, i
     return 0;
 }
 
+#define PK_LSM_DISPATCH(KERNEL, ...)                                                                       \
+    do {                                                                                                    \
+        const long wblocks = (rows + 3) / 4;                                                                \
+        const dim3 wgrid((unsigned)(wblocks < 16384 ? wblocks : 16384));                                    \
+        if (N <= 64) hipLaunchKernelGGL((KERNEL<1>), wgrid, dim3(256), 0, st, __VA_ARGS__);                 \
+        else if (N <= 256) hipLaunchKernelGGL((KERNEL<4>), wgrid, dim3(256), 0, st, __VA_ARGS__);           \
+        else if (N <= 1024) hipLaunchKernelGGL((KERNEL<16>), wgrid, dim3(256), 0, st, __VA_ARGS__);         \
+        else hipLaunchKernelGGL((KERNEL<32>), wgrid, dim3(256), 0, st, __VA_ARGS__);                        \
+    } while (0)
+
 extern "C" int pk_logsoftmax_fwd(void* stream, const float* x, int64_t rows, int64_t N, float* y) {
     if (rows == 0) return 0;
-    int blocks = (int)(rows < 8192 ? rows : 8192);
-    hipLaunchKernelGGL(logsoftmax_fwd_kernel, dim3(blocks), dim3(256), 0, pk_stream(stream), x, (long)rows, (long)N, y);
+    hipStream_t st = pk_stream(stream);
+    if (N <= 2048) {
+        PK_LSM_DISPATCH(logsoftmax_fwd_wave_kernel, x, (long)rows, (long)N, y);
+    } else {
+        int blocks = (int)(rows < 8192 ? rows : 8192);
+        hipLaunchKernelGGL(logsoftmax_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, (long)rows, (long)N, y);
+    }
     PK_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int pk_logsoftmax_bwd(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, float* dx) {
     if (rows == 0) return 0;
-    int blocks = (int)(rows < 8192 ? rows : 8192);
-    hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(blocks), dim3(256), 0, pk_stream(stream), dy, y, (long)rows, (long)N,
-                       dx);
+    hipStream_t st = pk_stream(stream);
+    if (N <= 2048) {
+        PK_LSM_DISPATCH(logsoftmax_bwd_wave_kernel, dy, y, (long)rows, (long)N, dx);
+    } else {
+        int blocks = (int)(rows < 8192 ? rows : 8192);
+        hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, y, (long)rows, (long)N, dx);
+    }
     PK_LAUNCH_CHECK();
     return 0;
 }
+#undef PK_LSM_DISPATCH
 
 // ---------------------------------------------------------------------------------------------
 // Perf mode: BatchNorm backward straight from the bf16 gate gradients the persistent recurrence
@@ -726,7 +839,7 @@ extern "C" int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* 
     if (use_bn) hipLaunchKernelGGL((bnb_reduce_kernel<0>), grid, dim3(256), 0, st, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x, (long)ldx, (long)M, mean, var, eps, partial);
     else hipLaunchKernelGGL((bnb_reduce_kernel<1>), grid, dim3(256), 0, st, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x, (long)ldx, (long)M, mean, var, eps, partial);
     PK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, partial, rb, N, sum_g,
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st, partial, rb, N, sum_g,
                        use_bn ? sum_gx : (float*)nullptr);
     PK_LAUNCH_CHECK();
     if (use_bn) hipLaunchKernelGGL((bnb_apply_kernel<0>), grid, dim3(256), 0, st, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x, (long)ldx, (long)M, mean, var, eps, gamma, sum_g, sum_gx, (float)(1.0 / count), (unsigned short*)out, (long)out_pitch);

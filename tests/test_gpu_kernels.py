@@ -141,7 +141,7 @@ def test_layernorm(rows, F):
         assert rel_err(a.grad, r.grad) < 1e-5
 
 
-@pytest.mark.parametrize("rows,N", [(1, 1), (5, 48), (300, 1938)])
+@pytest.mark.parametrize("rows,N", [(1, 1), (5, 48), (7, 64), (9, 200), (33, 1000), (300, 1938), (3, 2048), (6, 3400)])
 def test_logsoftmax(rows, N):
     g = torch.Generator().manual_seed(rows + N)
     x = torch.randn(rows, N, generator=g) * 4

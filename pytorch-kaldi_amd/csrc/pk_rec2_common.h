@@ -246,5 +246,5 @@ struct BoolC {  // (an int: 0 = no edge, 1 = even-H edge in 8-byte halves, 2 = o
 // host-side plumbing shared by both translation units (defined in pk_rec_persist2.hip)
 int pk_rec2_make_plan(int R, int H, Plan2& pl);
 int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidir, int H);
-int pk_rec2_host_setup(R2Args& a);                 // error word, trash page, handshake table, tuning knobs
+int pk_rec2_host_setup(R2Args& a, bool backward);                 // error word, trash page, handshake table, tuning knobs
 int pk_rec2_reset_handshake(hipStream_t st);       // before every launch

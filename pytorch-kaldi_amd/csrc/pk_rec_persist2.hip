@@ -24,6 +24,8 @@
 //    barrier per step); projections / saved gates of step t+1 are prefetched
 //    right after the poll of step t returns, so HBM latency is off the
 //    dependency chain; every spin is bounded (host-visible error word).
+#include <stdlib.h>
+
 #include "pk_rec2_common.h"
 
 namespace {
@@ -491,7 +493,7 @@ unsigned long long* g2_trace = nullptr;  // set by pk_persist2_set_trace (diagno
 unsigned* g2_err_host = nullptr;
 unsigned* g2_err_dev = nullptr;
 int g2_force_safe = 0;
-int g2_poll_delay = 0;
+int g2_poll_delay = -1;  // < 0: per-pass defaults (pk_rec2_host_setup)
 unsigned* g2_xcd_tab = nullptr;  // [256][16] handshake words (library-owned scratch, one launch at a time)
 float* g2_trash = nullptr;        // write-only dump page for masked-off vector stores
 constexpr size_t XCD_TAB_BYTES = 256 * 16 * sizeof(unsigned);
@@ -532,11 +534,26 @@ int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidi
     return 0;
 }
 
-int pk_rec2_host_setup(R2Args& a) {
+// Idle time between a workgroup's publish and its first poll of the next step, in s_sleep units of 64 clocks.  A poll
+// that arrives before the other members' stores costs a second L2 round trip (~2300 clocks); measured at the BASELINE
+// geometry (tools/trace_rec2.py, DELAY sweep): forward 6460 -> 6300 clocks/step at 4 units (re-polls 0.36 -> 0.06 per
+// step), backward 9020 -> 8380 at 8 units (0.48 -> 0.08).  PK_POLL_DELAY_FWD / PK_POLL_DELAY_BWD override.
+static int default_poll_delay(bool backward) {
+    static int env[2] = {-2, -2};
+    int& e = env[backward ? 1 : 0];
+    if (e == -2) {
+        const char* v = getenv(backward ? "PK_POLL_DELAY_BWD" : "PK_POLL_DELAY_FWD");
+        e = v ? atoi(v) : -1;
+    }
+    if (e >= 0) return e;
+    return backward ? 8 : 4;
+}
+
+int pk_rec2_host_setup(R2Args& a, bool backward) {
     int rc = ensure_err2();
     if (rc) return rc;
     a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe;
-    a.trash = g2_trash; a.poll_delay = g2_poll_delay;
+    a.trash = g2_trash; a.poll_delay = g2_poll_delay >= 0 ? g2_poll_delay : default_poll_delay(backward);
     return 0;
 }
 int pk_rec2_reset_handshake(hipStream_t st) {
@@ -545,7 +562,7 @@ int pk_rec2_reset_handshake(hipStream_t st) {
 }
 
 extern "C" void pk_persist2_set_mode(int force_safe) { g2_force_safe = force_safe ? 1 : 0; }
-extern "C" void pk_persist2_set_poll_delay(int units) { g2_poll_delay = units < 0 ? 0 : units; }
+extern "C" void pk_persist2_set_poll_delay(int units) { g2_poll_delay = units; }  // < 0: back to the per-pass defaults
 extern "C" void pk_persist2_set_trace(void* dev_buf) { g2_trace = (unsigned long long*)dev_buf; }
 extern "C" unsigned pk_persist2_error_count(void) { return g2_err_host ? *g2_err_host : 0u; }
 extern "C" void pk_persist2_error_reset(void) {
@@ -571,7 +588,7 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.P = P; a.pscale = pscale; a.pshift = pshift; a.U = U; a.mask = mask; a.mask_scalar = mask_scalar;
     a.Y = Y; a.S = S; a.Yb = (unsigned short*)Yb; a.Xb = nullptr; a.Ypitch = (int)y_pitch;
     a.dY = nullptr; a.dP2 = nullptr; a.dGb = nullptr; a.Gpitch = 0;
-    rc = pk_rec2_host_setup(a);
+    rc = pk_rec2_host_setup(a, false);
     if (rc) return rc;
     // the bf16 layer output is the mailbox: poison it with the sentinel
     PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
@@ -620,7 +637,7 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.P = nullptr; a.pscale = nullptr; a.pshift = nullptr; a.U = U; a.mask = mask; a.mask_scalar = mask_scalar;
     a.Y = const_cast<float*>(Y); a.S = const_cast<float*>(S); a.Yb = nullptr; a.Xb = nullptr; a.Ypitch = 0;
     a.dY = dY; a.dP2 = dP2; a.dGb = (unsigned short*)dGb; a.Gpitch = (int)g_pitch;
-    rc = pk_rec2_host_setup(a);
+    rc = pk_rec2_host_setup(a, true);
     if (rc) return rc;
     PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
     const size_t atile = (size_t)RMAX * (G * KPAD + 8) * 2;

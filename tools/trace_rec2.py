@@ -24,7 +24,7 @@ net = getattr(nn_amd, kind)(opts, 40).cuda().train()
 x = torch.randn(T, B, 40, device="cuda", requires_grad=True)
 lib = _lib.load()
 lib.pk_persist2_set_mode(int(os.environ.get("SAFE", "0")))
-lib.pk_persist2_set_poll_delay(int(os.environ.get("DELAY", "0")))
+lib.pk_persist2_set_poll_delay(int(os.environ.get("DELAY", "-1")))  # -1: the library defaults
 names = ["poll", "prefetch-issue+barrier", "mfma", "gate math", "publish", "loop tail"]
 for rep in range(2):
     tr_f = torch.zeros(T, 8, dtype=torch.int64, device="cuda")

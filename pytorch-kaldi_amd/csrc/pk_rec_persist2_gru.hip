@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
         if (t > 0) {
 #pragma unroll
             for (int i = 0; i < NCH; ++i) goff[i] = cbase[i] + (unsigned)(t - 1) * cstep[i];
+            for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);  // see pk_rec2_host_setup
             dead = fast ? poll_to_lds<NCH, true>(rsY, goff, clds, A0, a.err, a.spin_limit, lane, dead, retries)
                         : poll_to_lds<NCH, false>(rsY, goff, clds, A0, a.err, a.spin_limit, lane, dead, retries);
         }
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
         if (t > 0) {  // (x_0 = 0: nothing to multiply at the first step)
 #pragma unroll
             for (int i = 0; i < NCH; ++i) goff[i] = cbase[i] + (unsigned)t * cstep[i];
+            for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);  // see pk_rec2_host_setup
             dead = fast ? poll_to_lds<NCH, true>(rsX, goff, clds, A1, a.err, a.spin_limit, lane, dead, retries)
                         : poll_to_lds<NCH, false>(rsX, goff, clds, A1, a.err, a.spin_limit, lane, dead, retries);
             PK_BARRIER_LDS();
@@ -410,6 +412,7 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
             unsigned goff[NCHB];
 #pragma unroll
             for (int i = 0; i < NCHB; ++i) goff[i] = cbB[i] + (unsigned)(it - 1) * csB[i];
+            for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);  // see pk_rec2_host_setup
             dead = fast ? poll_to_lds<NCHB, true>(rs, goff, clB, smem, a.err, a.spin_limit, lane, dead, retries)
                         : poll_to_lds<NCHB, false>(rs, goff, clB, smem, a.err, a.spin_limit, lane, dead, retries);
         }
@@ -461,6 +464,7 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
             unsigned goff[NCHA];
 #pragma unroll
             for (int i = 0; i < NCHA; ++i) goff[i] = cbA[i] + (unsigned)it * csA[i];
+            for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);  // see pk_rec2_host_setup
             dead = fast ? poll_to_lds<NCHA, true>(rs, goff, clA, smem, a.err, a.spin_limit, lane, dead, retries)
                         : poll_to_lds<NCHA, false>(rs, goff, clA, smem, a.err, a.spin_limit, lane, dead, retries);
             PK_BARRIER_LDS();

@@ -68,6 +68,10 @@ class GradReducer:
         grid resident."""
         self.group = group
         self.overlap = overlap
+        if overlap:
+            # buckets launched from gradient hooks must not race gradients that arrive outside autograd
+            from . import functional as _F
+            _F.settings.wgrad_side = False
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.flats = flats  # dict name -> FlatParams or None
         self.buckets = []   # each: dict(params=[...], flat=tensor or None, pending=int)
@@ -136,6 +140,8 @@ class GradReducer:
         """Call after backward(): completes every bucket and re-arms for the next step."""
         if self.world == 1:
             return
+        from .functional import join_side
+        join_side()  # weight gradients accumulated from the side stream must be in the buckets
         for b in self.buckets:
             if not b["fired"]:
                 self._launch(b)

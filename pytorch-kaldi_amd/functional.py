@@ -35,6 +35,10 @@ class _Settings:
         # makes the step host-bound: 109 vs 32 ms at BASELINE config 2)
         self.mask_rng = os.environ.get("PK_MASK_RNG", "device")
         assert self.mask_rng in ("reference", "device"), self.mask_rng
+        # perf mode: weight-gradient GEMMs (dW, dU) of a recurrent layer / a Linear run on a second HIP stream, next to
+        # the following layer's recurrent backward, and accumulate straight into the parameters' flat .grad buffer
+        # (only for parameters owned by optim.FlatParams; see side_launch / join_side)
+        self.wgrad_side = os.environ.get("PK_WGRAD_SIDE", "1") != "0"
         assert self.precision in PREC, self.precision
         assert self.rec_algo in ("auto", "stepwise", "persistent"), self.rec_algo
 
@@ -173,6 +177,52 @@ def bf16_mode():
     return settings.precision == "bf16"
 
 
+
+# ----------------------------------------------------------------------------
+# Second stream for work that is off the backward dependency chain (weight gradients)
+# ----------------------------------------------------------------------------
+class _Side:
+    stream = None
+    pending = False
+
+
+def side_targets_ok(params):
+    """Weight gradients may bypass autograd only when every target parameter has a pre-allocated .grad that is a
+    view of an optim.FlatParams buffer (its consumers - fused optimizer step, gradient all-reduce, zero_grad -
+    call join_side() first)."""
+    return (settings.wgrad_side and bf16_mode() and params is not None and len(params) > 0
+            and all(getattr(q, "_pk_flat", False) and q.grad is not None for q in params))
+
+
+def side_launch(fn, keep):
+    """Run fn() on the side stream after everything enqueued so far on the current stream; `keep` are the tensors
+    fn reads or writes that autograd may free before the side stream is done."""
+    main = torch.cuda.current_stream()
+    if _Side.stream is None:
+        _Side.stream = torch.cuda.Stream()
+    side = _Side.stream
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        fn()
+    for t in keep:
+        if t is not None:
+            t.record_stream(side)
+    _Side.pending = True
+
+
+def join_side():
+    """Make the current stream wait for the side stream (before anything reads or rewrites .grad)."""
+    if _Side.pending:
+        torch.cuda.current_stream().wait_stream(_Side.stream)
+        _Side.pending = False
+
+
+def _accumulate_rows(params, rows):
+    """params[i].grad += rows[i] (row blocks of a concatenated weight gradient)."""
+    with torch.no_grad():
+        for q, r in zip(params, rows):
+            q.grad.add_(r)
+
 # ----------------------------------------------------------------------------
 # Linear:  y = x W^T + b        (nn.Linear; neural_networks.py:111, 139-148)
 # ----------------------------------------------------------------------------
@@ -196,6 +246,7 @@ class LinearFn(torch.autograd.Function):
         ctx.dims = (M, N, K)
         ctx.has_bias = bias is not None
         ctx.in_shape = x.shape
+        ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -212,8 +263,15 @@ class LinearFn(torch.autograd.Function):
                 gemm_bf16(M, K, N, dyb, dyb.shape[1], 1, wb, wb.shape[1], 0, dx, K)
                 dx = dx.view(ctx.in_shape)
             if ctx.needs_input_grad[1]:  # dw[n,k] = sum_m dy[m,n] x[m,k]: both operands k-major
-                dw = _new(N, K, like=dy2)
-                gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K, splitk=_splitk_bf(_tiles_bf(N, K), M))
+                wp = ctx.wparam
+                if M >= 4096 and wp is not None and wp.is_contiguous() and side_targets_ok([wp]):
+                    # off the dependency chain: accumulate into the flat .grad on the side stream (beta = 1)
+                    side_launch(lambda: gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0,
+                                                  splitk=_splitk_bf(_tiles_bf(N, K), M)), (dyb, xb))
+                else:
+                    dw = _new(N, K, like=dy2)
+                    gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K,
+                              splitk=_splitk_bf(_tiles_bf(N, K), M))
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum(dy2)
             return dx, dw, db
@@ -670,7 +728,8 @@ class RecLayerPerfFn(torch.autograd.Function):
     def forward(ctx, x, xb_in, Wcat, bcat, Ucat, gamma, beta, running_mean, running_var, mask, cfg):
         _need_gpu(x, Wcat, bcat, Ucat, gamma, beta, mask)
         lib = _lib.load()
-        cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar, xseg = cfg
+        cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar, xseg = cfg[:10]
+        ctx.wparams, ctx.uparams = (cfg[10], cfg[11]) if len(cfg) > 10 else (None, None)
         T, B, D = x.shape
         G = lib.pk_rec_num_gates(CELL[cell])
         NS = lib.pk_rec_num_saved(CELL[cell])
@@ -717,7 +776,7 @@ class RecLayerPerfFn(torch.autograd.Function):
             _lib.check(rc, "pk_rec_fwd_bf16")
         ctx.Xb = Xb
         ctx.save_for_backward(xb, Wb, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, Yb)
-        ctx.cfg = cfg[:-1] + (xseg,)
+        ctx.cfg = cfg[:9] + (xseg,)
         ctx.in_shape = x.shape
         ctx.has_bias = bcat is not None
         if use_bn and training:
@@ -749,9 +808,23 @@ class RecLayerPerfFn(torch.autograd.Function):
             rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
                                      float(mask_scalar), _p(Y), _p(S), _p(dY), None, _p(dGb), Gp)
             _lib.check(rc, "pk_rec_bwd_bf16")
-        dU = _new(GH, H, like=dY)
-        _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, None, dU, Yb, dGb, ctx.Xb)
+        # weight gradients are off the dependency chain (the next thing on it is the layer below's recurrent
+        # backward): with flat-bucket parameters they run on the side stream and accumulate straight into .grad
+        side_u = side_targets_ok(ctx.uparams)
+        side_w = side_targets_ok(ctx.wparams)
+        Xb = ctx.Xb
         ctx.Xb = None
+        dU = _new(GH, H, like=dY)
+
+        def do_dU():
+            _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, None, dU, Yb, dGb, Xb)
+            if side_u:
+                _accumulate_rows(ctx.uparams, [dU[g * H:(g + 1) * H] for g in range(G)])
+
+        if side_u:
+            side_launch(do_dU, (Y, S, Yb, dGb, Xb, dU))
+        else:
+            do_dU()
         # BatchNorm backward (or plain sum of the two directions) straight from dGb -> bf16 projection gradient
         dPb = torch.empty(TB, _up(GH, 64), device=dY.device, dtype=torch.bfloat16)
         part = _new(int(lib.pk_bn_partial_floats(TB, GH)), like=dY)
@@ -767,22 +840,34 @@ class RecLayerPerfFn(torch.autograd.Function):
             dgamma, dbeta = sum_gx, sum_g
         elif ctx.has_bias:
             dbias = sum_g
+        # dW[n,d] = sum_m dP[m,n] x[m,d]: both operands k-major; with a re-pitched input the columns come out re-pitched
+        Kx = D if xseg is None else xseg[0] * xseg[2]
+        dWp = _new(GH, Kx, like=dY)
+        dW = None
+
+        def do_dW():
+            nonlocal dW
+            gemm_bf16(GH, Kx, TB, dPb, dPb.shape[1], 0, xb, xb.shape[1], 0, dWp, Kx,
+                      splitk=_splitk_bf(_tiles_bf(GH, Kx), TB))
+            if xseg is None:
+                dW = dWp
+            else:
+                nseg, seglen, segpad = xseg
+                dW = torch.cat([dWp[:, s_ * segpad:s_ * segpad + seglen] for s_ in range(nseg)], 1)
+            if side_w:
+                _accumulate_rows(ctx.wparams, [dW[g * H:(g + 1) * H] for g in range(G)])
+
+        if side_w:
+            side_launch(do_dW, (dPb, xb, dWp))
         dx = None
         if ctx.needs_input_grad[0]:  # dx[m,d] = sum_n dP[m,n] W[n,d]: A k-contiguous, B = W (plain pitch) k-major
             Wb2 = Wb if xseg is None else cvt_bf16(Wcat)
             dx = _new(TB, D, like=dY)
             gemm_bf16(TB, D, GH, dPb, dPb.shape[1], 1, Wb2, Wb2.shape[1], 0, dx, D)
             dx = dx.view(T, B, D)
-        # dW[n,d] = sum_m dP[m,n] x[m,d]: both operands k-major; with a re-pitched input the columns come out re-pitched
-        Kx = D if xseg is None else xseg[0] * xseg[2]
-        dWp = _new(GH, Kx, like=dY)
-        gemm_bf16(GH, Kx, TB, dPb, dPb.shape[1], 0, xb, xb.shape[1], 0, dWp, Kx, splitk=_splitk_bf(_tiles_bf(GH, Kx), TB))
-        if xseg is None:
-            dW = dWp
-        else:
-            nseg, seglen, segpad = xseg
-            dW = torch.cat([dWp[:, s_ * segpad:s_ * segpad + seglen] for s_ in range(nseg)], 1)
-        return dx, None, dW, dbias, dU, dgamma, dbeta, None, None, None, None
+        if not side_w:
+            do_dW()
+        return dx, None, (None if side_w else dW), dbias, (None if side_u else dU), dgamma, dbeta, None, None, None, None
 
 
 # ----------------------------------------------------------------------------

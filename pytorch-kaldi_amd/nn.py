@@ -304,7 +304,7 @@ class _Recurrent(nn.Module):
             cfg = (self.KIND, self._act[i], H, bool(self.bidir), use_bn, self.training, 1e-5, 0.05, scalar_i)
             if F_.perf_path_ok(self.KIND, H, bool(self._use_ln[i]), use_bn, self.training):
                 y, bmean, bvar, xb = F_.RecLayerPerfFn.apply(x, xb, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, mask_i,
-                                                           cfg + (xseg,))
+                                                           cfg + (xseg, [m.weight for m in Ws], [m.weight for m in Us]))
                 xseg = (2 if self.bidir else 1, H, (H + 7) // 8 * 8)
             else:
                 lng = self.ln[i].gamma if self._use_ln[i] else None

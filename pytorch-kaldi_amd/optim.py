@@ -44,8 +44,11 @@ class FlatParams:
                 self.flat[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
+                p._pk_flat = True  # functional.side_targets_ok: weight gradients may accumulate here from a side stream
 
     def zero_grad(self):
+        from .functional import join_side
+        join_side()
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):  # keep .grad aliased to the flat buffer
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
@@ -96,6 +99,8 @@ class FusedOptimizer:
     def step(self):
         if not self.flat.flat.is_cuda:
             raise _lib.PkError("fused optimizer step runs on the GPU only (no CPU fallback)")
+        from .functional import join_side
+        join_side()  # weight-gradient GEMMs still running on the side stream
         lib = _lib.load()
         lr = float(self.param_groups[0]["lr"])
         f = self.flat

@@ -356,3 +356,38 @@ def test_full_size_properties(prec):
     numeric = (vals[0] - vals[1]) / (2 * eps)
     assert abs(numeric - analytic) < (2e-2 if prec == "fp32" else 1e-1) * max(abs(numeric), abs(analytic), 1e-3), (numeric, analytic)
     importlib.import_module("pytorch-kaldi_amd.functional").set_precision("fp32")
+
+
+def test_side_stream_weight_gradients_equal_the_autograd_path():
+    """Perf mode: dW / dU GEMMs on the second stream accumulating into the flat .grad buffer (FlatParams) give the
+    same gradients as the plain autograd path, step after step (zero_grad / optimizer step join the side stream)."""
+    optim_ = importlib.import_module("pytorch-kaldi_amd.optim")
+    F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+    nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
+    opts = {"ligru_lay": "72,72", "ligru_drop": "0.0,0.0", "ligru_use_laynorm_inp": "False", "ligru_use_batchnorm_inp": "False",
+            "ligru_use_laynorm": "False,False", "ligru_use_batchnorm": "True,True", "ligru_bidir": "True",
+            "ligru_act": "relu,relu", "ligru_orthinit": "True", "use_cuda": "True", "to_do": "train"}
+    old_prec, old_side = F_.settings.precision, F_.settings.wgrad_side
+    F_.set_precision("bf16")
+    try:
+        grads = {}
+        for side in (False, True):
+            F_.settings.wgrad_side = side
+            torch.manual_seed(5)
+            net = nn_amd.liGRU(dict(opts), 24).cuda().train()
+            head = nn_amd.MLP({"dnn_lay": "37", "dnn_drop": "0.0", "dnn_use_laynorm_inp": "False",
+                               "dnn_use_batchnorm_inp": "False", "dnn_use_batchnorm": "False", "dnn_use_laynorm": "False",
+                               "dnn_act": "softmax", "use_cuda": "True", "to_do": "train"}, 144).cuda().train()
+            flat, hflat = optim_.FlatParams(net), optim_.FlatParams(head)
+            x = torch.randn(300, 16, 24, generator=torch.Generator().manual_seed(6)).cuda()  # 4800 rows: Linear takes the side path too
+            for _ in range(2):  # second pass: accumulation on top of a zeroed buffer again
+                flat.zero_grad()
+                hflat.zero_grad()
+                head(net(x).reshape(4800, 144)).square().mean().backward()
+                F_.join_side()
+            grads[side] = torch.cat((flat.grad, hflat.grad)).clone()
+        assert float(grads[True].abs().max()) > 0
+        assert rel_err(grads[True], grads[False]) < 1e-6
+    finally:
+        F_.set_precision(old_prec)
+        F_.settings.wgrad_side = old_side

@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1: launch the gradient all-reduce bucket by bucket from backward hooks instead of after backward")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim instead of the fused flat optimizers")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the step as one HIP graph (auto: the launch-bound non-sequence recipes on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     return ap.parse_args()
@@ -82,10 +84,22 @@ class Trainer:
         self.T, self.B = (args.T, args.B) if rcp["seq"] else (1, args.B)
         self.batches = [self.R.synthetic_batch(rcp, self.T, self.B, 4234 + 17 * rank + i, "cuda") for i in range(2)]
         self.n_params = sum(p.numel() for n in self.nns.values() for p in n.parameters())
+        self.graphed = None
 
     def step(self, i):
-        rcp = self.rcp
         inp = self.batches[i % len(self.batches)]
+        if self.graphed is not None:
+            return self.graphed(inp)
+        return self.step_on(inp)
+
+    def enable_graph(self):
+        """Launch-bound recipes: replay the whole step as one HIP graph (pytorch-kaldi_amd/graphs.py).  Call after
+        a few eager steps."""
+        G = importlib.import_module("pytorch-kaldi_amd.graphs")
+        self.graphed = G.GraphedStep(self.step_on, list(self.opts.values())).capture(self.batches[0])
+
+    def step_on(self, inp):
+        rcp = self.rcp
         outs = self.U.forward_model(rcp["fea_dict"], rcp["lab_dict"], rcp["arch_dict"], rcp["model"], self.nns,
                                     self.costs, inp, self.inp_out_dict, self.T, self.B, "train", [])
         for o in self.opts.values():
@@ -161,7 +175,7 @@ def profile_entry_points(tr, steps=2):
     prof = _lib.Profiler()
     with prof:
         for i in range(steps):
-            tr.step(i)
+            tr.step_on(tr.batches[i % len(tr.batches)])  # eager even when the timed region replays a HIP graph
         torch.cuda.synchronize()
     return prof.summary(steps)
 
@@ -276,6 +290,13 @@ def main():
         tr.step(i)
         torch.cuda.synchronize()
         log("warmup step %d done" % i)
+    use_graph = args.graph == "on" or (args.graph == "auto" and not tr.rcp["seq"] and world == 1 and not args.torch_optim)
+    if use_graph:
+        if args.warmup == 0:
+            tr.step(0)  # lazy one-time initialisation must not land inside the capture
+        tr.enable_graph()
+        tr.step(0)      # first replay (graph upload) outside the timed region
+        log("step captured into a HIP graph")
     barrier()
     t0 = time.perf_counter()
     loss = None
@@ -301,7 +322,7 @@ def main():
                                   "3200-sample raw waveform chunks" if tr.rcp["nfea"] == 3200
                                   else "%d-dim features" % tr.rcp["nfea"], tr.rcp["n_cd"], tr.rcp["n_mono"]),
                    "global_batch": tr.B * world, "seq_len": tr.T, "parallelism": "dp%d" % world,
-                   "rec_algo": args.algo, "mask_rng": args.mask_rng, "allreduce": "overlapped" if args.overlap else "after-backward", "optimizer": "torch" if args.torch_optim else "fused-flat",
+                   "rec_algo": args.algo, "mask_rng": args.mask_rng, "allreduce": "overlapped" if args.overlap else "after-backward", "optimizer": "torch" if args.torch_optim else "fused-flat", "hip_graph": bool(use_graph),
                    "params": tr.n_params},
         "loss_final": round(float(loss), 5),
     }

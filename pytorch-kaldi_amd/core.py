@@ -28,6 +28,8 @@ import numpy as np
 import torch
 
 from . import dp as _dp
+from ._lib import PkError
+from .graphs import GraphedStep
 from .optim import fused_optimizer_init
 from .utils import forward_model, model_init, strtobool
 
@@ -209,6 +211,26 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
     counts = {i: load_counts(forward_count_files[i]) for i in range(len(forward_outs))
               if to_do == "forward" and forward_normalize_post[i]}
 
+    def train_step(inp_):
+        outs = forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp_, inp_out_dict, 0 if not seq_model else
+                             inp_.shape[0], local, to_do, forward_outs)
+        for opt in optimizers.keys():
+            optimizers[opt].zero_grad()
+        outs["loss_final"].backward()
+        if reducer is not None:
+            reducer.finish()
+        for opt in optimizers.keys():
+            if not strtobool(config[arch_dict[opt][0]]["arch_freeze"]):
+                optimizers[opt].step()
+        return {"loss_final": outs["loss_final"].detach(), "err_final": outs["err_final"].detach()}
+
+    # fixed-shape (non-sequence) training batches on one GPU are launch-bound: after a few eager batches the whole
+    # step is replayed as one HIP graph (graphs.py); PK_HIPGRAPH=0 keeps it eager
+    GRAPH_WARMUP = 3
+    graph_ok = (to_do == "train" and not seq_model and world == 1 and os.environ.get("PK_HIPGRAPH", "1") != "0"
+                and N_batches > GRAPH_WARMUP + 1)
+    graphed = None
+
     start_time = time.time()
     loss_sum = torch.zeros((), device=device)
     err_sum = torch.zeros((), device=device)
@@ -232,16 +254,18 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
             inp = data_set[b0:b0 + local, :].contiguous().to(device, non_blocking=True)
         nb = local if to_do != "forward" else 1
         if to_do == "train":
-            outs_dict = forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out_dict, max_len, nb,
-                                      to_do, forward_outs)
-            for opt in optimizers.keys():
-                optimizers[opt].zero_grad()
-            outs_dict["loss_final"].backward()
-            if reducer is not None:
-                reducer.finish()
-            for opt in optimizers.keys():
-                if not strtobool(config[arch_dict[opt][0]]["arch_freeze"]):
-                    optimizers[opt].step()
+            if graphed is not None:
+                outs_dict = graphed(inp)
+            elif graph_ok and i == GRAPH_WARMUP:
+                try:
+                    graphed = GraphedStep(train_step, [optimizers[k] for k in optimizers]).capture(inp)
+                    outs_dict = graphed(inp)
+                except (RuntimeError, PkError) as e:  # e.g. an Adam recipe: stay eager
+                    sys.stderr.write("run_nn_dp: HIP-graph capture not used (%s)\n" % (e,))
+                    graphed, graph_ok = None, False
+                    outs_dict = train_step(inp)
+            else:
+                outs_dict = train_step(inp)
         else:
             with torch.no_grad():
                 outs_dict = forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out_dict, max_len, nb,

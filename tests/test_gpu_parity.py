@@ -391,3 +391,51 @@ def test_side_stream_weight_gradients_equal_the_autograd_path():
     finally:
         F_.set_precision(old_prec)
         F_.settings.wgrad_side = old_side
+
+
+def test_hip_graph_replay_trains_like_eager_steps():
+    """graphs.GraphedStep: an MLP training step (forward, NLL, backward, fused RMSprop) captured once and replayed on
+    new batches ends with the same parameters, optimizer state and step count as the eager loop."""
+    optim_ = importlib.import_module("pytorch-kaldi_amd.optim")
+    graphs = importlib.import_module("pytorch-kaldi_amd.graphs")
+    F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+    nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
+    opts = {"dnn_lay": "64,48,11", "dnn_drop": "0.0,0.0,0.0", "dnn_use_laynorm_inp": "False", "dnn_use_batchnorm_inp": "False",
+            "dnn_use_batchnorm": "True,True,False", "dnn_use_laynorm": "False,False,False", "dnn_act": "relu,relu,softmax",
+            "use_cuda": "True", "to_do": "train"}
+    g = torch.Generator().manual_seed(9)
+    batches = [torch.randn(32, 20, generator=g).cuda() for _ in range(7)]
+    labels = [torch.randint(0, 11, (32,), generator=g).cuda() for _ in range(7)]
+    packed = [torch.cat((b, l.float()[:, None]), 1) for b, l in zip(batches, labels)]
+    old = F_.settings.precision
+    F_.set_precision("bf16")
+    try:
+        results = []
+        for use_graph in (False, True):
+            torch.manual_seed(4)
+            net = nn_amd.MLP(dict(opts), 20).cuda().train()
+            opt = optim_.FusedOptimizer(optim_.FlatParams(net), "rmsprop", 1e-3, alpha=0.95, eps=1e-8)
+
+            def step(inp):
+                opt.zero_grad()
+                loss = torch.nn.functional.nll_loss(net(inp[:, :20]), inp[:, 20].long())
+                loss.backward()
+                opt.step()
+                return loss.detach()
+
+            losses = [step(packed[i]) for i in range(3)]
+            if use_graph:
+                gs = graphs.GraphedStep(step, [opt]).capture(packed[3])
+                losses += [gs(packed[i]).clone() for i in range(3, 7)]
+            else:
+                losses += [step(packed[i]) for i in range(3, 7)]
+            torch.cuda.synchronize()
+            results.append((opt.flat.flat.clone(), opt.bufs["square_avg"].clone(), opt.steps, torch.stack(losses),
+                            net.bn[0].num_batches_tracked.item()))
+        (p0, s0, n0, l0, t0), (p1, s1, n1, l1, t1) = results
+        assert n0 == n1 == 7 and t0 == t1 == 7
+        assert torch.equal(l0, l1) and torch.equal(p0, p1) and torch.equal(s0, s1)
+        with pytest.raises(Exception):
+            graphs.GraphedStep(step, [optim_.FusedOptimizer(optim_.FlatParams(nn_amd.MLP(dict(opts), 20).cuda()), "adam", 1e-3)])
+    finally:
+        F_.set_precision(old)

@@ -313,11 +313,12 @@ class _Recurrent(nn.Module):
                 xb = xseg = None
             if use_bn and self.training:
                 n = x.shape[0] * x.shape[1] * (2 if self.bidir else 1)
-                with torch.no_grad():  # BatchNorm1d(momentum=0.05) running statistics, per gate
-                    for k, b in enumerate(bns):
-                        b.running_mean.mul_(0.95).add_(bmean[k * H:(k + 1) * H], alpha=0.05)
-                        b.running_var.mul_(0.95).add_(bvar[k * H:(k + 1) * H], alpha=0.05 * n / (n - 1))
-                        b.num_batches_tracked += 1
+                with torch.no_grad():  # BatchNorm1d(momentum=0.05) running statistics, per gate: four multi-tensor launches
+                    means, vars_ = [b.running_mean for b in bns], [b.running_var for b in bns]
+                    torch._foreach_mul_(means + vars_, 0.95)
+                    torch._foreach_add_(means, [bmean[k * H:(k + 1) * H] for k in range(len(bns))], alpha=0.05)
+                    torch._foreach_add_(vars_, [bvar[k * H:(k + 1) * H] for k in range(len(bns))], alpha=0.05 * n / (n - 1))
+                    torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
             x = y
         return x
 

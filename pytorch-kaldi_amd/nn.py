@@ -301,6 +301,10 @@ class _Recurrent(nn.Module):
                 if not self.training:
                     rmean = torch.cat([b.running_mean for b in bns], 0)
                     rvar = torch.cat([b.running_var for b in bns], 0)
+            if use_bn and self.training and x.shape[0] * x.shape[1] * (2 if self.bidir else 1) <= 1:
+                # what torch's BatchNorm1d raises for the reference in the same situation (one row, training mode)
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                                 % (tuple(x.shape),))
             cfg = (self.KIND, self._act[i], H, bool(self.bidir), use_bn, self.training, 1e-5, 0.05, scalar_i)
             if F_.perf_path_ok(self.KIND, H, bool(self._use_ln[i]), use_bn, self.training):
                 y, bmean, bvar, xb = F_.RecLayerPerfFn.apply(x, xb, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, mask_i,

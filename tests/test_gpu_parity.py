@@ -238,7 +238,10 @@ def test_bf16_mode_is_close(kind, pre, act, H):
 @pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("LSTM", "lstm", "tanh"), ("RNN", "rnn", "tanh"),
                                           ("GRU", "gru", "tanh"), ("minimalGRU", "minimalgru", "relu")])
 @pytest.mark.parametrize("H,T,B,bidir", [(550, 12, 5, True), (40, 9, 3, True), (20, 7, 4, False), (14, 5, 33, True),
-                                         (129, 6, 2, True)])
+                                         (129, 6, 2, True),
+                                         (8, 1, 2, False),      # one step, two sequences
+                                         (576, 3, 2, True),     # widest layer the register-resident U covers
+                                         (24, 4, 300, True)])   # 600 rows: more than one launch of the cluster grid
 @pytest.mark.parametrize("safe", [0, 1])
 def test_bf16_persistent_matches_bf16_stepwise(kind, pre, act, H, T, B, bidir, safe):
     """The perf-mode persistent kernels (bf16 exchange through L2, MFMA B fragments in registers) and the
@@ -439,3 +442,15 @@ def test_hip_graph_replay_trains_like_eager_steps():
             graphs.GraphedStep(step, [optim_.FusedOptimizer(optim_.FlatParams(nn_amd.MLP(dict(opts), 20).cuda()), "adam", 1e-3)])
     finally:
         F_.set_precision(old)
+
+
+def test_single_row_batchnorm_training_raises_like_torch():
+    """T = B = 1 with BatchNorm in training mode: torch's BatchNorm1d (the reference) raises ValueError."""
+    from engine_util import nn_amd
+
+    net = nn_amd.liGRU(_rec_opts("ligru", [8], "relu", bidir=False), 5).cuda().train()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        net(torch.randn(1, 1, 5).cuda())
+    ref = torch.nn.BatchNorm1d(8).train()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        ref(torch.randn(1, 8))

@@ -33,8 +33,12 @@ namespace {
 // ============================================================================
 // forward
 // ============================================================================
-template <int CELL>
+// ACT >= 0: the activation is a compile-time constant (relu, tanh: what the shipped recipes use) and the switch in
+// pk_act folds away; ACT < 0: run-time a.act.  With the run-time switch the gate math of one step executes ~40 scalar
+// branches (one switch per row and use), which shows up as several hundred clocks on the dependency chain.
+template <int CELL, int ACT>
 __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
+    const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
     constexpr int LDA = KPAD + 8;                 // bf16 elements per A-tile row (1168 B: odd multiple of 16 B)
     constexpr int ATILE = RMAX * LDA * 2;         // bytes
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
 #pragma unroll
             for (int g = 0; g < G; ++g) pr[g] = pre[g][r] * psc[g] + psh[g] + acc[g][r];
             float h, cc, s[NS];
-            pk_cell_fwd<CELL>(a.act, pr, hprev[r], cprev[r], msk[r], h, cc, s);
+            pk_cell_fwd<CELL>(act, pr, hprev[r], cprev[r], msk[r], h, cc, s);
             h = rvf[r] != 0.f ? h : 0.f;  // rows / units outside the layer carry exact zeros (published as padding)
             cc = rvf[r] != 0.f ? cc : 0.f;
             hprev[r] = h;
@@ -260,8 +264,9 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
 // ============================================================================
 // backward: dL/dh_{t-1} = direct + [dgates_t] . [U_0; U_1; ...]
 // ============================================================================
-template <int CELL>
+template <int CELL, int ACT>
 __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
+    const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
     constexpr bool LSTM = (CELL == PK_CELL_LSTM);
     constexpr int LDA = G * KPAD + 8;
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
             const float cp = LSTM ? sin[NIN - 1][r] : 0.f;
             const float dh = dy + dh_dir[r] + acc0[r] + acc1[r];
             float dg[G], dhd, dcp;
-            pk_cell_bwd<CELL>(a.act, s, hp, cp, msk[r], dh, dc_car[r], dg, dhd, dcp);
+            pk_cell_bwd<CELL>(act, s, hp, cp, msk[r], dh, dc_car[r], dg, dhd, dcp);
             // rows / units outside the layer: exact zeros (select, not multiply: their inputs are arbitrary)
             dh_dir[r] = rvf[r] != 0.f ? dhd : 0.f;
             dc_car[r] = rvf[r] != 0.f ? dcp : 0.f;
@@ -536,8 +541,9 @@ int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidi
 
 // Idle time between a workgroup's publish and its first poll of the next step, in s_sleep units of 64 clocks.  A poll
 // that arrives before the other members' stores costs a second L2 round trip (~2300 clocks); measured at the BASELINE
-// geometry (tools/trace_rec2.py, DELAY sweep): forward 6460 -> 6300 clocks/step at 4 units (re-polls 0.36 -> 0.06 per
-// step), backward 9020 -> 8380 at 8 units (0.48 -> 0.08).  PK_POLL_DELAY_FWD / PK_POLL_DELAY_BWD override.
+// geometry (tools/trace_rec2.py, DELAY sweep, Li-GRU): 0 units: 0.36 / 0.48 re-polls per step (forward / backward),
+// 6 units: 0.04 / 0.03 and the shortest steps (backward 7080 clocks vs 7320 at 4 and 7290 at 8).
+// PK_POLL_DELAY_FWD / PK_POLL_DELAY_BWD override.
 static int default_poll_delay(bool backward) {
     static int env[2] = {-2, -2};
     int& e = env[backward ? 1 : 0];
@@ -546,7 +552,7 @@ static int default_poll_delay(bool backward) {
         e = v ? atoi(v) : -1;
     }
     if (e >= 0) return e;
-    return backward ? 8 : 4;
+    return 6;
 }
 
 int pk_rec2_host_setup(R2Args& a, bool backward) {
@@ -568,6 +574,26 @@ extern "C" unsigned pk_persist2_error_count(void) { return g2_err_host ? *g2_err
 extern "C" void pk_persist2_error_reset(void) {
     if (g2_err_host) *g2_err_host = 0u;
 }
+
+typedef void (*Rec2Kernel)(R2Args);
+inline int act_slot(int act) { return act == PK_ACT_RELU ? 0 : act == PK_ACT_TANH ? 1 : 2; }
+template <int CELL>
+Rec2Kernel pick_fwd(int act) {
+    return act == PK_ACT_RELU ? rec2_fwd_kernel<CELL, PK_ACT_RELU> : act == PK_ACT_TANH ? rec2_fwd_kernel<CELL, PK_ACT_TANH>
+                                                                                       : rec2_fwd_kernel<CELL, -1>;
+}
+template <int CELL>
+Rec2Kernel pick_bwd(int act) {
+    return act == PK_ACT_RELU ? rec2_bwd_kernel<CELL, PK_ACT_RELU> : act == PK_ACT_TANH ? rec2_bwd_kernel<CELL, PK_ACT_TANH>
+                                                                                       : rec2_bwd_kernel<CELL, -1>;
+}
+inline Rec2Kernel pick_fwd(int cell, int act) {
+    return cell == PK_CELL_LIGRU ? pick_fwd<PK_CELL_LIGRU>(act) : cell == PK_CELL_RNN ? pick_fwd<PK_CELL_RNN>(act) : pick_fwd<PK_CELL_LSTM>(act);
+}
+inline Rec2Kernel pick_bwd(int cell, int act) {
+    return cell == PK_CELL_LIGRU ? pick_bwd<PK_CELL_LIGRU>(act) : cell == PK_CELL_RNN ? pick_bwd<PK_CELL_RNN>(act) : pick_bwd<PK_CELL_LSTM>(act);
+}
+
 
 extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
                                const float* pscale, const float* pshift, const float* U, const float* mask,
@@ -595,14 +621,11 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     const int G = pk_cell_gates(cell);
     const size_t lds = 2 * (size_t)RMAX * (KPAD + 8) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024 + 512) + 16;
     {   // dynamic LDS above the 64 KB default needs the opt-in (exact size: the kernels also hold a little static LDS)
-        const void* fn = cell == PK_CELL_LIGRU ? (const void*)rec2_fwd_kernel<PK_CELL_LIGRU>
-                         : cell == PK_CELL_RNN ? (const void*)rec2_fwd_kernel<PK_CELL_RNN>
-                                               : (const void*)rec2_fwd_kernel<PK_CELL_LSTM>;
-        static size_t granted[3] = {0, 0, 0};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
+        static size_t granted[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
         const int slot = cell == PK_CELL_LIGRU ? 0 : cell == PK_CELL_RNN ? 1 : 2;
-        if (granted[slot] < lds) {
-            PK_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            granted[slot] = lds;
+        if (granted[slot][act_slot(act)] < lds) {
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)pick_fwd(cell, act), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            granted[slot][act_slot(act)] = lds;
         }
     }
     for (int l = 0; l < pl.launches; ++l) {
@@ -610,9 +633,7 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
-        if (cell == PK_CELL_LIGRU) hipLaunchKernelGGL((rec2_fwd_kernel<PK_CELL_LIGRU>), grid, block, lds, st, a);
-        else if (cell == PK_CELL_RNN) hipLaunchKernelGGL((rec2_fwd_kernel<PK_CELL_RNN>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((rec2_fwd_kernel<PK_CELL_LSTM>), grid, block, lds, st, a);
+        hipLaunchKernelGGL(pick_fwd(cell, act), grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }
     return 0;
@@ -644,14 +665,11 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0);
     const size_t lds = (2 * atile > 96 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(nin + G) * 1024 + (size_t)G * 512) + 16;
     {
-        const void* fn = cell == PK_CELL_LIGRU ? (const void*)rec2_bwd_kernel<PK_CELL_LIGRU>
-                         : cell == PK_CELL_RNN ? (const void*)rec2_bwd_kernel<PK_CELL_RNN>
-                                               : (const void*)rec2_bwd_kernel<PK_CELL_LSTM>;
-        static size_t granted[3] = {0, 0, 0};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
+        static size_t granted[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
         const int slot = cell == PK_CELL_LIGRU ? 0 : cell == PK_CELL_RNN ? 1 : 2;
-        if (granted[slot] < lds) {
-            PK_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            granted[slot] = lds;
+        if (granted[slot][act_slot(act)] < lds) {
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)pick_bwd(cell, act), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            granted[slot][act_slot(act)] = lds;
         }
     }
     for (int l = 0; l < pl.launches; ++l) {
@@ -659,9 +677,7 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
-        if (cell == PK_CELL_LIGRU) hipLaunchKernelGGL((rec2_bwd_kernel<PK_CELL_LIGRU>), grid, block, lds, st, a);
-        else if (cell == PK_CELL_RNN) hipLaunchKernelGGL((rec2_bwd_kernel<PK_CELL_RNN>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((rec2_bwd_kernel<PK_CELL_LSTM>), grid, block, lds, st, a);
+        hipLaunchKernelGGL(pick_bwd(cell, act), grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }
     return 0;

@@ -21,8 +21,10 @@ namespace {
 // ============================================================================
 // forward
 // ============================================================================
-template <int CELL>
+// ACT: compile-time activation (relu / tanh) or -1 = run-time a.act, as in pk_rec_persist2.hip
+template <int CELL, int ACT>
 __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
+    const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), G1 = G - 1, NS = pk_cell_saved(CELL);
     constexpr bool GRU = (CELL == PK_CELL_GRU);
     constexpr int LDA = KPAD + 8;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float at = pre[G1][r] * psc[G1] + psh[G1] + acca[r] + accb[r];
-            float h = pk_cell_fwd_p2<CELL>(a.act, at, zt[r], hprev[r], msk[r]);
+            float h = pk_cell_fwd_p2<CELL>(act, at, zt[r], hprev[r], msk[r]);
             h = rvf[r] != 0.f ? h : 0.f;
             hprev[r] = h;
             hv[r] = h;
@@ -263,8 +265,9 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
 // ============================================================================
 // backward
 // ============================================================================
-template <int CELL>
+template <int CELL, int ACT>
 __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
+    const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), G1 = G - 1, NS = pk_cell_saved(CELL);
     constexpr bool GRU = (CELL == PK_CELL_GRU);
     constexpr int LDB = G1 * KPAD + 8;           // tile of [dz(,dr)]_{t+1}
@@ -442,11 +445,11 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
         for (int r = 0; r < 4; ++r) {
             const float z = sin[0][r], at = sin[G1][r], hp = sin[G][r];
             const float dh = sin[G + 1][r] + dh_dir[r] + acc0[r] + acc1[r];
-            const float cand = pk_act(a.act, at) * msk[r];
+            const float cand = pk_act(act, at) * msk[r];
             const bool ok = rvf[r] != 0.f;
             dzp[r] = ok ? dh * (hp - cand) * z * (1.f - z) : 0.f;
             dhd[r] = ok ? dh * z : 0.f;
-            da[r] = ok ? dh * (1.f - z) * msk[r] * pk_act_grad_from_in(a.act, at) : 0.f;
+            da[r] = ok ? dh * (1.f - z) * msk[r] * pk_act_grad_from_in(act, at) : 0.f;
             patchB[G1 * 256 + (kq * 4 + r) * 16 + (lane & 15)] = to_bf_pub(da[r]);
         }
         PK_LDS_ORDER();
@@ -507,7 +510,19 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
     }
 }
 
-size_t granted_lds[2][2] = {{0, 0}, {0, 0}};
+size_t granted_lds[2][2][3] = {{{0, 0, 0}, {0, 0, 0}}, {{0, 0, 0}, {0, 0, 0}}};
+typedef void (*Rec2gKernel)(R2Args);
+inline int act_slot(int act) { return act == PK_ACT_RELU ? 0 : act == PK_ACT_TANH ? 1 : 2; }
+template <int CELL>
+Rec2gKernel pick_fwd(int act) {
+    return act == PK_ACT_RELU ? rec2g_fwd_kernel<CELL, PK_ACT_RELU> : act == PK_ACT_TANH ? rec2g_fwd_kernel<CELL, PK_ACT_TANH>
+                                                                                        : rec2g_fwd_kernel<CELL, -1>;
+}
+template <int CELL>
+Rec2gKernel pick_bwd(int act) {
+    return act == PK_ACT_RELU ? rec2g_bwd_kernel<CELL, PK_ACT_RELU> : act == PK_ACT_TANH ? rec2g_bwd_kernel<CELL, PK_ACT_TANH>
+                                                                                        : rec2g_bwd_kernel<CELL, -1>;
+}
 
 }  // namespace
 
@@ -536,18 +551,17 @@ extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, 
     PK_CHECK_HIP(hipMemsetAsync(Xb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     const size_t lds = 2 * (size_t)RMAX * (KPAD + 8) * 2 + 4 * ((size_t)(2 * G + 1) * 1024 + 512) + 16;
     const int slot = cell == PK_CELL_GRU ? 0 : 1;
-    const void* fn = cell == PK_CELL_GRU ? (const void*)rec2g_fwd_kernel<PK_CELL_GRU> : (const void*)rec2g_fwd_kernel<PK_CELL_MINGRU>;
-    if (granted_lds[0][slot] < lds) {
-        PK_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        granted_lds[0][slot] = lds;
+    const Rec2gKernel fn = cell == PK_CELL_GRU ? pick_fwd<PK_CELL_GRU>(act) : pick_fwd<PK_CELL_MINGRU>(act);
+    if (granted_lds[0][slot][act_slot(act)] < lds) {
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        granted_lds[0][slot][act_slot(act)] = lds;
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
-        if (cell == PK_CELL_GRU) hipLaunchKernelGGL((rec2g_fwd_kernel<PK_CELL_GRU>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((rec2g_fwd_kernel<PK_CELL_MINGRU>), grid, block, lds, st, a);
+        hipLaunchKernelGGL(fn, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }
     return 0;
@@ -578,18 +592,17 @@ extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, 
     const size_t lds = (size_t)RMAX * (G1 * KPAD + 8) * 2 + (size_t)RMAX * (KPAD + 8) * 2 +
                        4 * ((size_t)(G + 2) * 1024 + (size_t)G * 512) + 16;
     const int slot = cell == PK_CELL_GRU ? 0 : 1;
-    const void* fn = cell == PK_CELL_GRU ? (const void*)rec2g_bwd_kernel<PK_CELL_GRU> : (const void*)rec2g_bwd_kernel<PK_CELL_MINGRU>;
-    if (granted_lds[1][slot] < lds) {
-        PK_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        granted_lds[1][slot] = lds;
+    const Rec2gKernel fn = cell == PK_CELL_GRU ? pick_bwd<PK_CELL_GRU>(act) : pick_bwd<PK_CELL_MINGRU>(act);
+    if (granted_lds[1][slot][act_slot(act)] < lds) {
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        granted_lds[1][slot][act_slot(act)] = lds;
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
-        if (cell == PK_CELL_GRU) hipLaunchKernelGGL((rec2g_bwd_kernel<PK_CELL_GRU>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((rec2g_bwd_kernel<PK_CELL_MINGRU>), grid, block, lds, st, a);
+        hipLaunchKernelGGL(fn, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }
     return 0;

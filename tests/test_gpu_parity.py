@@ -236,7 +236,9 @@ def test_bf16_mode_is_close(kind, pre, act, H):
 
 
 @pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("LSTM", "lstm", "tanh"), ("RNN", "rnn", "tanh"),
-                                          ("GRU", "gru", "tanh"), ("minimalGRU", "minimalgru", "relu")])
+                                          ("GRU", "gru", "tanh"), ("minimalGRU", "minimalgru", "relu"),
+                                          # the kernels are specialised for relu / tanh: these take the run-time switch
+                                          ("liGRU", "ligru", "leaky_relu"), ("GRU", "gru", "sigmoid"), ("LSTM", "lstm", "elu")])
 @pytest.mark.parametrize("H,T,B,bidir", [(550, 12, 5, True), (40, 9, 3, True), (20, 7, 4, False), (14, 5, 33, True),
                                          (129, 6, 2, True),
                                          (8, 1, 2, False),      # one step, two sequences

@@ -46,11 +46,13 @@ constexpr int RMAX = 16;     // rows per cluster (one MFMA M tile)
         if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
+// Is any part of a polled 16-byte chunk still the fill pattern?  A chunk is written by ONE 16-byte store of one
+// producer lane; its dwords are written atomically and a published dword never equals 0xFFFFFFFF (to_bf_pub cannot
+// emit a 0xFFFF half), so the chunk is complete iff none of its four dwords is all ones: an unsigned max and one
+// compare (the half-by-half test this replaces cost 16+ VALU operations per chunk, on the dependency chain).
 __device__ __forceinline__ bool has_sent16(const u32x4 v) {
-    bool s = false;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) s = s || ((v[e] & 0xFFFFu) == 0xFFFFu) || ((v[e] >> 16) == 0xFFFFu);
-    return s;
+    const unsigned m01 = v[0] > v[1] ? v[0] : v[1], m23 = v[2] > v[3] ? v[2] : v[3];
+    return (m01 > m23 ? m01 : m23) == 0xFFFFFFFFu;
 }
 // bf16 with the sentinel pattern excluded (any NaN becomes the canonical quiet NaN 0x7FC0)
 __device__ __forceinline__ unsigned short to_bf_pub(float f) {

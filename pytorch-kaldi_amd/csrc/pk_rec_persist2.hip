@@ -539,11 +539,11 @@ int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidi
     return 0;
 }
 
-// Idle time between a workgroup's publish and its first poll of the next step, in s_sleep units of 64 clocks.  A poll
-// that arrives before the other members' stores costs a second L2 round trip (~2300 clocks); measured at the BASELINE
-// geometry (tools/trace_rec2.py, DELAY sweep, Li-GRU): 0 units: 0.36 / 0.48 re-polls per step (forward / backward),
-// 6 units: 0.04 / 0.03 and the shortest steps (backward 7080 clocks vs 7320 at 4 and 7290 at 8).
-// PK_POLL_DELAY_FWD / PK_POLL_DELAY_BWD override.
+// Idle time between a workgroup's publish and its first poll of the next step, in s_sleep units of 64 clocks
+// (PK_POLL_DELAY_FWD / PK_POLL_DELAY_BWD override).  A poll that arrives before the other members' stores is repeated;
+// while the sentinel test was expensive that cost ~2300 clocks and 6 units were best (re-polls 0.4 -> 0.04 per step);
+// with the dword-level test a re-poll is cheap and the DELAY sweep of tools/trace_rec2.py (Li-GRU, BASELINE geometry) is
+// flat between 0 and 2 units (forward 5160-5200, backward 5750-5870 clocks per step) and rises beyond.
 static int default_poll_delay(bool backward) {
     static int env[2] = {-2, -2};
     int& e = env[backward ? 1 : 0];
@@ -552,7 +552,7 @@ static int default_poll_delay(bool backward) {
         e = v ? atoi(v) : -1;
     }
     if (e >= 0) return e;
-    return 6;
+    return backward ? 1 : 2;
 }
 
 int pk_rec2_host_setup(R2Args& a, bool backward) {

@@ -54,12 +54,11 @@ __device__ __forceinline__ bool has_sent16(const u32x4 v) {
     const unsigned m01 = v[0] > v[1] ? v[0] : v[1], m23 = v[2] > v[3] ? v[2] : v[3];
     return (m01 > m23 ? m01 : m23) == 0xFFFFFFFFu;
 }
-// bf16 with the sentinel pattern excluded (any NaN becomes the canonical quiet NaN 0x7FC0)
+// bf16 (round to nearest even: the gfx950 v_cvt_pk_bf16_f32) with the sentinel pattern excluded: the one NaN encoding
+// that would read as "not written yet" becomes the canonical quiet NaN
 __device__ __forceinline__ unsigned short to_bf_pub(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)0x7FC0;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+    const unsigned short u = __builtin_bit_cast(unsigned short, (__bf16)f);
+    return u == (unsigned short)0xFFFF ? (unsigned short)0x7FC0 : u;
 }
 __device__ __forceinline__ bool spin_check2(int& spins, int spin_limit, unsigned* err, int lane) {
     if (++spins > spin_limit) {

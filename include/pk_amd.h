@@ -192,13 +192,15 @@ int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, int T, int B
  * padded) and dGb [ndir*T*B][g_pitch] bf16 gate gradients (gate g at column g*Hp) are laid out as the
  * k-major operands pk_gemm_bf16 needs for dU / dW.  Columns beyond ndir*Hp (G*Hp) of a row are left
  * undefined.  Pitches are multiples of 8 elements; H <= 576.  dP2 may be NULL (the fp32 gate-gradient
- * slabs are then not written: pk_bn_bwd_bf16 works from dGb). */
+ * slabs are then not written: pk_bn_bwd_bf16 works from dGb).  * prefilled != 0: the caller has already filled the exchange buffer(s) (Yb, Xb / dGb) with 0xFF bytes - e.g. on
+ * another stream, next to the projection GEMM - and the entry point skips its own hipMemsetAsync.
+ */
 int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
                     const float* pscale, const float* pshift, const float* U, const float* mask, float mask_scalar,
-                    float* Y, float* S, uint16_t* Yb, int64_t y_pitch);
+                    float* Y, float* S, uint16_t* Yb, int64_t y_pitch, int prefilled);
 int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
                     float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, uint16_t* dGb,
-                    int64_t g_pitch);
+                    int64_t g_pitch, int prefilled);
 /* diagnostics: when non-NULL, cluster 0 / member 0 / wave 0 of every following launch writes
  * T x 8 shader-clock stamps (phase boundaries of each step) to this device buffer. */
 void pk_persist2_set_trace(void* dev_buf);
@@ -213,9 +215,10 @@ void pk_persist2_set_poll_delay(int units);
  * written.  The backward leaves the fp32 gate gradients unwritten (dGb only, gates [z,(r,)a] at g*Hp). */
 int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
                       const float* pscale, const float* pshift, const float* U, const float* mask, float mask_scalar,
-                      float* Y, float* S, uint16_t* Yb, uint16_t* Xb, int64_t y_pitch);
+                      float* Y, float* S, uint16_t* Yb, uint16_t* Xb, int64_t y_pitch, int prefilled);
 int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
-                      float mask_scalar, const float* Y, const float* S, const float* dY, uint16_t* dGb, int64_t g_pitch);
+                      float mask_scalar, const float* Y, const float* S, const float* dY, uint16_t* dGb, int64_t g_pitch,
+                      int prefilled);
 unsigned pk_persist2_error_count(void);
 void pk_persist2_error_reset(void);
 

@@ -597,7 +597,7 @@ inline Rec2Kernel pick_bwd(int cell, int act) {
 
 extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
                                const float* pscale, const float* pshift, const float* U, const float* mask,
-                               float mask_scalar, float* Y, float* S, uint16_t* Yb, int64_t y_pitch) {
+                               float mask_scalar, float* Y, float* S, uint16_t* Yb, int64_t y_pitch, int prefilled) {
     int rc = pk_rec2_check("pk_rec_fwd_bf16", 1, cell, T, B, bidir, H);
     if (rc) return rc;
     hipStream_t st = pk_stream(stream);
@@ -617,7 +617,7 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     rc = pk_rec2_host_setup(a, false);
     if (rc) return rc;
     // the bf16 layer output is the mailbox: poison it with the sentinel
-    PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
+    if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     const int G = pk_cell_gates(cell);
     const size_t lds = 2 * (size_t)RMAX * (KPAD + 8) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024 + 512) + 16;
     {   // dynamic LDS above the 64 KB default needs the opt-in (exact size: the kernels also hold a little static LDS)
@@ -641,7 +641,7 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
 
 extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
                                const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
-                               float* dP2, uint16_t* dGb, int64_t g_pitch) {
+                               float* dP2, uint16_t* dGb, int64_t g_pitch, int prefilled) {
     int rc = pk_rec2_check("pk_rec_bwd_bf16", 1, cell, T, B, bidir, H);
     if (rc) return rc;
     hipStream_t st = pk_stream(stream);
@@ -660,7 +660,7 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.dY = dY; a.dP2 = dP2; a.dGb = (unsigned short*)dGb; a.Gpitch = (int)g_pitch;
     rc = pk_rec2_host_setup(a, true);
     if (rc) return rc;
-    PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
+    if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
     const size_t atile = (size_t)RMAX * (G * KPAD + 8) * 2;
     const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0);
     const size_t lds = (2 * atile > 96 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(nin + G) * 1024 + (size_t)G * 512) + 16;

@@ -528,7 +528,7 @@ Rec2gKernel pick_bwd(int act) {
 
 extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
                                  const float* pscale, const float* pshift, const float* U, const float* mask,
-                                 float mask_scalar, float* Y, float* S, uint16_t* Yb, uint16_t* Xb, int64_t y_pitch) {
+                                 float mask_scalar, float* Y, float* S, uint16_t* Yb, uint16_t* Xb, int64_t y_pitch, int prefilled) {
     int rc = pk_rec2_check("pk_rec2p_fwd_bf16", cell == PK_CELL_GRU || cell == PK_CELL_MINGRU, cell, T, B, bidir, H);
     if (rc) return rc;
     hipStream_t st = pk_stream(stream);
@@ -547,8 +547,8 @@ extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, 
     a.dY = nullptr; a.dP2 = nullptr; a.dGb = nullptr; a.Gpitch = 0;
     rc = pk_rec2_host_setup(a, false);
     if (rc) return rc;
-    PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
-    PK_CHECK_HIP(hipMemsetAsync(Xb, 0xFF, (size_t)T * B * y_pitch * 2, st));
+    if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
+    if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Xb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     const size_t lds = 2 * (size_t)RMAX * (KPAD + 8) * 2 + 4 * ((size_t)(2 * G + 1) * 1024 + 512) + 16;
     const int slot = cell == PK_CELL_GRU ? 0 : 1;
     const Rec2gKernel fn = cell == PK_CELL_GRU ? pick_fwd<PK_CELL_GRU>(act) : pick_fwd<PK_CELL_MINGRU>(act);
@@ -569,7 +569,7 @@ extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, 
 
 extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
                                  const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
-                                 uint16_t* dGb, int64_t g_pitch) {
+                                 uint16_t* dGb, int64_t g_pitch, int prefilled) {
     int rc = pk_rec2_check("pk_rec2p_bwd_bf16", cell == PK_CELL_GRU || cell == PK_CELL_MINGRU, cell, T, B, bidir, H);
     if (rc) return rc;
     hipStream_t st = pk_stream(stream);
@@ -588,7 +588,7 @@ extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, 
     a.dY = dY; a.dP2 = nullptr; a.dGb = (unsigned short*)dGb; a.Gpitch = (int)g_pitch;
     rc = pk_rec2_host_setup(a, true);
     if (rc) return rc;
-    PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
+    if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
     const size_t lds = (size_t)RMAX * (G1 * KPAD + 8) * 2 + (size_t)RMAX * (KPAD + 8) * 2 +
                        4 * ((size_t)(G + 2) * 1024 + (size_t)G * 512) + 16;
     const int slot = cell == PK_CELL_GRU ? 0 : 1;

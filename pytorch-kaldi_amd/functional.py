@@ -598,7 +598,7 @@ class RecLayerFn(torch.autograd.Function):
             Hp = _up(H, 8)
             Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
             rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
-                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1])
+                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1], 0)
             _lib.check(rc, "pk_rec_fwd_bf16")
         else:
             rc = lib.pk_rec_fwd(_stream(), algo, prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
@@ -642,7 +642,7 @@ class RecLayerFn(torch.autograd.Function):
             Hp = _up(H, 8)
             dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16)
             rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
-                                     float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dP2), _p(dGb), dGb.shape[1])
+                                     float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dP2), _p(dGb), dGb.shape[1], 0)
             _lib.check(rc, "pk_rec_bwd_bf16")
         else:
             rc = lib.pk_rec_bwd(_stream(), ctx.algo, ctx.prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat),
@@ -710,6 +710,35 @@ def perf_path_ok(cell, H, use_ln, use_bn, training):
     return training or not use_bn or not torch.is_grad_enabled()
 
 
+class _Prefill:
+    """0xFF fill of the persistent kernels' exchange buffers on a third stream (next to the projection GEMM)."""
+    stream = None
+
+    def __init__(self):
+        self.done = 0
+
+    def start(self, *bufs):
+        if not settings.wgrad_side:  # PK_WGRAD_SIDE=0 keeps the whole step on one stream
+            return
+        main = torch.cuda.current_stream()
+        if _Prefill.stream is None:
+            _Prefill.stream = torch.cuda.Stream()
+        st = _Prefill.stream
+        st.wait_stream(main)  # the fresh blocks may still be in use by work enqueued earlier on the main stream
+        with torch.cuda.stream(st):
+            for b in bufs:
+                if b is not None:
+                    b.view(torch.int16).fill_(-1)
+        for b in bufs:
+            if b is not None:
+                b.record_stream(st)
+        self.done = 1
+
+    def wait(self):
+        if self.done:
+            torch.cuda.current_stream().wait_stream(_Prefill.stream)
+
+
 class RecLayerPerfFn(torch.autograd.Function):
     """Perf-mode (bf16 MFMA operands) recurrent layer: same math as RecLayerFn, but every GEMM operand
     lives in HBM as bf16 and nothing is converted twice:
@@ -745,6 +774,18 @@ class RecLayerPerfFn(torch.autograd.Function):
             assert nseg * seglen == D and xb_in.shape[0] == TB
             xb, Wb, K = xb_in, cvt_bf16(Wcat, nseg, seglen, segpad), nseg * segpad
             assert Wb.shape[1] == xb.shape[1]
+        # the kernels' bf16 exchange buffers must hold the 0xFF "not written yet" pattern: they are filled on a third
+        # stream next to the projection GEMM / BatchNorm statistics instead of in front of the recurrence (the backward
+        # one, dGb, too: 295 MB that would otherwise be filled on the critical path of backward)
+        Hp = _up(H, 8)
+        Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
+        dGb = None
+        if any(ctx.needs_input_grad):  # a backward pass will follow
+            dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=x.device, dtype=torch.bfloat16)
+        two_phase = cell in ("GRU", "minimalGRU")
+        Xb = torch.empty_like(Yb) if two_phase else None  # two exchanges per step: h and r*h (z*h)
+        fill = _Prefill()
+        fill.start(Yb, Xb, dGb)
         P = _new(TB, GH, like=Wcat)
         gemm_bf16(TB, GH, K, xb, xb.shape[1], 1, Wb, Wb.shape[1], 1, P, GH)
         mean = var = None
@@ -760,20 +801,18 @@ class RecLayerPerfFn(torch.autograd.Function):
             pshift = bcat.contiguous() if bcat is not None else torch.zeros(GH, device=x.device)
         Y = _new(T, B, ndir * H, like=Wcat)
         S = _new(ndir, TB, NS * H, like=Wcat)
-        Hp = _up(H, 8)
-        Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
         _lib.raise_if_persist_failed()
-        Xb = None
-        if cell in ("GRU", "minimalGRU"):  # two exchanges per step: h and r*h (z*h)
-            Xb = torch.empty_like(Yb)
+        fill.wait()
+        if two_phase:
             rc = lib.pk_rec2p_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
                                        _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), _p(Xb),
-                                       Yb.shape[1])
+                                       Yb.shape[1], fill.done)
             _lib.check(rc, "pk_rec2p_fwd_bf16")
         else:
             rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
-                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1])
+                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1], fill.done)
             _lib.check(rc, "pk_rec_fwd_bf16")
+        ctx.dGb = dGb if fill.done else None
         ctx.Xb = Xb
         ctx.save_for_backward(xb, Wb, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, Yb)
         ctx.cfg = cfg[:9] + (xseg,)
@@ -798,15 +837,18 @@ class RecLayerPerfFn(torch.autograd.Function):
         TB, GH = T * B, G * H
         Hp = _up(H, 8)
         dY = dY.contiguous()
-        dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16)
+        dGb, prefilled = ctx.dGb, 1  # filled with the "not written" pattern during forward (third stream)
+        ctx.dGb = None
+        if dGb is None:
+            dGb, prefilled = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16), 0
         Gp = dGb.shape[1]
         if ctx.Xb is not None:
             rc = lib.pk_rec2p_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
-                                       float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dGb), Gp)
+                                       float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dGb), Gp, prefilled)
             _lib.check(rc, "pk_rec2p_bwd_bf16")
         else:
             rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
-                                     float(mask_scalar), _p(Y), _p(S), _p(dY), None, _p(dGb), Gp)
+                                     float(mask_scalar), _p(Y), _p(S), _p(dY), None, _p(dGb), Gp, prefilled)
             _lib.check(rc, "pk_rec_bwd_bf16")
         # weight gradients are off the dependency chain (the next thing on it is the layer below's recurrent
         # backward): with flat-bucket parameters they run on the side stream and accumulate straight into .grad

@@ -755,6 +755,7 @@ class RecLayerPerfFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, xb_in, Wcat, bcat, Ucat, gamma, beta, running_mean, running_var, mask, cfg):
+        ctx.set_materialize_grads(False)  # no 147 MB zero tensor for the (non-differentiable) bf16 twin in backward
         _need_gpu(x, Wcat, bcat, Ucat, gamma, beta, mask)
         lib = _lib.load()
         cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar, xseg = cfg[:10]
@@ -826,6 +827,8 @@ class RecLayerPerfFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dY, _dm, _dv, _dyb):
+        if dY is None:  # the layer output did not reach the loss
+            return (None,) * 11
         lib = _lib.load()
         xb, Wb, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, Yb = ctx.saved_tensors
         cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar, xseg = ctx.cfg

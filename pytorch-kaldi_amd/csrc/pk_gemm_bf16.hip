@@ -202,7 +202,7 @@ __device__ __forceinline__ void epilogue(const BArgs& p, const f32x4 (&acc)[4][4
 // STAGES = 1: single buffer, two barriers per k-tile, 3-4 workgroups per CU (32 KB each): the overlap of
 //             loads and MFMA comes from the co-resident workgroups instead of from the software pipeline.
 template <bool A_KC, bool B_KC, int STAGES>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 3) void gemm_bf16x_kernel(BArgs p) {
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 4) void gemm_bf16x_kernel(BArgs p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [STAGES][A 16 KB | B 16 KB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;

@@ -456,3 +456,27 @@ def test_single_row_batchnorm_training_raises_like_torch():
     ref = torch.nn.BatchNorm1d(8).train()
     with pytest.raises(ValueError, match="more than 1 value per channel"):
         ref(torch.randn(1, 8))
+
+
+@pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("GRU", "gru", "tanh"), ("LSTM", "lstm", "tanh")])
+def test_bf16_eval_forward_is_close(kind, pre, act):
+    """Validation / forward chunks (to_do != train, module.eval(), no_grad): the perf pipeline folds the running
+    BatchNorm statistics and the (1 - p) dropout scalar and must stay within the bf16 tolerance of the fp32 path."""
+    from engine_util import F_amd, nn_amd
+
+    opts = _rec_opts(pre, [72, 72], act)
+    opts["to_do"] = "valid"
+    torch.manual_seed(17)
+    net = getattr(nn_amd, kind)(opts, 30).cuda()
+    with torch.no_grad():
+        for b in net.buffers():
+            if b.dtype.is_floating_point:
+                b.add_(0.2 * torch.rand_like(b))
+    net.eval()
+    x = torch.randn(31, 6, 30, generator=torch.Generator().manual_seed(2)).cuda()
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        F_amd.set_precision(prec)
+        with torch.no_grad():
+            outs[prec] = net(x).cpu()
+    assert rel_err(outs["bf16"], outs["fp32"]) < 3e-2

@@ -43,7 +43,7 @@ constexpr int RMAX = 16;     // rows per cluster (one MFMA M tile)
 
 #define PK_TRACE(slot)                                                                      \
     do {                                                                                    \
-        if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        if (TR && a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
 // Is any part of a polled 16-byte chunk still the fill pattern?  A chunk is written by ONE 16-byte store of one
@@ -240,6 +240,26 @@ struct BoolC {  // (an int: 0 = no edge, 1 = even-H edge in 8-byte halves, 2 = o
         if (edge == 0) CALL(BoolC<0>());        \
         else if (edge == 1) CALL(BoolC<1>());   \
         else CALL(BoolC<2>());                  \
+    } while (0)
+// inside a time loop that was instantiated for a wave whose units do not straddle H (SE == 0) the dispatch is static;
+// SE < 0 keeps the run-time one.  (The scalar branches of the run-time forms - this one, the XCD fast/safe select and
+// the trace hooks - cost ~4 % of a step when they sit in the loop.)
+#define PK_EDGE_DISPATCH_S(CALL)               \
+    do {                                        \
+        if constexpr (SE == 0) {                \
+            CALL(BoolC<0>());                   \
+        } else {                                \
+            PK_EDGE_DISPATCH(CALL);             \
+        }                                       \
+    } while (0)
+#define PK_RUN_SPECIALISED(RUN, FAST_RT)                                              \
+    do {                                                                              \
+        const int edge_u = __builtin_amdgcn_readfirstlane(edge);                      \
+        if (FAST_RT) {                                                                \
+            if (edge_u == 0) RUN(BoolC<1>(), BoolC<0>()); else RUN(BoolC<1>(), BoolC<-1>()); \
+        } else {                                                                      \
+            if (edge_u == 0) RUN(BoolC<0>(), BoolC<0>()); else RUN(BoolC<0>(), BoolC<-1>()); \
+        }                                                                             \
     } while (0)
 
 }  // namespace

@@ -36,7 +36,7 @@ namespace {
 // ACT >= 0: the activation is a compile-time constant (relu, tanh: what the shipped recipes use) and the switch in
 // pk_act folds away; ACT < 0: run-time a.act.  With the run-time switch the gate math of one step executes ~40 scalar
 // branches (one switch per row and use), which shows up as several hundred clocks on the dependency chain.
-template <int CELL, int ACT>
+template <int CELL, int ACT, bool TR>
 __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
@@ -173,7 +173,12 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     __syncthreads();
 
     bool dead = false;
-    const bool fast = cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0;
+    // (made explicitly wave-uniform: the specialised loops below must be entered through scalar branches)
+    const bool fast_rt = __builtin_amdgcn_readfirstlane((int)(cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0)) != 0;
+    // the time loop, instantiated per (XCD-local fast path?, static edge case?) so that neither choice is a branch in it
+    auto run = [&](auto FASTC, auto SEC) {
+    constexpr bool fast = decltype(FASTC)::value != 0;
+    constexpr int SE = decltype(SEC)::value;
     for (int t = 0; t < T; ++t) {
         const int step_idx = t;
         PK_TRACE(0);
@@ -203,11 +208,11 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
         // to drain before the next poll): fp32 outputs of the previous step, projections of the next one
         if (t > 0) {
 #define PK_FO(E) flush_outputs(t - 1, E)
-            PK_EDGE_DISPATCH(PK_FO);
+            PK_EDGE_DISPATCH_S(PK_FO);
         }
         if (t + 1 < T) {
 #define PK_LP1(E) load_proj(t + 1, E)
-            PK_EDGE_DISPATCH(PK_LP1);
+            PK_EDGE_DISPATCH_S(PK_LP1);
         }
         if (t > 0) {
             const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
@@ -257,6 +262,8 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
         PK_LDS_ORDER();
         PK_TRACE(5);
     }
+    };
+    PK_RUN_SPECIALISED(run, fast_rt);
 #define PK_FOL(E) flush_outputs(T - 1, E)
     PK_EDGE_DISPATCH(PK_FOL);
 }
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
 // ============================================================================
 // backward: dL/dh_{t-1} = direct + [dgates_t] . [U_0; U_1; ...]
 // ============================================================================
-template <int CELL, int ACT>
+template <int CELL, int ACT, bool TR>
 __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
@@ -389,9 +396,10 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
             if (LSTM) iv[NIN - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto load_step = [&](int t) {
+    auto load_step = [&](int t, auto SEC) {  // SEC: BoolC<0> = static no-edge case, BoolC<-1> = run-time dispatch
+        constexpr int SE = decltype(SEC)::value;
 #define PK_LS(E) load_step_e(t, E)
-        PK_EDGE_DISPATCH(PK_LS);
+        PK_EDGE_DISPATCH_S(PK_LS);
     };
     auto flush_outputs_e = [&](int tt, auto E) {
         const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
@@ -399,16 +407,21 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
         for (int g = 0; g < G; ++g)
             st4<decltype(E)::value>(a.dP2, vG0 + ts * vGs + g * H, vnv, trash, patch_get_vec(patchG + g * 256, lane));
     };
-    auto flush_outputs = [&](int tt) {
+    auto flush_outputs = [&](int tt, auto SEC) {
+        constexpr int SE = decltype(SEC)::value;
         if (a.dP2 == nullptr) return;  // perf mode: BatchNorm backward works from the bf16 copy
 #define PK_FOB(E) flush_outputs_e(tt, E)
-        PK_EDGE_DISPATCH(PK_FOB);
+        PK_EDGE_DISPATCH_S(PK_FOB);
     };
-    load_step(T - 1);
+    load_step(T - 1, BoolC<-1>());
     __syncthreads();
 
     bool dead = false;
-    const bool fast = cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0;
+    // (made explicitly wave-uniform: the specialised loops below must be entered through scalar branches)
+    const bool fast_rt = __builtin_amdgcn_readfirstlane((int)(cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0)) != 0;
+    auto run = [&](auto FASTC, auto SEC) {  // see the forward kernel; FASTC < 0: run-time choice
+    const bool fast = decltype(FASTC)::value < 0 ? fast_rt : decltype(FASTC)::value != 0;
+    constexpr int SE = decltype(SEC)::value;
     int it = 0;
     for (int t = T - 1; t >= 0; --t, ++it) {
         const int step_idx = it;
@@ -433,8 +446,8 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
         PK_TRACE(2);
         // off the dependency chain, behind the barrier: fp32 gate gradients of the previous step (if wanted) and
         // the saved tensors of the next one
-        if (t < T - 1) flush_outputs(t + 1);
-        if (t > 0) load_step(t - 1);
+        if (t < T - 1) flush_outputs(t + 1, SEC);
+        if (t > 0) load_step(t - 1, SEC);
         if (t < T - 1) {
             const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
 #pragma unroll
@@ -491,7 +504,11 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
         }
         PK_TRACE(5);
     }
-    flush_outputs(0);
+    };
+    // (one copy, run-time choices: with this larger loop instantiated per fast / edge case the backward kernel measured
+    // 2-4 % SLOWER on the same box, while the forward kernel gains 4 % from it)
+    run(BoolC<-1>(), BoolC<-1>());
+    flush_outputs(0, BoolC<-1>());
 }
 
 unsigned long long* g2_trace = nullptr;  // set by pk_persist2_set_trace (diagnostics only)
@@ -577,23 +594,26 @@ extern "C" void pk_persist2_error_reset(void) {
 
 typedef void (*Rec2Kernel)(R2Args);
 inline int act_slot(int act) { return act == PK_ACT_RELU ? 0 : act == PK_ACT_TANH ? 1 : 2; }
+// the phase trace (pk_persist2_set_trace, tools/trace_rec2.py) is compiled into the Li-GRU / relu kernels only
 template <int CELL>
 Rec2Kernel pick_fwd(int act) {
-    return act == PK_ACT_RELU ? rec2_fwd_kernel<CELL, PK_ACT_RELU> : act == PK_ACT_TANH ? rec2_fwd_kernel<CELL, PK_ACT_TANH>
-                                                                                       : rec2_fwd_kernel<CELL, -1>;
+    return act == PK_ACT_RELU ? rec2_fwd_kernel<CELL, PK_ACT_RELU, false>
+         : act == PK_ACT_TANH ? rec2_fwd_kernel<CELL, PK_ACT_TANH, false> : rec2_fwd_kernel<CELL, -1, false>;
 }
 template <int CELL>
 Rec2Kernel pick_bwd(int act) {
-    return act == PK_ACT_RELU ? rec2_bwd_kernel<CELL, PK_ACT_RELU> : act == PK_ACT_TANH ? rec2_bwd_kernel<CELL, PK_ACT_TANH>
-                                                                                       : rec2_bwd_kernel<CELL, -1>;
+    return act == PK_ACT_RELU ? rec2_bwd_kernel<CELL, PK_ACT_RELU, false>
+         : act == PK_ACT_TANH ? rec2_bwd_kernel<CELL, PK_ACT_TANH, false> : rec2_bwd_kernel<CELL, -1, false>;
 }
+inline bool traced(int cell, int act) { return g2_trace != nullptr && cell == PK_CELL_LIGRU && act == PK_ACT_RELU; }
 inline Rec2Kernel pick_fwd(int cell, int act) {
+    if (traced(cell, act)) return rec2_fwd_kernel<PK_CELL_LIGRU, PK_ACT_RELU, true>;
     return cell == PK_CELL_LIGRU ? pick_fwd<PK_CELL_LIGRU>(act) : cell == PK_CELL_RNN ? pick_fwd<PK_CELL_RNN>(act) : pick_fwd<PK_CELL_LSTM>(act);
 }
 inline Rec2Kernel pick_bwd(int cell, int act) {
+    if (traced(cell, act)) return rec2_bwd_kernel<PK_CELL_LIGRU, PK_ACT_RELU, true>;
     return cell == PK_CELL_LIGRU ? pick_bwd<PK_CELL_LIGRU>(act) : cell == PK_CELL_RNN ? pick_bwd<PK_CELL_RNN>(act) : pick_bwd<PK_CELL_LSTM>(act);
 }
-
 
 extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
                                const float* pscale, const float* pshift, const float* U, const float* mask,
@@ -621,11 +641,12 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     const int G = pk_cell_gates(cell);
     const size_t lds = 2 * (size_t)RMAX * (KPAD + 8) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024 + 512) + 16;
     {   // dynamic LDS above the 64 KB default needs the opt-in (exact size: the kernels also hold a little static LDS)
-        static size_t granted[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
+        static size_t granted[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
         const int slot = cell == PK_CELL_LIGRU ? 0 : cell == PK_CELL_RNN ? 1 : 2;
-        if (granted[slot][act_slot(act)] < lds) {
+        const int as = traced(cell, act) ? 3 : act_slot(act);
+        if (granted[slot][as] < lds) {
             PK_CHECK_HIP(hipFuncSetAttribute((const void*)pick_fwd(cell, act), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            granted[slot][act_slot(act)] = lds;
+            granted[slot][as] = lds;
         }
     }
     for (int l = 0; l < pl.launches; ++l) {
@@ -665,11 +686,12 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0);
     const size_t lds = (2 * atile > 96 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(nin + G) * 1024 + (size_t)G * 512) + 16;
     {
-        static size_t granted[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
+        static size_t granted[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
         const int slot = cell == PK_CELL_LIGRU ? 0 : cell == PK_CELL_RNN ? 1 : 2;
-        if (granted[slot][act_slot(act)] < lds) {
+        const int as = traced(cell, act) ? 3 : act_slot(act);
+        if (granted[slot][as] < lds) {
             PK_CHECK_HIP(hipFuncSetAttribute((const void*)pick_bwd(cell, act), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            granted[slot][act_slot(act)] = lds;
+            granted[slot][as] = lds;
         }
     }
     for (int l = 0; l < pl.launches; ++l) {

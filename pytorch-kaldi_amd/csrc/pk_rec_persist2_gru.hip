@@ -25,6 +25,7 @@ namespace {
 template <int CELL, int ACT>
 __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
+    constexpr bool TR = false;  // no phase trace in the two-phase kernels
     constexpr int G = pk_cell_gates(CELL), G1 = G - 1, NS = pk_cell_saved(CELL);
     constexpr bool GRU = (CELL == PK_CELL_GRU);
     constexpr int LDA = KPAD + 8;
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
 template <int CELL, int ACT>
 __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
+    constexpr bool TR = false;  // no phase trace in the two-phase kernels
     constexpr int G = pk_cell_gates(CELL), G1 = G - 1, NS = pk_cell_saved(CELL);
     constexpr bool GRU = (CELL == PK_CELL_GRU);
     constexpr int LDB = G1 * KPAD + 8;           // tile of [dz(,dr)]_{t+1}

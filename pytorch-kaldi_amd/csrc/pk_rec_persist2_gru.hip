@@ -155,9 +155,13 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
     __syncthreads();
 
     bool dead = false;
-    const bool fast = cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0;
+    const bool fast_rt = __builtin_amdgcn_readfirstlane((int)(cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0)) != 0;
     unsigned char* A0 = smem;
     unsigned char* A1 = smem + ATILE;
+    // the time loop, instantiated per (XCD-local fast path?, static edge case?) as in pk_rec_persist2.hip (forward)
+    auto run = [&](auto FASTC, auto SEC) {
+    constexpr bool fast = decltype(FASTC)::value != 0;
+    constexpr int SE = decltype(SEC)::value;
     for (int t = 0; t < T; ++t) {
         const int step_idx = t;
         PK_TRACE(0);
@@ -181,11 +185,11 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
         else PK_LDS_ORDER();
         if (t > 0) {
 #define PKG_FO(E) flush_outputs(t - 1, E)
-            PK_EDGE_DISPATCH(PKG_FO);
+            PK_EDGE_DISPATCH_S(PKG_FO);
         }
         if (t + 1 < T) {
 #define PKG_LP1(E) load_proj(t + 1, E)
-            PK_EDGE_DISPATCH(PKG_LP1);
+            PK_EDGE_DISPATCH_S(PKG_LP1);
         }
         if (t > 0) {
             const unsigned char* Ar = A0 + (lane & 15) * (LDA * 2) + kq * 16;
@@ -259,6 +263,8 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
         PK_LDS_ORDER();
         PK_TRACE(5);
     }
+    };
+    PK_RUN_SPECIALISED(run, fast_rt);
 #define PKG_FOL(E) flush_outputs(T - 1, E)
     PK_EDGE_DISPATCH(PKG_FOL);
 }

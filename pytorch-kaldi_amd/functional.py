@@ -226,6 +226,21 @@ def _accumulate_rows(params, rows):
 # ----------------------------------------------------------------------------
 # Linear:  y = x W^T + b        (nn.Linear; neural_networks.py:111, 139-148)
 # ----------------------------------------------------------------------------
+_XB_LAST = None  # (source tensor [kept alive: its memory cannot be reused], data_ptr, shape, strides, version, bf16 copy)
+
+
+def _cvt_bf16_shared(x2):
+    """bf16 copy of a Linear input, shared by consecutive layers that read the SAME tensor (the senone and the
+    monophone head both take the last recurrent layer's output: one 64000 x 1100 conversion instead of two)."""
+    global _XB_LAST
+    key = (x2.data_ptr(), tuple(x2.shape), tuple(x2.stride()), x2._version)
+    if _XB_LAST is not None and _XB_LAST[1] == key and x2.numel() >= (1 << 20):
+        return _XB_LAST[2]
+    xb = cvt_bf16(x2)
+    _XB_LAST = (x2, key, xb) if x2.numel() >= (1 << 20) else None
+    return xb
+
+
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -237,7 +252,7 @@ class LinearFn(torch.autograd.Function):
         y = _new(M, N, like=x2)
         ctx.bf = bf16_mode()
         if ctx.bf:  # perf mode: operands rounded to bf16 once, saved in bf16 for backward
-            xb, wb = cvt_bf16(x2), cvt_bf16(weight)
+            xb, wb = _cvt_bf16_shared(x2), cvt_bf16(weight)
             gemm_bf16(M, N, K, xb, xb.shape[1], 1, wb, wb.shape[1], 1, y, N, bias=bias)
             ctx.save_for_backward(xb, wb)
         else:

@@ -196,3 +196,51 @@ def test_run_nn_dp_replays_the_reference_chunk_loop(tmp_path):
     for (_, a), (_, b) in zip(got, want):
         assert a.shape == b.shape
         assert rel_err(torch.from_numpy(a.copy()), torch.from_numpy(b.copy())) < 1e-4
+
+
+@pytest.mark.gpu
+def test_run_nn_dp_hip_graph_replay_equals_eager(tmp_path, monkeypatch):
+    """Non-sequence recipe (an MLP trunk in place of the Li-GRU): run_nn_dp replays the training step as a HIP graph after
+    three eager batches; the chunk must end with the same parameters, optimizer state and loss as the eager loop."""
+    g = Golden(CASE)
+    meta = g.meta
+    cp = configparser.ConfigParser()
+    cp.read_string(engine_cfg(g, "ck0", tmp_path))
+    a1 = cp["architecture1"]
+    for k in [k for k in a1 if k.startswith("ligru_")]:
+        del a1[k]
+    a1["arch_class"], a1["arch_seq_model"] = "MLP", "False"
+    a1.update({"dnn_lay": "32,32", "dnn_drop": "0.0,0.0", "dnn_use_laynorm_inp": "False", "dnn_use_batchnorm_inp": "False",
+               "dnn_use_batchnorm": "True,True", "dnn_use_laynorm": "False,False", "dnn_act": "relu,relu"})
+    cp["batches"]["batch_size_train"] = "8"
+    arch_dict = {k: list(v) for k, v in meta["arch_dict"].items()}
+    arch_dict["liGRU_layers"][2] = False
+    data, end = g.arrays["data_set"], g.arrays["data_end_index"]  # 80+ frames: 10 batches of 8
+
+    def reader(cfg_file, is_production, shared_list, output_folder):
+        shared_list.extend([meta["data_name"], end, {k: list(v) for k, v in meta["fea_dict"].items()}, meta["lab_dict"],
+                            arch_dict, data])
+
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PK_HIPGRAPH", mode)
+        out = tmp_path / ("g" + mode)
+        out.mkdir()
+        cp["exp"]["out_folder"] = str(out)
+        cp["exp"]["out_info"] = str(out / "ck.info")
+        path = out / "ck.cfg"
+        with open(path, "w") as f:
+            cp.write(f)
+        core.run_nn_dp(*([None] * 6), str(path), True, str(path), reader=reader)
+        info = configparser.ConfigParser()
+        info.read(out / "ck.info")
+        cks = [torch.load(out / ("ck_architecture%d.pkl" % i), weights_only=False) for i in (1, 2, 3)]
+        results[mode] = (float(info["results"]["loss"]), float(info["results"]["err"]), cks)
+    assert data.shape[0] // 8 >= 6
+    assert results["0"][0] == results["1"][0] and results["0"][1] == results["1"][1]
+    for ce, cg in zip(results["0"][2], results["1"][2]):
+        for k, v in ce["model_par"].items():
+            assert torch.equal(v.cpu(), cg["model_par"][k].cpu()), k
+        for idx, ent in ce["optimizer_par"]["state"].items():
+            assert torch.equal(ent["square_avg"].cpu(), cg["optimizer_par"]["state"][idx]["square_avg"].cpu())
+            assert float(ent["step"]) == float(cg["optimizer_par"]["state"][idx]["step"])

@@ -117,6 +117,30 @@ class BatchAssembler:
         return max_len, out
 
 
+def rank_columns(batch_size, rank, world):
+    """Columns (sentences of a batch) this rank keeps: [r*B/N, (r+1)*B/N)."""
+    if batch_size % world != 0:
+        raise RuntimeError("batch size %d does not split over %d ranks" % (batch_size, world))
+    local = batch_size // world
+    return local, np.arange(rank * local, (rank + 1) * local)
+
+
+def make_reducer(nns, optimizers, world):
+    """Gradient all-reduce over the flat buckets of the fused optimizers (None on one rank)."""
+    if world <= 1:
+        return None
+    return _dp.GradReducer({k: nns[k] for k in nns}, flats={k: optimizers[k].flat for k in nns}, overlap=False)
+
+
+def mean_over_ranks(loss_sum, err_sum, world):
+    """Chunk loss / error of the whole job: mean of the per-rank sums (equal shards)."""
+    if world <= 1:
+        return loss_sum, err_sum
+    both = torch.stack((loss_sum, err_sum))
+    torch.distributed.all_reduce(both)
+    return both[0] / world, both[1] / world
+
+
 def _default_reader():
     try:
         import data_io  # the reference's, when running inside a PyTorch-Kaldi checkout
@@ -164,8 +188,6 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
 
     rank, world, local_rank = _dp.init_from_env()
     device = torch.device("cuda", torch.cuda.current_device())
-    if batch_size % world != 0 and to_do != "forward":
-        raise RuntimeError("batch size %d does not split over %d ranks" % (batch_size, world))
     read = reader if reader is not None else _default_reader()
 
     if processed_first:
@@ -189,9 +211,7 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
             nns[net].load_state_dict(checkpoint_load["model_par"])
             optimizers[net].load_state_dict(checkpoint_load["optimizer_par"])
             optimizers[net].param_groups[0]["lr"] = float(config[arch_dict[net][0]]["arch_lr"])
-    reducer = None
-    if to_do == "train" and world > 1:
-        reducer = _dp.GradReducer([nns[k] for k in nns], flats=[optimizers[k].flat for k in nns], overlap=False)
+    reducer = make_reducer(nns, optimizers, world) if to_do == "train" else None
 
     post_file = {}
     if to_do == "forward" and rank == 0:
@@ -206,8 +226,7 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
         N_batches = int(data_set.shape[0] / batch_size)
     end = np.asarray(data_end_index, dtype=np.int64)
     assembler = BatchAssembler(data_set, data_end_index, device) if seq_model else None
-    local = batch_size // world if to_do != "forward" else 1
-    cols = np.arange(rank * local, (rank + 1) * local)
+    local, cols = rank_columns(batch_size, rank, world) if to_do != "forward" else (1, np.arange(1))
     counts = {i: load_counts(forward_count_files[i]) for i in range(len(forward_outs))
               if to_do == "forward" and forward_normalize_post[i]}
 
@@ -281,10 +300,8 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
             loss_sum += outs_dict["loss_final"].detach()
             err_sum += outs_dict["err_final"].detach()
     # the only host sync of the chunk (the reference syncs once per batch for its progress bar, core.py:689)
-    if to_do != "forward" and world > 1:
-        both = torch.stack((loss_sum, err_sum))
-        torch.distributed.all_reduce(both)
-        loss_sum, err_sum = both[0] / world, both[1] / world
+    if to_do != "forward":
+        loss_sum, err_sum = mean_over_ranks(loss_sum, err_sum, world)
     torch.cuda.synchronize()
     elapsed_time_chunk = time.time() - start_time
     loss_tot = loss_sum / max(N_batches, 1)

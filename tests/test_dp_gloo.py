@@ -85,3 +85,58 @@ def test_shard_batch_shapes():
     assert torch.equal(DP.shard_batch(y, 3, 4), y[6:8])
     with pytest.raises(ValueError):
         DP.shard_batch(x, 0, 3)
+
+
+def _core_worker(rank, world, port, out):
+    """The data-parallel plumbing of core.run_nn_dp on CPU modules: column assignment, reducer over the fused
+    optimizers' flat buckets, loss / error averaging."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    DP = importlib.import_module("pytorch-kaldi_amd.dp")
+    OPT = importlib.import_module("pytorch-kaldi_amd.optim")
+    core = importlib.import_module("pytorch-kaldi_amd.core")
+    DP.init_from_env("gloo")
+    nns = {"trunk": _model(0), "head": torch.nn.Linear(3, 2)}
+    torch.manual_seed(1)
+    nns["head"].reset_parameters()
+    optimizers = {k: OPT.FusedOptimizer(OPT.FlatParams(m), "sgd", 0.1) for k, m in nns.items()}
+    reducer = core.make_reducer(nns, optimizers, world)
+    x, y = _batch()
+    local, cols = core.rank_columns(x.shape[1], rank, world)
+    assert local == 4 and list(cols) == list(range(rank * 4, rank * 4 + 4))
+    for o in optimizers.values():
+        o.zero_grad()
+    loss = ((nns["head"](nns["trunk"](x[:, cols])) - y[:, cols, :2]) ** 2).mean()
+    loss.backward()
+    reducer.finish()
+    l, e = core.mean_over_ranks(loss.detach(), torch.tensor(float(rank)), world)
+    if rank == 0:
+        torch.save({"grads": {k: o.flat.grad.clone() for k, o in optimizers.items()}, "loss": l, "err": e}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_nn_dp_plumbing_two_ranks(tmp_path):
+    out = str(tmp_path / "core.pt")
+    mp.spawn(_core_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    OPT = importlib.import_module("pytorch-kaldi_amd.optim")
+    nns = {"trunk": _model(0), "head": torch.nn.Linear(3, 2)}
+    torch.manual_seed(1)
+    nns["head"].reset_parameters()
+    flats = {k: OPT.FlatParams(m) for k, m in nns.items()}
+    x, y = _batch()
+    ref = {k: torch.zeros_like(f.grad) for k, f in flats.items()}
+    losses = []
+    for r in range(2):
+        for f in flats.values():
+            f.zero_grad()
+        cols = list(range(r * 4, r * 4 + 4))
+        loss = ((nns["head"](nns["trunk"](x[:, cols])) - y[:, cols, :2]) ** 2).mean()
+        loss.backward()
+        losses.append(float(loss))
+        for k, f in flats.items():
+            ref[k] += f.grad / 2
+    for k in ref:
+        assert torch.allclose(got["grads"][k], ref[k], atol=1e-6), k
+    assert abs(float(got["loss"]) - sum(losses) / 2) < 1e-6 and abs(float(got["err"]) - 0.5) < 1e-6

@@ -259,6 +259,23 @@ void pk_persist_error_reset(void);
  * Writes 0 to *h_bad_count if every layout assumption holds. */
 int pk_selftest_mfma(void* stream, int* h_bad_count);
 
+/* ---- chunk loader pieces (next row): binary Kaldi matrix tables and the whole-chunk transforms
+ * of data_io.load_chunk.  Host memory; plain files (the reference reads through Kaldi pipes, which stay outside).
+ * pk_ark_open: path + byte offset (0 for an ark read from its start; the offset of an scp entry otherwise).
+ * pk_ark_next: key_expected = 1 reads "<key> " first (ark), 0 expects a bare matrix (scp entry).  Returns 1 and the
+ *   dimensions, 0 at end of file, 2 on a malformed table.  FM / DM (data_io.py:1106-1131), CM (:1150-1198), CM2, CM3.
+ * pk_ark_read / pk_ark_skip: consume the announced matrix (row-major float32 into dst). */
+typedef struct pk_ark pk_ark;
+pk_ark* pk_ark_open(const char* path, int64_t offset);
+void pk_ark_close(pk_ark* a);
+int pk_ark_next(pk_ark* a, int key_expected, char* key, int keycap, int64_t* rows, int64_t* cols);
+int pk_ark_read(pk_ark* a, float* dst);
+int pk_ark_skip(pk_ark* a);
+/* data_io.py:228-241 context_window on the concatenated chunk: out [(rows-left-right)][cols*(left+right+1)] */
+int pk_context_window(const float* x, int64_t rows, int64_t cols, int left, int right, float* out);
+/* data_io.py:263: x <- (x - mean) / std per column (population std, double accumulation), in place */
+int pk_mean_var_norm(float* x, int64_t rows, int64_t cols);
+
 #ifdef __cplusplus
 }
 #endif

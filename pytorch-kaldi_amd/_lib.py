@@ -67,6 +67,13 @@ SIGNATURES = {
     "pk_conv_fwd_work_floats": (c_int64, [c_int, c_int, c_int]),
     "pk_conv_partial_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "pk_conv1d_pool_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "pk_ark_open": (P, [ctypes.c_char_p, c_int64]),
+    "pk_ark_close": (None, [P]),
+    "pk_ark_next": (c_int, [P, c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
+    "pk_ark_read": (c_int, [P, P]),
+    "pk_ark_skip": (c_int, [P]),
+    "pk_context_window": (c_int, [P, c_int64, c_int64, c_int, c_int, P]),
+    "pk_mean_var_norm": (c_int, [P, c_int64, c_int64]),
     "pk_rmsprop_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float]),
     "pk_sgd_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_int]),
     "pk_adam_step": (c_int, [P, P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int]),

@@ -1,0 +1,189 @@
+// pk_io.hip - host-side readers for the chunk loader: Kaldi binary matrix tables and the two
+// whole-chunk transforms the reference applies after loading.  No device code in this file; it is part of
+// libpk_amd.so so that the chunk loop needs no second library.
+//
+//   pk_ark_*            data_io.py:762-783 (read_key), :1062-1131 (read_mat_ark, read_mat, _read_mat_binary),
+//                       :1150-1198 (_read_compressed_mat); 'CM2' / 'CM3' follow Kaldi's compressed-matrix.h, which the
+//                       reference's reader refuses
+//   pk_context_window   data_io.py:228-241 (np.roll based splicing of the concatenated chunk, edges trimmed)
+//   pk_mean_var_norm    data_io.py:263 ((x - mean) / std per column, population std, double accumulation)
+//
+// Plain files only: the reference reads through Kaldi pipes ("ark:copy-feats scp:... ark:- |"), which stay outside.
+#include <errno.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "pk_common.h"
+
+struct pk_ark {
+    FILE* f;
+    char kind;  // 'F' float32, 'D' float64, '1' CM, '2' CM2, '3' CM3: matrix announced by pk_ark_next, not yet read
+    int64_t rows, cols;
+    float cm_min, cm_range;
+};
+
+namespace {
+
+bool read_exact(FILE* f, void* dst, size_t n) { return fread(dst, 1, n, f) == n; }
+
+}  // namespace
+
+extern "C" pk_ark* pk_ark_open(const char* path, int64_t offset) {
+    FILE* f = fopen(path, "rb");
+    if (f == nullptr) {
+        pk_set_error("pk_ark_open: cannot open %s: %s", path, strerror(errno));
+        return nullptr;
+    }
+    if (offset > 0 && fseeko(f, (off_t)offset, SEEK_SET) != 0) {
+        pk_set_error("pk_ark_open: cannot seek %s to %lld", path, (long long)offset);
+        fclose(f);
+        return nullptr;
+    }
+    pk_ark* a = new pk_ark();
+    a->f = f;
+    a->kind = 0;
+    a->rows = a->cols = 0;
+    a->cm_min = a->cm_range = 0.f;
+    return a;
+}
+
+extern "C" void pk_ark_close(pk_ark* a) {
+    if (a == nullptr) return;
+    if (a->f) fclose(a->f);
+    delete a;
+}
+
+// Reads "<key> " (unless key_expected == 0: a bare matrix, as an scp entry with an offset points at), the "\0B" marker
+// and the matrix header.  Returns 1 with *rows / *cols set, 0 at a clean end of file, < 0 on a malformed table.
+extern "C" int pk_ark_next(pk_ark* a, int key_expected, char* key, int keycap, int64_t* rows, int64_t* cols) {
+    PK_REQUIRE(a != nullptr && a->f != nullptr, "pk_ark_next: closed table");
+    PK_REQUIRE(a->kind == 0, "pk_ark_next: the previous matrix has not been read (pk_ark_read / pk_ark_skip)");
+    if (key != nullptr && keycap > 0) key[0] = 0;
+    if (key_expected) {
+        int n = 0, c;
+        while ((c = fgetc(a->f)) != EOF && c != ' ') {
+            if (c == '\n' || c == '\r' || c == '\t') continue;  // the reference strips whitespace around a key
+            PK_REQUIRE(key != nullptr && n + 1 < keycap, "pk_ark_next: key longer than %d bytes", keycap);
+            key[n++] = (char)c;
+        }
+        if (key != nullptr && keycap > 0) key[n < keycap ? n : keycap - 1] = 0;
+        if (n == 0) return 0;  // end of file
+    }
+    char mark[2];
+    PK_REQUIRE(read_exact(a->f, mark, 2), "pk_ark_next: truncated table");
+    PK_REQUIRE(mark[0] == 0 && mark[1] == 'B', "pk_ark_next: not a binary Kaldi table (text tables are not supported)");
+    char tag[3];
+    PK_REQUIRE(read_exact(a->f, tag, 3), "pk_ark_next: truncated matrix header");
+    if (tag[0] == 'C' && tag[1] == 'M') {
+        a->kind = tag[2] == ' ' ? '1' : tag[2];
+        if (a->kind != '1') {  // "CM2" / "CM3" are followed by the separating blank
+            PK_REQUIRE((a->kind == '2' || a->kind == '3') && fgetc(a->f) == ' ', "pk_ark_next: unknown compressed header");
+        }
+        struct { float mn, range; int32_t rows, cols; } gh;
+        PK_REQUIRE(read_exact(a->f, &gh, 16), "pk_ark_next: truncated compressed header");
+        a->cm_min = gh.mn; a->cm_range = gh.range; a->rows = gh.rows; a->cols = gh.cols;
+    } else {
+        PK_REQUIRE((tag[0] == 'F' || tag[0] == 'D') && tag[1] == 'M' && tag[2] == ' ', "pk_ark_next: unknown matrix header '%c%c%c'",
+                   tag[0], tag[1], tag[2]);
+        a->kind = tag[0];
+        unsigned char dims[10];
+        PK_REQUIRE(read_exact(a->f, dims, 10) && dims[0] == 4 && dims[5] == 4, "pk_ark_next: bad dimension block");
+        int32_t r, c;
+        memcpy(&r, dims + 1, 4);
+        memcpy(&c, dims + 6, 4);
+        a->rows = r; a->cols = c;
+    }
+    PK_REQUIRE(a->rows >= 0 && a->cols >= 0, "pk_ark_next: negative dimensions");
+    *rows = a->rows; *cols = a->cols;
+    return 1;
+}
+
+// The matrix announced by pk_ark_next -> dst[rows*cols] (row-major float32).
+extern "C" int pk_ark_read(pk_ark* a, float* dst) {
+    PK_REQUIRE(a != nullptr && a->kind != 0, "pk_ark_read: no pending matrix (call pk_ark_next first)");
+    const int64_t R = a->rows, C = a->cols, n = R * C;
+    const char kind = a->kind;
+    a->kind = 0;
+    if (kind == 'F') {
+        PK_REQUIRE(read_exact(a->f, dst, (size_t)n * 4), "pk_ark_read: truncated float matrix");
+    } else if (kind == 'D') {
+        std::vector<double> buf((size_t)n);
+        PK_REQUIRE(read_exact(a->f, buf.data(), (size_t)n * 8), "pk_ark_read: truncated double matrix");
+        for (int64_t i = 0; i < n; ++i) dst[i] = (float)buf[(size_t)i];
+    } else if (kind == '1') {
+        // per-column percentile headers, then the bytes column-major (data_io.py:1168-1196)
+        std::vector<uint16_t> hdr((size_t)C * 4);
+        std::vector<uint8_t> bytes((size_t)n);
+        PK_REQUIRE(read_exact(a->f, hdr.data(), (size_t)C * 8) && read_exact(a->f, bytes.data(), (size_t)n),
+                   "pk_ark_read: truncated compressed matrix");
+        for (int64_t c = 0; c < C; ++c) {
+            float p[4];
+            for (int q = 0; q < 4; ++q)
+                p[q] = (float)((double)hdr[(size_t)c * 4 + q] * (double)a->cm_range * 1.52590218966964e-05 + (double)a->cm_min);
+            const float s0 = (p[1] - p[0]) / 64.0f, s1 = (p[2] - p[1]) / 128.0f, s2 = (p[3] - p[2]) / 63.0f;
+            const uint8_t* col = bytes.data() + (size_t)c * R;
+            for (int64_t r = 0; r < R; ++r) {
+                const int v = col[r];
+                float x;
+                if (v <= 64) x = p[0] + s0 * (float)v;
+                else if (v <= 192) x = p[1] + s1 * (float)(v - 64);
+                else x = p[2] + s2 * (float)(v - 192);
+                dst[r * C + c] = x;
+            }
+        }
+    } else if (kind == '2') {
+        std::vector<uint16_t> buf((size_t)n);
+        PK_REQUIRE(read_exact(a->f, buf.data(), (size_t)n * 2), "pk_ark_read: truncated CM2 matrix");
+        const float inc = a->cm_range * (1.0f / 65535.0f);
+        for (int64_t i = 0; i < n; ++i) dst[i] = a->cm_min + inc * (float)buf[(size_t)i];
+    } else {
+        std::vector<uint8_t> buf((size_t)n);
+        PK_REQUIRE(read_exact(a->f, buf.data(), (size_t)n), "pk_ark_read: truncated CM3 matrix");
+        const float inc = a->cm_range * (1.0f / 255.0f);
+        for (int64_t i = 0; i < n; ++i) dst[i] = a->cm_min + inc * (float)buf[(size_t)i];
+    }
+    return 0;
+}
+
+extern "C" int pk_ark_skip(pk_ark* a) {
+    PK_REQUIRE(a != nullptr && a->kind != 0, "pk_ark_skip: no pending matrix");
+    const int64_t n = a->rows * a->cols;
+    int64_t bytes = a->kind == 'F' ? n * 4 : a->kind == 'D' ? n * 8 : a->kind == '1' ? a->cols * 8 + n : a->kind == '2' ? n * 2 : n;
+    a->kind = 0;
+    PK_REQUIRE(fseeko(a->f, (off_t)bytes, SEEK_CUR) == 0, "pk_ark_skip: seek failed");
+    return 0;
+}
+
+// out[(rows - left - right)][cols * (left + right + 1)]: block `lag + left` of output row i is input row
+// i + left + lag, lag = -left .. right - exactly what the np.roll construction keeps after trimming (data_io.py:228-241).
+extern "C" int pk_context_window(const float* x, int64_t rows, int64_t cols, int left, int right, float* out) {
+    PK_REQUIRE(left >= 0 && right >= 0 && rows >= (int64_t)left + right, "pk_context_window: %lld rows cannot hold a -%d..+%d window",
+               (long long)rows, left, right);
+    const int64_t orows = rows - left - right, W = left + right + 1;
+    for (int64_t i = 0; i < orows; ++i)
+        for (int64_t b = 0; b < W; ++b) memcpy(out + (i * W + b) * cols, x + (i + b) * cols, (size_t)cols * sizeof(float));
+    return 0;
+}
+
+// x <- (x - mean) / std per column (population std, as np.std), accumulated in double like the reference's float64 chunk
+extern "C" int pk_mean_var_norm(float* x, int64_t rows, int64_t cols) {
+    PK_REQUIRE(rows > 0 && cols > 0, "pk_mean_var_norm: empty chunk");
+    std::vector<double> mean((size_t)cols, 0.0), m2((size_t)cols, 0.0);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) mean[(size_t)c] += x[r * cols + c];
+    for (int64_t c = 0; c < cols; ++c) mean[(size_t)c] /= (double)rows;
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) {
+            const double d = x[r * cols + c] - mean[(size_t)c];
+            m2[(size_t)c] += d * d;
+        }
+    for (int64_t c = 0; c < cols; ++c) m2[(size_t)c] = sqrt(m2[(size_t)c] / (double)rows);
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) x[r * cols + c] = (float)((x[r * cols + c] - mean[(size_t)c]) / m2[(size_t)c]);
+    return 0;
+}

@@ -5,5 +5,5 @@ import sys
 
 _pkg = importlib.import_module("pytorch-kaldi_amd")
 sys.modules[__name__] = _pkg
-for _sub in ("_lib", "functional", "nn", "build", "utils", "optim", "dp", "core", "recipes"):
+for _sub in ("_lib", "functional", "nn", "build", "utils", "optim", "dp", "core", "recipes", "graphs", "data_io"):
     sys.modules[__name__ + "." + _sub] = importlib.import_module("pytorch-kaldi_amd." + _sub)

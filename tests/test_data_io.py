@@ -1,0 +1,100 @@
+"""Native Kaldi table reader and chunk transforms (pytorch-kaldi_amd/data_io.py, csrc/pk_io.hip) against
+tests/golden/io_kaldi_tables.npz, which oracle/make_golden.py::io_case produced with the reference's own
+data_io.read_mat_ark / read_mat / context_window and the normalisation lines of load_chunk."""
+import importlib
+import struct
+
+import numpy as np
+import pytest
+
+from golden_util import Golden
+
+dio = importlib.import_module("pytorch-kaldi_amd.data_io")
+CASE = "io_kaldi_tables"
+
+
+@pytest.fixture()
+def table(tmp_path):
+    g = Golden(CASE)
+    path = tmp_path / "t.ark"
+    path.write_bytes(bytes(g.arrays["ark"]))
+    return g, path
+
+
+def test_read_mat_ark_float_double_compressed(table):
+    g, path = table
+    got = list(dio.read_mat_ark("ark:" + str(path)))
+    assert [k for k, _ in got] == g.meta["keys"] == ["uttA", "uttB", "uttC"]
+    for k, m in got:
+        ref = g.arrays["mat/" + k]
+        assert m.dtype == np.float32 and m.shape == ref.shape
+        if k == "uttA":
+            assert np.array_equal(m, ref)                       # float32 records: bit-exact
+        elif k == "uttB":
+            assert np.array_equal(m, ref.astype(np.float32))    # float64 records: rounded once
+        else:
+            assert np.allclose(m, ref, rtol=0, atol=2e-6)       # compressed: same piecewise-linear decode
+
+
+def test_read_mat_scp_offsets(table, tmp_path):
+    g, path = table
+    scp = tmp_path / "t.scp"
+    scp.write_text("".join("%s %s:%d\n" % (k, path, off) for k, off in g.meta["offsets"].items()))
+    got = dict(dio.read_mat_scp(scp))
+    assert sorted(got) == sorted(g.meta["offsets"])
+    for k, m in got.items():
+        assert np.allclose(m, g.arrays["scp/" + k].astype(np.float32), rtol=0, atol=2e-6)
+
+
+def test_cm2_cm3_records(tmp_path):
+    """The 16-bit / 8-bit compressed forms (Kaldi compressed-matrix.h; the reference's reader refuses them)."""
+    rng = np.random.RandomState(5)
+    u16 = rng.randint(0, 65536, (4, 3)).astype("<u2")
+    u8 = rng.randint(0, 256, (2, 5)).astype("u1")
+    path = tmp_path / "c.ark"
+    with open(path, "wb") as f:
+        f.write(b"a \0BCM2 " + struct.pack("<ffii", -2.0, 5.0, 4, 3) + u16.tobytes())
+        f.write(b"b \0BCM3 " + struct.pack("<ffii", 1.0, 0.5, 2, 5) + u8.tobytes())
+    got = dict(dio.read_mat_ark(path))
+    assert np.allclose(got["a"], -2.0 + 5.0 / 65535.0 * u16.astype(np.float64), atol=1e-6)
+    assert np.allclose(got["b"], 1.0 + 0.5 / 255.0 * u8.astype(np.float64), atol=1e-6)
+
+
+def test_malformed_tables_raise(tmp_path):
+    p = tmp_path / "bad.ark"
+    p.write_bytes(b"utt [ 1 2 ]\n")  # a text table
+    with pytest.raises(IOError, match="binary"):
+        list(dio.read_mat_ark(p))
+    p.write_bytes(b"utt \0BFM \x04\x02\x00\x00\x00\x04\x02\x00\x00\x00\x00\x00")  # 2x2 floats announced, 2 bytes present
+    with pytest.raises(RuntimeError, match="truncated"):
+        list(dio.read_mat_ark(p))
+    with pytest.raises(IOError, match="cannot open"):
+        list(dio.read_mat_ark(tmp_path / "missing.ark"))
+    assert list(dio.read_mat_ark(_empty(tmp_path))) == []
+
+
+def _empty(tmp_path):
+    p = tmp_path / "empty.ark"
+    p.write_bytes(b"")
+    return p
+
+
+def test_context_window_matches_reference():
+    g = Golden(CASE)
+    out = dio.context_window(g.arrays["cw/fea"], g.meta["left"], g.meta["right"])
+    assert out.dtype == np.float32 and np.array_equal(out, g.arrays["cw/out"].astype(np.float32))
+    same = dio.context_window(g.arrays["cw/fea"], 0, 0)
+    assert np.array_equal(same, g.arrays["cw/fea"])
+    with pytest.raises(ValueError):
+        dio.context_window(np.zeros((3, 2), np.float32), 2, 2)
+
+
+def test_finish_chunk_matches_load_chunk_lines():
+    g = Golden(CASE)
+    data_set, end = dio.finish_chunk(g.arrays["cw/fea"], g.arrays["chunk/lab"], g.arrays["chunk/end_index"],
+                                     g.meta["left"], g.meta["right"])
+    ref = g.arrays["chunk/data_set"]
+    assert data_set.shape == ref.shape and data_set.dtype == np.float32
+    assert np.allclose(data_set, ref, rtol=0, atol=2e-6)
+    assert np.array_equal(data_set[:, -1], ref[:, -1].astype(np.float32))  # labels: exact
+    assert np.array_equal(end, g.arrays["chunk/end_index_out"])

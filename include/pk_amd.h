@@ -271,6 +271,9 @@ void pk_ark_close(pk_ark* a);
 int pk_ark_next(pk_ark* a, int key_expected, char* key, int keycap, int64_t* rows, int64_t* cols);
 int pk_ark_read(pk_ark* a, float* dst);
 int pk_ark_skip(pk_ark* a);
+/* integer-vector tables (alignments / pdf ids, data_io.py:790-838) on the same handle: 1 + *n / 0 end / 2 malformed */
+int pk_ivec_next(pk_ark* a, char* key, int keycap, int64_t* n);
+int pk_ivec_read(pk_ark* a, int32_t* dst);
 /* data_io.py:228-241 context_window on the concatenated chunk: out [(rows-left-right)][cols*(left+right+1)] */
 int pk_context_window(const float* x, int64_t rows, int64_t cols, int left, int right, float* out);
 /* data_io.py:263: x <- (x - mean) / std per column (population std, double accumulation), in place */

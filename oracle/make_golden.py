@@ -332,6 +332,18 @@ def io_case(name, seed):
         arrays["mat/" + k] = np.asarray(m)
     for k, off in offsets.items():  # the scp route: "file:offset"
         arrays["scp/" + k] = np.asarray(ref_io.read_mat("%s:%d" % (path, off), tmp))
+    # integer vectors (alignments), written and read back by the reference
+    ipath = os.path.join(tmp, "ali.ark")
+    vecs = {"uttA": g.randint(0, 1938, 17).astype(np.int32), "uttE": np.array([], dtype=np.int32),
+            "uttB": g.randint(-5, 5, 4).astype(np.int32)}
+    with open(ipath, "wb") as f:
+        for k, v in vecs.items():
+            ref_io.write_vec_int(f, tmp, v, key=k)
+    arrays["ali_ark"] = np.frombuffer(open(ipath, "rb").read(), dtype=np.uint8)
+    ikeys = []
+    for k, v in ref_io.read_vec_int_ark(ipath, tmp):
+        ikeys.append(k)
+        arrays["ali/" + k] = np.asarray(v, dtype=np.int32)
     # chunk transforms
     fea = g.randn(31, 4).astype(np.float32)
     lab = g.randint(3, 9, 31)
@@ -346,7 +358,7 @@ def io_case(name, seed):
     e = end_index - left                                                 # :259-260
     e[-1] = e[-1] - right
     arrays["chunk/end_index_out"] = e
-    _save(name, {"keys": keys, "offsets": offsets, "left": left, "right": right, "seed": seed}, arrays)
+    _save(name, {"keys": keys, "ali_keys": ikeys, "offsets": offsets, "left": left, "right": right, "seed": seed}, arrays)
 
 
 def main():

@@ -72,6 +72,8 @@ SIGNATURES = {
     "pk_ark_next": (c_int, [P, c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64)]),
     "pk_ark_read": (c_int, [P, P]),
     "pk_ark_skip": (c_int, [P]),
+    "pk_ivec_next": (c_int, [P, ctypes.c_char_p, c_int, ctypes.POINTER(c_int64)]),
+    "pk_ivec_read": (c_int, [P, P]),
     "pk_context_window": (c_int, [P, c_int64, c_int64, c_int, c_int, P]),
     "pk_mean_var_norm": (c_int, [P, c_int64, c_int64]),
     "pk_rmsprop_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float]),

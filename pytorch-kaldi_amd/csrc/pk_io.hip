@@ -2,6 +2,7 @@
 // whole-chunk transforms the reference applies after loading.  No device code in this file; it is part of
 // libpk_amd.so so that the chunk loop needs no second library.
 //
+//   pk_ivec_*           data_io.py:790-838 (read_vec_int_ark / read_vec_int: alignments, pdf ids)
 //   pk_ark_*            data_io.py:762-783 (read_key), :1062-1131 (read_mat_ark, read_mat, _read_mat_binary),
 //                       :1150-1198 (_read_compressed_mat); 'CM2' / 'CM3' follow Kaldi's compressed-matrix.h, which the
 //                       reference's reader refuses
@@ -22,7 +23,7 @@
 
 struct pk_ark {
     FILE* f;
-    char kind;  // 'F' float32, 'D' float64, '1' CM, '2' CM2, '3' CM3: matrix announced by pk_ark_next, not yet read
+    char kind;  // 'F' float32, 'D' float64, '1' CM, '2' CM2, '3' CM3, 'I' int vector: record announced, not yet read
     int64_t rows, cols;
     float cm_min, cm_range;
 };
@@ -103,9 +104,48 @@ extern "C" int pk_ark_next(pk_ark* a, int key_expected, char* key, int keycap, i
     return 1;
 }
 
+// Integer-vector tables (alignments / pdf ids; data_io.py:790-838): "<key> \0B \4 <int32 n> (\4 <int32 v>) x n".
+// pk_ivec_next returns 1 and *n, 0 at end of file, 2 on a malformed table; pk_ivec_read fills dst[n].
+extern "C" int pk_ivec_next(pk_ark* a, char* key, int keycap, int64_t* n) {
+    PK_REQUIRE(a != nullptr && a->f != nullptr, "pk_ivec_next: closed table");
+    PK_REQUIRE(a->kind == 0, "pk_ivec_next: the previous record has not been read");
+    int len = 0, c;
+    while ((c = fgetc(a->f)) != EOF && c != ' ') {
+        if (c == '\n' || c == '\r' || c == '\t') continue;
+        PK_REQUIRE(key != nullptr && len + 1 < keycap, "pk_ivec_next: key longer than %d bytes", keycap);
+        key[len++] = (char)c;
+    }
+    if (key != nullptr && keycap > 0) key[len < keycap ? len : keycap - 1] = 0;
+    if (len == 0) return 0;
+    unsigned char hdr[7];
+    PK_REQUIRE(read_exact(a->f, hdr, 7), "pk_ivec_next: truncated table");
+    PK_REQUIRE(hdr[0] == 0 && hdr[1] == 'B' && hdr[2] == 4, "pk_ivec_next: not a binary int32 vector (text tables are not supported)");
+    int32_t cnt;
+    memcpy(&cnt, hdr + 3, 4);
+    PK_REQUIRE(cnt >= 0, "pk_ivec_next: negative length");
+    a->kind = 'I';
+    a->rows = cnt;
+    a->cols = 1;
+    *n = cnt;
+    return 1;
+}
+
+extern "C" int pk_ivec_read(pk_ark* a, int32_t* dst) {
+    PK_REQUIRE(a != nullptr && a->kind == 'I', "pk_ivec_read: no pending vector (call pk_ivec_next first)");
+    const int64_t n = a->rows;
+    a->kind = 0;
+    std::vector<unsigned char> buf((size_t)n * 5);
+    PK_REQUIRE(read_exact(a->f, buf.data(), (size_t)n * 5), "pk_ivec_read: truncated vector");
+    for (int64_t i = 0; i < n; ++i) {
+        PK_REQUIRE(buf[(size_t)i * 5] == 4, "pk_ivec_read: element %lld is not an int32", (long long)i);
+        memcpy(dst + i, buf.data() + (size_t)i * 5 + 1, 4);
+    }
+    return 0;
+}
+
 // The matrix announced by pk_ark_next -> dst[rows*cols] (row-major float32).
 extern "C" int pk_ark_read(pk_ark* a, float* dst) {
-    PK_REQUIRE(a != nullptr && a->kind != 0, "pk_ark_read: no pending matrix (call pk_ark_next first)");
+    PK_REQUIRE(a != nullptr && a->kind != 0 && a->kind != 'I', "pk_ark_read: no pending matrix (call pk_ark_next first)");
     const int64_t R = a->rows, C = a->cols, n = R * C;
     const char kind = a->kind;
     a->kind = 0;

@@ -2,6 +2,7 @@
 reference's ``data_io`` so that a loader written against it reads the same.
 
     read_mat_ark / read_mat_scp   data_io.py:1039-1085  (binary float / double / compressed matrices, plain files)
+    read_vec_int_ark              data_io.py:790-838    (alignment / pdf-id vectors)
     context_window                data_io.py:228-241
     normalize_chunk               data_io.py:263        (mean / variance normalisation of the concatenated chunk)
     finish_chunk                  data_io.py:244-274    (load_chunk after load_dataset: splice, normalise, label shift,
@@ -66,6 +67,30 @@ def read_mat_ark(path):
             yield item
     finally:
         t.close()
+
+
+def read_vec_int_ark(path):
+    """generator(key, int32 vector) over a binary integer-vector ark (alignments / pdf ids), data_io.py:790-808."""
+    path = str(path)
+    if path.startswith("ark:"):
+        path = path[4:]
+    t = _Table(path)
+    try:
+        while True:
+            n = ctypes.c_int64()
+            rc = t.lib.pk_ivec_next(t.h, t.key, _KEYCAP, ctypes.byref(n))
+            if rc == 0:
+                return
+            if rc != 1:
+                raise IOError(t.lib.pk_last_error().decode())
+            vec = np.empty(n.value, dtype=np.int32)
+            _lib.check(t.lib.pk_ivec_read(t.h, _fp(vec)), "pk_ivec_read")
+            yield t.key.value.decode("latin1"), vec
+    finally:
+        t.close()
+
+
+read_ali_ark = read_vec_int_ark  # data_io.py:785-787
 
 
 def read_mat(rxfile):

@@ -98,3 +98,18 @@ def test_finish_chunk_matches_load_chunk_lines():
     assert np.allclose(data_set, ref, rtol=0, atol=2e-6)
     assert np.array_equal(data_set[:, -1], ref[:, -1].astype(np.float32))  # labels: exact
     assert np.array_equal(end, g.arrays["chunk/end_index_out"])
+
+
+def test_read_vec_int_ark(tmp_path):
+    g = Golden(CASE)
+    path = tmp_path / "ali.ark"
+    path.write_bytes(bytes(g.arrays["ali_ark"]))
+    got = list(dio.read_vec_int_ark(path))
+    assert [k for k, _ in got] == g.meta["ali_keys"] == ["uttA", "uttE", "uttB"]
+    for k, v in got:
+        assert v.dtype == np.int32 and np.array_equal(v, g.arrays["ali/" + k])
+    assert dio.read_ali_ark is dio.read_vec_int_ark
+    bad = tmp_path / "bad.ark"
+    bad.write_bytes(b"utt [ 1 2 3 ]\n")
+    with pytest.raises(IOError, match="binary"):
+        list(dio.read_vec_int_ark(bad))

@@ -15,6 +15,7 @@ stay with the reference's reader; these functions cover tables that already exis
 import ctypes
 
 import numpy as np
+import torch
 
 from . import _lib
 
@@ -155,3 +156,27 @@ def finish_chunk(data_set, data_lab, end_index_fea, left, right):
     data_lab = data_lab - data_lab.min()
     data_lab = data_lab[left:-right] if right > 0 else data_lab[left:]
     return np.column_stack((data_set, data_lab.astype(np.float32))), end_index_fea
+
+
+def finish_chunk_device(data_set, data_lab, end_index_fea, left, right, device):
+    """finish_chunk with the splicing and the normalisation done on `device`: the UN-spliced features cross PCIe
+    (1/(left+right+1) of the bytes the reference uploads: 176 MB instead of 1.9 GB for a 1.1 M-frame fMLLR chunk with
+    an 11-frame window) and the chunk is born resident, which is what run_nn_dp's BatchAssembler gathers from.
+    Statistics are accumulated in float64 like the reference's (data_io.py:263).  Returns (tensor [rows, feat+1], end_index)."""
+    x = torch.as_tensor(np.ascontiguousarray(data_set, dtype=np.float32)).to(device, non_blocking=True)
+    rows, W = x.shape[0], left + right + 1
+    if rows < left + right:
+        raise ValueError("finish_chunk_device: %d rows cannot hold a -%d..+%d window" % (rows, left, right))
+    if W > 1:
+        x = torch.cat([x[b:rows - left - right + b] for b in range(W)], 1)
+    xd = x.double()
+    mean = xd.mean(0)
+    std = (xd - mean).pow(2).mean(0).sqrt()
+    x = ((xd - mean) / std).float()
+    end_index_fea = np.asarray(end_index_fea).copy() - left
+    end_index_fea[-1] = end_index_fea[-1] - right
+    lab = np.asarray(data_lab)
+    lab = lab - lab.min()
+    lab = lab[left:-right] if right > 0 else lab[left:]
+    lab_t = torch.as_tensor(lab.astype(np.float32)).to(device, non_blocking=True)
+    return torch.cat((x, lab_t[:, None]), 1), end_index_fea

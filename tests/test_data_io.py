@@ -113,3 +113,17 @@ def test_read_vec_int_ark(tmp_path):
     bad.write_bytes(b"utt [ 1 2 3 ]\n")
     with pytest.raises(IOError, match="binary"):
         list(dio.read_vec_int_ark(bad))
+
+
+def test_finish_chunk_device_matches_host_path():
+    import torch
+
+    g = Golden(CASE)
+    got, end = dio.finish_chunk_device(g.arrays["cw/fea"], g.arrays["chunk/lab"], g.arrays["chunk/end_index"],
+                                       g.meta["left"], g.meta["right"], torch.device("cpu"))
+    ref = g.arrays["chunk/data_set"]
+    assert tuple(got.shape) == ref.shape and got.dtype == torch.float32
+    assert np.allclose(got.numpy(), ref, rtol=0, atol=2e-6)
+    assert np.array_equal(end, g.arrays["chunk/end_index_out"])
+    none, _ = dio.finish_chunk_device(g.arrays["cw/fea"], g.arrays["chunk/lab"], g.arrays["chunk/end_index"], 0, 0, "cpu")
+    assert none.shape == (31, 5)

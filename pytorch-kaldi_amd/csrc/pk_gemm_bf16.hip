@@ -274,78 +274,6 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 4) void gemm_bf16x_kernel(BA
     epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, split, lane);
 }
 
-// Wide variant for the shapes with many rows: block tile 256 x 128 x 64, 8 waves (4 x 2, wave tile 64 x 64 as above),
-// THREE LDS stages of 48 KB (A rows 0-127 | A rows 128-255 | B) and a prefetch distance of two k-tiles.  The PMC
-// counters of the 128 x 128 kernel say why: its waves spend 55-65 % of their cycles in s_waitcnt (SQ_WAIT_ANY) with
-// the MFMA pipe 20-24 % busy and no LDS bank conflicts - one k-tile of prefetch does not cover the HBM/L2 latency.
-// Only loads are in flight in the main loop, so the counted s_waitcnt vmcnt(6) (the six LDS-DMA loads of the
-// newest stage) is exact: loads retire in order.
-constexpr int WIDE_STAGE = 49152;
-template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(512) void gemm_bf16w_kernel(BArgs p) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [3][A0 16 KB | A1 16 KB | B 16 KB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);
-    if (item >= p.items) return;
-    const int tn = item % p.tiles_n;
-    const int tm = (item / p.tiles_n) % p.tiles_m;
-    const int split = item / (p.tiles_n * p.tiles_m);
-    const int m0 = tm * 256, n0 = tn * TN;
-    const int kbeg = split * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
-    const int nk = (kend - kbeg + TK - 1) / TK;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    TileSrc<A_KC, 512> sa0, sa1;
-    TileSrc<B_KC, 512> sb;
-    sa0.init(p.A, p.lda, m0, p.M, kbeg, tid);
-    sa1.init(p.A, p.lda, m0 + 128, p.M, kbeg, tid);
-    sb.init(p.B, p.ldb, n0, p.N, kbeg, tid);
-    auto issue = [&](int kt) {
-        unsigned char* buf = smem + (kt % 3) * WIDE_STAGE;
-        const int k0 = kbeg + kt * TK;
-        if (k0 + TK <= kend) {
-            sa0.issue(buf, wave);
-            sa1.issue(buf + 16384, wave);
-            sb.issue(buf + 32768, wave);
-        } else {
-            stage<A_KC, 512>(p.A, p.lda, m0, p.M, k0, kend, p.zeros, buf, tid, wave);
-            stage<A_KC, 512>(p.A, p.lda, m0 + 128, p.M, k0, kend, p.zeros, buf + 16384, tid, wave);
-            stage<B_KC, 512>(p.B, p.ldb, n0, p.N, k0, kend, p.zeros, buf + 32768, tid, wave);
-        }
-    };
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // stage kt landed for every wave; everyone is done reading stage kt-1
-        if (kt + 2 < nk) issue(kt + 2);
-        const unsigned char* cur = smem + (kt % 3) * WIDE_STAGE;
-        const unsigned char* abuf = cur + (wm >> 1) * 16384;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = frag<A_KC>(abuf, (wm & 1) * 64 + i * 16, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = frag<B_KC>(cur + 32768, wn * 64 + j * 16, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-        }
-    }
-    epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, split, lane);
-}
-
 __global__ void splitk_reduce_bf_kernel(const float* __restrict__ ws, int splitk, int M, int N, float alpha, float beta,
                                         const float* __restrict__ bias, float* __restrict__ C, long ldc) {
     const long total = (long)M * N;
@@ -403,21 +331,14 @@ extern "C" int pk_cvt_bf16(void* stream, const float* src, int64_t ld_src, int64
     return 0;
 }
 
-// 256-row block tiles when that pads M by at most 15 % more than 128-row tiles would (PK_GEMM_WIDE=0|1 forces)
-static int wide_tile_rows(int M) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("PK_GEMM_WIDE");
-        forced = (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : 2;
-    }
-    if (forced == 0) return 128;
-    if (forced == 1) return M >= 256 ? 256 : 128;
-    if (forced == 2) return 128;  // measured slower than 3-4 co-resident 128-row workgroups (tools/bench_gemm.py)
-    const long pad128 = (long)((M + 127) / 128) * 128, pad256 = (long)((M + 255) / 256) * 256;
-    return (M >= 256 && pad256 * 100 <= pad128 * 115) ? 256 : 128;
+// Rows of the block tile used for this M.  A 256 x 128 tile with three LDS stages (8 waves, prefetch distance two) was
+// built and measured slower than 3-4 co-resident 128 x 128 workgroups (493 vs 615 TFLOP/s on the 64 000-row projection:
+// one large workgroup runs its waves in lock step, independent small ones stagger their load and MFMA phases); it was
+// removed again - DESIGN.md 5.2 keeps the numbers.  The entry point stays so that callers size split-K from it.
+extern "C" int pk_gemm_bf16_tile_m(int M) {
+    (void)M;
+    return TM;
 }
-
-extern "C" int pk_gemm_bf16_tile_m(int M) { return wide_tile_rows(M); }
 
 extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
                             const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc,
@@ -436,11 +357,10 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
     p.alpha = alpha; p.beta = beta;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.bias = bias;
-    const int tile_m = wide_tile_rows(M);
-    p.tiles_m = (M + tile_m - 1) / tile_m;
+    p.tiles_m = (M + TM - 1) / TM;
     p.tiles_n = (N + TN - 1) / TN;
-    void* zp = nullptr;
-    PK_CHECK_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)));
+    static void* zp = nullptr;  // looked up once (also keeps the call out of a HIP-graph capture)
+    if (zp == nullptr) PK_CHECK_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)));
     p.zeros = (const unsigned short*)zp;
     if (splitk < 1) splitk = 1;
     if (splitk > 1) {
@@ -459,26 +379,9 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
     p.items = splitk * p.tiles_m * p.tiles_n;
     p.per_xcd = (p.items + 7) / 8;
     dim3 grid((unsigned)(p.per_xcd * 8)), block(256);
-    if (tile_m == 256) {
-        static bool attr_w = false;
-        if (!attr_w) {
-            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WIDE_STAGE));
-            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WIDE_STAGE));
-            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WIDE_STAGE));
-            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16w_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WIDE_STAGE));
-            attr_w = true;
-        }
-        const dim3 wblock(512);
-        const size_t wlds = 3 * WIDE_STAGE;
-        if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16w_kernel<true, true>), grid, wblock, wlds, st, p);
-        else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16w_kernel<true, false>), grid, wblock, wlds, st, p);
-        else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16w_kernel<false, true>), grid, wblock, wlds, st, p);
-        else hipLaunchKernelGGL((gemm_bf16w_kernel<false, false>), grid, wblock, wlds, st, p);
-        PK_LAUNCH_CHECK();
-    } else {
-    // measured on MI355X (tools/bench_gemm.py): the single-buffer / 3-4 workgroups per CU variant wins on the
-    // row-streaming shapes (A k-contiguous: 630-644 vs 534-552 TFLOP/s at M = 64000), the double-buffered one on
-    // the split-K k-major shapes (357 vs 331).  PK_GEMM_STAGES=1|2 forces one of them.
+    // measured on MI355X (tools/bench_gemm.py): the single-buffer variant with four workgroups per CU wins on the
+    // row-streaming shapes (A k-contiguous: 640-680 vs 530-540 TFLOP/s at M = 64000), the double-buffered one on
+    // the split-K k-major shapes (687 vs 661).  PK_GEMM_STAGES=1|2 forces one of them.
     static int forced = -1;
     if (forced < 0) {
         const char* e = getenv("PK_GEMM_STAGES");
@@ -501,7 +404,6 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
     else PK_LAUNCH_BF(1);
 #undef PK_LAUNCH_BF
     PK_LAUNCH_CHECK();
-    }
     if (splitk > 1) {
         const long total = (long)M * N;
         int blocks = (int)((total + 255) / 256);

@@ -135,7 +135,7 @@ def algorithmic_flops(rcp, T, B):
         # conv FLOPs of the four blocks (194.26 MFLOP/frame fwd; conv1 has no dX) + the MLP trunk
         total += frames * (101.45e6 * 2 + (78.34e6 + 12.10e6 + 2.38e6) * 3)
         din = 3300
-        for H in [int(v) for v in rcp["cfg"]["architecture4"]["dnn_lay"].split(",")]:
+        for H in [int(v) for v in rcp["cfg"][rcp["trunk"]]["dnn_lay"].split(",")]:
             total += 2.0 * frames * din * H * 3
             din = H
         feat = din
@@ -223,16 +223,22 @@ def cpu_baseline(args, rcp_name):
     torch.manual_seed(2234)
     nets = {"architecture1": getattr(nn_amd, kind)(dict(a1, use_cuda="False", to_do="train"), rcp["nfea"])}
     feat = nets["architecture1"].out_dim
-    if "architecture4" in cfg:  # SincNet recipe: an MLP trunk between the front-end and the heads
-        nets["architecture4"] = nn_amd.MLP(dict(cfg["architecture4"]), feat)
-        feat = nets["architecture4"].out_dim
-    nets["architecture2"] = nn_amd.MLP(dict(cfg["architecture2"]), feat)
-    if rcp["n_mono"]:
-        nets["architecture3"] = nn_amd.MLP(dict(cfg["architecture3"]), feat)
+    trunk, s_cd, s_mono = rcp["trunk"], rcp["head_cd"], rcp["head_mono"]
+    if trunk:  # SincNet recipe: an MLP trunk between the front-end and the heads
+        nets[trunk] = nn_amd.MLP(dict(cfg[trunk]), feat)
+        feat = nets[trunk].out_dim
+    nets[s_cd] = nn_amd.MLP(dict(cfg[s_cd]), feat)
+    if s_mono:
+        nets[s_mono] = nn_amd.MLP(dict(cfg[s_mono]), feat)
     sds = {k: {n: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in n)
                for n, v in net.state_dict().items()} for k, net in nets.items()}
-    leaves = [v for sd in sds.values() for v in sd.values() if v.requires_grad]
-    opt = torch.optim.RMSprop(leaves, lr=4e-4, alpha=0.95, eps=1e-8)
+    opts = []
+    for k, sd in sds.items():  # one optimizer per architecture, as the shipped cfg sets them (run_nn: optimizer_init)
+        leaves = [v for v in sd.values() if v.requires_grad]
+        if cfg[k]["arch_opt"] == "sgd":
+            opts.append(torch.optim.SGD(leaves, lr=float(cfg[k]["arch_lr"])))
+        else:
+            opts.append(torch.optim.RMSprop(leaves, lr=float(cfg[k]["arch_lr"]), alpha=0.95, eps=1e-8))
     T, B = (50, 8) if rcp["seq"] else (1, 128)
 
     def one_step(seed):
@@ -244,16 +250,17 @@ def cpu_baseline(args, rcp_name):
             h = h.reshape(T * B, -1)
         else:
             h = O.arch_forward(kind, dict(a1), sds["architecture1"], x)
-            if "architecture4" in cfg:
-                h = O.mlp_forward(dict(cfg["architecture4"]), sds["architecture4"], h)
-        loss = torch.nn.functional.nll_loss(O.mlp_forward(dict(cfg["architecture2"]), sds["architecture2"], h), lab_cd)
-        if rcp["n_mono"]:
+            if trunk:
+                h = O.mlp_forward(dict(cfg[trunk]), sds[trunk], h)
+        loss = torch.nn.functional.nll_loss(O.mlp_forward(dict(cfg[s_cd]), sds[s_cd], h), lab_cd)
+        if s_mono:
             lab_m = inp[..., rcp["nfea"] + 1].reshape(-1).long()
-            loss = loss + torch.nn.functional.nll_loss(
-                O.mlp_forward(dict(cfg["architecture3"]), sds["architecture3"], h), lab_m)
-        opt.zero_grad()
+            loss = loss + torch.nn.functional.nll_loss(O.mlp_forward(dict(cfg[s_mono]), sds[s_mono], h), lab_m)
+        for opt in opts:
+            opt.zero_grad()
         loss.backward()
-        opt.step()
+        for opt in opts:
+            opt.step()
 
     one_step(1)  # warm-up
     t0 = time.time()
@@ -273,7 +280,7 @@ def cpu_baseline(args, rcp_name):
     except OSError:
         pass
     return {"value": round(n * T * B / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of the same network (fwd+bwd+RMSprop) at T=%d, B=%d on %s, torch-CPU oracle fp32" %
+            "sample": "%d steps of the same network (fwd+bwd+the cfg optimizers) at T=%d, B=%d on %s, torch-CPU oracle fp32" %
                       (n, T, B, model or "host CPU")}
 
 

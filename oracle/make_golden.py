@@ -361,10 +361,31 @@ def io_case(name, seed):
     _save(name, {"keys": keys, "ali_keys": ikeys, "offsets": offsets, "left": left, "right": right, "seed": seed}, arrays)
 
 
+def cfg_case(name):
+    """The architecture / model / batch sections of the shipped cfg files BASELINE.json names, as parsed by
+    configparser: pins pytorch-kaldi_amd/recipes.py (what bench.py builds) to the reference's recipes."""
+    files = {"timit_ligru": "cfg/TIMIT_baselines/TIMIT_liGRU_fmllr.cfg", "timit_lstm": "cfg/TIMIT_baselines/TIMIT_LSTM_fmllr.cfg",
+             "libri_gru": "cfg/Librispeech_baselines/libri_GRU_fmllr.cfg", "timit_mlp": "cfg/TIMIT_baselines/TIMIT_MLP_fmllr.cfg",
+             "timit_sincnet": "cfg/TIMIT_baselines/TIMIT_SincNet_raw.cfg"}
+    out = {}
+    for key, rel in files.items():
+        cfg = configparser.ConfigParser()
+        cfg.read(os.path.join(REF, rel))
+        out[key] = {"file": rel, "model": cfg["model"]["model"].split("\n"),
+                    "sections": {sec: dict(cfg[sec]) for sec in cfg.sections() if sec.startswith("architecture")}}
+    path = os.path.join(OUT, name + ".json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote %s (%d bytes)" % (path, os.path.getsize(path)))
+
+
 def main():
     torch.set_num_threads(1)  # bit-stable fixtures
     if os.environ.get("PK_GOLDEN_ONLY") == "chunk":  # regenerate only the chunk-loop fixture
         chunk_case("chunk_ligru_run_nn", 1234)
+        return
+    if os.environ.get("PK_GOLDEN_ONLY") == "cfg":
+        cfg_case("cfg_recipes")
         return
     if os.environ.get("PK_GOLDEN_ONLY") == "io":
         io_case("io_kaldi_tables", 77)
@@ -424,6 +445,7 @@ def main():
 
     # --- either side of the path: Kaldi tables and the chunk transforms of data_io.load_chunk ---
     io_case("io_kaldi_tables", 77)
+    cfg_case("cfg_recipes")
 
 
 if __name__ == "__main__":

@@ -209,6 +209,10 @@ void pk_persist2_set_trace(void* dev_buf);
 void pk_persist2_set_mode(int force_safe);
 /* tuning: idle time (units of 64 clocks) between a workgroup's publish and its first poll of the next step */
 void pk_persist2_set_poll_delay(int units);
+/* LSTM only: 4 = four waves per workgroup (the kernels every cell uses), 8 = eight waves, two per group of 16 hidden
+ * units, each holding half of the recurrent-matrix fragments (pk_rec_persist2_lstm.hip).  Default: PK_LSTM_WAVES. */
+void pk_persist2_set_lstm_waves(int waves);
+int pk_persist2_get_lstm_waves(void);
 /* two-phase cells (GRU :629-641, minimalGRU :1291-1302): the candidate GEMM consumes a gate of the same
  * step, so every step is two cluster-wide exchanges.  Xb [T*B][y_pitch] (bf16 r*h / z*h, laid out like Yb)
  * is the second exchange buffer and the k-major operand of the dU_h GEMM; of S only the z(,r),a slots are

@@ -61,6 +61,8 @@ SIGNATURES = {
     "pk_persist2_set_trace": (None, [P]),
     "pk_persist2_set_mode": (None, [c_int]),
     "pk_persist2_set_poll_delay": (None, [c_int]),
+    "pk_persist2_set_lstm_waves": (None, [c_int]),
+    "pk_persist2_get_lstm_waves": (c_int, []),
     "pk_persist2_error_count": (ctypes.c_uint, []),
     "pk_persist2_error_reset": (None, []),
     "pk_conv1d_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),

@@ -26,6 +26,7 @@ struct R2Args {
     int force_safe;             // 1 = always use the placement-independent write-through exchange
     unsigned* xcd_tab;          // [C][16] placement handshake words (0xFFFFFFFF before the launch)
     unsigned long long* trace;  // optional [T][8] phase time stamps of (cluster 0, member 0, wave 0); null = off
+    int helper_delay;           // eight-wave LSTM kernels: extra s_sleep units before the second wave of a pair polls
 };
 
 struct Plan2 {
@@ -269,3 +270,6 @@ int pk_rec2_make_plan(int R, int H, Plan2& pl);
 int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidir, int H);
 int pk_rec2_host_setup(R2Args& a, bool backward);                 // error word, trash page, handshake table, tuning knobs
 int pk_rec2_reset_handshake(hipStream_t st);       // before every launch
+// eight-wave LSTM kernels (pk_rec_persist2_lstm.hip): on unless PK_LSTM_WAVES=4; the launch loop over pl.launches
+int pk_rec2l_enabled();
+int pk_rec2l_launch(hipStream_t st, R2Args& a, const Plan2& pl, int act, bool backward);

@@ -577,6 +577,7 @@ int pk_rec2_host_setup(R2Args& a, bool backward) {
     if (rc) return rc;
     a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe;
     a.trash = g2_trash; a.poll_delay = g2_poll_delay >= 0 ? g2_poll_delay : default_poll_delay(backward);
+    a.helper_delay = 0;
     return 0;
 }
 int pk_rec2_reset_handshake(hipStream_t st) {
@@ -638,6 +639,7 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     if (rc) return rc;
     // the bf16 layer output is the mailbox: poison it with the sentinel
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
+    if (cell == PK_CELL_LSTM && pk_rec2l_enabled()) return pk_rec2l_launch(st, a, pl, act, false);
     const int G = pk_cell_gates(cell);
     const size_t lds = 2 * (size_t)RMAX * (KPAD + 8) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024 + 512) + 16;
     {   // dynamic LDS above the 64 KB default needs the opt-in (exact size: the kernels also hold a little static LDS)
@@ -682,6 +684,7 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     rc = pk_rec2_host_setup(a, true);
     if (rc) return rc;
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
+    if (cell == PK_CELL_LSTM && pk_rec2l_enabled()) return pk_rec2l_launch(st, a, pl, act, true);
     const size_t atile = (size_t)RMAX * (G * KPAD + 8) * 2;
     const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0);
     const size_t lds = (2 * atile > 96 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(nin + G) * 1024 + (size_t)G * 512) + 16;

@@ -71,7 +71,7 @@ int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha, const floa
  * contiguous - the dW / dU shapes whose reduction runs over the T*B rows); likewise B with N / ldb.
  * Bases 16-byte aligned, pitches multiples of 8 elements; elements between K and the next multiple of
  * 8 inside a k-contiguous row must be zero (pk_cvt_bf16 writes them so).  splitk as pk_gemm. */
-/* rows of the block tile pk_gemm_bf16 will use for this M (128 or 256): callers size split-K from it */
+/* rows of the block tile pk_gemm_bf16 will use for this M (128 today): callers size split-K from it */
 int pk_gemm_bf16_tile_m(int M);
 int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
                  const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc, const float* bias,

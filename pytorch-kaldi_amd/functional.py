@@ -119,7 +119,7 @@ def _tiles(M, N):
 
 
 def _tiles_bf(M, N):
-    """Output tiles of the bf16-operand GEMM: the library picks 128- or 256-row block tiles from M."""
+    """Output tiles of the bf16-operand GEMM (the library reports its block-tile height for this M)."""
     tm = int(_lib.load().pk_gemm_bf16_tile_m(int(M)))
     return ((M + tm - 1) // tm) * ((N + 127) // 128)
 

@@ -361,6 +361,82 @@ def io_case(name, seed):
     _save(name, {"keys": keys, "ali_keys": ikeys, "offsets": offsets, "left": left, "right": right, "seed": seed}, arrays)
 
 
+def loader_case(name, seed):
+    """The reference's chunk loader ITSELF - data_io.load_chunk -> load_dataset (data_io.py:16-225, 244-274): key
+    filtering, splitting of long sentences, the two length sorts, concatenation, end indices, context window,
+    normalisation, label shift - on tables on disk.  Its two Kaldi pipes are satisfied by stand-in programs put on PATH
+    for this run only: `copy-feats scp:X ark:-` re-emits the scp's records through the reference's own read_mat /
+    write_mat, `ali-to-pdf MODEL ark:- ark:-` is a pass-through (the stored alignments already are pdf-ids).
+    Pins pytorch-kaldi_amd/data_io.py::load_dataset / load_chunk."""
+    import gzip
+    import stat
+    import tempfile
+
+    import data_io as ref_io
+
+    g = np.random.RandomState(seed)
+    tmp = tempfile.mkdtemp()
+    bindir = os.path.join(tmp, "bin")
+    os.makedirs(bindir)
+    stubs = {
+        "copy-feats": "#!%s\nimport sys\nsys.path.insert(0, %r)\nimport data_io\nout = sys.stdout.buffer\n"
+                      "for line in open(sys.argv[1].split(':', 1)[1]):\n    key, rx = line.strip().split(' ', 1)\n"
+                      "    data_io.write_mat(%r, out, data_io.read_mat(rx, %r), key=key)\nout.flush()\n"
+                      % (sys.executable, REF, tmp, tmp),
+        "ali-to-pdf": "#!%s\nimport sys\nsys.stdout.buffer.write(sys.stdin.buffer.read())\n" % sys.executable,
+    }
+    for prog, text in stubs.items():
+        path = os.path.join(bindir, prog)
+        with open(path, "w") as f:
+            f.write(text)
+        os.chmod(path, os.stat(path).st_mode | stat.S_IEXEC)
+    D = 6
+    lengths = {"spk1_a": 30, "spk1_b": 50, "spk2_a": 55, "spk2_b": 70, "spk3_a": 130, "spk3_b": 30, "spk4_a": 12,
+               "spk4_b": 63, "no_ali": 21}
+    feats = {k: (g.randn(n, D) * g.uniform(0.5, 2.0, D) + g.uniform(-1, 1, D)).astype(np.float32) for k, n in lengths.items()}
+    labs = {k: g.randint(2, 40, n).astype(np.int32) for k, n in lengths.items() if k != "no_ali"}
+    labs["no_fea"] = g.randint(2, 40, 17).astype(np.int32)
+    ark = os.path.join(tmp, "fea.ark")
+    offsets = {}
+    with open(ark, "wb") as f:
+        for k in sorted(feats, reverse=True):  # file order differs from the sorted order the loader imposes
+            f.write((k + " ").encode())
+            offsets[k] = f.tell()
+            ref_io.write_mat(tmp, f, feats[k])
+    scp = os.path.join(tmp, "fea.scp")
+    with open(scp, "w") as f:
+        for k in sorted(feats, reverse=True):
+            f.write("%s %s:%d\n" % (k, ark, offsets[k]))
+    labdir = os.path.join(tmp, "ali")
+    os.makedirs(labdir)
+    ali_plain = os.path.join(tmp, "ali.ark")
+    with open(ali_plain, "wb") as f:
+        for k in sorted(labs):
+            ref_io.write_vec_int(f, tmp, labs[k], key=k)
+    with open(ali_plain, "rb") as f, gzip.open(os.path.join(labdir, "ali.1.gz"), "wb") as z:
+        z.write(f.read())
+    open(os.path.join(labdir, "final.mdl"), "w").close()
+    arrays = {"fea_ark": np.frombuffer(open(ark, "rb").read(), dtype=np.uint8),
+              "ali_ark": np.frombuffer(open(ali_plain, "rb").read(), dtype=np.uint8)}
+    runs = {"seq_msl50": (0, 0, 50, False), "cw_3_2_msl1000": (3, 2, 1000, False), "forward_cw_2_2": (2, 2, -1, True),
+            "dict_msl40": (0, 0, {"chunk_size_fea": 40, "chunk_step_fea": 40, "chunk_size_lab": 40, "chunk_step_lab": 40,
+                                  "window_shift": 1, "window_size": 1}, False)}
+    meta_runs = {}
+    old_path = os.environ["PATH"]
+    os.environ["PATH"] = bindir + os.pathsep + old_path
+    try:
+        for rname, (left, right, msl, fea_only) in runs.items():
+            names, data_set, end_index = ref_io.load_chunk(scp, "", None if fea_only else labdir,
+                                                            None if fea_only else "ali-to-pdf", left, right, msl, tmp, fea_only)
+            arrays[rname + "/data_set"] = np.asarray(data_set)
+            arrays[rname + "/end_index"] = np.asarray(end_index)
+            meta_runs[rname] = {"left": left, "right": right, "max_sequence_length": msl, "fea_only": fea_only,
+                                "names": list(names), "dtype": str(np.asarray(data_set).dtype)}
+    finally:
+        os.environ["PATH"] = old_path
+    _save(name, {"offsets": offsets, "scp_order": sorted(feats, reverse=True), "runs": meta_runs, "seed": seed}, arrays)
+
+
 def cfg_case(name):
     """The architecture / model / batch sections of the shipped cfg files BASELINE.json names, as parsed by
     configparser: pins pytorch-kaldi_amd/recipes.py (what bench.py builds) to the reference's recipes."""
@@ -389,6 +465,9 @@ def main():
         return
     if os.environ.get("PK_GOLDEN_ONLY") == "io":
         io_case("io_kaldi_tables", 77)
+        return
+    if os.environ.get("PK_GOLDEN_ONLY") == "loader":
+        loader_case("io_chunk_loader", 91)
         return
     # --- recurrent family -----------------------------------------------------
     module_case("ligru_bidir_bn", "liGRU", rec_opts("ligru", [24, 16], "relu"), 7, (9, 3, 7), 100)
@@ -445,6 +524,7 @@ def main():
 
     # --- either side of the path: Kaldi tables and the chunk transforms of data_io.load_chunk ---
     io_case("io_kaldi_tables", 77)
+    loader_case("io_chunk_loader", 91)
     cfg_case("cfg_recipes")
 
 

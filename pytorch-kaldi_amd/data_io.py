@@ -8,11 +8,22 @@ reference's ``data_io`` so that a loader written against it reads the same.
     finish_chunk                  data_io.py:244-274    (load_chunk after load_dataset: splice, normalise, label shift,
                                                          column-stack; returns float32 where the reference carries
                                                          float64 until run_nn's .float())
+    load_dataset                  data_io.py:57-225     (everything load_dataset does AFTER its two Kaldi pipes: key
+                                                         filtering, splitting of long sentences, the two length sorts,
+                                                         concatenation, end indices)
+    load_chunk                    data_io.py:244-274    (tables on disk -> [names, data_set, end_index]; takes the
+                                                         feature scp / ark and the alignment ark(s) directly instead of
+                                                         the fea_opts / lab_opts command strings)
 
 The Kaldi pipelines inside ``fea_opts`` / ``lab_opts`` (apply-cmvn, add-deltas, ali-to-pdf ...) are external programs and
 stay with the reference's reader; these functions cover tables that already exist on disk.
 """
 import ctypes
+import glob
+import gzip
+import os
+import shutil
+import tempfile
 
 import numpy as np
 import torch
@@ -71,11 +82,22 @@ def read_mat_ark(path):
 
 
 def read_vec_int_ark(path):
-    """generator(key, int32 vector) over a binary integer-vector ark (alignments / pdf ids), data_io.py:790-808."""
+    """generator(key, int32 vector) over a binary integer-vector ark (alignments / pdf ids), data_io.py:790-808.
+    A ".gz" file is inflated to a temporary file first (the reference pipes `gunzip -c`, data_io.py:45-47)."""
     path = str(path)
     if path.startswith("ark:"):
         path = path[4:]
-    t = _Table(path)
+    tmp = None
+    if path.endswith(".gz"):
+        with gzip.open(path, "rb") as z, tempfile.NamedTemporaryFile(prefix="pk_ali_", suffix=".ark", delete=False) as f:
+            shutil.copyfileobj(z, f)
+            tmp = path = f.name
+    try:
+        t = _Table(path)
+    except Exception:
+        if tmp:
+            os.unlink(tmp)
+        raise
     try:
         while True:
             n = ctypes.c_int64()
@@ -89,6 +111,8 @@ def read_vec_int_ark(path):
             yield t.key.value.decode("latin1"), vec
     finally:
         t.close()
+        if tmp:
+            os.unlink(tmp)
 
 
 read_ali_ark = read_vec_int_ark  # data_io.py:785-787
@@ -180,3 +204,97 @@ def finish_chunk_device(data_set, data_lab, end_index_fea, left, right, device):
     lab = lab[left:-right] if right > 0 else lab[left:]
     lab_t = torch.as_tensor(lab.astype(np.float32)).to(device, non_blocking=True)
     return torch.cat((x, lab_t[:, None]), 1), end_index_fea
+
+
+def _chunk_config(max_sequence_length):
+    """data_io.py:114-127: an int means the same size and step for features and labels."""
+    if isinstance(max_sequence_length, dict):
+        return tuple(int(max_sequence_length[k]) for k in ("chunk_size_fea", "chunk_step_fea", "chunk_size_lab", "chunk_step_lab"))
+    if isinstance(max_sequence_length, (int, np.integer)):
+        m = int(max_sequence_length)
+        return m, m, m, m
+    raise ValueError("Unknown type of max_sequence_length")
+
+
+def _split_sentence(fea, lab, cfg, fea_only):
+    """data_io.py:70-112: a sentence longer than the chunk size is cut into chunks of that size; the tail stays with
+    the last chunk unless it is longer than a quarter of the size (500 -> a 625-frame sentence is one 500 + one 125)."""
+    size_f, step_f, size_l, step_l = cfg
+    zeros = lambda f: np.zeros((f.shape[0],))  # noqa: E731
+    if not (len(fea) > size_f and size_f > 0):
+        return [fea], [zeros(fea) if fea_only else lab]
+    feas, labs = [], []
+    threshold = size_f + size_f / 4
+    for i in range((len(fea) + size_f - 1) // size_f):
+        start = i * step_f
+        last = not (len(fea) - start > threshold) if start < len(fea) else True
+        f = fea[start:] if last else fea[start:start + size_f]
+        if fea_only:
+            l = zeros(f)
+        else:
+            l = lab[i * step_l:] if last else lab[i * step_l:i * step_l + size_l]
+        feas.append(f)
+        labs.append(l)
+        if last:
+            break
+    return feas, labs
+
+
+def load_dataset(fea, lab, max_sequence_length, fea_only=False):
+    """What the reference's load_dataset does once its Kaldi pipes have delivered (data_io.py:41-54, 57-225).
+    fea: {key: (frames, dim) array}; lab: {key: integer vector} (ignored when fea_only).  Returns the reference's
+    [names, fea_conc, lab_conc, end_index_fea, end_index_lab]:
+      * alignments without features and features without alignments are dropped (:41-54);
+      * sentences are visited by (length, key), long ones split (:129-141), the chunks then stably re-sorted by
+        length and concatenated (:143-164).  As in the reference, `names` keeps the order BEFORE that second sort."""
+    if not fea_only:
+        lab = {k: v for k, v in lab.items() if k in fea}
+        fea = {k: v for k, v in fea.items() if k in lab}
+    cfg = _chunk_config(max_sequence_length)
+    names, feas, labs = [], [], []
+    for k in sorted(sorted(fea.keys()), key=lambda k: len(fea[k])):
+        f_chunks, l_chunks = _split_sentence(fea[k], None if fea_only else lab[k], cfg, fea_only)
+        for j in range(len(f_chunks)):
+            feas.append(f_chunks[j])
+            labs.append(l_chunks[j])
+            names.append(k + "_split" + str(j) if len(f_chunks) > 1 else k)
+    if not feas:
+        raise ValueError("load_dataset: no sentence has both features and an alignment")
+    order = sorted(range(len(feas)), key=lambda i: feas[i].shape[0])  # stable, like sorted() on the zipped pairs
+    feas, labs = [feas[i] for i in order], [labs[i] for i in order]
+    end_fea = np.cumsum([f.shape[0] for f in feas])
+    end_lab = np.cumsum([l.shape[0] for l in labs])
+    return [names, np.concatenate(feas), np.concatenate(labs), np.asarray(end_fea), np.asarray(end_lab)]
+
+
+def _read_features(rspec):
+    rspec = str(rspec)
+    if rspec.startswith("scp:"):
+        return dict(read_mat_scp(rspec[4:]))
+    if rspec.endswith(".scp"):
+        return dict(read_mat_scp(rspec))
+    return dict(read_mat_ark(rspec))
+
+
+def _read_alignments(rspec):
+    """One alignment ark (plain or .gz), or a folder holding ali*.gz (the reference's `gunzip -c folder/ali*.gz`)."""
+    rspec = str(rspec)
+    files = sorted(glob.glob(os.path.join(rspec, "ali*.gz"))) if os.path.isdir(rspec) else [rspec]
+    if not files:
+        raise IOError("no ali*.gz under %s" % rspec)
+    out = {}
+    for f in files:
+        out.update(read_vec_int_ark(f))
+    return out
+
+
+def load_chunk(fea_rspec, lab_rspec, left, right, max_sequence_length, fea_only=False):
+    """The reference's load_chunk (data_io.py:244-274) for tables that already exist on disk: `fea_rspec` is a feature
+    scp ("key file:offset" lines) or ark, `lab_rspec` an integer-vector ark of pdf-ids (plain, .gz, or a folder of
+    ali*.gz) - i.e. what `copy-feats scp:... ark:- | <fea_opts>` and `gunzip -c ali*.gz | ali-to-pdf ...` would deliver.
+    Returns [data_name, data_set (float32, features + one label column), end_index_fea]."""
+    fea = _read_features(fea_rspec)
+    lab = {} if fea_only else _read_alignments(lab_rspec)
+    names, data_set, data_lab, end_index_fea, _ = load_dataset(fea, lab, max_sequence_length, fea_only)
+    data_set, end_index_fea = finish_chunk(data_set, data_lab, end_index_fea, left, right)
+    return [names, data_set, end_index_fea]

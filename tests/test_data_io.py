@@ -127,3 +127,68 @@ def test_finish_chunk_device_matches_host_path():
     assert np.array_equal(end, g.arrays["chunk/end_index_out"])
     none, _ = dio.finish_chunk_device(g.arrays["cw/fea"], g.arrays["chunk/lab"], g.arrays["chunk/end_index"], 0, 0, "cpu")
     assert none.shape == (31, 5)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# The chunk loader one level up: tests/golden/io_chunk_loader.npz holds what the reference's own load_chunk returned
+# (oracle/make_golden.py::loader_case ran it with stand-ins for the two Kaldi programs its pipes call).
+# --------------------------------------------------------------------------------------------------------------
+LOADER = "io_chunk_loader"
+
+
+@pytest.fixture()
+def loader_tables(tmp_path):
+    import gzip
+
+    g = Golden(LOADER)
+    ark = tmp_path / "fea.ark"
+    ark.write_bytes(bytes(g.arrays["fea_ark"]))
+    scp = tmp_path / "fea.scp"
+    scp.write_text("".join("%s %s:%d\n" % (k, ark, g.meta["offsets"][k]) for k in g.meta["scp_order"]))
+    ali = tmp_path / "ali.ark"
+    ali.write_bytes(bytes(g.arrays["ali_ark"]))
+    folder = tmp_path / "alidir"
+    folder.mkdir()
+    raw = bytes(g.arrays["ali_ark"])
+    # two gzip parts, split at a record boundary, as a Kaldi alignment folder holds them (ali.1.gz, ali.2.gz ...)
+    cut = raw.index(b"spk3_a ")
+    for i, part in enumerate((raw[:cut], raw[cut:]), 1):
+        with gzip.open(folder / ("ali.%d.gz" % i), "wb") as z:
+            z.write(part)
+    return g, scp, ark, ali, folder
+
+
+@pytest.mark.parametrize("run", ["seq_msl50", "cw_3_2_msl1000", "forward_cw_2_2", "dict_msl40"])
+@pytest.mark.parametrize("fea_kind,lab_kind", [("scp", "ark"), ("ark", "folder")])
+def test_load_chunk_matches_reference(loader_tables, run, fea_kind, lab_kind):
+    g, scp, ark, ali, folder = loader_tables
+    m = g.meta["runs"][run]
+    fea_rspec = ("scp:" + str(scp)) if fea_kind == "scp" else str(ark)
+    lab_rspec = None if m["fea_only"] else (str(ali) if lab_kind == "ark" else str(folder))
+    names, data_set, end_index = dio.load_chunk(fea_rspec, lab_rspec, m["left"], m["right"], m["max_sequence_length"],
+                                                m["fea_only"])
+    ref = g.arrays[run + "/data_set"]
+    assert names == m["names"]                      # incl. the reference's quirk: names keep the pre-sort order
+    assert np.array_equal(end_index, g.arrays[run + "/end_index"])
+    assert data_set.dtype == np.float32 and data_set.shape == ref.shape
+    assert np.array_equal(data_set[:, -1], ref[:, -1].astype(np.float32))          # label column: exact
+    assert np.allclose(data_set[:, :-1], ref[:, :-1], rtol=0, atol=2e-5)           # float32 vs the reference's float64
+
+
+def test_load_dataset_drops_unmatched_keys_and_splits(loader_tables):
+    g, scp, ark, ali, folder = loader_tables
+    fea = dict(dio.read_mat_scp(str(scp)))
+    lab = dict(dio.read_vec_int_ark(str(ali)))
+    assert "no_ali" in fea and "no_fea" in lab
+    names, fea_conc, lab_conc, end_fea, end_lab = dio.load_dataset(fea, lab, 50)
+    assert not any(n.startswith(("no_ali", "no_fea")) for n in names)
+    assert np.array_equal(end_fea, end_lab) and end_fea[-1] == fea_conc.shape[0] == lab_conc.shape[0]
+    # 130 frames at chunk size 50 -> 50 + 50 + 30; 63 -> 50 + 13 (more than a quarter would have stayed whole: 55 does)
+    assert [n for n in names if n.startswith("spk3_a")] == ["spk3_a_split0", "spk3_a_split1", "spk3_a_split2"]
+    assert "spk2_a" in names and "spk4_b_split1" in names
+    lens = np.diff(np.concatenate(([0], end_fea)))
+    assert np.all(np.diff(lens) >= 0)               # chunks are concatenated by increasing length
+    with pytest.raises(ValueError):
+        dio.load_dataset(fea, lab, "50")
+    with pytest.raises(ValueError):
+        dio.load_dataset({"a": fea["spk1_a"]}, {"b": lab["spk1_a"]}, 50)

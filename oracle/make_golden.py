@@ -437,6 +437,105 @@ def loader_case(name, seed):
     _save(name, {"offsets": offsets, "scp_order": sorted(feats, reverse=True), "runs": meta_runs, "seed": seed}, arrays)
 
 
+def reader_case(name, seed):
+    """The reference's chunk reader, data_io.read_lab_fea (data_io.py:536-655: what core.run_nn starts in its reader
+    thread), on chunk cfg files that name two feature streams with different context windows and two label sets.  Kaldi
+    pipes are satisfied as in loader_case.  Pins pytorch-kaldi_amd/data_io.py::read_lab_fea / dict_fea_lab_arch."""
+    import gzip
+    import stat
+    import tempfile
+
+    import data_io as ref_io
+
+    g = np.random.RandomState(seed)
+    tmp = tempfile.mkdtemp()
+    bindir = os.path.join(tmp, "bin")
+    os.makedirs(bindir)
+    stubs = {
+        "copy-feats": "#!%s\nimport sys\nsys.path.insert(0, %r)\nimport data_io\nout = sys.stdout.buffer\n"
+                      "for line in open(sys.argv[1].split(':', 1)[1]):\n    key, rx = line.strip().split(' ', 1)\n"
+                      "    data_io.write_mat(%r, out, data_io.read_mat(rx, %r), key=key)\nout.flush()\n"
+                      % (sys.executable, REF, tmp, tmp),
+        "ali-to-pdf": "#!%s\nimport sys\nsys.stdout.buffer.write(sys.stdin.buffer.read())\n" % sys.executable,
+    }
+    for prog, text in stubs.items():
+        path = os.path.join(bindir, prog)
+        with open(path, "w") as f:
+            f.write(text)
+        os.chmod(path, os.stat(path).st_mode | stat.S_IEXEC)
+    lengths = {"a1": 14, "a2": 9, "b1": 23, "b2": 14, "c1": 31, "c2": 18}
+    dims = {"fbank": 5, "mfcc": 3}
+    arrays, offsets = {}, {}
+    for stream, D in dims.items():
+        ark = os.path.join(tmp, stream + ".ark")
+        offsets[stream] = {}
+        with open(ark, "wb") as f:
+            for k in sorted(lengths):
+                f.write((k + " ").encode())
+                offsets[stream][k] = f.tell()
+                ref_io.write_mat(tmp, f, (g.randn(lengths[k], D) * 2 + 1).astype(np.float32))
+        with open(os.path.join(tmp, stream + ".scp"), "w") as f:
+            for k in sorted(lengths):
+                f.write("%s %s:%d\n" % (k, ark, offsets[stream][k]))
+        arrays[stream + "_ark"] = np.frombuffer(open(ark, "rb").read(), dtype=np.uint8)
+    for labname, hi in (("lab_cd", 37), ("lab_mono", 11)):
+        d = os.path.join(tmp, labname)
+        os.makedirs(d)
+        plain = os.path.join(tmp, labname + ".ark")
+        with open(plain, "wb") as f:
+            for k in sorted(lengths):
+                ref_io.write_vec_int(f, tmp, g.randint(1, hi, lengths[k]).astype(np.int32), key=k)
+        with open(plain, "rb") as f, gzip.open(os.path.join(d, "ali.1.gz"), "wb") as z:
+            z.write(f.read())
+        open(os.path.join(d, "final.mdl"), "w").close()
+        arrays[labname + "_ark"] = np.frombuffer(open(plain, "rb").read(), dtype=np.uint8)
+
+    def cfg_text(to_do, streams, seq, msl):
+        fea = "\n\n".join("fea_name=%s\n\tfea_lst={TMP}/%s.scp\n\tfea_opts=\n\tcw_left=%d\n\tcw_right=%d" % (n, n, l, r)
+                          for n, l, r in streams)
+        lab = "\n\n".join("lab_name=%s\n\tlab_folder={TMP}/%s\n\tlab_opts=ali-to-pdf" % (n, n) for n in ("lab_cd", "lab_mono"))
+        if len(streams) == 2:
+            model = ["conc1=concatenate(%s,%s)" % (streams[0][0], streams[1][0]), "out_dnn1=compute(net1,conc1)"]
+        else:
+            model = ["out_dnn1=compute(net1,%s)" % streams[0][0]]
+        model += ["out_dnn2=compute(head_cd,out_dnn1)", "out_dnn3=compute(head_mono,out_dnn1)",
+                  "loss_mono=cost_nll(out_dnn3,lab_mono)", "loss_mono_w=mult_constant(loss_mono,1.0)",
+                  "loss_cd=cost_nll(out_dnn2,lab_cd)", "loss_final=sum(loss_cd,loss_mono_w)", "err_final=cost_err(out_dnn2,lab_cd)"]
+        txt = "[exp]\nto_do = %s\n\n[batches]\nmax_seq_length_train = %d\nmax_seq_length_valid = %d\n\n" % (to_do, msl, msl)
+        txt += "[data_chunk]\nfea = " + fea.replace("\n", "\n\t").replace("\t\t", "\t") + "\nlab = " + lab.replace("\n", "\n\t").replace("\t\t", "\t") + "\n\n"
+        txt += "[architecture1]\narch_name = net1\narch_seq_model = %s\n\n[architecture2]\narch_name = head_cd\narch_seq_model = False\n\n" % seq
+        txt += "[architecture3]\narch_name = head_mono\narch_seq_model = False\n\n[model]\nmodel = " + "\n\t".join(model) + "\n"
+        return txt
+
+    runs = {"train_mlp_two_streams": ("train", [("fbank", 2, 1), ("mfcc", 0, 0)], False, 1000, False),
+            "train_seq_split": ("train", [("fbank", 0, 0)], True, 20, False),
+            "valid_mlp_one_stream": ("valid", [("mfcc", 1, 1)], False, 1000, False),
+            "forward_production": ("forward", [("fbank", 2, 1), ("mfcc", 1, 2)], False, 1000, True)}
+    meta_runs = {}
+    old_path = os.environ["PATH"]
+    os.environ["PATH"] = bindir + os.pathsep + old_path
+    try:
+        for i, (rname, (to_do, streams, seq, msl, fea_only)) in enumerate(runs.items()):
+            text = cfg_text(to_do, streams, seq, msl)
+            path = os.path.join(tmp, rname + ".cfg")
+            with open(path, "w") as f:
+                f.write(text.replace("{TMP}", tmp))
+            np.random.seed(seed + i)  # the reader shuffles non-sequence training chunks with the global numpy RNG
+            shared = []
+            ref_io.read_lab_fea(path, fea_only, shared, tmp)
+            data_name, end_index, fea_dict, lab_dict, arch_dict, data_set = shared
+            arrays[rname + "/data_set"] = np.asarray(data_set)
+            arrays[rname + "/end_index"] = np.asarray(end_index)
+            meta_runs[rname] = {"cfg": text, "fea_only": fea_only, "np_seed": seed + i, "names": list(data_name),
+                                "fea_dict": {k: [v if isinstance(v, str) else int(v) for v in vals] for k, vals in fea_dict.items()},
+                                "lab_dict": {k: ([v if isinstance(v, str) else int(v) for v in vals] if isinstance(vals, list) else vals)
+                                             for k, vals in lab_dict.items()},
+                                "arch_dict": {k: [v[0], v[1], bool(v[2])] for k, v in arch_dict.items()}}
+    finally:
+        os.environ["PATH"] = old_path
+    _save(name, {"offsets": offsets, "runs": meta_runs, "seed": seed, "tmp": tmp}, arrays)
+
+
 def cfg_case(name):
     """The architecture / model / batch sections of the shipped cfg files BASELINE.json names, as parsed by
     configparser: pins pytorch-kaldi_amd/recipes.py (what bench.py builds) to the reference's recipes."""
@@ -468,6 +567,9 @@ def main():
         return
     if os.environ.get("PK_GOLDEN_ONLY") == "loader":
         loader_case("io_chunk_loader", 91)
+        return
+    if os.environ.get("PK_GOLDEN_ONLY") == "reader":
+        reader_case("io_chunk_reader", 57)
         return
     # --- recurrent family -----------------------------------------------------
     module_case("ligru_bidir_bn", "liGRU", rec_opts("ligru", [24, 16], "relu"), 7, (9, 3, 7), 100)
@@ -525,6 +627,7 @@ def main():
     # --- either side of the path: Kaldi tables and the chunk transforms of data_io.load_chunk ---
     io_case("io_kaldi_tables", 77)
     loader_case("io_chunk_loader", 91)
+    reader_case("io_chunk_reader", 57)
     cfg_case("cfg_recipes")
 
 

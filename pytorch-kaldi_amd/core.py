@@ -142,11 +142,17 @@ def mean_over_ranks(loss_sum, err_sum, world):
 
 
 def _default_reader():
+    """PK_READER=tables: the pipe-free reader of this package (data_io.read_lab_fea: chunk cfg files whose fea_opts are
+    empty, i.e. tables that already exist on disk); otherwise the reference's reader with its Kaldi pipes."""
+    if os.environ.get("PK_READER", "reference") == "tables":
+        from . import data_io as pk_io
+        return pk_io.read_lab_fea
     try:
         import data_io  # the reference's, when running inside a PyTorch-Kaldi checkout
     except ImportError as e:
-        raise RuntimeError("run_nn_dp needs a chunk reader: put PyTorch-Kaldi's data_io.py on sys.path or pass "
-                           "reader=callable(cfg_file, is_production, shared_list, output_folder)") from e
+        raise RuntimeError("run_nn_dp needs a chunk reader: put PyTorch-Kaldi's data_io.py on sys.path, set "
+                           "PK_READER=tables, or pass reader=callable(cfg_file, is_production, shared_list, "
+                           "output_folder)") from e
     return data_io.read_lab_fea
 
 

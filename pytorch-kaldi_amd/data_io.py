@@ -14,6 +14,11 @@ reference's ``data_io`` so that a loader written against it reads the same.
     load_chunk                    data_io.py:244-274    (tables on disk -> [names, data_set, end_index]; takes the
                                                          feature scp / ark and the alignment ark(s) directly instead of
                                                          the fea_opts / lab_opts command strings)
+    read_lab_fea                  data_io.py:536-655    (the chunk reader core.run_nn starts in its reader thread, same
+                                                         signature and shared_list contract, for chunk cfg files whose
+                                                         fea_opts are empty: several feature streams with different
+                                                         context windows, several label sets, shuffle)
+    dict_fea_lab_arch             utils.py:1889-1994    (which streams / labels / architectures the [model] lines use)
 
 The Kaldi pipelines inside ``fea_opts`` / ``lab_opts`` (apply-cmvn, add-deltas, ali-to-pdf ...) are external programs and
 stay with the reference's reader; these functions cover tables that already exist on disk.
@@ -21,7 +26,9 @@ stay with the reference's reader; these functions cover tables that already exis
 import ctypes
 import glob
 import gzip
+import configparser
 import os
+import re
 import shutil
 import tempfile
 
@@ -298,3 +305,112 @@ def load_chunk(fea_rspec, lab_rspec, left, right, max_sequence_length, fea_only=
     names, data_set, data_lab, end_index_fea, _ = load_dataset(fea, lab, max_sequence_length, fea_only)
     data_set, end_index_fea = finish_chunk(data_set, data_lab, end_index_fea, left, right)
     return [names, data_set, end_index_fea]
+
+
+def _truth(v):
+    v = str(v).strip().lower()
+    if v in ("y", "yes", "t", "true", "on", "1"):
+        return True
+    if v in ("n", "no", "f", "false", "off", "0"):
+        return False
+    raise ValueError("invalid truth value %r" % v)
+
+
+def dict_fea_lab_arch(config, fea_only):
+    """utils.py:1889-1994: the feature streams, label sets and architectures the [model] lines actually use, each in
+    order of first use.  fea_dict[name] = [name, fea_lst, fea_opts, cw_left, cw_right] (strings), lab_dict[name] =
+    [name, lab_folder, lab_opts], arch_dict[name] = [section, name, seq_model]."""
+    fea_field, lab_field = config["data_chunk"]["fea"], config["data_chunk"]["lab"]
+    fea_names = re.findall("fea_name=(.*)\n", fea_field.replace(" ", ""))
+    lab_names = re.findall("lab_name=(.*)\n", lab_field.replace(" ", ""))
+    fea_dict, lab_dict, arch_dict = {}, {}, {}
+    for line in config["model"]["model"].split("\n"):
+        _, operation, inp1, inp2 = re.findall(r"(.*)=(.*)\((.*),(.*)\)", line)[0]
+        for inp in (inp1, inp2):
+            if inp in fea_names and inp not in fea_dict:
+                pat = "fea_name=" + inp + "\nfea_lst=(.*)\nfea_opts=(.*)\ncw_left=(.*)\ncw_right=(.*)"
+                fea_dict[inp] = (inp + "," + ",".join(re.findall(pat, fea_field)[0])).split(",")
+        for inp in (inp1, inp2):
+            if inp in lab_names and inp not in lab_dict and not fea_only:
+                pat = "lab_name=" + inp + "\nlab_folder=(.*)\nlab_opts=(.*)"
+                lab_dict[inp] = (inp + "," + ",".join(re.findall(pat, lab_field)[0])).split(",")
+        if operation == "compute" and inp1 not in arch_dict:
+            secs = [sec for sec in config.sections() if config[sec].get("arch_name") == inp1]
+            if not secs:
+                raise ValueError("no [architecture*] section has arch_name = %s" % inp1)
+            arch_dict[inp1] = [secs[0], inp1, _truth(config[secs[0]]["arch_seq_model"])]
+    return [fea_dict, lab_dict, arch_dict]
+
+
+def read_lab_fea(cfg_file, fea_only, shared_list, output_folder=None):
+    """The reference's chunk reader (data_io.py:536-655; `core.run_nn` runs it in a thread, core.py:492 / 511) for chunk
+    cfg files whose feature pipelines are empty, i.e. whose tables already exist on disk: appends
+    [data_name, data_end_index, fea_dict, lab_dict, arch_dict, data_set] to `shared_list`.
+
+    Per (feature stream, label set) pair one load_chunk; streams with narrower context windows are trimmed to the widest
+    one (:577-581); labels are taken from the first stream, streams are stacked left to right and get their column
+    ranges appended to fea_dict (:590-592, :601-604), label columns follow (:622-627); non-sequence training chunks are
+    shuffled with the global numpy RNG (:633-635).  `fea_opts` / `lab_opts` must be empty (or `lab_opts = pdf-ids`):
+    a pipeline needs Kaldi and stays with the reference's reader.  data_set is float32 (the reference hands float64 to
+    run_nn, which converts it)."""
+    if not os.path.exists(cfg_file):
+        raise IOError("The config file %s does not exist!" % cfg_file)
+    config = configparser.ConfigParser()
+    config.read(cfg_file)
+    to_do = config["exp"]["to_do"]
+    if to_do == "train":
+        max_seq_length = int(config["batches"]["max_seq_length_train"])
+    elif to_do == "valid":
+        max_seq_length = int(config["batches"]["max_seq_length_valid"])
+    else:
+        max_seq_length = -1  # forward: sentences are never split
+    fea_dict, lab_dict, arch_dict = dict_fea_lab_arch(config, fea_only)
+    cw_left_max = max(int(fea_dict[f][3]) for f in fea_dict)
+    cw_right_max = max(int(fea_dict[f][4]) for f in fea_dict)
+    fea_index = 0
+    data_set = labs = data_end_index = data_name = None
+    for cnt_fea, fea in enumerate(fea_dict):
+        fea_scp, fea_opts = fea_dict[fea][1], fea_dict[fea][2]
+        cw_left, cw_right = int(fea_dict[fea][3]), int(fea_dict[fea][4])
+        if fea_opts.strip():
+            raise ValueError("read_lab_fea: fea_opts of %s is a Kaldi pipeline (%r); materialise it into an ark / scp "
+                             "first or use the reference's reader" % (fea, fea_opts))
+        if fea_only:
+            lab_dict.update({"lab_name": "none"})
+        for cnt_lab, lab in enumerate(lab_dict):
+            lab_folder = None
+            if not fea_only:
+                lab_folder, lab_opts = lab_dict[lab][1], lab_dict[lab][2]
+                if lab_opts.strip() not in ("", "pdf-ids"):
+                    raise ValueError("read_lab_fea: lab_opts of %s is %r; store pdf-ids (ali-to-pdf run once) and set "
+                                     "lab_opts = pdf-ids, or use the reference's reader" % (lab, lab_opts))
+            name_fea, set_fea, end_fea = load_chunk(fea_scp, lab_folder, cw_left, cw_right, max_seq_length, fea_only)
+            lo, hi = cw_left_max - cw_left, set_fea.shape[0] - (cw_right_max - cw_right)
+            labs_fea, set_fea = set_fea[lo:hi, -1], set_fea[lo:hi, 0:-1]
+            end_fea = end_fea - lo
+            end_fea[-1] = end_fea[-1] - (cw_right_max - cw_right)
+            if cnt_fea == 0 and cnt_lab == 0:
+                data_set, labs, data_end_index, data_name = set_fea, labs_fea, end_fea, name_fea
+            else:
+                if cnt_fea == 0:
+                    labs = np.column_stack((labs, labs_fea))
+                if cnt_lab == 0:
+                    data_set = np.column_stack((data_set, set_fea))
+                if data_name != name_fea:
+                    raise ValueError("different sentence ids are detected for the different features. Please check "
+                                     "again input feature lists")
+                if not (data_end_index == end_fea).all():
+                    raise ValueError("end_index must be the same for all the sentences")
+            if cnt_lab == 0:
+                fea_dict[fea].append(fea_index)
+                fea_index = fea_index + set_fea.shape[1]
+                fea_dict[fea].append(fea_index)
+                fea_dict[fea].append(fea_dict[fea][6] - fea_dict[fea][5])
+    if not fea_only:
+        for cnt_lab, lab in enumerate(lab_dict):
+            lab_dict[lab].append(data_set.shape[1] + cnt_lab)
+    data_set = np.column_stack((data_set, labs))
+    seq_model = any(arch_dict[a][2] for a in arch_dict)
+    if not seq_model and to_do != "forward":
+        np.random.shuffle(data_set)
+    shared_list.extend([data_name, data_end_index, fea_dict, lab_dict, arch_dict, data_set])

@@ -192,3 +192,72 @@ def test_load_dataset_drops_unmatched_keys_and_splits(loader_tables):
         dio.load_dataset(fea, lab, "50")
     with pytest.raises(ValueError):
         dio.load_dataset({"a": fea["spk1_a"]}, {"b": lab["spk1_a"]}, 50)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# The chunk reader of core.run_nn's reader thread: tests/golden/io_chunk_reader.npz holds what the reference's own
+# read_lab_fea appended to its shared_list (oracle/make_golden.py::reader_case).
+# --------------------------------------------------------------------------------------------------------------
+READER = "io_chunk_reader"
+
+
+@pytest.fixture()
+def reader_tables(tmp_path):
+    import gzip
+
+    g = Golden(READER)
+    for stream in ("fbank", "mfcc"):
+        ark = tmp_path / (stream + ".ark")
+        ark.write_bytes(bytes(g.arrays[stream + "_ark"]))
+        (tmp_path / (stream + ".scp")).write_text(
+            "".join("%s %s:%d\n" % (k, ark, off) for k, off in sorted(g.meta["offsets"][stream].items())))
+    for lab in ("lab_cd", "lab_mono"):
+        (tmp_path / lab).mkdir()
+        with gzip.open(tmp_path / lab / "ali.1.gz", "wb") as z:
+            z.write(bytes(g.arrays[lab + "_ark"]))
+    return g, tmp_path
+
+
+@pytest.mark.parametrize("run", ["train_mlp_two_streams", "train_seq_split", "valid_mlp_one_stream", "forward_production"])
+def test_read_lab_fea_matches_reference(reader_tables, run):
+    g, tmp = reader_tables
+    m = g.meta["runs"][run]
+    cfg = tmp / (run + ".cfg")
+    cfg.write_text(m["cfg"].replace("{TMP}", str(tmp)).replace("lab_opts=ali-to-pdf", "lab_opts=pdf-ids"))
+    np.random.seed(m["np_seed"])
+    shared = []
+    dio.read_lab_fea(str(cfg), m["fea_only"], shared, str(tmp))
+    data_name, end_index, fea_dict, lab_dict, arch_dict, data_set = shared
+    fix = lambda v: v.replace(g.meta["tmp"], str(tmp)).replace("ali-to-pdf", "pdf-ids") if isinstance(v, str) else v  # noqa: E731
+    assert data_name == m["names"]
+    assert np.array_equal(end_index, g.arrays[run + "/end_index"])
+    assert list(fea_dict) == list(m["fea_dict"]) and list(lab_dict) == list(m["lab_dict"])   # order of first use
+    for k, v in m["fea_dict"].items():
+        assert fea_dict[k] == [fix(x) for x in v], k
+    for k, v in m["lab_dict"].items():
+        assert lab_dict[k] == ([fix(x) for x in v] if isinstance(v, list) else v), k
+    assert {k: [v[0], v[1], bool(v[2])] for k, v in arch_dict.items()} == m["arch_dict"]
+    ref = g.arrays[run + "/data_set"]
+    nfea = max(v[6] for v in m["fea_dict"].values())
+    assert data_set.dtype == np.float32 and data_set.shape == ref.shape
+    assert np.array_equal(data_set[:, nfea:], ref[:, nfea:].astype(np.float32))   # label columns (same shuffle): exact
+    assert np.allclose(data_set[:, :nfea], ref[:, :nfea], rtol=0, atol=2e-5)
+
+
+def test_read_lab_fea_refuses_kaldi_pipelines(reader_tables):
+    g, tmp = reader_tables
+    m = g.meta["runs"]["valid_mlp_one_stream"]
+    text = m["cfg"].replace("{TMP}", str(tmp))
+    cfg = tmp / "piped.cfg"
+    cfg.write_text(text)                                      # lab_opts=ali-to-pdf: transition-ids would need the model
+    with pytest.raises(ValueError, match="lab_opts"):
+        dio.read_lab_fea(str(cfg), False, [], str(tmp))
+    cfg.write_text(text.replace("fea_opts=", "fea_opts=apply-cmvn --utt2spk=ark:u2s ark:cmvn.ark ark:- ark:- |"))
+    with pytest.raises(ValueError, match="fea_opts"):
+        dio.read_lab_fea(str(cfg), False, [], str(tmp))
+
+
+def test_run_nn_dp_picks_the_table_reader(monkeypatch):
+    core = importlib.import_module("pytorch-kaldi_amd.core")
+    monkeypatch.setenv("PK_READER", "tables")
+    assert core._default_reader() is dio.read_lab_fea

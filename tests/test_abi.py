@@ -1,7 +1,6 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every
 symbol include/pk_amd.h declares, and the product path refuses to run without a GPU
 (no CPU fallback, no route through oracle/)."""
-import ctypes
 import importlib
 import os
 import re

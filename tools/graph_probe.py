@@ -1,4 +1,4 @@
-import argparse, importlib, sys, time, torch
+import argparse, sys, time, torch
 sys.path.insert(0, "/root/repo")
 import bench
 args = argparse.Namespace(recipe=sys.argv[1] if len(sys.argv) > 1 else "timit_mlp", T=500, B=128, prec="bf16", algo="auto", layers=None,

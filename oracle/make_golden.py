@@ -536,6 +536,35 @@ def reader_case(name, seed):
     _save(name, {"offsets": offsets, "runs": meta_runs, "seed": seed, "tmp": tmp}, arrays)
 
 
+def oracle_extra_cases():
+    """More option combinations of the same classes, used to pin the ORACLE only (prefix "ora_": tests/test_oracle_golden.py
+    takes them, the GPU module-case lists do not until the engine has been run against them on hardware): per-step
+    LayerNorm in the gated cells, input normalisations, eval mode of the other cells, BatchNorm in SincNet / CNN."""
+    module_case("ora_lstm_bidir_ln_lninp", "LSTM", rec_opts("lstm", [16, 12], "tanh", bn=False, ln=True, drop=0.1, ln_inp=True),
+                7, (8, 3, 7), 900)
+    module_case("ora_lstm_eval", "LSTM", rec_opts("lstm", [14], "tanh"), 6, (7, 4, 6), 905, to_do="valid", training=False)
+    module_case("ora_gru_bidir_ln_bninp", "GRU", rec_opts("gru", [12, 10], "tanh", bn=False, ln=True, bn_inp=True),
+                5, (9, 4, 5), 910)
+    module_case("ora_gru_eval", "GRU", rec_opts("gru", [11], "relu", bidir=False), 5, (6, 3, 5), 915, to_do="valid",
+                training=False)
+    module_case("ora_mingru_uni_plain_relu", "minimalGRU", rec_opts("minimalgru", [13], "relu", bn=False, bidir=False, drop=0.0),
+                6, (7, 5, 6), 920)
+    module_case("ora_mingru_bidir_ln", "minimalGRU", rec_opts("minimalgru", [10, 10], "tanh", bn=False, ln=True),
+                4, (6, 3, 4), 925)
+    module_case("ora_rnn_eval", "RNN", rec_opts("rnn", [12, 9], "relu"), 5, (8, 3, 5), 930, to_do="valid", training=False)
+    sinc = {"sinc_N_filt": "6,5", "sinc_len_filt": "21,5", "sinc_max_pool_len": "3,2",
+            "sinc_use_laynorm_inp": "False", "sinc_use_batchnorm_inp": "True",
+            "sinc_use_laynorm": "False,False", "sinc_use_batchnorm": "True,True",
+            "sinc_act": "relu,tanh", "sinc_drop": "0.0,0.0",
+            "sinc_sample_rate": "16000", "sinc_min_low_hz": "50", "sinc_min_band_hz": "50"}
+    module_case("ora_sincnet_bn_bninp", "SincNet", sinc, 160, (6, 160), 940, x_scale=0.1)
+    cnn = {"cnn_N_filt": "7,5", "cnn_len_filt": "7,3", "cnn_max_pool_len": "2,2",
+           "cnn_use_laynorm_inp": "True", "cnn_use_batchnorm_inp": "False",
+           "cnn_use_laynorm": "True,False", "cnn_use_batchnorm": "False,True",
+           "cnn_act": "leaky_relu,relu", "cnn_drop": "0.0,0.0"}
+    module_case("ora_cnn_lninp_eval", "CNN", cnn, 90, (5, 90), 950, x_scale=0.5, to_do="valid", training=False)
+
+
 def cfg_case(name):
     """The architecture / model / batch sections of the shipped cfg files BASELINE.json names, as parsed by
     configparser: pins pytorch-kaldi_amd/recipes.py (what bench.py builds) to the reference's recipes."""
@@ -570,6 +599,9 @@ def main():
         return
     if os.environ.get("PK_GOLDEN_ONLY") == "reader":
         reader_case("io_chunk_reader", 57)
+        return
+    if os.environ.get("PK_GOLDEN_ONLY") == "oracle_extra":
+        oracle_extra_cases()
         return
     # --- recurrent family -----------------------------------------------------
     module_case("ligru_bidir_bn", "liGRU", rec_opts("ligru", [24, 16], "relu"), 7, (9, 3, 7), 100)
@@ -617,6 +649,8 @@ def main():
            "cnn_use_laynorm": "False,True", "cnn_use_batchnorm": "True,False",
            "cnn_act": "relu,tanh", "cnn_drop": "0.0,0.0"}
     module_case("cnn_bn_ln", "CNN", cnn, 120, (5, 120), 710, x_scale=0.5)
+
+    oracle_extra_cases()
 
     # --- one level up: the shipped recipe through utils.forward_model ------------
     e2e_case("e2e_ligru_two_heads", 800, T=10, B=4, H=16, n_cd=23, n_mono=7)

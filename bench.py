@@ -339,6 +339,8 @@ def main():
                    "params": tr.n_params},
         "loss_final": round(float(loss), 5),
     }
+    if tr.rcp["cfg"]["architecture1"]["arch_class"] == "LSTM":
+        out["config"]["lstm_waves"] = int(_lib.load().pk_persist2_get_lstm_waves())  # DESIGN.md 6.1 (PK_LSTM_WAVES)
     # roofline of the dominant kernel class, measured live with HIP events (every rank runs the two extra steps:
     # they contain the gradient all-reduce)
     summ = profile_entry_points(tr)

@@ -261,3 +261,56 @@ def test_run_nn_dp_picks_the_table_reader(monkeypatch):
     core = importlib.import_module("pytorch-kaldi_amd.core")
     monkeypatch.setenv("PK_READER", "tables")
     assert core._default_reader() is dio.read_lab_fea
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Size-independent properties on random shapes (hypothesis): writer -> native reader round trip, context window and
+# chunk normalisation against their numpy definitions.
+# --------------------------------------------------------------------------------------------------------------
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.lists(st.tuples(st.integers(1, 40), st.integers(1, 24), st.booleans()), min_size=1, max_size=6), st.integers(0, 2 ** 31 - 1))
+def test_ark_round_trip_random_tables(shapes, seed):
+    import tempfile
+
+    core = importlib.import_module("pytorch-kaldi_amd.core")
+    rng = np.random.RandomState(seed)
+    mats = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = tmp + "/r.ark"
+        with open(path, "wb") as f:
+            for i, (rows, cols, dbl) in enumerate(shapes):
+                m = rng.randn(rows, cols).astype(np.float64 if dbl else np.float32)
+                mats["utt_%d" % i] = m
+                core.write_mat(f, m, "utt_%d" % i)
+        got = list(dio.read_mat_ark(path))
+    assert [k for k, _ in got] == list(mats)
+    for k, m in got:
+        assert m.dtype == np.float32 and np.array_equal(m, mats[k].astype(np.float32))
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 60), st.integers(1, 9), st.integers(0, 4), st.integers(0, 4), st.integers(0, 2 ** 31 - 1))
+def test_context_window_matches_definition(rows, cols, left, right, seed):
+    fea = np.random.RandomState(seed).randn(rows, cols).astype(np.float32)
+    if rows < left + right:
+        with pytest.raises(ValueError):
+            dio.context_window(fea, left, right)
+        return
+    out = dio.context_window(fea, left, right)
+    n = rows - left - right
+    want = np.concatenate([fea[b:b + n] for b in range(left + right + 1)], axis=1) if n > 0 else np.empty((0, cols * (left + right + 1)))
+    assert out.shape == (n, cols * (left + right + 1)) and np.array_equal(out, want.astype(np.float32))
+
+
+@settings(max_examples=30, deadline=None)
+@given(st.integers(2, 300), st.integers(1, 12), st.integers(0, 2 ** 31 - 1))
+def test_normalize_chunk_gives_zero_mean_unit_variance(rows, cols, seed):
+    rng = np.random.RandomState(seed)
+    x = (rng.randn(rows, cols) * rng.uniform(0.1, 30, cols) + rng.uniform(-50, 50, cols)).astype(np.float32)
+    ref = (x.astype(np.float64) - x.astype(np.float64).mean(0)) / x.astype(np.float64).std(0)
+    y = dio.normalize_chunk(x.copy())
+    assert np.allclose(y, ref, rtol=0, atol=5e-4 * max(1.0, float(np.abs(ref).max())))
+    assert np.all(np.abs(y.astype(np.float64).mean(0)) < 1e-4)

@@ -314,3 +314,23 @@ def test_normalize_chunk_gives_zero_mean_unit_variance(rows, cols, seed):
     y = dio.normalize_chunk(x.copy())
     assert np.allclose(y, ref, rtol=0, atol=5e-4 * max(1.0, float(np.abs(ref).max())))
     assert np.all(np.abs(y.astype(np.float64).mean(0)) < 1e-4)
+
+
+def test_reader_edge_cases(tmp_path):
+    """Empty matrices are legal records; damaged tables raise instead of returning garbage."""
+    core = importlib.import_module("pytorch-kaldi_amd.core")
+    lib_err = importlib.import_module("pytorch-kaldi_amd._lib").PkError
+    p = tmp_path / "z.ark"
+    with open(p, "wb") as f:
+        core.write_mat(f, np.zeros((0, 5), np.float32), "empty")
+        core.write_mat(f, np.ones((2, 5), np.float32), "two")
+    assert [(k, m.shape) for k, m in dio.read_mat_ark(str(p))] == [("empty", (0, 5)), ("two", (2, 5))]
+    data = p.read_bytes()
+    p.write_bytes(data[:-7])
+    with pytest.raises(lib_err, match="truncated"):
+        list(dio.read_mat_ark(str(p)))
+    p.write_bytes(b"key \0BXX garbage")
+    with pytest.raises(IOError, match="unknown matrix header"):
+        list(dio.read_mat_ark(str(p)))
+    with pytest.raises(IOError):
+        list(dio.read_mat_ark(str(tmp_path / "missing.ark")))

@@ -565,6 +565,67 @@ def oracle_extra_cases():
     module_case("ora_cnn_lninp_eval", "CNN", cnn, 90, (5, 90), 950, x_scale=0.5, to_do="valid", training=False)
 
 
+def model_lang_case(name, seed):
+    """The [model] mini-language one level up (utils.model_init / forward_model, utils.py:2031-2103, 2296-2420) on a
+    graph that uses every operation the e2e recipe does not: two input streams, concatenate, avg, mult, sum,
+    sum_constant, mult_constant, mse - as a training step on a (T, B, .) batch fed to non-sequence networks (the
+    (T*B, .) views of :2323-2337) and as a forward pass that stops at forward_outs[-1] (:2341).  Networks are the
+    reference's MLP; the fixture pins pytorch-kaldi_amd/utils.py::model_init / forward_model."""
+    import utils as ref_utils
+
+    n_cd, n_mono, T, B = 9, 4, 5, 3
+    mlp = {"arch_library": "neural_networks", "arch_class": "MLP", "arch_pretrain_file": "none", "arch_freeze": "False",
+           "arch_seq_model": "False", "dnn_drop": "0.0,0.0", "dnn_use_laynorm_inp": "False", "dnn_use_batchnorm_inp": "False",
+           "dnn_use_batchnorm": "False,False", "dnn_use_laynorm": "False,False", "dnn_act": "tanh,relu"}
+    head = dict(mlp, dnn_drop="0.0", dnn_use_batchnorm="False", dnn_use_laynorm="False", dnn_act="softmax")
+    cfg = configparser.ConfigParser()
+    cfg["exp"] = {"to_do": "train", "use_cuda": "False"}
+    cfg["architecture1"] = dict(mlp, arch_name="net1", dnn_lay="12,7")
+    cfg["architecture2"] = dict(mlp, arch_name="net2", dnn_lay="10,7")
+    cfg["architecture3"] = dict(head, arch_name="head_cd", dnn_lay=str(n_cd))
+    cfg["architecture4"] = dict(head, arch_name="head_mono", dnn_lay=str(n_mono))
+    model = ["conc1=concatenate(fbank,mfcc)", "out_dnn1=compute(net1,conc1)", "out_dnn2=compute(net2,mfcc)",
+             "avg1=avg(out_dnn1,out_dnn2)", "mul1=mult(out_dnn1,out_dnn2)", "s1=sum(avg1,mul1)", "s2=sum_constant(s1,0.5)",
+             "out_dnn3=compute(head_cd,s2)", "out_dnn4=compute(head_mono,out_dnn1)", "loss_mono=cost_nll(out_dnn4,lab_mono)",
+             "loss_mono_w=mult_constant(loss_mono,0.3)", "loss_cd=cost_nll(out_dnn3,lab_cd)", "loss_mse=mse(out_dnn1,out_dnn2)",
+             "loss_a=sum(loss_cd,loss_mono_w)", "loss_final=sum(loss_a,loss_mse)", "err_final=cost_err(out_dnn3,lab_cd)"]
+    fea_dict = {"fbank": ["fbank", "lst", "", "0", "0", 0, 5, 5], "mfcc": ["mfcc", "lst", "", "0", "0", 5, 8, 3]}
+    lab_dict = {"lab_mono": ["lab_mono", "f", "o", 8], "lab_cd": ["lab_cd", "f", "o", 9]}
+    arch_dict = {"net1": ["architecture1", "net1", False], "net2": ["architecture2", "net2", False],
+                 "head_cd": ["architecture3", "head_cd", False], "head_mono": ["architecture4", "head_mono", False]}
+    inp_out_dict = {k: list(v) for k, v in fea_dict.items()}
+    torch.manual_seed(seed)
+    nns, costs = ref_utils.model_init(inp_out_dict, model, cfg, arch_dict, False, False, "train")
+    for k, net in nns.items():
+        _perturb(net, seed + len(k))
+    g = torch.Generator().manual_seed(seed + 2)
+    inp = torch.randn(T, B, 10, generator=g)
+    inp[:, :, 8] = torch.randint(0, n_mono, (T, B), generator=g).float()
+    inp[:, :, 9] = torch.randint(0, n_cd, (T, B), generator=g).float()
+    arrays = {"inp": inp}
+    for n, net in nns.items():
+        for k, v in net.state_dict().items():
+            arrays["sd/%s/%s" % (n, k)] = v.clone()
+    outs = ref_utils.forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out_dict, T, B, "train", [])
+    outs["loss_final"].backward()
+    for k, v in outs.items():
+        arrays["train/" + k] = v.detach()
+    for n, net in nns.items():
+        for k, q in net.named_parameters():
+            if q.grad is not None:
+                arrays["grad/%s/%s" % (n, k)] = q.grad
+    for net in nns.values():
+        net.eval()
+    fwd = ref_utils.forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp[:, 0, :], inp_out_dict, T, 1,
+                                  "forward", ["out_dnn3"])
+    for k, v in fwd.items():
+        arrays["forward/" + k] = v.detach()
+    meta = {"options": {sec: dict(cfg[sec]) for sec in cfg.sections() if sec.startswith("architecture")}, "model": model,
+            "fea_dict": fea_dict, "lab_dict": lab_dict, "arch_dict": arch_dict, "inp_out_dict": inp_out_dict, "T": T, "B": B,
+            "seed": seed, "train_keys": sorted(outs), "forward_keys": sorted(fwd)}
+    _save(name, meta, arrays)
+
+
 def cfg_case(name):
     """The architecture / model / batch sections of the shipped cfg files BASELINE.json names, as parsed by
     configparser: pins pytorch-kaldi_amd/recipes.py (what bench.py builds) to the reference's recipes."""
@@ -599,6 +660,9 @@ def main():
         return
     if os.environ.get("PK_GOLDEN_ONLY") == "reader":
         reader_case("io_chunk_reader", 57)
+        return
+    if os.environ.get("PK_GOLDEN_ONLY") == "model_lang":
+        model_lang_case("e2e_model_language", 333)
         return
     if os.environ.get("PK_GOLDEN_ONLY") == "oracle_extra":
         oracle_extra_cases()
@@ -654,6 +718,7 @@ def main():
 
     # --- one level up: the shipped recipe through utils.forward_model ------------
     e2e_case("e2e_ligru_two_heads", 800, T=10, B=4, H=16, n_cd=23, n_mono=7)
+    model_lang_case("e2e_model_language", 333)
 
     # --- two levels up: the chunk loop core.run_nn (train from scratch, continue, validate, forward) ---
     chunk_case("chunk_ligru_run_nn", 1234)

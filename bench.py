@@ -375,6 +375,10 @@ def main():
             # of the same launch at this geometry (profiles/r01_pmc_traffic.json; null for any other geometry)
             rb = rec_launch_bytes(tr.rcp, tr.T, tr.B, dom)
             if rb:
+                # a recurrent launch is T strictly dependent steps: neither roofline binds it, the per-step latency does
+                # (one cross-CU hand-off, ~0.85 us on this chip, is the floor of a step)
+                roof["dependent_steps_per_launch"] = tr.T
+                roof["us_per_step"] = round(d["avg_ms"] * 1e3 / tr.T, 3)
                 roof["algorithmic_bytes_per_launch"] = rb
                 roof["hbm_gbps"] = round(rb / (d["avg_ms"] * 1e-3) / 1e9, 1)
                 roof["hbm_frac"] = round(rb / (d["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK, 5)

@@ -1,0 +1,48 @@
+"""The committed bench lines (profiles/r01_*.json, printed by bench.py on an MI355X) carry every field of the driver's
+contract, name BASELINE.json's metric and workload, and are internally consistent (value = frames / time, roofline
+fraction = achieved / peak)."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASE = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+LINES = ["profiles/r01_bench_bf16.json", "profiles/r01_bench_fp32_with_cpu_baseline.json",
+         "profiles/r01_timit_lstm_8wave_bench.json", "profiles/r01_timit_lstm_4wave_bench.json"]
+
+
+def _line(rel):
+    return json.loads(open(os.path.join(ROOT, rel)).read().strip().split("\n")[-1])
+
+
+@pytest.mark.parametrize("rel", LINES)
+def test_contract_fields(rel):
+    d = _line(rel)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None                      # BASELINE.md holds no published number for this metric
+    assert d["data"] == "synthetic" and d["dtype"] in ("bf16", "fp32")
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # whole-job throughput = frames of all timed steps / their wall time
+    frames_per_step = d["config"]["global_batch"] * d["config"]["seq_len"]
+    assert abs(d["value"] - frames_per_step / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+
+
+def test_headline_line_names_the_baseline_workload():
+    d = _line(LINES[0])
+    assert "frames" in BASE["metric"].lower() or "frames" in json.dumps(BASE).lower()
+    assert d["config"]["workload"].startswith("timit_ligru") and d["config"]["seq_len"] == 500 and d["config"]["global_batch"] == 128
+    assert d["dtype"] == "bf16" and d["n_gpus"] == 1
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1
+    assert d["roofline"]["traffic"] is not None          # PMC-measured HBM bytes of the dominant launch

@@ -190,6 +190,176 @@ def e2e_case(name, seed, T, B, H, n_cd, n_mono):
     _save(name, meta, arrays)
 
 
+def _recipe_cfg(H_lay=None, n_cd=1938, n_mono=48, drop=None):
+    """The shipped Li-GRU recipe as an in-memory ConfigParser (cfg/TIMIT_baselines/TIMIT_liGRU_fmllr.cfg), CPU,
+    N_out placeholders resolved (utils.py:707-722 does that with hmm-info); optionally scaled down."""
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(REF, "cfg/TIMIT_baselines/TIMIT_liGRU_fmllr.cfg"))
+    cfg["exp"]["to_do"] = "train"
+    cfg["exp"]["use_cuda"] = "False"
+    a1 = cfg["architecture1"]
+    if H_lay is not None:
+        n = len(H_lay)
+        a1["ligru_lay"] = ",".join(map(str, H_lay))
+        for k in ("ligru_drop", "ligru_use_laynorm", "ligru_use_batchnorm", "ligru_act"):
+            a1[k] = ",".join(a1[k].split(",")[:n])
+    if drop is not None:
+        a1["ligru_drop"] = ",".join([str(drop)] * len(a1["ligru_lay"].split(",")))
+    cfg["architecture2"]["dnn_lay"] = str(n_cd)
+    cfg["architecture3"]["dnn_lay"] = str(n_mono)
+    return cfg
+
+
+def _recipe_dicts(nfea):
+    fea_dict = {"fmllr": ["fmllr", "lst", "opts", "0", "0", 0, nfea, nfea]}
+    lab_dict = {"lab_cd": ["lab_cd", "f", "o", nfea], "lab_mono": ["lab_mono", "f", "o", nfea + 1]}
+    arch_dict = {"liGRU_layers": ["architecture1", "liGRU_layers", True],
+                 "MLP_layers": ["architecture2", "MLP_layers", False],
+                 "MLP_layers2": ["architecture3", "MLP_layers2", False]}
+    return fea_dict, lab_dict, arch_dict
+
+
+def train_case(name, seed, T=20, B=4, H=(32, 32), n_cd=23, n_mono=7, n_batches=5, n_steps=30, lr=None):
+    """CE-loss trajectory of the reference: the shipped Li-GRU recipe (scaled down) trained for `n_steps` optimizer
+    steps exactly as the chunk loop does it (core.py:616-642: forward_model, zero_grad, loss_final.backward(),
+    optimizers[opt].step()) with the reference's own utils.model_init / optimizer_init (RMSprop lr 4e-4, alpha .95,
+    eps 1e-8 per architecture).  `n_batches` synthetic batches are cycled, so the loss actually falls (the labels
+    can be memorised).  Stored: initial parameters, every batch, the drop masks of every step, loss_final / err_final
+    at every step, and the final parameters + RMSprop state."""
+    import utils as ref_utils
+
+    cfg = _recipe_cfg(list(H), n_cd, n_mono)
+    if lr is not None:  # the recipe's 4e-4 barely moves a 32-unit network in 30 steps; a larger rate makes the
+        for sec in ("architecture1", "architecture2", "architecture3"):  # trajectory sensitive to gradient errors
+            cfg[sec]["arch_lr"] = str(lr)
+    nfea = 11
+    fea_dict, lab_dict, arch_dict = _recipe_dicts(nfea)
+    model = cfg["model"]["model"].split("\n")
+    inp_out_dict = {"fmllr": fea_dict["fmllr"][5:]}
+    torch.manual_seed(seed)
+    nns, costs = ref_utils.model_init(inp_out_dict, model, cfg, arch_dict, False, False, "train")
+    optimizers = ref_utils.optimizer_init(nns, cfg, arch_dict)
+    sd0 = {n: {k: v.clone() for k, v in net.state_dict().items()} for n, net in nns.items()}
+    g = torch.Generator().manual_seed(seed + 2)
+    batches = []
+    for _ in range(n_batches):
+        inp = torch.randn(T, B, nfea + 2, generator=g)
+        inp[:, :, nfea] = torch.randint(0, n_cd, (T, B), generator=g).float()
+        inp[:, :, nfea + 1] = torch.randint(0, n_mono, (T, B), generator=g).float()
+        batches.append(inp)
+    torch.manual_seed(seed + 3)
+    losses, errs = [], []
+    with _MaskTap() as tap:
+        for step in range(n_steps):
+            inp = batches[step % n_batches]
+            outs = ref_utils.forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out_dict,
+                                           T, B, "train", [])
+            for opt in optimizers:
+                optimizers[opt].zero_grad()
+            outs["loss_final"].backward()
+            for opt in optimizers:
+                optimizers[opt].step()
+            losses.append(float(outs["loss_final"]))
+            errs.append(float(outs["err_final"]))
+    arrays = {"batches": torch.stack(batches), "loss": np.array(losses, dtype=np.float64),
+              "err": np.array(errs, dtype=np.float64)}
+    for n, net in nns.items():
+        for k, v in sd0[n].items():
+            arrays["sd/%s/%s" % (n, k)] = v
+        for k, v in net.state_dict().items():
+            arrays["sd_final/%s/%s" % (n, k)] = v
+    for i, m in enumerate(tap.masks):
+        arrays["mask/%d" % i] = m
+    opts = {sec: dict(cfg[sec]) for sec in ("architecture1", "architecture2", "architecture3")}
+    meta = {"options": opts, "model": model, "nfea": nfea, "T": T, "B": B, "seed": seed, "n_cd": n_cd,
+            "n_mono": n_mono, "n_masks": len(tap.masks), "n_batches": n_batches, "n_steps": n_steps,
+            "n_lay": len(H)}
+    _save(name, meta, arrays)
+    print("  loss %.4f -> %.4f, err %.3f -> %.3f" % (losses[0], losses[-1], errs[0], errs[-1]))
+
+
+def _rows_sample(t, cap=8192):
+    """Row subsample of a gradient / output tensor that keeps a fixture small: every `stride`-th row of the 2-D view."""
+    t2 = t.reshape(t.shape[0], -1) if t.dim() > 1 else t.reshape(1, -1)
+    stride = max(1, -(-t2.numel() // cap))
+    if t.dim() <= 1:
+        return t2[0, ::stride], stride
+    stride = min(stride, t2.shape[0])
+    return t2[::stride], stride
+
+
+def _projections(t, seed, k=4):
+    """k projections of the flattened tensor on seeded Rademacher directions (numpy RandomState: bit-stable across
+    platforms): a whole-tensor checksum that, unlike a norm, also sees sign / position errors."""
+    v = t.detach().double().reshape(-1).numpy()
+    rs = np.random.RandomState(seed)
+    return np.array([float(np.dot(v, rs.randint(0, 2, v.size) * 2.0 - 1.0)) for _ in range(k)])
+
+
+def scale_case(name, seed, T=500, B=4):
+    """Config-scale golden: the UNSCALED recipe - liGRU 5 x 550 bidirectional,
+    BatchNorm, relu, drop 0.2, 1938 + 48 softmax heads - through the reference's utils.model_init / forward_model at the
+    metric's sequence length T = 500 (B = 4 keeps the reference's O(T^2) autograd to minutes).  The 10.1 M parameters
+    are NOT stored: they are what `torch.manual_seed(seed)` + model_init gives (the engine's classes reproduce the
+    reference's initialisation; per-tensor checksums are stored so that a mismatch is reported as such).  Stored:
+    input, drop masks, the reference's ReLU kink pattern (a_t > 0, bit-packed) for the kink-forced gradient check,
+    loss / err, row samples + norms + projections of the three outputs and of every parameter gradient."""
+    import utils as ref_utils
+
+    torch.set_num_threads(8)
+    cfg = _recipe_cfg()
+    nfea = 40
+    fea_dict, lab_dict, arch_dict = _recipe_dicts(nfea)
+    model = cfg["model"]["model"].split("\n")
+    inp_out_dict = {"fmllr": fea_dict["fmllr"][5:]}
+    torch.manual_seed(seed)
+    nns, costs = ref_utils.model_init(inp_out_dict, model, cfg, arch_dict, False, False, "train")
+    g = torch.Generator().manual_seed(seed + 2)
+    inp = torch.randn(T, B, nfea + 2, generator=g)
+    inp[:, :, nfea] = torch.randint(0, 1938, (T, B), generator=g).float()
+    inp[:, :, nfea + 1] = torch.randint(0, 48, (T, B), generator=g).float()
+    arrays, meta_ck = {"inp": inp}, {}
+    for n, net in nns.items():
+        for k, v in net.state_dict().items():
+            if v.is_floating_point():
+                arrays["init_ck/%s/%s" % (n, k)] = np.concatenate(([float(v.double().norm())], _projections(v, 7)))
+    rec = nns["liGRU_layers"]
+    kinks = [[] for _ in rec.act]
+    hooks = [a.register_forward_hook(lambda m, i, o, lst=kinks[li]: lst.append(i[0].detach() > 0))
+             for li, a in enumerate(rec.act)]
+    torch.manual_seed(seed + 3)
+    with _MaskTap() as tap:
+        outs = ref_utils.forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out_dict,
+                                       T, B, "train", [])
+    for h in hooks:
+        h.remove()
+    outs["loss_final"].backward()
+    arrays["loss_final"], arrays["err_final"] = outs["loss_final"], outs["err_final"]
+    for k in ("out_dnn1", "out_dnn2", "out_dnn3"):
+        o = outs[k].detach().reshape(T * B, -1)
+        smp, stride = _rows_sample(o, 65536)
+        arrays["out/%s/rows" % k], meta_ck["out/%s/stride" % k] = smp, stride
+        arrays["out/%s/ck" % k] = np.concatenate(([float(o.double().norm())], _projections(o, 11)))
+    for li, lst in enumerate(kinks):  # (T, 2B, H) booleans in the reference's row order, bit-packed
+        k = torch.stack(lst).numpy()
+        assert k.shape == (T, 2 * B, 550)
+        arrays["kink/%d" % li] = np.packbits(k.reshape(-1))
+    for n, net in nns.items():
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                continue
+            smp, stride = _rows_sample(p.grad, 8192)
+            arrays["grad/%s/%s/rows" % (n, k)], meta_ck["grad/%s/%s/stride" % (n, k)] = smp, stride
+            arrays["grad/%s/%s/ck" % (n, k)] = np.concatenate(([float(p.grad.double().norm())], _projections(p.grad, 13)))
+    for i, m in enumerate(tap.masks):
+        arrays["mask/%d" % i] = m.to(torch.uint8)
+    opts = {sec: dict(cfg[sec]) for sec in ("architecture1", "architecture2", "architecture3")}
+    meta = {"options": opts, "model": model, "nfea": nfea, "T": T, "B": B, "seed": seed, "n_masks": len(tap.masks),
+            "strides": meta_ck, "H": 550, "n_lay": 5}
+    _save(name, meta, arrays)
+    print("  loss_final %.6f err_final %.4f" % (float(outs["loss_final"]), float(outs["err_final"])))
+
+
 def chunk_case(name, seed):
     """Drive the reference's own chunk loop, core.run_nn (core.py:439-753), on an in-memory synthetic chunk: train a
     tiny Li-GRU recipe for one chunk from scratch (checkpoint ck0), continue for a second chunk from ck0 (-> ck1 +
@@ -664,6 +834,12 @@ def main():
     if os.environ.get("PK_GOLDEN_ONLY") == "model_lang":
         model_lang_case("e2e_model_language", 333)
         return
+    if os.environ.get("PK_GOLDEN_ONLY") == "train":
+        train_case("train_ligru_30steps", 4100, lr=0.004)
+        return
+    if os.environ.get("PK_GOLDEN_ONLY") == "scale":
+        scale_case("scale_ligru_T500", 4234)
+        return
     if os.environ.get("PK_GOLDEN_ONLY") == "oracle_extra":
         oracle_extra_cases()
         return
@@ -719,6 +895,8 @@ def main():
     # --- one level up: the shipped recipe through utils.forward_model ------------
     e2e_case("e2e_ligru_two_heads", 800, T=10, B=4, H=16, n_cd=23, n_mono=7)
     model_lang_case("e2e_model_language", 333)
+    train_case("train_ligru_30steps", 4100, lr=0.004)   # CE-loss trajectory over 30 optimizer steps
+    scale_case("scale_ligru_T500", 4234)      # the unscaled recipe at T = 500 (minutes of CPU time)
 
     # --- two levels up: the chunk loop core.run_nn (train from scratch, continue, validate, forward) ---
     chunk_case("chunk_ligru_run_nn", 1234)

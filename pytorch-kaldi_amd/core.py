@@ -27,6 +27,7 @@ import time
 import numpy as np
 import torch
 
+from . import _lib
 from . import dp as _dp
 from ._lib import PkError
 from .graphs import GraphedStep
@@ -84,34 +85,65 @@ class BatchAssembler:
         pad = torch.zeros(1, data_set.shape[1], dtype=data_set.dtype, device=data_set.device)
         self.src = torch.cat((data_set, pad), 0)
         self.device = device
-        self._pinned = [None, None]
-        self._flip = 0
+        self._ring = []  # pinned staging slots [buffer, event of its last H2D copy]
+        self._slot = 0
 
-    def index_map(self, snt_index, batch_size, cols=None):
-        """(max_len, len(cols)) source-row map of the batch starting at sentence ``snt_index``.  Draws one
-        ``random.randint`` per sentence of the WHOLE batch, in order, like the reference does, so that every
-        rank (and the oracle) sees the same padding whatever columns it keeps."""
+    RING = 4
+
+    def _draw(self, snt_index, batch_size, cols):
+        """One ``random.randint`` per sentence of the WHOLE batch, in order, like the reference does (core.py:588),
+        so that every rank (and the oracle) sees the same padding whatever columns it keeps."""
         lens = self.len[snt_index:snt_index + batch_size]
         max_len = int(lens.max())
         left = np.array([random.randint(0, int(max_len - n)) for n in lens], dtype=np.int64)
         cols = np.arange(batch_size) if cols is None else np.asarray(cols)
+        return max_len, left[cols], lens[cols], self.beg[snt_index + cols]
+
+    def index_map(self, snt_index, batch_size, cols=None):
+        """(max_len, len(cols)) source-row map of the batch starting at sentence ``snt_index`` (host version)."""
+        max_len, left, lens, beg = self._draw(snt_index, batch_size, cols)
         t = np.arange(max_len, dtype=np.int64)[:, None]
-        rel = t - left[cols][None, :]
-        valid = (rel >= 0) & (rel < lens[cols][None, :])
-        idx = np.where(valid, self.beg[snt_index + cols][None, :] + rel, self.n_rows)
+        rel = t - left[None, :]
+        valid = (rel >= 0) & (rel < lens[None, :])
+        idx = np.where(valid, beg[None, :] + rel, self.n_rows)
         return max_len, idx
 
+    def _stage(self, host):
+        """Asynchronous H2D copy of a small int64 array through a ring of pinned slots.  A slot is rewritten only
+        after the event recorded behind its previous copy has completed: the host runs several batches ahead of the
+        GPU (no sync inside a chunk), so an unguarded slot would be overwritten while its DMA is still pending."""
+        n = host.numel()
+        if len(self._ring) < self.RING:
+            self._ring.append([torch.empty(max(n, 64), dtype=torch.int64).pin_memory(), None])
+            slot = self._ring[-1]
+        else:
+            slot = self._ring[self._slot]
+            self._slot = (self._slot + 1) % self.RING
+            if slot[1] is not None:
+                slot[1].synchronize()
+            if slot[0].numel() < n:
+                slot[0] = torch.empty(n, dtype=torch.int64).pin_memory()
+        slot[0][:n].copy_(host.reshape(-1))
+        dev = slot[0][:n].to(self.src.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        slot[1] = ev
+        return dev.view(host.shape)
+
     def batch(self, snt_index, batch_size, cols=None):
-        max_len, idx = self.index_map(snt_index, batch_size, cols)
-        it = torch.from_numpy(idx.reshape(-1))
         if self.src.is_cuda:
-            buf = self._pinned[self._flip]
-            if buf is None or buf.numel() < it.numel():
-                buf = self._pinned[self._flip] = torch.empty(max(it.numel(), 1), dtype=torch.int64).pin_memory()
-            self._flip ^= 1
-            buf[:it.numel()].copy_(it)
-            it = buf[:it.numel()].to(self.src.device, non_blocking=True)
-        out = self.src.index_select(0, it).view(max_len, idx.shape[1], -1)
+            # only (left, lens, beg) - 3 x B integers - cross PCIe; the (max_len, B) row map is built on the device
+            max_len, left, lens, beg = self._draw(snt_index, batch_size, cols)
+            llb = self._stage(torch.from_numpy(np.stack((left, lens, beg))))
+            rel = torch.arange(max_len, device=self.src.device)[:, None] - llb[0][None, :]
+            idx = torch.where((rel >= 0) & (rel < llb[1][None, :]), llb[2][None, :] + rel, self.n_rows)
+            ncol = idx.shape[1]
+            it = idx.reshape(-1)
+        else:
+            max_len, idx = self.index_map(snt_index, batch_size, cols)
+            ncol = idx.shape[1]
+            it = torch.from_numpy(idx.reshape(-1))
+        out = self.src.index_select(0, it).view(max_len, ncol, -1)
         if out.device != self.device:
             out = out.pin_memory().to(self.device, non_blocking=True) if self.device.type == "cuda" else out.to(self.device)
         return max_len, out
@@ -309,6 +341,9 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
     if to_do != "forward":
         loss_sum, err_sum = mean_over_ranks(loss_sum, err_sum, world)
     torch.cuda.synchronize()
+    # a bounded-spin time-out of a persistent recurrent kernel invalidates that launch's results: it must surface
+    # BEFORE this chunk's .pkl / .info are written (the counter is host-mapped, read after the sync above)
+    _lib.raise_if_persist_failed()
     elapsed_time_chunk = time.time() - start_time
     loss_tot = loss_sum / max(N_batches, 1)
     err_tot = err_sum / max(N_batches, 1)

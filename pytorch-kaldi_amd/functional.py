@@ -62,6 +62,53 @@ def set_rec_algo(a):
 
 
 # ----------------------------------------------------------------------------
+# Kink-forced test mode (protocol 3b).  A ReLU recurrence is piecewise linear: a 1e-7
+# forward difference that moves a pre-activation a_t across 0 changes WHICH linear piece is differentiated, and two
+# correct fp32 runs of the reference then differ by 4e-4 (T=100) .. 3e-3 (T=500) in gradient norm.  To grade
+# gradients at 1e-4 at any T the backward pass can be told the reference's own pattern (a_t > 0): the saved
+# pre-activation of every (step, row, unit) keeps its magnitude and takes the reference's sign before BPTT runs, so
+# both sides differentiate the same piece.  Test infrastructure: off unless set_forced_kinks() is called.
+# ----------------------------------------------------------------------------
+class _Kinks:
+    queue = None   # list of bool tensors (T, R, H) in the reference's row order (rows >= B = time-reversed copies),
+    report = None  # one per recurrent layer call, consumed in call order; report: (flipped, total, max |a| flipped)
+
+
+def set_forced_kinks(patterns):
+    """patterns: list of (T, R, H) bool tensors, one per recurrent layer in forward order, or None to switch off.
+    Returns the report list that fills up as layers consume their pattern."""
+    _Kinks.queue = None if patterns is None else list(patterns)
+    _Kinks.report = []
+    return _Kinks.report
+
+
+_KINK_SLOT = {"liGRU": 1, "RNN": 0, "GRU": 2, "minimalGRU": 1}
+
+
+def _force_kinks(S, cell, T, B, ndir, H):
+    if _Kinks.queue is None:
+        return
+    if cell not in _KINK_SLOT:
+        raise _lib.PkError("kink-forced mode covers the cells whose candidate goes through act(a): %s" % cell)
+    k = _Kinks.queue.pop(0).to(S.device)
+    NS = S.shape[2] // H
+    flipped, worst = 0, 0.0
+    for d in range(ndir):  # S[d] is indexed by ORIGINAL time; the reference's reversed rows run backwards in time
+        a = S[d].view(T, B, NS, H)[:, :, _KINK_SLOT[cell], :]
+        kd = k[:, d * B:(d + 1) * B]
+        if d == 1:
+            kd = torch.flip(kd, [0])
+        diff = (a > 0) != kd
+        n = int(diff.sum())
+        if n:
+            flipped += n
+            worst = max(worst, float(a[diff].abs().max()))
+        mag = a.abs().clamp_min(1e-30)
+        a.copy_(torch.where(kd, mag, -mag))
+    _Kinks.report.append((flipped, ndir * T * B * H, worst))
+
+
+# ----------------------------------------------------------------------------
 # small helpers
 # ----------------------------------------------------------------------------
 def _p(t):
@@ -620,6 +667,7 @@ class RecLayerFn(torch.autograd.Function):
                                 _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(ln_gamma), _p(ln_beta), _p(Y),
                                 _p(S), _p(LNS), _p(work))
             _lib.check(rc, "pk_rec_fwd")
+        _force_kinks(S, cell, T, B, ndir, H)
         ctx.bf = bf
         ctx.Yb = Yb
         if bf:
@@ -828,6 +876,7 @@ class RecLayerPerfFn(torch.autograd.Function):
             rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
                                      _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1], fill.done)
             _lib.check(rc, "pk_rec_fwd_bf16")
+        _force_kinks(S, cell, T, B, ndir, H)
         ctx.dGb = dGb if fill.done else None
         ctx.Xb = Xb
         ctx.save_for_backward(xb, Wb, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, Yb)

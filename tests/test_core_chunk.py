@@ -58,6 +58,32 @@ def test_batch_assembler_matches_reference_padding_loop():
         assert random.getstate() == state_after  # same RNG consumption whatever columns a rank keeps
 
 
+@pytest.mark.gpu
+def test_batch_assembler_device_path_with_the_host_running_ahead():
+    """The device path uploads (left, lens, beg) through a ring of pinned slots guarded by events and builds the row
+    map on the GPU.  200 batches are enqueued behind a long-running kernel without any host sync - the host is far
+    ahead of the DMA engine, the situation in which an unguarded staging buffer hands a batch the padding of a later
+    one - and every batch must equal the reference's padding loop bit for bit."""
+    rng = np.random.RandomState(3)
+    lens = rng.randint(5, 60, size=64)
+    end = np.cumsum(lens)
+    data = torch.randn(int(end[-1]), 7, generator=torch.Generator().manual_seed(1))
+    dev = torch.device("cuda")
+    asm = core.BatchAssembler(data.cuda(), end, dev)
+    starts = [int(s) for s in rng.randint(0, 64 - 8, size=200)]
+    random.seed(5)
+    want = [reference_batch(data, end, s, 8) for s in starts]
+    random.seed(5)
+    busy = torch.randn(4096, 4096, device=dev)
+    for _ in range(20):  # keep the GPU queue occupied so that the copies below stay pending while the host loops
+        busy = busy @ busy
+        busy = busy / busy.norm()
+    got = [asm.batch(s, 8) for s in starts]
+    torch.cuda.synchronize()
+    for (wl, w), (gl, g_) in zip(want, got):
+        assert wl == gl and torch.equal(g_.cpu(), w)
+
+
 def test_sentence_lengths_and_counts(tmp_path):
     assert list(core.sentence_lengths([3, 7, 12])) == [3, 4, 5]
     p = tmp_path / "counts"

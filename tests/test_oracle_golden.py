@@ -6,7 +6,7 @@ import torch
 import pk_oracle as O
 from golden_util import Golden, check_grads, list_cases, rel_err
 
-MODULE_CASES = [c for c in list_cases() if not c.startswith(("e2e_", "chunk_", "io_"))]
+MODULE_CASES = [c for c in list_cases() if not c.startswith(("e2e_", "chunk_", "io_", "train_", "scale_"))]
 TOL = 2e-6  # same arithmetic, same library: only summation-order noise is allowed
 
 
@@ -78,3 +78,42 @@ def test_oracle_e2e_forward_model():
             if float(ref.norm()) < 1e-9:
                 continue
             assert rel_err(sd[k].grad, ref) < 5e-5, (arch, k)
+
+
+def test_oracle_loss_trajectory():
+    """CE-loss match, CPU leg: the oracle (pk_oracle forward + two_head_loss, torch.optim.RMSprop as utils.py:2148-2164
+    configures it) replays the reference's 30 training steps of tests/golden/train_ligru_30steps.npz - same initial
+    parameters, same batches, same drop masks - and reproduces loss_final / err_final of every step."""
+    g = Golden("train_ligru_30steps")
+    m = g.meta
+    opts, nfea, n_lay = m["options"], m["nfea"], m["n_lay"]
+    sds, optims = {}, {}
+    for arch, sec in (("liGRU_layers", "architecture1"), ("MLP_layers", "architecture2"), ("MLP_layers2", "architecture3")):
+        sd = g.group("sd/%s/" % arch)
+        for k in sd:
+            if sd[k].is_floating_point() and "running" not in k:
+                sd[k].requires_grad_(True)
+        sds[arch] = sd
+        o = opts[sec]
+        optims[arch] = torch.optim.RMSprop([v for v in sd.values() if v.requires_grad], lr=float(o["arch_lr"]),
+                                           alpha=float(o["opt_alpha"]), eps=float(o["opt_eps"]),
+                                           momentum=float(o["opt_momentum"]), weight_decay=float(o["opt_weight_decay"]))
+    batches, masks = g.t("batches"), g.masks()
+    for step in range(m["n_steps"]):
+        inp = batches[step % m["n_batches"]]
+        out1 = O.recurrent_forward("liGRU", opts["architecture1"], sds["liGRU_layers"], inp[:, :, :nfea],
+                                   drop_masks=masks[step * n_lay:(step + 1) * n_lay])
+        loss, err, _, _ = O.two_head_loss(out1, sds["MLP_layers"], opts["architecture2"], sds["MLP_layers2"],
+                                          opts["architecture3"], inp[:, :, nfea].reshape(-1).long(),
+                                          inp[:, :, nfea + 1].reshape(-1).long())
+        for o in optims.values():
+            o.zero_grad()
+        loss.backward()
+        for o in optims.values():
+            o.step()
+        assert abs(float(loss) - g.arrays["loss"][step]) < 2e-5 * g.arrays["loss"][step], step
+        assert abs(float(err) - g.arrays["err"][step]) < 1e-9, step
+    for arch, sd in sds.items():
+        for k, ref in g.group("sd_final/%s/" % arch).items():
+            if ref.is_floating_point() and float(ref.norm()) > 0:
+                assert rel_err(sd[k], ref) < 5e-5, (arch, k)

@@ -51,6 +51,7 @@ def parse():
                     help="replay the step as one HIP graph (auto: the launch-bound non-sequence recipes on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--cpu-T", type=int, default=500, help="sequence length of the CPU baseline sample (batch 8)")
     return ap.parse_args()
 
 
@@ -239,14 +240,19 @@ def cpu_baseline(args, rcp_name):
             opts.append(torch.optim.SGD(leaves, lr=float(cfg[k]["arch_lr"])))
         else:
             opts.append(torch.optim.RMSprop(leaves, lr=float(cfg[k]["arch_lr"]), alpha=0.95, eps=1e-8))
-    T, B = (50, 8) if rcp["seq"] else (1, 128)
+    # sequence recipes: the metric's sequence length (the reference's autograd cost per frame GROWS with T, SURVEY.md
+    # 3.3), a batch of 8 so that a step is seconds of CPU work
+    T, B = (args.cpu_T, 8) if rcp["seq"] else (1, 128)
 
     def one_step(seed):
         inp = R.synthetic_batch(rcp, T, B, seed)
         x = inp[..., :rcp["nfea"]]
         lab_cd = inp[..., rcp["nfea"]].reshape(-1).long()
         if rcp["seq"]:
-            h = O.recurrent_forward(kind, dict(a1), sds["architecture1"], x)
+            # index_like_reference: the projections are indexed inside the time loop as the reference does it
+            # (neural_networks.py:1133-1134) - that is what makes its backward O(T^2), and with it the port runs
+            # within 4-11 % of the reference's own speed (profiles/r02_cpu_port_vs_reference.json)
+            h = O.recurrent_forward(kind, dict(a1), sds["architecture1"], x, index_like_reference=True)
             h = h.reshape(T * B, -1)
         else:
             h = O.arch_forward(kind, dict(a1), sds["architecture1"], x)
@@ -280,8 +286,10 @@ def cpu_baseline(args, rcp_name):
     except OSError:
         pass
     return {"value": round(n * T * B / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of the same network (fwd+bwd+the cfg optimizers) at T=%d, B=%d on %s, torch-CPU oracle fp32" %
-                      (n, T, B, model or "host CPU")}
+            "sample": "%d steps of the same network (fwd+bwd+the cfg optimizers) at T=%d, B=%d on %s, torch-CPU oracle fp32, "
+                      "projections indexed in the time loop like the reference; the reference's own classes run 1.04x "
+                      "(T=500) / 1.11x (T=50) slower than this port on the build host (profiles/r02_cpu_port_vs_reference.json)"
+                      % (n, T, B, model or "host CPU")}
 
 
 def main():

@@ -195,12 +195,26 @@ def make_drop_masks(kind, options, batch, to_do="train", generator=None):
     return masks
 
 
+def _act_kink_forced(name, a, pattern):
+    """Value act(a); derivative taken on the linear piece `pattern` (a_t > 0 as ANOTHER run saw it) instead of this
+    run's own sign of a (two runs that differ by rounding noise then differentiate the same
+    piecewise-linear function).  ReLU only - the smooth activations have no kinks."""
+    if name != "relu":
+        raise ValueError("kink-forced derivative is defined for relu")
+    lin = a * pattern.to(a.dtype)
+    return lin + (torch.relu(a) - lin).detach()
+
+
 def recurrent_forward(kind, options, sd, x, training=True, to_do="train", drop_masks=None,
-                      index_like_reference=False, return_all=False):
+                      index_like_reference=False, return_all=False, kinks=None):
     """Forward of LSTM/GRU/liGRU/minimalGRU/RNN exactly as the reference orders
     it: pack bidirectional on the batch axis, per-gate Linear over all steps,
     per-gate BatchNorm over the T*rows rows, python time loop from h=0, stack,
     unpack (neural_networks.py:402-483, 579-655, 1082-1155, 1243-1316, 1396-1461).
+
+    ``kinks``: optional list (one per layer) of (T, rows, H) bool tensors = the pattern (a_t > 0) of another run; the
+    candidate's ReLU then takes its derivative from that pattern (test mode for long sequences, see
+    _act_kink_forced).
 
     ``index_like_reference=True`` indexes the projections with ``w_out[k]`` inside
     the loop as the reference does (this is what makes its backward O(T^2));
@@ -242,6 +256,11 @@ def recurrent_forward(kind, options, sd, x, training=True, to_do="train", drop_m
         def U(name, h):
             return F.linear(h, sd["%s.%d.weight" % (name, i)])
 
+        def cand(at, k):
+            if kinks is not None:
+                return _act_kink_forced(acts[i], at, kinks[i][k])
+            return activation(acts[i], at)
+
         hs = []
         ht = h0
         ct = h0
@@ -249,18 +268,18 @@ def recurrent_forward(kind, options, sd, x, training=True, to_do="train", drop_m
             if kind == "liGRU":  # :1133-1136
                 zt = torch.sigmoid(proj["wz"][k] + U("uz", ht))
                 at = proj["wh"][k] + U("uh", ht)
-                hcand = activation(acts[i], at) * mask
+                hcand = cand(at, k) * mask
                 ht = zt * ht + (1 - zt) * hcand
             elif kind == "minimalGRU":  # :1294-1297
                 zt = torch.sigmoid(proj["wz"][k] + U("uz", ht))
                 at = proj["wh"][k] + U("uh", zt * ht)
-                hcand = activation(acts[i], at) * mask
+                hcand = cand(at, k) * mask
                 ht = zt * ht + (1 - zt) * hcand
             elif kind == "GRU":  # :632-636
                 zt = torch.sigmoid(proj["wz"][k] + U("uz", ht))
                 rt = torch.sigmoid(proj["wr"][k] + U("ur", ht))
                 at = proj["wh"][k] + U("uh", rt * ht)
-                hcand = activation(acts[i], at) * mask
+                hcand = cand(at, k) * mask
                 ht = zt * ht + (1 - zt) * hcand
             elif kind == "LSTM":  # :460-464
                 ft = torch.sigmoid(proj["wfx"][k] + U("ufh", ht))
@@ -270,7 +289,7 @@ def recurrent_forward(kind, options, sd, x, training=True, to_do="train", drop_m
                 ht = ot * activation(acts[i], ct)
             elif kind == "RNN":  # :1441-1442
                 at = proj["wh"][k] + U("uh", ht)
-                ht = activation(acts[i], at) * mask
+                ht = cand(at, k) * mask
             else:
                 raise ValueError(kind)
             if use_ln[i]:

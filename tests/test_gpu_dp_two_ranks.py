@@ -1,0 +1,62 @@
+"""The data-parallel path EXECUTED on hardware: two ranks (one process each, torch.distributed.run) on the one GPU of
+the box, through dp.GradReducer over the fused optimizers' flat buckets, with the persistent recurrent kernels and the
+side-stream weight gradients of the perf pipeline running in both processes at once.
+
+Parity definition: per-replica BatchNorm statistics, gradients averaged over the shards - i.e. the
+two-rank parameters after K optimizer steps equal a single process that runs the two shards in turn on the same
+parameters and steps with the averaged gradient (tests/dp_two_ranks_gpu.py --reference).
+
+Backend: "nccl" (= RCCL) is tried first.  RCCL refuses two ranks on one device ("Duplicate GPU detected"); when it
+does, the same run goes over gloo on the device tensors - every kernel, stream and bucket of the path still runs, only
+the transport differs - and the test says which backend ran.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "dp_two_ranks_gpu.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_dp(out, prec, overlap, backend):
+    env = dict(os.environ, PK_DP_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), WORKER, "--out", out, "--prec", prec, "--overlap", str(overlap)]
+    return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+
+
+@pytest.mark.parametrize("prec,overlap", [("fp32", 0), ("bf16", 0), ("bf16", 1)])
+def test_two_ranks_on_one_gpu_equal_the_shard_average(tmp_path, prec, overlap):
+    ref_out, dp_out = str(tmp_path / "ref.pt"), str(tmp_path / "dp.pt")
+    r = subprocess.run([sys.executable, WORKER, "--reference", "--out", ref_out, "--prec", prec], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-3000:]
+    used = None
+    for backend in ("nccl", "gloo"):
+        r = _run_dp(dp_out, prec, overlap, backend)
+        if r.returncode == 0:
+            used = backend
+            break
+        dup = "uplicate GPU" in r.stdout or "invalid usage" in r.stdout.lower() or "ncclInvalidUsage" in r.stdout
+        assert backend == "nccl" and dup, "two-rank run failed on %s:\n%s" % (backend, r.stdout[-4000:])
+    print("two ranks on one GPU ran over", used)
+    ref, got = torch.load(ref_out), torch.load(dp_out)
+    # fp32 mode: same kernels, same order within a shard - the only difference is the order of the two-term average
+    tol = 2e-6 if prec == "fp32" else 2e-3
+    for k in ref:
+        den = float(ref[k].double().norm())
+        err = float((got[k].double() - ref[k].double()).norm()) / den
+        assert err < tol, (k, err, used)

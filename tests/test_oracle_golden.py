@@ -1,5 +1,6 @@
 """Pins oracle/pk_oracle.py to the reference: every fixture in tests/golden was
 produced by the reference's own classes (oracle/make_golden.py)."""
+import numpy as np
 import pytest
 import torch
 
@@ -117,3 +118,72 @@ def test_oracle_loss_trajectory():
         for k, ref in g.group("sd_final/%s/" % arch).items():
             if ref.is_floating_point() and float(ref.norm()) > 0:
                 assert rel_err(sd[k], ref) < 5e-5, (arch, k)
+
+
+def test_oracle_config_scale_golden():
+    """The UNSCALED recipe (liGRU 5 x 550 bidirectional + 1938 / 48 heads) at T = 500, B = 4 against the reference's
+    own run (tests/golden/scale_ligru_T500.npz).  Parameters come from the seed through this package's model_init
+    mirror and classes (checksums of the reference's initialisation are in the fixture); gradients are taken with the
+    reference's kink pattern, so the comparison holds on any CPU / thread count (Appendix B: two unforced fp32 runs of
+    the reference differ by 3e-3 at this length)."""
+    import configparser
+    import importlib
+
+    g = Golden("scale_ligru_T500")
+    m = g.meta
+    T, B, H, L, nfea = m["T"], m["B"], m["H"], m["n_lay"], m["nfea"]
+    U = importlib.import_module("pytorch-kaldi_amd.utils")
+    cfg = configparser.ConfigParser()
+    cfg["exp"] = {"to_do": "train", "use_cuda": "False"}
+    for sec, opts in m["options"].items():
+        cfg[sec] = {k: v.replace("%", "%%") for k, v in opts.items()}
+        cfg[sec]["arch_library"] = "pytorch-kaldi_amd.nn"
+    arch_dict = {"liGRU_layers": ["architecture1", "liGRU_layers", True], "MLP_layers": ["architecture2", "MLP_layers", False],
+                 "MLP_layers2": ["architecture3", "MLP_layers2", False]}
+    torch.manual_seed(m["seed"])
+    nns, _ = U.model_init({"fmllr": [0, nfea, nfea]}, m["model"], cfg, arch_dict, False, False, "train")
+
+    def ck(t, seed):
+        v = t.detach().double().reshape(-1).numpy()
+        rs = np.random.RandomState(seed)
+        return np.concatenate(([float(np.linalg.norm(v))], [float(np.dot(v, rs.randint(0, 2, v.size) * 2.0 - 1.0))
+                                                            for _ in range(4)]))
+
+    sds = {}
+    for n, net in nns.items():
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        for k in sd:
+            if sd[k].is_floating_point():
+                ref = g.arrays["init_ck/%s/%s" % (n, k)]
+                assert np.abs(ck(sd[k], 7) - ref).max() <= 1e-5 * max(1.0, ref[0]), ("initialisation differs", n, k)
+                if "running" not in k:
+                    sd[k].requires_grad_(True)
+        sds[n] = sd
+    inp = g.t("inp")
+    masks = [g.t("mask/%d" % i).float() for i in range(m["n_masks"])]
+    kinks = [torch.from_numpy(np.unpackbits(g.arrays["kink/%d" % i])[:T * 2 * B * H].reshape(T, 2 * B, H).astype(bool))
+             for i in range(L)]
+    out1 = O.recurrent_forward("liGRU", m["options"]["architecture1"], sds["liGRU_layers"], inp[:, :, :nfea],
+                               drop_masks=masks, kinks=kinks)
+    loss, err, out2, out3 = O.two_head_loss(out1, sds["MLP_layers"], m["options"]["architecture2"], sds["MLP_layers2"],
+                                            m["options"]["architecture3"], inp[:, :, nfea].reshape(-1).long(),
+                                            inp[:, :, nfea + 1].reshape(-1).long())
+    loss.backward()
+    st = m["strides"]
+    for k, o in (("out_dnn1", out1), ("out_dnn2", out2), ("out_dnn3", out3)):
+        o = o.reshape(T * B, -1)
+        assert rel_err(o[::st["out/%s/stride" % k]], g.t("out/%s/rows" % k)) < TOL, k
+        assert abs(ck(o, 11)[0] - g.arrays["out/%s/ck" % k][0]) < TOL * g.arrays["out/%s/ck" % k][0]
+    assert abs(float(loss) - float(g.t("loss_final"))) < 1e-6 * float(g.t("loss_final"))
+    assert float(err) == float(g.t("err_final"))
+    for n, sd in sds.items():
+        for k, v in sd.items():
+            key = "grad/%s/%s" % (n, k)
+            if key + "/rows" not in g.arrays:
+                assert v.grad is None or not v.requires_grad
+                continue
+            gr = v.grad
+            rows = gr.reshape(gr.shape[0], -1)[::st[key + "/stride"]] if gr.dim() > 1 else gr[::st[key + "/stride"]]
+            ref = g.t(key + "/rows")
+            if float(ref.norm()) > 1e-9:
+                assert rel_err(rows, ref) < 5e-5, (n, k)

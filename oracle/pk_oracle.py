@@ -123,8 +123,63 @@ def flip_time(x):
     return torch.flip(x, dims=[0])
 
 
+# ----------------------------------------------------------------------------
+# bf16-operand model of the engine's perf mode (test infrastructure, like the rest of this file).
+# The HIP engine's "bf16" mode computes the SAME algorithm with the operands of every GEMM - projections, the
+# recurrent h_{t-1}.U^T, Linear layers, and in backward dY.W, dY^T.x, dgates.U, dgates^T.h - rounded to bf16
+# (round-to-nearest-even, v_cvt_pk_bf16_f32) and the products accumulated in fp32; everything element-wise (gates,
+# BatchNorm, LayerNorm, softmax, state) stays fp32.  `with bf16_operands():` makes every matrix product of this oracle
+# do exactly that, so a test can separate (i) "the engine implements the bf16-operand algorithm" (engine vs this model:
+# tight) from (ii) "how far the bf16-operand algorithm is from the reference's fp32 results on this network" (this
+# model vs the golden arrays: intrinsic, network-dependent).
+# ----------------------------------------------------------------------------
+_EMUL = {"bf16": False}
+
+
+class bf16_operands:
+    def __enter__(self):
+        self.prev = _EMUL["bf16"]
+        _EMUL["bf16"] = True
+        return self
+
+    def __exit__(self, *exc):
+        _EMUL["bf16"] = self.prev
+
+
+def _rb(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _Bf16Linear(torch.autograd.Function):
+    """y = round(x) . round(w)^T in fp32; backward dx = round(g) . round(w), dw = round(g)^T . round(x)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xb, wb = _rb(x), _rb(w)
+        ctx.save_for_backward(xb, wb)
+        return F.linear(xb, wb)
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, wb = ctx.saved_tensors
+        gb = _rb(g)
+        dx = gb.matmul(wb)
+        dw = gb.reshape(-1, gb.shape[-1]).t().matmul(xb.reshape(-1, xb.shape[-1]))
+        return dx, dw
+
+
+def _mm(x, w):
+    """x . w^T - the one place a GEMM operand enters."""
+    if _EMUL["bf16"]:
+        return _Bf16Linear.apply(x, w)
+    return F.linear(x, w)
+
+
 def _linear(x, sd, prefix):
     b = sd.get(prefix + ".bias")
+    if _EMUL["bf16"]:
+        y = _mm(x, sd[prefix + ".weight"])
+        return y if b is None else y + b
     return F.linear(x, sd[prefix + ".weight"], b)
 
 
@@ -254,7 +309,7 @@ def recurrent_forward(kind, options, sd, x, training=True, to_do="train", drop_m
             proj = {k: v.unbind(0) for k, v in proj.items()}
 
         def U(name, h):
-            return F.linear(h, sd["%s.%d.weight" % (name, i)])
+            return _mm(h, sd["%s.%d.weight" % (name, i)])
 
         def cand(at, k):
             if kinks is not None:

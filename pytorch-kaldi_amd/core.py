@@ -84,7 +84,7 @@ class BatchAssembler:
         self.n_rows = data_set.shape[0]
         pad = torch.zeros(1, data_set.shape[1], dtype=data_set.dtype, device=data_set.device)
         self.src = torch.cat((data_set, pad), 0)
-        self.device = device
+        self.device = torch.empty(0, device=device).device  # normalised ("cuda" -> "cuda:<current>")
         self._ring = []  # pinned staging slots [buffer, event of its last H2D copy]
         self._slot = 0
 

@@ -58,6 +58,7 @@ def main():
     world = 2
     if a.reference:
         F_, nns, opts = build(a.prec)
+        g0 = None
         for step in range(a.steps):
             x, lab = batch(step)
             acc = {k: torch.zeros_like(o.flat.grad) for k, o in opts.items()}
@@ -80,27 +81,32 @@ def main():
             for k, o in opts.items():
                 o.flat.grad.copy_(acc[k])
                 o.step()
+            if g0 is None:
+                g0 = {k: v.cpu() for k, v in acc.items()}
         torch.cuda.synchronize()
         _lib.raise_if_persist_failed()
-        torch.save({k: o.flat.flat.cpu() for k, o in opts.items()}, a.out)
+        torch.save({"params": {k: o.flat.flat.cpu() for k, o in opts.items()}, "grad0": g0}, a.out)
         return
     os.environ["LOCAL_RANK"] = "0"  # both ranks on the one GPU of the box
     rank, w, _ = DP.init_from_env(os.environ.get("PK_DP_BACKEND", "nccl"))
     assert w == world
     F_, nns, opts = build(a.prec)
     red = DP.GradReducer(nns, flats={k: o.flat for k, o in opts.items()}, bucket_bytes=64 << 10, overlap=bool(a.overlap))
+    g0 = None
     for step in range(a.steps):
         x, lab = batch(step)
         for o in opts.values():
             o.zero_grad()
         loss_of(nns, DP.shard_batch(x, rank, world), DP.shard_batch(lab, rank, world)).backward()
         red.finish()
+        if g0 is None:
+            g0 = {k: o.flat.grad.cpu() for k, o in opts.items()}
         for o in opts.values():
             o.step()
     torch.cuda.synchronize()
     _lib.raise_if_persist_failed()
     if rank == 0:
-        torch.save({k: o.flat.flat.cpu() for k, o in opts.items()}, a.out)
+        torch.save({"params": {k: o.flat.flat.cpu() for k, o in opts.items()}, "grad0": g0}, a.out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

@@ -54,9 +54,20 @@ def test_two_ranks_on_one_gpu_equal_the_shard_average(tmp_path, prec, overlap):
         assert backend == "nccl" and dup, "two-rank run failed on %s:\n%s" % (backend, r.stdout[-4000:])
     print("two ranks on one GPU ran over", used)
     ref, got = torch.load(ref_out), torch.load(dp_out)
-    # fp32 mode: same kernels, same order within a shard - the only difference is the order of the two-term average
-    tol = 2e-6 if prec == "fp32" else 2e-3
-    for k in ref:
-        den = float(ref[k].double().norm())
-        err = float((got[k].double() - ref[k].double()).norm()) / den
-        assert err < tol, (k, err, used)
+
+    def err(a, b):
+        return float((a.double() - b.double()).norm()) / float(b.double().norm())
+
+    # the averaged gradient of the first step: same kernels on the same shards, only the transport differs
+    # (bf16: the weight-gradient GEMMs accumulate with split-K partials whose order is fixed, like fp32)
+    for k in ref["grad0"]:
+        e = err(got["grad0"][k], ref["grad0"][k])
+        print("first-step averaged gradient", k, "%.2e" % e)
+        assert e < (2e-6 if prec == "fp32" else 1e-3), (k, e, used)
+    # parameters after three RMSprop steps: the update g / (sqrt(v) + eps) is +-lr / sqrt(1 - alpha) for ANY non-zero
+    # g on the first step, so rounding-level differences in near-zero gradient elements become lr-sized parameter
+    # differences - a loose tolerance here, the tight one is on the gradient above
+    for k in ref["params"]:
+        e = err(got["params"][k], ref["params"][k])
+        print("parameters after 3 steps", k, "%.2e" % e)
+        assert e < (1e-3 if prec == "fp32" else 5e-2), (k, e, used)

@@ -12,15 +12,19 @@ reference itself produced (oracle/make_golden.py imports /root/reference unmodif
                                    posteriors / loss at 1e-4, gradients at 1e-4 with the kink-forced backward
                                    (functional.set_forced_kinks).
 
-bf16 tolerances: operands are rounded to bf16 (unit round-off u = 2^-9) once per GEMM, products
-accumulate in fp32, so one GEMM stage adds a norm-relative error of about u*sqrt(2/3)*sqrt(2) = 2.3e-3 to its output
-(both operands rounded, independent errors, norm-relative => independent of K); a recurrent layer is two stages
-(projection, recurrence - whose feedback re-circulates the error through T steps, bounded by the update gate / the
-activation's contraction) and a head one, and independent stages add in quadrature:
-    outputs   tol = 4 * u * sqrt(stages)            (stages = 2 per recurrent layer + 1 per Linear)
-    gradients tol = 4 * u * sqrt(2 * stages + 2)    (the forward error of every stage + the dX / dW GEMMs of backward)
-with u = 2^-9 and a safety factor of 4 on the random-error model (worst tensor of a fixture, tiny layers where a
-single rounding is a visible fraction of the norm).
+bf16 mode is graded in two steps:
+  (A) the engine implements the bf16-OPERAND form of the reference algorithm: every GEMM operand (projections,
+      h_{t-1}.U^T, Linear layers; in backward dY.W, dY^T.x, dgates.U, dgates^T.h) rounded to bf16 (unit round-off
+      u = 2^-9), products accumulated in fp32, everything element-wise in fp32.  oracle/pk_oracle.py models exactly that
+      (`with O.bf16_operands():` - the fp32 oracle, itself pinned to the reference at 2e-6, with operand rounding), so
+      engine vs model must be TIGHT: 5e-3 on outputs, 2e-2 on gradients (what remains is fp32 summation order moving a
+      few values across a bf16 rounding boundary or a ReLU kink);
+  (B) engine vs the reference's own fp32 arrays: bounded by how far the bf16-operand algorithm ITSELF is from fp32 on that
+      network - 1.5 x the model's deviation + 4u.  Analytically one GEMM stage adds u*sqrt(2/3)*sqrt(2) = 2.3e-3
+      norm-relative (independent of K), stages add in quadrature (outputs land at 2-5e-3 for the 2-3 layer fixtures,
+      5e-2 with an input LayerNorm on a 6-dim input); gradients of ReLU networks are dominated by kink flips instead
+      (a pre-activation within a bf16 rounding error of 0 changes the linear piece): 5-13 % on the tiny fixtures,
+      where one flip is a visible fraction of a 9-step, 3-sequence gradient - both numbers are printed by the test.
 """
 import configparser
 import importlib
@@ -30,7 +34,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import Golden, check_grads, grad_err, list_cases, rel_err
+from golden_util import Golden, analytically_zero, grad_err, list_cases, rel_err
 
 pytestmark = pytest.mark.gpu
 U_BF16 = 2.0 ** -9
@@ -39,17 +43,33 @@ BF16_CASES = [c for c in list_cases() if not c.startswith(("e2e_", "chunk_", "io
               and Golden(c).meta["arch_class"] in REC + ("MLP",)]
 
 
-def bf16_tols(n_rec_layers, n_linear):
-    stages = 2 * n_rec_layers + n_linear
-    return 4 * U_BF16 * math.sqrt(stages), 4 * U_BF16 * math.sqrt(2 * stages + 2)
+TIGHT_OUT, TIGHT_GRAD = 5e-3, 2e-2
 
 
-def _stages(meta):
-    o = {k.lower(): v for k, v in meta["options"].items()}
-    if meta["arch_class"] == "MLP":
-        return 0, len(o["dnn_lay"].split(","))
-    pre = {"liGRU": "ligru", "LSTM": "lstm", "GRU": "gru", "minimalGRU": "minimalgru", "RNN": "rnn"}[meta["arch_class"]]
-    return len(o[pre + "_lay"].split(",")), 0
+def model_bound(e_model):
+    """(B): engine-vs-reference bound from the bf16-operand model's own deviation from the reference."""
+    return 1.5 * e_model + 4 * U_BF16
+
+
+def emulate_module(g):
+    """The bf16-operand model on a module fixture: y, dx, grads (CPU)."""
+    import pk_oracle as O
+
+    m = g.meta
+    sd = g.group("sd/")
+    for k in sd:
+        if sd[k].is_floating_point() and "running" not in k:
+            sd[k].requires_grad_(True)
+    x = g.t("x").clone().requires_grad_(True)
+    with O.bf16_operands():
+        y = O.arch_forward(m["arch_class"], m["options"], sd, x, training=m["training"], to_do=m["to_do"],
+                           drop_masks=g.masks() or None)
+        dx = grads = None
+        if "dx" in g.arrays:
+            (y * g.t("cot")).sum().backward()
+            dx = x.grad
+            grads = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
+    return y.detach(), dx, grads
 
 
 @pytest.fixture(autouse=True)
@@ -59,6 +79,17 @@ def _restore_mode():
     F_.set_precision("fp32")
     F_.set_rec_algo("auto")
     F_.set_forced_kinks(None)
+
+
+def _two_step(name, got, model, ref, tight, total=None):
+    """(A) engine vs bf16-operand model, (B) engine vs reference within the model's own deviation."""
+    if total is None:
+        e_a, e_m, e_b = rel_err(got, model), rel_err(model, ref), rel_err(got, ref)
+    else:
+        e_a, e_m, e_b = grad_err(got, model, total), grad_err(model, ref, total), grad_err(got, ref, total)
+    assert e_a < tight, (name, "engine vs bf16-operand model", e_a)
+    assert e_b < model_bound(e_m), (name, "engine vs reference", e_b, "model vs reference", e_m)
+    return e_a, e_m, e_b
 
 
 @pytest.mark.parametrize("case", BF16_CASES)
@@ -73,17 +104,25 @@ def test_golden_module_bf16(case):
     net = build_engine(m, g.group("sd/"))
     has_bwd = "dx" in g.arrays
     y, dx, grads = run_engine(net, m, g.t("x"), g.masks(), g.t("cot") if has_bwd else None)
-    tol_out, tol_grad = bf16_tols(*_stages(m))
-    e = rel_err(y, g.t("y"))
-    assert e < tol_out, (e, tol_out)
+    ym, dxm, gm = emulate_module(g)
+    rep = {"y": _two_step("y", y, ym, g.t("y"), TIGHT_OUT)}
     if has_bwd:
-        e = rel_err(dx, g.t("dx"))
-        assert e < tol_grad, (e, tol_grad)
-        check_grads(grads, g.group("grad/"), m, tol_grad, zero_tol=tol_grad)
+        rep["dx"] = _two_step("dx", dx, dxm, g.t("dx"), TIGHT_GRAD)
+        ref = g.group("grad/")
+        total = float(torch.sqrt(sum((v.double() ** 2).sum() for v in ref.values())))
+        worst = (0.0, 0.0, 0.0)
+        for k, r in ref.items():
+            if analytically_zero(m, k):
+                assert float(grads[k].double().norm()) <= TIGHT_GRAD * total, k
+                continue
+            worst = max(worst, _two_step(k, grads[k], gm[k], r, TIGHT_GRAD, total), key=lambda t: t[2])
+        rep["worst grad"] = worst
+    print("\n%s bf16: " % case + "; ".join("%s engine-vs-model %.1e, model-vs-ref %.1e, engine-vs-ref %.1e" % ((k,) + v)
+                                           for k, v in rep.items()))
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     for k, ref in g.group("sd_after/").items():  # running statistics of BatchNorm: one projection stage
         if ref.is_floating_point():
-            assert rel_err(sd[k], ref) < tol_out, k
+            assert rel_err(sd[k], ref) < 4 * U_BF16, k
         else:
             assert int(sd[k]) == int(ref), k
 
@@ -121,7 +160,33 @@ def _with_masks(rec, masks):
     return orig, fwd
 
 
+def _oracle_recipe(g, sds_prefix="sd/"):
+    """Oracle-side parameter dicts of a recipe fixture (leaf tensors with requires_grad)."""
+    sds = {}
+    for arch in ("liGRU_layers", "MLP_layers", "MLP_layers2"):
+        sd = g.group("%s%s/" % (sds_prefix, arch))
+        for k in sd:
+            if sd[k].is_floating_point() and "running" not in k:
+                sd[k].requires_grad_(True)
+        sds[arch] = sd
+    return sds
+
+
+def _oracle_step(O, m, sds, inp, masks, emulate):
+    import contextlib
+
+    nfea = m["nfea"]
+    with (O.bf16_operands() if emulate else contextlib.nullcontext()):
+        out1 = O.recurrent_forward("liGRU", m["options"]["architecture1"], sds["liGRU_layers"], inp[:, :, :nfea],
+                                   drop_masks=masks)
+        loss, err, out2, out3 = O.two_head_loss(out1, sds["MLP_layers"], m["options"]["architecture2"], sds["MLP_layers2"],
+                                                m["options"]["architecture3"], inp[:, :, nfea].reshape(-1).long(),
+                                                inp[:, :, nfea + 1].reshape(-1).long())
+    return out1, out2, out3, loss, err
+
+
 def test_golden_e2e_bf16():
+    import pk_oracle as O
     from engine_util import F_amd
 
     g = Golden("e2e_ligru_two_heads")
@@ -136,21 +201,49 @@ def test_golden_e2e_bf16():
     outs["loss_final"].backward()
     torch.cuda.synchronize()
     rec.forward = orig
-    tol_out, tol_grad = bf16_tols(2, 1)
-    for k in ("out_dnn1", "out_dnn2", "out_dnn3"):
-        assert rel_err(outs[k].reshape(g.t(k).shape), g.t(k)) < tol_out, k
-    # the loss is a mean over T*B frames of per-frame errors of either sign: a fraction of the per-tensor tolerance
-    assert abs(float(outs["loss_final"]) - float(g.t("loss_final"))) < 0.25 * tol_out * abs(float(g.t("loss_final")))
+    osd = _oracle_recipe(g)
+    o1, o2, o3, oloss, _ = _oracle_step(O, m, osd, g.t("inp"), g.masks(), True)
+    oloss.backward()
+    for k, om in (("out_dnn1", o1), ("out_dnn2", o2), ("out_dnn3", o3)):
+        _two_step(k, outs[k].reshape(g.t(k).shape), om.reshape(g.t(k).shape), g.t(k), TIGHT_OUT)
+    lref = float(g.t("loss_final"))
+    assert abs(float(outs["loss_final"]) - float(oloss)) < TIGHT_OUT * lref
+    assert abs(float(outs["loss_final"]) - lref) < model_bound(abs(float(oloss) - lref) / lref) * lref
     for name, net in nns.items():
         ref = g.group("grad/%s/" % name)
-        got = {k: (p.grad.detach().cpu() if p.grad is not None else None) for k, p in net.named_parameters()}
-        meta = {"arch_class": "MLP" if name.startswith("MLP") else "liGRU", "options": m["options"][arch_dict[name][0]]}
-        check_grads(got, ref, meta, tol_grad, zero_tol=tol_grad)
+        total = float(torch.sqrt(sum((v.double() ** 2).sum() for v in ref.values())))
+        for k, p_ in net.named_parameters():
+            if k in ref and float(ref[k].norm()) > 1e-6 * total:
+                _two_step((name, k), p_.grad, osd[name][k].grad, ref[k], TIGHT_GRAD, total)
 
 
 # --------------------------------------------------------------------------------------------------------------------
 # CE-loss match (BASELINE.json "frames/sec ...; CE-loss match"): the training trajectory
 # --------------------------------------------------------------------------------------------------------------------
+def _model_trajectory(g, n_steps):
+    """The bf16-operand model trained like the fixture (CPU): loss per step."""
+    import pk_oracle as O
+
+    m = g.meta
+    sds = _oracle_recipe(g)
+    optims = []
+    for arch, sec in (("liGRU_layers", "architecture1"), ("MLP_layers", "architecture2"), ("MLP_layers2", "architecture3")):
+        o = m["options"][sec]
+        optims.append(torch.optim.RMSprop([v for v in sds[arch].values() if v.requires_grad], lr=float(o["arch_lr"]),
+                                          alpha=float(o["opt_alpha"]), eps=float(o["opt_eps"])))
+    batches, masks, n_lay = g.t("batches"), g.masks(), m["n_lay"]
+    losses = []
+    for step in range(n_steps):
+        _, _, _, loss, _ = _oracle_step(O, m, sds, batches[step % m["n_batches"]], masks[step * n_lay:(step + 1) * n_lay], True)
+        for o in optims:
+            o.zero_grad()
+        loss.backward()
+        for o in optims:
+            o.step()
+        losses.append(float(loss.detach()))
+    return np.array(losses)
+
+
 @pytest.mark.parametrize("prec,mode", [("fp32", "torch-optim"), ("fp32", "fused"), ("bf16", "fused")])
 def test_ce_loss_trajectory(prec, mode):
     """30 optimizer steps of the (scaled) shipped Li-GRU recipe, reference drop masks, loss_final / err_final of
@@ -189,23 +282,32 @@ def test_ce_loss_trajectory(prec, mode):
     ref_loss, ref_err = g.arrays["loss"], g.arrays["err"]
     assert ref_loss[-1] < ref_loss[0] - 0.2  # the fixture really trains (5.08 -> 4.75)
     rel = np.abs(loss - ref_loss) / np.abs(ref_loss)
-    # fp32: north_star's 1e-4 at EVERY step.  bf16: the loss averages T*B = 80 frames x 2 heads of per-frame errors of
-    # either sign, and the parameters drift apart by one gradient tolerance per step: 1.5e-3 over 30 steps
-    tol = 1e-4 if prec == "fp32" else 1.5e-3
-    assert rel.max() < tol, (prec, mode, float(rel.max()), int(rel.argmax()))
-    # frame error rate: a count over 80 frames; fp32 reproduces the argmax of every frame, bf16 may flip a near-tie
-    flips = np.abs(err - ref_err) * m["T"] * m["B"]
-    assert flips.max() < (0.5 if prec == "fp32" else 2.5), flips.max()
-    # final parameters
-    tol_p = 1e-4 if prec == "fp32" else 2e-2
-    for name, net in nns.items():
-        ref = g.group("sd_final/%s/" % name)
-        for k, v in net.state_dict().items():
-            if v.is_floating_point() and float(ref[k].norm()) > 0:
-                e = rel_err(v, ref[k])
-                assert e < tol_p, (name, k, e)
-            elif not v.is_floating_point():
-                assert int(v) == int(ref[k]), (name, k)
+    flips = np.abs(err - ref_err) * m["T"] * m["B"]  # frame error rate: a count over T*B = 80 frames
+    if prec == "fp32":
+        # north_star's 1e-4 at EVERY step, the argmax of every frame, and the final parameters
+        assert rel.max() < 1e-4, (mode, float(rel.max()), int(rel.argmax()))
+        assert flips.max() < 0.5, flips.max()
+        for name, net in nns.items():
+            ref = g.group("sd_final/%s/" % name)
+            for k, v in net.state_dict().items():
+                if v.is_floating_point() and float(ref[k].norm()) > 0:
+                    assert rel_err(v, ref[k]) < 1e-4, (name, k, rel_err(v, ref[k]))
+                elif not v.is_floating_point():
+                    assert int(v) == int(ref[k]), (name, k)
+        return
+    # bf16: (A) the engine follows the bf16-operand model step for step while the two are still the same trajectory
+    # (a training run amplifies any difference - also the model's and the engine's different fp32 summation orders -
+    # so the tight comparison is made over the first steps), (B) over all 30 steps it stays within the model's own
+    # distance from the reference's fp32 run
+    model = _model_trajectory(g, m["n_steps"])
+    rel_model = np.abs(model - ref_loss) / ref_loss
+    rel_a = np.abs(loss - model) / model
+    print("\nCE trajectory bf16: engine-vs-model first 5 steps %.1e, all %.1e; model-vs-reference %.1e; "
+          "engine-vs-reference %.1e" % (rel_a[:5].max(), rel_a.max(), rel_model.max(), rel.max()))
+    assert rel_a[:5].max() < 2e-4, rel_a[:5]
+    assert rel.max() < model_bound(rel_model.max()), (float(rel.max()), float(rel_model.max()))
+    assert flips.max() < 4.5, flips.max()
+    assert loss[-1] < loss[0] - 0.2  # and it trains
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -227,6 +329,9 @@ def _rows(t, stride):
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_config_scale_golden(prec):
+    """fp32: posteriors / loss / kink-forced gradients at 1e-4 against the reference's own run.  bf16 (the mode bench.py
+    times, same network, same T): the two-step grading against the bf16-operand model run here on the host CPU from the
+    same seed-derived parameters."""
     from engine_util import F_amd
 
     g = Golden("scale_ligru_T500")
@@ -241,6 +346,7 @@ def test_config_scale_golden(prec):
                 ref = g.arrays["init_ck/%s/%s" % (name, k)]
                 got = _ck(v, 7)
                 assert np.abs(got - ref).max() <= 1e-5 * max(1.0, ref[0]), ("initialisation differs", name, k)
+    init = {n: {k: v.detach().cpu().clone() for k, v in net.state_dict().items()} for n, net in nns.items()}
     masks = [g.t("mask/%d" % i).float().cuda() for i in range(m["n_masks"])]
     kinks = [torch.from_numpy(np.unpackbits(g.arrays["kink/%d" % i])[:T * 2 * B * H].reshape(T, 2 * B, H).astype(bool))
              for i in range(L)]
@@ -251,43 +357,70 @@ def test_config_scale_golden(prec):
     outs["loss_final"].backward()
     torch.cuda.synchronize()
     rec.forward = orig
-    tol_out, tol_grad = (1e-4, 1e-4) if prec == "fp32" else bf16_tols(L, 1)
     st = m["strides"]
-    for k in ("out_dnn1", "out_dnn2", "out_dnn3"):
-        o = outs[k].reshape(T * B, -1)
-        e = rel_err(_rows(o, st["out/%s/stride" % k]), g.t("out/%s/rows" % k))
-        assert e < tol_out, (k, e)
-        ck, ref = _ck(o, 11), g.arrays["out/%s/ck" % k]
-        assert abs(ck[0] - ref[0]) < tol_out * ref[0], k                      # whole-tensor norm
-        assert np.abs(ck[1:] - ref[1:]).max() < 4 * tol_out * ref[0], k      # +-1 projections: |<d, r>| ~ ||d||
-    lref = float(g.t("loss_final"))
-    assert abs(float(outs["loss_final"]) - lref) < (1e-4 if prec == "fp32" else 0.25 * tol_out) * abs(lref)
-    eref = float(g.t("err_final"))
-    assert abs(float(outs["err_final"]) - eref) * T * B < (0.5 if prec == "fp32" else 8.5)
-    if report is not None:
+    lref, eref = float(g.t("loss_final")), float(g.t("err_final"))
+    gtotal = math.sqrt(sum(float(g.arrays[k][0]) ** 2 for k in g.arrays if k.startswith("grad/") and k.endswith("/ck")))
+
+    def grad_items():
+        for name, net in nns.items():
+            for k, p in net.named_parameters():
+                key = "grad/%s/%s" % (name, k)
+                if key + "/rows" not in g.arrays:
+                    assert p.grad is None or float(p.grad.abs().max()) == 0.0, (name, k)
+                    continue
+                ref_ck = g.arrays[key + "/ck"]
+                if ref_ck[0] < 1e-6 * gtotal:  # analytically-zero gradients (rounding noise in the reference)
+                    assert float(p.grad.norm()) < 1e-4 * gtotal
+                    continue
+                yield name, k, key, p, g.t(key + "/rows"), ref_ck
+
+    if prec == "fp32":
+        for k in ("out_dnn1", "out_dnn2", "out_dnn3"):
+            o = outs[k].reshape(T * B, -1)
+            e = rel_err(_rows(o, st["out/%s/stride" % k]), g.t("out/%s/rows" % k))
+            assert e < 1e-4, (k, e)
+            ck, ref = _ck(o, 11), g.arrays["out/%s/ck" % k]
+            assert abs(ck[0] - ref[0]) < 1e-4 * ref[0], k                      # whole-tensor norm
+            assert np.abs(ck[1:] - ref[1:]).max() < 4e-4 * ref[0], k          # +-1 projections: |<d, r>| ~ ||d||
+        assert abs(float(outs["loss_final"]) - lref) < 1e-4 * abs(lref)
+        assert abs(float(outs["err_final"]) - eref) * T * B < 0.5
         # the reference's kink pattern differs from the engine's own only where a_t is rounding noise
         assert len(report) == L
         for flipped, total, worst in report:
             assert flipped < 2e-4 * total and worst < 1e-4, report
-    # gradients: row samples of every tensor (norm-relative, floored like check_grads) + whole-tensor checksums
-    total = math.sqrt(sum(float(g.arrays[k][0]) ** 2 for k in g.arrays if k.startswith("grad/") and k.endswith("/ck")))
-    worst = 0.0
-    for name, net in nns.items():
-        for k, p in net.named_parameters():
-            key = "grad/%s/%s" % (name, k)
-            if key + "/rows" not in g.arrays:
-                assert p.grad is None or float(p.grad.abs().max()) == 0.0, (name, k)
-                continue
-            ref_rows, ref_ck = g.t(key + "/rows"), g.arrays[key + "/ck"]
-            if ref_ck[0] < 1e-6 * total:  # analytically-zero gradients (rounding noise in the reference)
-                assert float(p.grad.norm()) < 1e-4 * total
-                continue
+        worst = 0.0
+        for name, k, key, p, ref_rows, ref_ck in grad_items():
             got_rows = _rows(p.grad, st[key + "/stride"])
             frac = float(ref_rows.double().norm()) / ref_ck[0]  # share of the tensor the sample holds
-            e = grad_err(got_rows, ref_rows, total * frac)
+            e = grad_err(got_rows, ref_rows, gtotal * frac)
             worst = max(worst, e)
-            assert e < tol_grad, (name, k, e)
+            assert e < 1e-4, (name, k, e)
             ck = _ck(p.grad, 13)
-            assert abs(ck[0] - ref_ck[0]) < tol_grad * max(ref_ck[0], 1e-3 * total), (name, k)
-            assert np.abs(ck[1:] - ref_ck[1:]).max() < 4 * tol_grad * max(ref_ck[0], 1e-3 * total), (name, k)
-    print("config-scale golden [%s]: worst gradient row-sample error %.2e" % (prec, worst))
+            assert abs(ck[0] - ref_ck[0]) < 1e-4 * max(ref_ck[0], 1e-3 * gtotal), (name, k)
+            assert np.abs(ck[1:] - ref_ck[1:]).max() < 4e-4 * max(ref_ck[0], 1e-3 * gtotal), (name, k)
+        print("\nconfig-scale golden [fp32]: worst gradient row-sample error %.2e; kink report %s" % (worst, report))
+        return
+    # ---- bf16: the bf16-operand model on the host CPU, same parameters / input / masks (a few seconds)
+    import pk_oracle as O
+
+    osd = {}
+    for n in init:
+        osd[n] = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in init[n].items()}
+    o1, o2, o3, oloss, oerr = _oracle_step(O, m, osd, g.t("inp"), [mk.cpu() for mk in masks], True)
+    oloss.backward()
+    rep = {}
+    for k, om in (("out_dnn1", o1), ("out_dnn2", o2), ("out_dnn3", o3)):
+        s_ = st["out/%s/stride" % k]
+        rep[k] = _two_step(k, _rows(outs[k].reshape(T * B, -1), s_), _rows(om.detach().reshape(T * B, -1), s_),
+                           g.t("out/%s/rows" % k), TIGHT_OUT)
+    assert abs(float(outs["loss_final"]) - float(oloss)) < TIGHT_OUT * lref
+    assert abs(float(outs["loss_final"]) - lref) < model_bound(abs(float(oloss) - lref) / lref) * lref
+    assert abs(float(outs["err_final"]) - eref) * T * B < 8.5
+    worst = (0.0, 0.0, 0.0)
+    for name, k, key, p, ref_rows, ref_ck in grad_items():
+        s_ = st[key + "/stride"]
+        frac = float(ref_rows.double().norm()) / ref_ck[0]
+        worst = max(worst, _two_step((name, k), _rows(p.grad, s_), _rows(osd[name][k].grad, s_), ref_rows, TIGHT_GRAD,
+                                     gtotal * frac), key=lambda t: t[2])
+    print("\nconfig-scale golden [bf16]: outputs (engine-vs-model, model-vs-ref, engine-vs-ref) %s; worst gradient %s"
+          % ({k: tuple("%.1e" % x for x in v) for k, v in rep.items()}, tuple("%.1e" % x for x in worst)))

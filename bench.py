@@ -34,8 +34,8 @@ HBM_PEAK = 8000.0                      # GB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)   # 100 x ~20 ms: a timed region of ~2 s
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--recipe", default="timit_ligru")
     ap.add_argument("--T", type=int, default=500)
     ap.add_argument("--B", type=int, default=128, help="sequences per GPU (weak scaling)")
@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step as one HIP graph (auto: the launch-bound non-sequence recipes on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the parity_mode (fp32) and other_configs sub-records of the default single-GPU run")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-T", type=int, default=500, help="sequence length of the CPU baseline sample (batch 8)")
     return ap.parse_args()
@@ -292,58 +294,119 @@ def cpu_baseline(args, rcp_name):
                       % (n, T, B, model or "host CPU")}
 
 
-def main():
-    args = parse()
-    DP = importlib.import_module("pytorch-kaldi_amd.dp")
-    rank, world, _ = DP.init_from_env()
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    tr = Trainer(args, rank, world)
+def roofline_of(tr, args, summ, prec):
+    """Roofline record of the dominant entry point (HIP events, profile_entry_points)."""
+    total_flops, rec_flops = algorithmic_flops(tr.rcp, tr.T, tr.B)
+    dom = max(summ, key=lambda k: summ[k]["ms_per_step"]) if summ else None
+    roof = {"bound": "mfma", "achieved": None, "peak": PEAK[prec], "unit": "TFLOP/s", "frac": None, "traffic": None}
+    if dom is None:
+        return roof, total_flops
+    d = summ[dom]
+    if dom in ("pk_rec_fwd", "pk_rec_bwd", "pk_rec_fwd_bf16", "pk_rec_bwd_bf16", "pk_rec2p_fwd_bf16", "pk_rec2p_bwd_bf16"):
+        # recurrent launches: fwd step GEMM = 1/3 of rec_flops, bwd carry GEMM = 1/3, deferred dU = 1/3
+        # (inside pk_rec_bwd in the fp32 library path, a separate pk_gemm_bf16 in the perf pipeline)
+        share = 2.0 if dom == "pk_rec_bwd" else 1.0
+        fl = rec_flops * share / 3.0 / d["calls_per_step"]
+    elif dom in ("pk_gemm", "pk_gemm_bf16"):
+        conv = tr.T * tr.B * (101.45e6 * 2 + 92.82e6 * 3) if tr.rcp["nfea"] == 3200 else 0.0
+        dU = rec_flops / 3.0 if dom == "pk_gemm_bf16" else 0.0   # deferred dU GEMMs of the perf pipeline
+        fl = (total_flops - rec_flops - conv + dU) / d["calls_per_step"]
+    elif dom in ("pk_conv1d_pool_fwd", "pk_conv1d_pool_bwd"):
+        # fp32 direct convolution = packed-FMA VALU work (the fp32 MFMA rate is the same 157 TFLOP/s)
+        per_frame = 194.27e6 if dom.endswith("fwd") else 194.27e6 + 92.82e6 + 101.45e6
+        fl = tr.T * tr.B * per_frame / d["calls_per_step"]
+        roof.update({"bound": "valu-fp32", "peak": 157.3})
+    else:
+        fl = 0.0
+    ach = fl / (d["avg_ms"] * 1e-3) / 1e12 if d["avg_ms"] > 0 else 0.0
+    roof.update({"kernel": dom, "achieved": round(ach, 3), "frac": round(ach / roof["peak"], 5),
+                 "avg_launch_ms": round(d["avg_ms"], 4), "launches_per_step": d["calls_per_step"], "flops_per_launch": fl})
+    if "rec" in dom and tr.rcp["seq"]:
+        # a recurrent launch is T strictly dependent steps: neither roofline binds it, the per-step latency does.  The
+        # floor of a step is one cross-CU hand-off (handoff-1to1 of MI355X_MICROARCH.md's price list: 0.8-1.0 us idle;
+        # profiles/r02_rec_step_floor.json holds this kernel's own empty-step measurement when it has been taken)
+        roof["dependent_steps_per_launch"] = tr.T
+        roof["us_per_step"] = round(d["avg_ms"] * 1e3 / tr.T, 3)
+        floor = 0.9
+        try:
+            floor = float(json.load(open(os.path.join(ROOT, "profiles", "r02_rec_step_floor.json")))["floor_us"])
+        except (OSError, ValueError, KeyError):
+            pass
+        roof["step_floor_us"] = floor
+        roof["latency_frac"] = round(floor / roof["us_per_step"], 4)
+    # algorithmic HBM bytes of one recurrent launch (DESIGN.md section 4) and the PMC-measured traffic
+    # of the same launch at this geometry (null for any other geometry)
+    rb = rec_launch_bytes(tr.rcp, tr.T, tr.B, dom)
+    if rb:
+        roof["algorithmic_bytes_per_launch"] = rb
+        roof["hbm_gbps"] = round(rb / (d["avg_ms"] * 1e-3) / 1e9, 1)
+        roof["hbm_frac"] = round(rb / (d["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK, 5)
+    for src in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", src)))
+            if dom in pm and args.recipe == "timit_ligru" and (tr.T, tr.B) == (500, 128) and args.layers is None:
+                roof["traffic"] = pm[dom]["traffic_bytes"]
+                roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % src
+                break
+        except (OSError, ValueError):
+            pass
+    return roof, total_flops
+
+
+def workload_name(recipe, tr):
+    return ("%s: %s, T=%d, B=%d per GPU, %s, %d+%d senone/phone heads, fwd+bwd+optimizer"
+            % (recipe, tr.rcp["cfg"]["architecture1"]["arch_class"], tr.T, tr.B,
+               "3200-sample raw waveform chunks" if tr.rcp["nfea"] == 3200 else "%d-dim features" % tr.rcp["nfea"],
+               tr.rcp["n_cd"], tr.rcp["n_mono"]))
+
+
+def measure(args, rank, world, steps, warmup):
+    """One configuration: build, warm up, time exactly `steps` steps between barriers, profile two more steps.
+    Returns (record, Trainer)."""
     import torch.distributed as dist
+
+    tr = Trainer(args, rank, world)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    log("model built")
-    for i in range(args.warmup):
+    log("%s/%s built" % (args.recipe, args.prec))
+    for i in range(warmup):
         tr.step(i)
         torch.cuda.synchronize()
-        log("warmup step %d done" % i)
     use_graph = args.graph == "on" or (args.graph == "auto" and not tr.rcp["seq"] and world == 1 and not args.torch_optim)
     if use_graph:
-        if args.warmup == 0:
+        if warmup == 0:
             tr.step(0)  # lazy one-time initialisation must not land inside the capture
         tr.enable_graph()
         tr.step(0)      # first replay (graph upload) outside the timed region
-        log("step captured into a HIP graph")
     barrier()
     t0 = time.perf_counter()
     loss = None
-    for i in range(args.steps):
+    for i in range(steps):
         loss = tr.step(i)
     barrier()
     dt = time.perf_counter() - t0
-    log("timed region done: %.3f s" % dt)
+    log("%s/%s timed region done: %.3f s" % (args.recipe, args.prec, dt))
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     _lib = importlib.import_module("pytorch-kaldi_amd._lib")
     _lib.raise_if_persist_failed()
-    frames = args.steps * tr.T * tr.B * world
-    ms_per_step = 1e3 * dt / args.steps
+    frames = steps * tr.T * tr.B * world
+    ms_per_step = 1e3 * dt / steps
     out = {
         "metric": "train_frames_per_sec", "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
-        "config": {"workload": "%s: %s, T=%d, B=%d per GPU, %s, %d+%d senone/phone heads, fwd+bwd+optimizer"
-                               % (args.recipe, tr.rcp["cfg"]["architecture1"]["arch_class"], tr.T, tr.B,
-                                  "3200-sample raw waveform chunks" if tr.rcp["nfea"] == 3200
-                                  else "%d-dim features" % tr.rcp["nfea"], tr.rcp["n_cd"], tr.rcp["n_mono"]),
+        "config": {"workload": workload_name(args.recipe, tr),
                    "global_batch": tr.B * world, "seq_len": tr.T, "parallelism": "dp%d" % world,
-                   "rec_algo": args.algo, "mask_rng": args.mask_rng, "allreduce": "overlapped" if args.overlap else "after-backward", "optimizer": "torch" if args.torch_optim else "fused-flat", "hip_graph": bool(use_graph),
+                   "rec_algo": args.algo, "mask_rng": args.mask_rng,
+                   "allreduce": "overlapped" if args.overlap else "after-backward",
+                   "optimizer": "torch" if args.torch_optim else "fused-flat", "hip_graph": bool(use_graph),
                    "params": tr.n_params},
         "loss_final": round(float(loss), 5),
     }
@@ -353,61 +416,74 @@ def main():
     # they contain the gradient all-reduce)
     summ = profile_entry_points(tr)
     if rank == 0:
-        total_flops, rec_flops = algorithmic_flops(tr.rcp, tr.T, tr.B)
-        dom = max(summ, key=lambda k: summ[k]["ms_per_step"]) if summ else None
-        roof = {"bound": "mfma", "achieved": None, "peak": PEAK[args.prec], "unit": "TFLOP/s", "frac": None,
-                "traffic": None}
-        if dom is not None:
-            d = summ[dom]
-            if dom in ("pk_rec_fwd", "pk_rec_bwd", "pk_rec_fwd_bf16", "pk_rec_bwd_bf16"):
-                # recurrent launches: fwd step GEMM = 1/3 of rec_flops, bwd carry GEMM = 1/3, deferred dU = 1/3
-                # (inside pk_rec_bwd in the fp32 library path, a separate pk_gemm_bf16 in the perf pipeline)
-                share = 2.0 if dom == "pk_rec_bwd" else 1.0
-                fl = rec_flops * share / 3.0 / d["calls_per_step"]
-            elif dom in ("pk_gemm", "pk_gemm_bf16"):
-                conv = tr.T * tr.B * (101.45e6 * 2 + 92.82e6 * 3) if tr.rcp["nfea"] == 3200 else 0.0
-                dU = rec_flops / 3.0 if dom == "pk_gemm_bf16" else 0.0   # deferred dU GEMMs of the perf pipeline
-                fl = (total_flops - rec_flops - conv + dU) / d["calls_per_step"]
-            elif dom in ("pk_conv1d_pool_fwd", "pk_conv1d_pool_bwd"):
-                # fp32 direct convolution = packed-FMA VALU work (the fp32 MFMA rate is the same 157 TFLOP/s)
-                per_frame = 194.27e6 if dom.endswith("fwd") else 194.27e6 + 92.82e6 + 101.45e6
-                fl = tr.T * tr.B * per_frame / d["calls_per_step"]
-                roof.update({"bound": "valu-fp32", "peak": 157.3})
-            else:
-                fl = 0.0
-            ach = fl / (d["avg_ms"] * 1e-3) / 1e12 if d["avg_ms"] > 0 else 0.0
-            roof.update({"kernel": dom, "achieved": round(ach, 3), "frac": round(ach / roof["peak"], 5),
-                         "avg_launch_ms": round(d["avg_ms"], 4), "launches_per_step": d["calls_per_step"],
-                         "flops_per_launch": fl})
-            # algorithmic HBM bytes of one recurrent launch and the PMC-measured traffic
-            # of the same launch at this geometry (profiles/r01_pmc_traffic.json; null for any other geometry)
-            rb = rec_launch_bytes(tr.rcp, tr.T, tr.B, dom)
-            if rb:
-                # a recurrent launch is T strictly dependent steps: neither roofline binds it, the per-step latency does
-                # (one cross-CU hand-off, ~0.85 us on this chip, is the floor of a step)
-                roof["dependent_steps_per_launch"] = tr.T
-                roof["us_per_step"] = round(d["avg_ms"] * 1e3 / tr.T, 3)
-                roof["algorithmic_bytes_per_launch"] = rb
-                roof["hbm_gbps"] = round(rb / (d["avg_ms"] * 1e-3) / 1e9, 1)
-                roof["hbm_frac"] = round(rb / (d["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK, 5)
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                if dom in pm and args.recipe == "timit_ligru" and (tr.T, tr.B) == (500, 128) and args.layers is None:
-                    roof["traffic"] = pm[dom]["traffic_bytes"]
-                    roof["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-            except (OSError, ValueError):
-                pass
+        roof, total_flops = roofline_of(tr, args, summ, args.prec)
         out["roofline"] = roof
         out["entry_points_ms_per_step"] = {k: round(v["ms_per_step"], 3) for k, v in
                                            sorted(summ.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+        out["whole_step_tflops"] = round(total_flops / (ms_per_step * 1e-3) / 1e12, 3)
+    return out, tr
+
+
+def release(tr):
+    """Drop a configuration's tensors before the next one is built (7-9 GB of activations per sequence recipe)."""
+    tr.nns = tr.opts = tr.batches = tr.graphed = tr.reducer = None
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+# the other BASELINE.json configurations (parity-test cases, reported beside the headline): recipe, steps, warmup
+OTHER_CONFIGS = [("timit_mlp", 400, 5), ("timit_lstm", 10, 2), ("libri_gru", 10, 2), ("timit_sincnet", 100, 5)]
+
+
+def main():
+    import copy
+
+    args = parse()
+    DP = importlib.import_module("pytorch-kaldi_amd.dp")
+    rank, world, _ = DP.init_from_env()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    out, tr = measure(args, rank, world, args.steps, args.warmup)
+    headline = args.recipe == "timit_ligru" and args.prec == "bf16" and (args.T, args.B) == (500, 128) and args.layers is None
+    if rank == 0:
         out["entry_points_note"] = ("HIP events around every C-ABI call of two extra eager steps on ONE stream; the timed "
                                     "region overlaps the weight-gradient GEMMs with the recurrences on a second stream")
-        out["whole_step_tflops"] = round(total_flops / (ms_per_step * 1e-3) / 1e12, 3)
+    release(tr)
+    if rank == 0 and world == 1 and headline and not args.no_extras:
+        # (1) the 1e-4-grade mode of the SAME workload: exact-fp32 MFMA, what tests/test_gpu_parity.py grades
+        a2 = copy.copy(args)
+        a2.prec = "fp32"
+        rec, tr2 = measure(a2, rank, world, 3, 1)
+        out["parity_mode"] = {k: rec[k] for k in ("dtype", "ms_per_step", "value", "unit", "steps", "warmup", "roofline",
+                                                  "entry_points_ms_per_step", "whole_step_tflops")}
+        out["parity_mode"]["note"] = ("same network, batch and sequence length in the engine's exact-fp32 mode (fp32 MFMA, "
+                                      "157.3 TFLOP/s peak): the mode the 1e-4 parity tests run in")
+        release(tr2)
+        # (2) the other BASELINE configurations, batch 128 per GPU
+        out["other_configs"] = []
+        for recipe, steps, warmup in OTHER_CONFIGS:
+            a3 = copy.copy(args)
+            a3.recipe, a3.prec = recipe, "bf16"
+            try:
+                rec, tr3 = measure(a3, rank, world, steps, warmup)
+                out["other_configs"].append({"recipe": recipe, "config": rec["config"], "dtype": rec["dtype"],
+                                             "ms_per_step": rec["ms_per_step"], "value": rec["value"], "unit":
+                                             "frames/s" if tr3.rcp["seq"] or recipe == "timit_mlp" else "chunks/s",
+                                             "steps": steps, "warmup": warmup, "roofline": rec["roofline"],
+                                             "entry_points_ms_per_step": dict(list(rec["entry_points_ms_per_step"].items())[:4])})
+                release(tr3)
+            except Exception as e:  # a recipe that fails must not take the headline line with it
+                out["other_configs"].append({"recipe": recipe, "error": "%s: %s" % (type(e).__name__, e)})
+        F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+        F_.set_precision(args.prec)
+    if rank == 0:
         log("roofline leg done")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.recipe)
         print(json.dumps(out), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

@@ -204,6 +204,9 @@ int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, in
 /* diagnostics: when non-NULL, cluster 0 / member 0 / wave 0 of every following launch writes
  * T x 8 shader-clock stamps (phase boundaries of each step) to this device buffer. */
 void pk_persist2_set_trace(void* dev_buf);
+/* diagnostics, traced (Li-GRU / relu) kernels only: 1 = every step skips its MFMA block and gate math, so that what is
+ * timed is the hand-off alone - the latency floor of a step (results of such a launch are meaningless). */
+void pk_persist2_set_empty_step(int on);
 /* 0 (default): clusters whose workgroups all run on one XCD exchange through that XCD's L2 (plain
  * stores + nt loads), others use write-through stores + agent-scope loads; 1: always the latter. */
 void pk_persist2_set_mode(int force_safe);

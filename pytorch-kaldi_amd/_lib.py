@@ -59,6 +59,7 @@ SIGNATURES = {
     "pk_rec2p_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, P, P, c_int64, c_int]),
     "pk_rec2p_bwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, c_int64, c_int]),
     "pk_persist2_set_trace": (None, [P]),
+    "pk_persist2_set_empty_step": (None, [c_int]),
     "pk_persist2_set_mode": (None, [c_int]),
     "pk_persist2_set_poll_delay": (None, [c_int]),
     "pk_persist2_set_lstm_waves": (None, [c_int]),

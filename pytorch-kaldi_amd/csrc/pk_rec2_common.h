@@ -27,6 +27,8 @@ struct R2Args {
     unsigned* xcd_tab;          // [C][16] placement handshake words (0xFFFFFFFF before the launch)
     unsigned long long* trace;  // optional [T][8] phase time stamps of (cluster 0, member 0, wave 0); null = off
     int helper_delay;           // eight-wave LSTM kernels: extra s_sleep units before the second wave of a pair polls
+    int empty_step;             // diagnostics (traced kernels only): skip the MFMA block and the gate math - what is left
+                                // of a step is the hand-off itself (poll, barrier, flush / prefetch issue, publish)
 };
 
 struct Plan2 {

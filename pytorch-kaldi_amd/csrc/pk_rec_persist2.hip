@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
 #define PK_LP1(E) load_proj(t + 1, E)
             PK_EDGE_DISPATCH_S(PK_LP1);
         }
-        if (t > 0) {
+        const bool empty = TR && a.empty_step != 0;  // diagnostics: the step without its arithmetic
+        if (t > 0 && !empty) {
             const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
@@ -235,7 +236,14 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
 #pragma unroll
             for (int g = 0; g < G; ++g) pr[g] = pre[g][r] * psc[g] + psh[g] + acc[g][r];
             float h, cc, s[NS];
-            pk_cell_fwd<CELL>(act, pr, hprev[r], cprev[r], msk[r], h, cc, s);
+            if (empty) {
+                h = 0.25f;
+                cc = 0.f;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) s[k] = pr[0];
+            } else {
+                pk_cell_fwd<CELL>(act, pr, hprev[r], cprev[r], msk[r], h, cc, s);
+            }
             h = rvf[r] != 0.f ? h : 0.f;  // rows / units outside the layer carry exact zeros (published as padding)
             cc = rvf[r] != 0.f ? cc : 0.f;
             hprev[r] = h;
@@ -448,7 +456,8 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
         // the saved tensors of the next one
         if (t < T - 1) flush_outputs(t + 1, SEC);
         if (t > 0) load_step(t - 1, SEC);
-        if (t < T - 1) {
+        const bool empty = TR && a.empty_step != 0;
+        if (t < T - 1 && !empty) {
             const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
 #pragma unroll
             for (int g = 0; g < G; ++g)
@@ -458,8 +467,8 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
                     if ((kk & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, Bf[g][kk], acc0, 0, 0, 0);
                     else acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, Bf[g][kk], acc1, 0, 0, 0);
                 }
-            if (NBUF == 1) PK_BARRIER_LDS();  // single A tile: everyone is done reading before the next poll refills it
         }
+        if (NBUF == 1 && t < T - 1) PK_BARRIER_LDS();  // single A tile: everyone is done reading before the next poll refills it
         PK_TRACE(3);
         float sin[NIN][4];
 #pragma unroll
@@ -474,7 +483,14 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
             const float cp = LSTM ? sin[NIN - 1][r] : 0.f;
             const float dh = dy + dh_dir[r] + acc0[r] + acc1[r];
             float dg[G], dhd, dcp;
-            pk_cell_bwd<CELL>(act, s, hp, cp, msk[r], dh, dc_car[r], dg, dhd, dcp);
+            if (empty) {
+                dhd = 0.f;
+                dcp = 0.f;
+#pragma unroll
+                for (int g = 0; g < G; ++g) dg[g] = 0.125f;
+            } else {
+                pk_cell_bwd<CELL>(act, s, hp, cp, msk[r], dh, dc_car[r], dg, dhd, dcp);
+            }
             // rows / units outside the layer: exact zeros (select, not multiply: their inputs are arbitrary)
             dh_dir[r] = rvf[r] != 0.f ? dhd : 0.f;
             dc_car[r] = rvf[r] != 0.f ? dcp : 0.f;
@@ -516,6 +532,7 @@ unsigned* g2_err_host = nullptr;
 unsigned* g2_err_dev = nullptr;
 int g2_force_safe = 0;
 int g2_poll_delay = -1;  // < 0: per-pass defaults (pk_rec2_host_setup)
+int g2_empty_step = 0;
 unsigned* g2_xcd_tab = nullptr;  // [256][16] handshake words (library-owned scratch, one launch at a time)
 float* g2_trash = nullptr;        // write-only dump page for masked-off vector stores
 constexpr size_t XCD_TAB_BYTES = 256 * 16 * sizeof(unsigned);
@@ -578,6 +595,7 @@ int pk_rec2_host_setup(R2Args& a, bool backward) {
     a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe;
     a.trash = g2_trash; a.poll_delay = g2_poll_delay >= 0 ? g2_poll_delay : default_poll_delay(backward);
     a.helper_delay = 0;
+    a.empty_step = g2_empty_step;
     return 0;
 }
 int pk_rec2_reset_handshake(hipStream_t st) {
@@ -588,6 +606,7 @@ int pk_rec2_reset_handshake(hipStream_t st) {
 extern "C" void pk_persist2_set_mode(int force_safe) { g2_force_safe = force_safe ? 1 : 0; }
 extern "C" void pk_persist2_set_poll_delay(int units) { g2_poll_delay = units; }  // < 0: back to the per-pass defaults
 extern "C" void pk_persist2_set_trace(void* dev_buf) { g2_trace = (unsigned long long*)dev_buf; }
+extern "C" void pk_persist2_set_empty_step(int on) { g2_empty_step = on ? 1 : 0; }
 extern "C" unsigned pk_persist2_error_count(void) { return g2_err_host ? *g2_err_host : 0u; }
 extern "C" void pk_persist2_error_reset(void) {
     if (g2_err_host) *g2_err_host = 0u;

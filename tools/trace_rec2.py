@@ -25,8 +25,13 @@ x = torch.randn(T, B, 40, device="cuda", requires_grad=True)
 lib = _lib.load()
 lib.pk_persist2_set_mode(int(os.environ.get("SAFE", "0")))
 lib.pk_persist2_set_poll_delay(int(os.environ.get("DELAY", "-1")))  # -1: the library defaults
+EMPTY = int(os.environ.get("EMPTY", "0"))  # 1: steps without MFMA block / gate math = the hand-off floor of a step
+lib.pk_persist2_set_empty_step(EMPTY)
 names = ["poll", "prefetch-issue+barrier", "mfma", "gate math", "publish", "loop tail"]
-for rep in range(2):
+prof = _lib.Profiler()
+for rep in range(3):
+    if rep == 2:
+        prof.__enter__()  # HIP events around every C-ABI call of the last repetition
     tr_f = torch.zeros(T, 8, dtype=torch.int64, device="cuda")
     lib.pk_persist2_set_trace(tr_f.data_ptr())
     y = net(x)
@@ -36,6 +41,11 @@ for rep in range(2):
     y.sum().backward()
     torch.cuda.synchronize()
     lib.pk_persist2_set_trace(None)
+prof.__exit__(None, None, None)
+launch_ms = {k: v["avg_ms"] for k, v in prof.summary(1).items() if k.startswith("pk_rec")}
+import json  # noqa: E402
+
+summary = {}
 for tag, tr in (("fwd", tr_f.cpu()), ("bwd", tr_b.cpu())):
     tr = tr[5:-5].double()
     d = tr[:, 1:6] - tr[:, 0:5]
@@ -46,3 +56,13 @@ for tag, tr in (("fwd", tr_f.cpu()), ("bwd", tr_b.cpu())):
     print("   poll retries per step: mean %.2f  max %d" % (tr[:, 6].mean(), int(tr[:, 6].max())))
     tail = tr[1:, 0] - tr[:-1, 5]
     print("   %-24s mean %8.0f  median %8.0f" % (names[5], tail.mean(), tail.median()))
+    summary[tag] = {"cycles_per_step_mean": float(step.mean()), "cycles_per_step_median": float(step.median()),
+                    "phases_mean": {n: float(d[:, i].mean()) for i, n in enumerate(names[:5])},
+                    "poll_retries_per_step": float(tr[:, 6].mean())}
+lib.pk_persist2_set_empty_step(0)
+if os.environ.get("JSON_OUT"):
+    with open(os.environ["JSON_OUT"], "w") as f:
+        json.dump({"kind": kind, "T": T, "B": B, "H": H, "empty_step": EMPTY, "unit": "s_memtime ticks",
+                   "launch_ms_hip_events": launch_ms,
+                   "us_per_step_hip_events": {k: v * 1e3 / T for k, v in launch_ms.items()}, **summary}, f, indent=1)
+print("launch ms (HIP events):", launch_ms)

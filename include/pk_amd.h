@@ -71,8 +71,13 @@ int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha, const floa
  * contiguous - the dW / dU shapes whose reduction runs over the T*B rows); likewise B with N / ldb.
  * Bases 16-byte aligned, pitches multiples of 8 elements; elements between K and the next multiple of
  * 8 inside a k-contiguous row must be zero (pk_cvt_bf16 writes them so).  splitk as pk_gemm. */
-/* rows of the block tile pk_gemm_bf16 will use for this M (128 today): callers size split-K from it */
+/* rows of the (square) block tile pk_gemm_bf16 uses for tall outputs of this M: 256 (eight-wave, eight-phase kernel) from
+ * 384 rows and columns on, else 128 */
 int pk_gemm_bf16_tile_m(int M);
+/* the split-K factor the library recommends for this shape (1 for short reductions) */
+int pk_gemm_bf16_auto_splitk(int M, int N, int K);
+/* tests / tools: 128 or 256 forces that block tile for every shape, 0 = automatic (also PK_GEMM_TILE) */
+void pk_gemm_bf16_set_tile(int tile);
 int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
                  const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc, const float* bias,
                  int splitk, float* workspace);

@@ -28,6 +28,8 @@ SIGNATURES = {
     "pk_gemm": (c_int, [P, c_int, c_int, c_int, c_int, c_float, P, c_int64, c_int64, P, c_int64, c_int64, c_float, P,
                         c_int64, P, c_int, P]),
     "pk_gemm_bf16_tile_m": (c_int, [c_int]),
+    "pk_gemm_bf16_auto_splitk": (c_int, [c_int, c_int, c_int]),
+    "pk_gemm_bf16_set_tile": (None, [c_int]),
     "pk_gemm_bf16": (c_int, [P, c_int, c_int, c_int, c_float, P, c_int64, c_int, P, c_int64, c_int, c_float, P, c_int64, P,
                              c_int, P]),
     "pk_cvt_bf16": (c_int, [P, P, c_int64, c_int64, c_int, c_int, c_int, P, c_int64]),

@@ -274,6 +274,292 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 4) void gemm_bf16x_kernel(BA
     epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, split, lane);
 }
 
+// ============================================================================
+// 256 x 256 x 64 block tile, 8 waves, eight phases per pair of k-tiles.
+//
+// The 128 x 128 kernels above top out at 640-680 TFLOP/s: every k-tile is [stage, wait for ALL loads, barrier, 32
+// MFMAs, barrier] and the waves of a workgroup idle together while the tile lands (PMC: matrix pipe 20-24 % busy,
+// 55-65 % of wave cycles in s_waitcnt).  This kernel removes the drain:
+//   * an operand k-tile is two PIECES of 128 rows x 64 k (16 KB - exactly the tile image of the kernels above, so the
+//     staging / swizzle / fragment code is shared): A-h0, A-h1, B-h0, B-h1;
+//   * a wave (2 x 4 grid: wm, wn) owns 64 rows of EACH A piece and 32 columns of EACH B piece, i.e. a 128 x 64 slice of
+//     the output in four quadrants - so every piece is read by all waves in exactly one phase of a k-tile:
+//       phase 1: read A-h0, B-h0  -> 16 MFMAs (A0 x B0)     phase 2: read B-h1 -> 16 MFMAs (A0 x B1)
+//       phase 3: read A-h1        -> 16 MFMAs (A1 x B1)     phase 4: (registers) -> 16 MFMAs (A1 x B0)
+//   * LDS holds two k-tiles = 8 piece slots (128 KB), filled by the LDS-DMA; a slot is refilled in the phase after the
+//     one that read it, for the k-tile TWO ahead, so every wave keeps five pieces (10 loads per lane) in flight behind
+//     the one it waits for, and the only wait in the loop is the counted `s_waitcnt vmcnt(10)` - never vmcnt(0);
+//   * a phase is [L: issue one piece, read fragments] barrier [M: 16 MFMAs] barrier, and the two waves that share a SIMD
+//     (w and w + 4: wm = 0 / 1) run ONE BARRIER = half a phase apart (the wm = 1 group takes one extra barrier before the
+//     loop, the wm = 0 group one after it): while one wave of a SIMD is in its MFMA block its partner is in its
+//     LDS-read / DMA-issue part instead of both wanting the matrix pipe at the same moment; s_setprio(1) around the
+//     MFMA block.  A piece is waited for in the L part of the phase BEFORE the one that reads it, and fragment reads
+//     are complete (lgkmcnt(0)) before the L part's barrier - that is what makes the half-phase offset safe in both
+//     directions (the group ahead finds the other group's share of a piece landed; the group behind has finished
+//     reading a slot before the group ahead refills it);
+// Out-of-range quadrants (N = 1100 leaves the last column of tiles 76 of 256 columns) skip their MFMAs.
+// ============================================================================
+constexpr int PIECE = 16384;
+template <int V>
+struct BoolK {
+    static constexpr int value = V;
+};
+
+// Fragment reads of the eight-phase kernel.  k-contiguous pieces: the compiler-visible ds_read_b128 of frag<true>.  k-major
+// pieces: the LDS transpose read issued from INLINE ASM - hipcc puts an s_waitcnt vmcnt(0) in front of the
+// __builtin_amdgcn_ds_read_tr16_b64 intrinsic whenever an LDS-DMA is in flight (it does not for plain LDS loads), which
+// would drain the five-piece prefetch every phase.  The asm form is invisible to that logic; the caller waits with
+// frag_wait() (lgkmcnt(0) + a scheduling barrier, so that no MFMA is hoisted above the wait) before the first use.
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+template <bool KC>
+__device__ __forceinline__ bf16x8 frag8(const unsigned char* buf, int sub, int kk, int lane) {
+    if (KC) {
+        return frag<true>(buf, sub, kk, lane);
+    } else {
+        const int g = lane >> 4, i = lane & 15;
+        const int col = sub + (i & 3) * 4;
+        u32x2v h[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int kr = kk * 32 + g * 8 + hh * 4 + (i >> 2);
+            const int ps = (col >> 3) ^ swz_km(kr);
+            const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)(buf + kr * 256 + ps * 16 + (col & 7) * 2);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(h[hh]) : "v"(addr) : "memory");
+        }
+        typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+        const u32x4v o = u32x4v{h[0][0], h[0][1], h[1][0], h[1][1]};
+        return __builtin_bit_cast(bf16x8, o);
+    }
+}
+template <bool ANY_ASM>
+__device__ __forceinline__ void frag_wait() {
+    if (ANY_ASM) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool KC>
+struct PieceSrc {  // two 16-byte LDS-DMA loads per lane and piece; addresses advance by a constant per k-tile
+    TileSrc<KC, 512> t;
+    const unsigned short* base;
+    long ld;
+    int r0, rmax;
+    __device__ __forceinline__ void init(const unsigned short* b, long l, int r0_, int rmax_, int k0, int tid) {
+        base = b; ld = l; r0 = r0_; rmax = rmax_;
+        t.init(b, l, r0_, rmax_, k0, tid);
+    }
+    // k-tile starting at k0 into `slot`.  CHECKED = false: the k-tile lies entirely below kend (the steady state: two
+    // loads from the running addresses); CHECKED = true: ragged or past the end - element-checked addresses, the zero
+    // page for k >= kend - so that the number of loads per phase is the same for every k-tile and the counted waits hold
+    template <bool CHECKED>
+    __device__ __forceinline__ void issue(int k0, int kend, const unsigned short* zeros, unsigned char* slot, int tid, int wave) {
+        if (!CHECKED || k0 + TK <= kend) {
+            t.issue(slot, wave);
+        } else {
+            stage<KC, 512>(base, ld, r0, rmax, k0, kend, zeros, slot, tid, wave);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) t.a[j] += t.step;
+        }
+    }
+};
+
+__device__ __forceinline__ void store_frag(const BArgs& p, const f32x4 v, int row, int col, int split, bool vec_ok) {
+    if (row >= p.M || col >= p.N) return;
+    float* dst = p.ws ? p.ws + ((long)split * p.M + row) * p.N + col : p.C + (long)row * p.ldc + col;
+    if (vec_ok && col + 3 < p.N) {
+        f32x4 o = v;
+        if (p.ws == nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = p.alpha * v[r] + (p.bias ? p.bias[col + r] : 0.f);
+            if (p.beta != 0.f) {
+                const f32x4 c = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] += p.beta * c[r];
+            }
+        }
+        *reinterpret_cast<f32x4*>(dst) = o;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (col + r >= p.N) continue;
+            float o = v[r];
+            if (p.ws == nullptr) {
+                o = p.alpha * o + (p.bias ? p.bias[col + r] : 0.f);
+                if (p.beta != 0.f) o += p.beta * dst[r];
+            }
+            dst[r] = o;
+        }
+    }
+}
+
+#define PK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(BArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [2 k-tiles][A-h0 | B-h0 | B-h1 | A-h1] x 16 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);  // XCD-aware mapping, as above
+    if (item >= p.items) return;
+    const int tn = item % p.tiles_n;
+    const int tm = (item / p.tiles_n) % p.tiles_m;
+    const int split = item / (p.tiles_n * p.tiles_m);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + TK - 1) / TK;
+    const bool a1_live = m0 + 128 < p.M, b1_live = n0 + 128 < p.N;  // uniform: second halves entirely out of range?
+
+    f32x4 acc[2][2][4][2];  // [A half][B half][i][j]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    PieceSrc<A_KC> sa0, sa1;
+    PieceSrc<B_KC> sb0, sb1;
+    sa0.init(p.A, p.lda, m0, p.M, kbeg, tid);
+    sa1.init(p.A, p.lda, m0 + 128, p.M, kbeg, tid);
+    sb0.init(p.B, p.ldb, n0, p.N, kbeg, tid);
+    sb1.init(p.B, p.ldb, n0 + 128, p.N, kbeg, tid);
+    auto slot = [&](int kt, int piece) { return smem + (((kt & 1) * 4 + piece) * PIECE); };
+    // piece ids in slot order: 0 = A-h0, 1 = B-h0, 2 = B-h1, 3 = A-h1
+    auto issueA0 = [&](int kt, auto C) { sa0.template issue<decltype(C)::value != 0>(kbeg + kt * TK, kend, p.zeros, slot(kt, 0), tid, wave); };
+    auto issueB0 = [&](int kt, auto C) { sb0.template issue<decltype(C)::value != 0>(kbeg + kt * TK, kend, p.zeros, slot(kt, 1), tid, wave); };
+    auto issueB1 = [&](int kt, auto C) { sb1.template issue<decltype(C)::value != 0>(kbeg + kt * TK, kend, p.zeros, slot(kt, 2), tid, wave); };
+    auto issueA1 = [&](int kt, auto C) { sa1.template issue<decltype(C)::value != 0>(kbeg + kt * TK, kend, p.zeros, slot(kt, 3), tid, wave); };
+
+    // prologue: k-tile 0 complete, k-tile 1 without its A-h1 (issued in phase 1 of k-tile 0)
+    issueA0(0, BoolK<1>()); issueB0(0, BoolK<1>()); issueB1(0, BoolK<1>()); issueA1(0, BoolK<1>());
+    issueA0(1, BoolK<1>()); issueB0(1, BoolK<1>()); issueB1(1, BoolK<1>());
+    PK_VMCNT(10);  // A-h0, B-h0 of k-tile 0 (my share)
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // the second wave of every SIMD runs one barrier (half a phase) behind
+
+    bf16x8 a[4][2], b[2][2][2];  // a: [i][kk] of the A half in use; b: [half][j][kk] (B0 lives until phase 4)
+#define PK_MFMA_BLOCK(AH, BH)                                                                                         \
+    do {                                                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                                \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)                   \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+                acc[AH][BH][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[BH][j][kk], a[i][kk], acc[AH][BH][i][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                \
+    } while (0)
+    // end of an L part: fragment reads complete (also what lets the slot be refilled next phase), then the barrier
+#define PK_END_L()                                         \
+    do {                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        __builtin_amdgcn_s_barrier();                      \
+    } while (0)
+    // One k-tile = four phases.  FQ: every quadrant of the tile is in range (no conditional MFMA blocks: the common case
+    // is straight-line code); CK: the loads issued here may be ragged / past the end (the last three k-tiles of a split).
+    // Reads:   L1: A-h0, B-h0     L2: B-h1          L3: A-h1          L4: -
+    // Refills: L1: A-h1(kt+1)     L2: A-h0(kt+2)    L3: B-h0(kt+2)    L4: B-h1(kt+2)     (the phase after the slot's read)
+    // Waits:   L1: B-h1(kt)       L2: A-h1(kt)      L3: -             L4: A-h0, B-h0(kt+1)   (one phase before the read)
+    auto ktile = [&](int kt, auto FQC, auto CKC) {
+        constexpr bool FQ = decltype(FQC)::value != 0;
+        // ---------------- phase 1: A0 x B0
+        issueA1(kt + 1, CKC);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[0][j][kk] = frag8<B_KC>(slot(kt, 1), wn * 32 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i][kk] = frag8<A_KC>(slot(kt, 0), wm * 64 + i * 16, kk, lane);
+        }
+        PK_VMCNT(10);
+        PK_END_L();
+        PK_MFMA_BLOCK(0, 0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase 2: A0 x B1
+        issueA0(kt + 2, CKC);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[1][j][kk] = frag8<B_KC>(slot(kt, 2), wn * 32 + j * 16, kk, lane);
+        PK_VMCNT(10);
+        PK_END_L();
+        if (FQ || b1_live) PK_MFMA_BLOCK(0, 1);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase 3: A1 x B1
+        issueB0(kt + 2, CKC);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i][kk] = frag8<A_KC>(slot(kt, 3), wm * 64 + i * 16, kk, lane);
+        PK_END_L();
+        if (FQ || (a1_live && b1_live)) PK_MFMA_BLOCK(1, 1);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase 4: A1 x B0 (both from registers)
+        issueB1(kt + 2, CKC);
+        PK_VMCNT(10);
+        __builtin_amdgcn_s_barrier();
+        if (FQ || a1_live) PK_MFMA_BLOCK(1, 0);
+        __builtin_amdgcn_s_barrier();
+    };
+    const int nk_full = (kend - kbeg) / TK;  // k-tiles that lie entirely below kend
+    auto run = [&](auto FQC) {
+        int kt = 0;
+        for (; kt + 2 < nk_full; ++kt) ktile(kt, FQC, BoolK<0>());  // everything issued here (up to k-tile kt + 2) is full
+        for (; kt < nk; ++kt) ktile(kt, FQC, BoolK<1>());
+    };
+    if (a1_live && b1_live) run(BoolK<1>());
+    else run(BoolK<0>());
+#undef PK_MFMA_BLOCK
+#undef PK_END_L
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // pairs with the extra barrier the other group took before the loop
+    PK_VMCNT(0);  // the zero-page DMAs of the two k-tiles past the end
+    const bool vec_ok = (((uintptr_t)(p.ws ? p.ws : p.C) & 15) == 0) && (((p.ws ? (long)p.N : p.ldc) & 3) == 0);
+    const bool interior = m0 + 256 <= p.M && n0 + 256 <= p.N;
+    if (vec_ok && interior && (p.ws != nullptr || p.beta == 0.f)) {
+        // the common case, straight-line: no bounds, no read-modify-write; 16 bytes per lane and store
+        const bool direct = p.ws == nullptr;
+        float* base = direct ? p.C : p.ws + (long)split * p.M * p.N;
+        const long ld = direct ? p.ldc : (long)p.N;
+        const float alpha = direct ? p.alpha : 1.f;
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + bh * 128 + wn * 32 + j * 16 + (lane >> 4) * 4;
+                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (direct && p.bias != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[r] = p.bias[col + r];
+                }
+#pragma unroll
+                for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = m0 + ah * 128 + wm * 64 + i * 16 + (lane & 15);
+                        const f32x4 v = acc[ah][bh][i][j];
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = alpha * v[r] + bv[r];
+                        *reinterpret_cast<f32x4*>(base + (long)row * ld + col) = o;
+                    }
+            }
+        return;
+    }
+    // (fully unrolled: a run-time index into the accumulator array would move the whole array to scratch memory)
+#pragma unroll
+    for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    store_frag(p, acc[ah][bh][i][j], m0 + ah * 128 + wm * 64 + i * 16 + (lane & 15),
+                               n0 + bh * 128 + wn * 32 + j * 16 + (lane >> 4) * 4, split, vec_ok);
+}
+
 __global__ void splitk_reduce_bf_kernel(const float* __restrict__ ws, int splitk, int M, int N, float alpha, float beta,
                                         const float* __restrict__ bias, float* __restrict__ C, long ldc) {
     const long total = (long)M * N;
@@ -331,13 +617,40 @@ extern "C" int pk_cvt_bf16(void* stream, const float* src, int64_t ld_src, int64
     return 0;
 }
 
-// Rows of the block tile used for this M.  A 256 x 128 tile with three LDS stages (8 waves, prefetch distance two) was
-// built and measured slower than 3-4 co-resident 128 x 128 workgroups (493 vs 615 TFLOP/s on the 64 000-row projection:
-// one large workgroup runs its waves in lock step, independent small ones stagger their load and MFMA phases); it was
-// removed again - DESIGN.md 5.2 keeps the numbers.  The entry point stays so that callers size split-K from it.
+// Which kernel a shape takes: the 256 x 256 eight-phase kernel needs at least one full-size tile of work per CU to
+// pay (one workgroup of 8 waves per CU); small outputs stay on the 128 x 128 kernels (3-4 workgroups per CU).
+// PK_GEMM_TILE=128|256 forces one of them (tools/bench_gemm.py measures both).
+static int g_gemm_tile_forced = -1;
+extern "C" void pk_gemm_bf16_set_tile(int tile) { g_gemm_tile_forced = (tile == 128 || tile == 256) ? tile : 0; }
+static int gemm_tile_for(int M, int N) {
+    int& forced = g_gemm_tile_forced;
+    if (forced < 0) {
+        const char* e = getenv("PK_GEMM_TILE");
+        forced = (e && atoi(e) == 128) ? 128 : (e && atoi(e) == 256) ? 256 : 0;
+    }
+    if (forced) return forced;
+    return (M >= 384 && N >= 384) ? 256 : 128;
+}
+
+// kept for callers that size work from the tile height (the tile is square)
 extern "C" int pk_gemm_bf16_tile_m(int M) {
-    (void)M;
-    return TM;
+    return gemm_tile_for(M, 1 << 30);
+}
+
+// Split-K factor the library recommends for C[M,N] = A.B over K: the dW / dU shapes have few output tiles and a long
+// reduction (K = T*B rows); the reduction is cut so that the grid covers the chip about twice (128-tiles, several
+// workgroups per CU) or once (256-tiles, one workgroup per CU), never below 512 k per slice.
+extern "C" int pk_gemm_bf16_auto_splitk(int M, int N, int K) {
+    if (K < 2048 || M <= 0 || N <= 0) return 1;
+    const int t = gemm_tile_for(M, N);
+    const long tiles = (long)((M + t - 1) / t) * ((N + t - 1) / t);
+    const long ncu = pk_num_cu();
+    long s = (t == 256 ? ncu : 2 * ncu) / (tiles > 0 ? tiles : 1);
+    if (s < 1) s = 1;
+    if (s > 32) s = 32;
+    const long kmax = K / 512 > 0 ? K / 512 : 1;
+    if (s > kmax) s = kmax;
+    return (int)s;
 }
 
 extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
@@ -357,8 +670,9 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
     p.alpha = alpha; p.beta = beta;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.bias = bias;
-    p.tiles_m = (M + TM - 1) / TM;
-    p.tiles_n = (N + TN - 1) / TN;
+    const int tile = gemm_tile_for(M, N);
+    p.tiles_m = (M + tile - 1) / tile;
+    p.tiles_n = (N + tile - 1) / tile;
     static void* zp = nullptr;  // looked up once (also keeps the call out of a HIP-graph capture)
     if (zp == nullptr) PK_CHECK_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)));
     p.zeros = (const unsigned short*)zp;
@@ -378,6 +692,32 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
     p.ws = splitk > 1 ? workspace : nullptr;
     p.items = splitk * p.tiles_m * p.tiles_n;
     p.per_xcd = (p.items + 7) / 8;
+    if (tile == 256) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PIECE));
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PIECE));
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PIECE));
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * PIECE));
+            attr_done = true;
+        }
+        dim3 grid256((unsigned)(p.per_xcd * 8)), block512(512);
+        const size_t lds256 = 8 * PIECE;
+        if (a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_256_kernel<true, true>), grid256, block512, lds256, st, p);
+        else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_bf16_256_kernel<true, false>), grid256, block512, lds256, st, p);
+        else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_bf16_256_kernel<false, true>), grid256, block512, lds256, st, p);
+        else hipLaunchKernelGGL((gemm_bf16_256_kernel<false, false>), grid256, block512, lds256, st, p);
+        PK_LAUNCH_CHECK();
+        if (splitk > 1) {
+            const long total = (long)M * N;
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_bf_kernel, dim3(blocks), dim3(256), 0, st, workspace, splitk, M, N, alpha, beta,
+                               bias, C, (long)ldc);
+            PK_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     dim3 grid((unsigned)(p.per_xcd * 8)), block(256);
     // measured on MI355X (tools/bench_gemm.py): the single-buffer variant with four workgroups per CU wins on the
     // row-streaming shapes (A k-contiguous: 640-680 vs 530-540 TFLOP/s at M = 64000), the double-buffered one on

@@ -166,9 +166,8 @@ def _tiles(M, N):
 
 
 def _tiles_bf(M, N):
-    """Output tiles of the bf16-operand GEMM (the library reports its block-tile height for this M)."""
-    tm = int(_lib.load().pk_gemm_bf16_tile_m(int(M)))
-    return ((M + tm - 1) // tm) * ((N + 127) // 128)
+    """The output shape of a bf16-operand GEMM, as _splitk_bf takes it."""
+    return (M, N)
 
 
 def _up(n, m):
@@ -213,11 +212,10 @@ def gemm_bf16(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, alpha=1.0, beta=0.0, 
 
 
 def _splitk_bf(out_tiles, K):
-    """Split the reduction of the dW / dU shapes (few output tiles, K = T*B rows) over the chip."""
-    if K < 2048:
-        return 1
-    s = max(1, (2 * 256) // max(1, out_tiles))
-    return int(min(32, s, max(1, K // 512)))
+    """Split the reduction of the dW / dU shapes (few output tiles, K = T*B rows) over the chip.  `out_tiles` is an
+    (M, N) pair: the library knows which block tile the shape takes."""
+    M, N = out_tiles
+    return int(_lib.load().pk_gemm_bf16_auto_splitk(int(M), int(N), int(K)))
 
 
 def bf16_mode():

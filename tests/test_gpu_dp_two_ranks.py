@@ -41,8 +41,12 @@ def _run_dp(out, prec, overlap, backend):
 @pytest.mark.parametrize("prec,overlap", [("fp32", 0), ("bf16", 0), ("bf16", 1)])
 def test_two_ranks_on_one_gpu_equal_the_shard_average(tmp_path, prec, overlap):
     ref_out, dp_out = str(tmp_path / "ref.pt"), str(tmp_path / "dp.pt")
+    # OMP_NUM_THREADS=1 is what torch.distributed.run gives its workers: the CPU-side initialisation (orthogonal_ = a
+    # LAPACK QR) rounds differently with another thread count, and a bf16 ReLU recurrence over T = 300 steps turns that
+    # rounding noise into a 2.6e-2 gradient difference (kink flips) - measured: with equal thread counts the two-rank run
+    # and this reference agree bit for bit in both precisions
     r = subprocess.run([sys.executable, WORKER, "--reference", "--out", ref_out, "--prec", prec], stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=240)
+                       stderr=subprocess.STDOUT, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-3000:]
     used = None
     for backend in ("nccl", "gloo"):
@@ -58,16 +62,16 @@ def test_two_ranks_on_one_gpu_equal_the_shard_average(tmp_path, prec, overlap):
     def err(a, b):
         return float((a.double() - b.double()).norm()) / float(b.double().norm())
 
-    # the averaged gradient of the first step: same kernels on the same shards, only the transport differs
-    # (bf16: the weight-gradient GEMMs accumulate with split-K partials whose order is fixed, like fp32)
+    # the averaged gradient of the first step: the same deterministic kernels on the same shards - only the transport and
+    # the order of the two-term average differ
     for k in ref["grad0"]:
         e = err(got["grad0"][k], ref["grad0"][k])
         print("first-step averaged gradient", k, "%.2e" % e)
-        assert e < (2e-6 if prec == "fp32" else 1e-3), (k, e, used)
+        assert e < 2e-6, (k, e, used)
     # parameters after three RMSprop steps: the update g / (sqrt(v) + eps) is +-lr / sqrt(1 - alpha) for ANY non-zero
-    # g on the first step, so rounding-level differences in near-zero gradient elements become lr-sized parameter
-    # differences - a loose tolerance here, the tight one is on the gradient above
+    # g on the first step, so a last-bit difference in a near-zero gradient element becomes an lr-sized parameter
+    # difference: looser than the gradient check
     for k in ref["params"]:
         e = err(got["params"][k], ref["params"][k])
         print("parameters after 3 steps", k, "%.2e" % e)
-        assert e < (1e-3 if prec == "fp32" else 5e-2), (k, e, used)
+        assert e < 2e-4, (k, e, used)

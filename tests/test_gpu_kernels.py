@@ -308,11 +308,37 @@ BF_GEMM_SHAPES = [
     (1100, 1100, 6400, 0, 0, 16),
     (1, 1, 8, 1, 1, 1),
     (5, 1938, 1100, 1, 1, 1),
+    # the 256 x 256 eight-phase kernel (M, N >= 384): every operand layout, a ragged last k-tile (1100 = 17 x 64 + 12),
+    # one k-tile only, a single short k-tile, out-of-range quadrants (N = 1100: the last tile column has 76 columns)
+    (512, 512, 192, 1, 1, 1),
+    (512, 512, 192, 0, 0, 1),
+    (512, 512, 192, 1, 0, 1),
+    (512, 512, 192, 0, 1, 1),
+    (700, 1100, 1100, 1, 1, 1),
+    (390, 1938, 1100, 1, 0, 1),
+    (384, 384, 64, 1, 1, 1),
+    (384, 400, 8, 0, 0, 1),
+    (640, 900, 136, 1, 0, 1),
+    (1100, 1104, 6400, 0, 0, 4),
+    (1938, 1100, 5000, 0, 0, 3),
 ]
 
 
+@pytest.mark.parametrize("tile", [0, 128, 256])
 @pytest.mark.parametrize("M,N,K,a_kc,b_kc,splitk", BF_GEMM_SHAPES)
-def test_gemm_bf16_operands(M, N, K, a_kc, b_kc, splitk):
+def test_gemm_bf16_operands(M, N, K, a_kc, b_kc, splitk, tile):
+    """tile: 0 = the library's own choice, 128 / 256 = that block tile forced for every shape."""
+    import importlib
+
+    lib = importlib.import_module("pytorch-kaldi_amd._lib").load()
+    lib.pk_gemm_bf16_set_tile(tile)
+    try:
+        _gemm_bf16_case(M, N, K, a_kc, b_kc, splitk)
+    finally:
+        lib.pk_gemm_bf16_set_tile(0)
+
+
+def _gemm_bf16_case(M, N, K, a_kc, b_kc, splitk):
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K + a_kc + 2 * b_kc)
     A = torch.randn(M, K, generator=g)
     B = torch.randn(K, N, generator=g)

@@ -172,13 +172,13 @@ def _oracle_recipe(g, sds_prefix="sd/"):
     return sds
 
 
-def _oracle_step(O, m, sds, inp, masks, emulate):
+def _oracle_step(O, m, sds, inp, masks, emulate, kinks=None):
     import contextlib
 
     nfea = m["nfea"]
     with (O.bf16_operands() if emulate else contextlib.nullcontext()):
         out1 = O.recurrent_forward("liGRU", m["options"]["architecture1"], sds["liGRU_layers"], inp[:, :, :nfea],
-                                   drop_masks=masks)
+                                   drop_masks=masks, kinks=kinks)
         loss, err, out2, out3 = O.two_head_loss(out1, sds["MLP_layers"], m["options"]["architecture2"], sds["MLP_layers2"],
                                                 m["options"]["architecture3"], inp[:, :, nfea].reshape(-1).long(),
                                                 inp[:, :, nfea + 1].reshape(-1).long())
@@ -350,7 +350,11 @@ def test_config_scale_golden(prec):
     masks = [g.t("mask/%d" % i).float().cuda() for i in range(m["n_masks"])]
     kinks = [torch.from_numpy(np.unpackbits(g.arrays["kink/%d" % i])[:T * 2 * B * H].reshape(T, 2 * B, H).astype(bool))
              for i in range(L)]
-    report = F_amd.set_forced_kinks(kinks) if prec == "fp32" else None
+    # both precisions differentiate the reference's own piecewise-linear function (kink-forced): at T = 500 ANY
+    # perturbation - 1e-7 of fp32 summation order, 4e-3 of bf16 rounding - otherwise moves thousands of ReLU
+    # pre-activations across 0 and the gradient comparison measures that chaos (3e-3 between two fp32 runs of the
+    # reference itself, Appendix B; 8-10 % for bf16 operands) instead of the arithmetic
+    report = F_amd.set_forced_kinks(kinks)
     rec = nns["liGRU_layers"]
     orig, rec.forward = _with_masks(rec, masks)
     outs = U.forward_model(fea_dict, lab_dict, arch_dict, m["model"], nns, costs, g.t("inp").cuda(), iod, T, B, "train", [])
@@ -406,7 +410,7 @@ def test_config_scale_golden(prec):
     osd = {}
     for n in init:
         osd[n] = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in init[n].items()}
-    o1, o2, o3, oloss, oerr = _oracle_step(O, m, osd, g.t("inp"), [mk.cpu() for mk in masks], True)
+    o1, o2, o3, oloss, oerr = _oracle_step(O, m, osd, g.t("inp"), [mk.cpu() for mk in masks], True, kinks=kinks)
     oloss.backward()
     rep = {}
     for k, om in (("out_dnn1", o1), ("out_dnn2", o2), ("out_dnn3", o3)):
@@ -422,5 +426,7 @@ def test_config_scale_golden(prec):
         frac = float(ref_rows.double().norm()) / ref_ck[0]
         worst = max(worst, _two_step((name, k), _rows(p.grad, s_), _rows(osd[name][k].grad, s_), ref_rows, TIGHT_GRAD,
                                      gtotal * frac), key=lambda t: t[2])
-    print("\nconfig-scale golden [bf16]: outputs (engine-vs-model, model-vs-ref, engine-vs-ref) %s; worst gradient %s"
-          % ({k: tuple("%.1e" % x for x in v) for k, v in rep.items()}, tuple("%.1e" % x for x in worst)))
+    flipped = sum(r[0] for r in report) / float(sum(r[1] for r in report))
+    print("\nconfig-scale golden [bf16]: outputs (engine-vs-model, model-vs-ref, engine-vs-ref) %s; worst kink-forced "
+          "gradient %s; share of ReLU pre-activations whose sign bf16 rounding changed: %.2e"
+          % ({k: tuple("%.1e" % x for x in v) for k, v in rep.items()}, tuple("%.1e" % x for x in worst), flipped))

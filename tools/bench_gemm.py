@@ -27,7 +27,11 @@ def up(n, m):
     return (n + m - 1) // m * m
 
 
-for name, M, N, K, akc, bkc in SHAPES:
+_lib = importlib.import_module("pytorch-kaldi_amd._lib")
+TILES = [int(t) for t in os.environ.get("TILES", "128,256").split(",")]
+REPS = int(os.environ.get("REPS", "10"))
+for tile, (name, M, N, K, akc, bkc) in [(t, sh) for sh in SHAPES for t in TILES]:
+    _lib.load().pk_gemm_bf16_set_tile(tile)
     A = torch.randn((M, up(K, 64)) if akc else (K, up(M, 64)), device="cuda").to(torch.bfloat16)
     B = torch.randn((N, up(K, 64)) if bkc else (K, up(N, 64)), device="cuda").to(torch.bfloat16)
     C = torch.empty(M, N, device="cuda")
@@ -41,10 +45,10 @@ for name, M, N, K, akc, bkc in SHAPES:
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    n = 10
+    n = REPS
     for _ in range(n):
         run()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    print("%s  M=%6d N=%5d K=%6d splitk=%2d  %.3f ms  %.0f TFLOP/s" % (name, M, N, K, sk, ms, 2.0 * M * N * K / ms / 1e9))
+    print("%s  tile %3d  M=%6d N=%5d K=%6d splitk=%2d  %.3f ms  %.0f TFLOP/s" % (name, tile, M, N, K, sk, ms, 2.0 * M * N * K / ms / 1e9))

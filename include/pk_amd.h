@@ -71,10 +71,10 @@ int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha, const floa
  * contiguous - the dW / dU shapes whose reduction runs over the T*B rows); likewise B with N / ldb.
  * Bases 16-byte aligned, pitches multiples of 8 elements; elements between K and the next multiple of
  * 8 inside a k-contiguous row must be zero (pk_cvt_bf16 writes them so).  splitk as pk_gemm. */
-/* rows of the (square) block tile pk_gemm_bf16 uses for tall outputs of this M: 256 (eight-wave, eight-phase kernel) from
- * 384 rows and columns on, else 128 */
+/* rows of the block tile of the k-contiguous shapes (128); the k-major x k-major weight-gradient shapes with at least
+ * 1024 rows and columns take a 256 x 256 tile (eight waves, eight phases per pair of k-tiles) */
 int pk_gemm_bf16_tile_m(int M);
-/* the split-K factor the library recommends for this shape (1 for short reductions) */
+/* the split-K factor the library recommends for a k-major x k-major product of this shape (1 for short reductions) */
 int pk_gemm_bf16_auto_splitk(int M, int N, int K);
 /* tests / tools: 128 or 256 forces that block tile for every shape, 0 = automatic (also PK_GEMM_TILE) */
 void pk_gemm_bf16_set_tile(int tile);

@@ -617,32 +617,38 @@ extern "C" int pk_cvt_bf16(void* stream, const float* src, int64_t ld_src, int64
     return 0;
 }
 
-// Which kernel a shape takes: the 256 x 256 eight-phase kernel needs at least one full-size tile of work per CU to
-// pay (one workgroup of 8 waves per CU); small outputs stay on the 128 x 128 kernels (3-4 workgroups per CU).
-// PK_GEMM_TILE=128|256 forces one of them (tools/bench_gemm.py measures both).
+// Which kernel a shape takes.  Measured on MI355X (tools/bench_gemm.py, profiles/r02_gemm_tiles.txt): both structures are
+// held at 0.65-0.8 PFLOP/s by what the L2 delivers to the LDS-DMA (PMC: matrix pipe 26 % busy, 58 % of wave cycles
+// parked in s_waitcnt / s_barrier, no LDS bank conflicts); the 256 x 256 tile halves the bytes per FLOP and wins where
+// the reduction is long and the output small - the split-K weight-gradient shapes dW (1100 x 1104 x 64000: 690 -> 770)
+// and the senone head's dW (1938 x 1100 x 64000: 670 -> 830) - while the row-streaming shapes (M = 64000, K ~ 1100:
+// 18 k-tiles per output tile, 282 MB of fp32 output) gain nothing from it (prologue / epilogue are not overlapped with
+// one workgroup per CU) and the 550 x 550 dU shape loses (3 x 3 tiles of which 28 % is padding).
+// PK_GEMM_TILE=128|256 / pk_gemm_bf16_set_tile() force one of them.
 static int g_gemm_tile_forced = -1;
 extern "C" void pk_gemm_bf16_set_tile(int tile) { g_gemm_tile_forced = (tile == 128 || tile == 256) ? tile : 0; }
-static int gemm_tile_for(int M, int N) {
+static int gemm_tile_for(int M, int N, int a_kc, int b_kc) {
     int& forced = g_gemm_tile_forced;
     if (forced < 0) {
         const char* e = getenv("PK_GEMM_TILE");
         forced = (e && atoi(e) == 128) ? 128 : (e && atoi(e) == 256) ? 256 : 0;
     }
     if (forced) return forced;
-    return (M >= 384 && N >= 384) ? 256 : 128;
+    return (!a_kc && !b_kc && M >= 1024 && N >= 1024) ? 256 : 128;
 }
 
-// kept for callers that size work from the tile height (the tile is square)
+// kept for callers that sized split-K from the tile height (rows of the block tile of a k-contiguous shape)
 extern "C" int pk_gemm_bf16_tile_m(int M) {
-    return gemm_tile_for(M, 1 << 30);
+    (void)M;
+    return TM;
 }
 
-// Split-K factor the library recommends for C[M,N] = A.B over K: the dW / dU shapes have few output tiles and a long
-// reduction (K = T*B rows); the reduction is cut so that the grid covers the chip about twice (128-tiles, several
+// Split-K factor the library recommends for a k-major x k-major product C[M,N] = A^T.B over K (the dW / dU shapes: few
+// output tiles, K = T*B rows): the reduction is cut so that the grid covers the chip about twice (128-tiles, several
 // workgroups per CU) or once (256-tiles, one workgroup per CU), never below 512 k per slice.
 extern "C" int pk_gemm_bf16_auto_splitk(int M, int N, int K) {
     if (K < 2048 || M <= 0 || N <= 0) return 1;
-    const int t = gemm_tile_for(M, N);
+    const int t = gemm_tile_for(M, N, 0, 0);
     const long tiles = (long)((M + t - 1) / t) * ((N + t - 1) / t);
     const long ncu = pk_num_cu();
     long s = (t == 256 ? ncu : 2 * ncu) / (tiles > 0 ? tiles : 1);
@@ -670,7 +676,7 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
     p.alpha = alpha; p.beta = beta;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.bias = bias;
-    const int tile = gemm_tile_for(M, N);
+    const int tile = gemm_tile_for(M, N, a_kc, b_kc);
     p.tiles_m = (M + tile - 1) / tile;
     p.tiles_n = (N + tile - 1) / tile;
     static void* zp = nullptr;  // looked up once (also keeps the call out of a HIP-graph capture)

@@ -16,7 +16,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
+#include <new>
 #include <vector>
 
 #include "pk_common.h"
@@ -31,6 +33,39 @@ struct pk_ark {
 namespace {
 
 bool read_exact(FILE* f, void* dst, size_t n) { return fread(dst, 1, n, f) == n; }
+
+// bytes between the current position and the end of the file (-1: not a seekable file)
+int64_t remaining_bytes(FILE* f) {
+    struct stat st;
+    const off_t pos = ftello(f);
+    if (pos < 0 || fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode)) return -1;
+    return (int64_t)st.st_size - (int64_t)pos;
+}
+
+// A damaged header must become an error code, not an allocation the size of its garbage dimensions: the payload a
+// record announces has to fit into what is left of the file (and into 63 bits).
+bool payload_fits(FILE* f, int64_t rows, int64_t cols, int64_t bytes_per_elem, int64_t extra) {
+    if (rows < 0 || cols < 0) return false;
+    if (cols != 0 && rows > (INT64_MAX / 16) / cols) return false;
+    const int64_t need = rows * cols * bytes_per_elem + extra;
+    const int64_t left = remaining_bytes(f);
+    return left < 0 || need <= left;
+}
+
+// "<key> ": the reference's read_key (data_io.py:762-783) reads up to the blank and strips whitespace AROUND the key;
+// white space inside a key is kept (Kaldi never writes any).  Returns the key length (0 at end of file), -1 when the
+// key does not fit.
+int read_key(FILE* f, char* key, int keycap) {
+    int n = 0, c;
+    while ((c = fgetc(f)) != EOF && c != ' ') {
+        if (n == 0 && (c == '\n' || c == '\r' || c == '\t')) continue;  // leading white space (e.g. the newline of a text scp)
+        if (key == nullptr || n + 1 >= keycap) return -1;
+        key[n++] = (char)c;
+    }
+    while (n > 0 && (key[n - 1] == '\n' || key[n - 1] == '\r' || key[n - 1] == '\t')) --n;  // trailing white space
+    if (key != nullptr && keycap > 0) key[n < keycap ? n : keycap - 1] = 0;
+    return n;
+}
 
 }  // namespace
 
@@ -66,13 +101,8 @@ extern "C" int pk_ark_next(pk_ark* a, int key_expected, char* key, int keycap, i
     PK_REQUIRE(a->kind == 0, "pk_ark_next: the previous matrix has not been read (pk_ark_read / pk_ark_skip)");
     if (key != nullptr && keycap > 0) key[0] = 0;
     if (key_expected) {
-        int n = 0, c;
-        while ((c = fgetc(a->f)) != EOF && c != ' ') {
-            if (c == '\n' || c == '\r' || c == '\t') continue;  // the reference strips whitespace around a key
-            PK_REQUIRE(key != nullptr && n + 1 < keycap, "pk_ark_next: key longer than %d bytes", keycap);
-            key[n++] = (char)c;
-        }
-        if (key != nullptr && keycap > 0) key[n < keycap ? n : keycap - 1] = 0;
+        const int n = read_key(a->f, key, keycap);
+        PK_REQUIRE(n >= 0, "pk_ark_next: key longer than %d bytes", keycap);
         if (n == 0) return 0;  // end of file
     }
     char mark[2];
@@ -100,6 +130,15 @@ extern "C" int pk_ark_next(pk_ark* a, int key_expected, char* key, int keycap, i
         a->rows = r; a->cols = c;
     }
     PK_REQUIRE(a->rows >= 0 && a->cols >= 0, "pk_ark_next: negative dimensions");
+    {
+        const int64_t bpe = a->kind == 'F' ? 4 : a->kind == 'D' ? 8 : a->kind == '2' ? 2 : 1;
+        const int64_t extra = a->kind == '1' ? a->cols * 8 : 0;
+        if (!payload_fits(a->f, a->rows, a->cols, bpe, extra)) {
+            const long long r_ = (long long)a->rows, c_ = (long long)a->cols;
+            a->kind = 0;
+            PK_REQUIRE(false, "pk_ark_next: a %lld x %lld matrix does not fit into the rest of the file (damaged table)", r_, c_);
+        }
+    }
     *rows = a->rows; *cols = a->cols;
     return 1;
 }
@@ -109,13 +148,8 @@ extern "C" int pk_ark_next(pk_ark* a, int key_expected, char* key, int keycap, i
 extern "C" int pk_ivec_next(pk_ark* a, char* key, int keycap, int64_t* n) {
     PK_REQUIRE(a != nullptr && a->f != nullptr, "pk_ivec_next: closed table");
     PK_REQUIRE(a->kind == 0, "pk_ivec_next: the previous record has not been read");
-    int len = 0, c;
-    while ((c = fgetc(a->f)) != EOF && c != ' ') {
-        if (c == '\n' || c == '\r' || c == '\t') continue;
-        PK_REQUIRE(key != nullptr && len + 1 < keycap, "pk_ivec_next: key longer than %d bytes", keycap);
-        key[len++] = (char)c;
-    }
-    if (key != nullptr && keycap > 0) key[len < keycap ? len : keycap - 1] = 0;
+    const int len = read_key(a->f, key, keycap);
+    PK_REQUIRE(len >= 0, "pk_ivec_next: key longer than %d bytes", keycap);
     if (len == 0) return 0;
     unsigned char hdr[7];
     PK_REQUIRE(read_exact(a->f, hdr, 7), "pk_ivec_next: truncated table");
@@ -123,6 +157,8 @@ extern "C" int pk_ivec_next(pk_ark* a, char* key, int keycap, int64_t* n) {
     int32_t cnt;
     memcpy(&cnt, hdr + 3, 4);
     PK_REQUIRE(cnt >= 0, "pk_ivec_next: negative length");
+    PK_REQUIRE(payload_fits(a->f, cnt, 1, 5, 0), "pk_ivec_next: a vector of %d elements does not fit into the rest of the file "
+               "(damaged table)", (int)cnt);
     a->kind = 'I';
     a->rows = cnt;
     a->cols = 1;
@@ -130,7 +166,20 @@ extern "C" int pk_ivec_next(pk_ark* a, char* key, int keycap, int64_t* n) {
     return 1;
 }
 
+static int ivec_read_body(pk_ark* a, int32_t* dst);
 extern "C" int pk_ivec_read(pk_ark* a, int32_t* dst) {
+    // no C++ exception may cross the C ABI (ctypes would std::terminate the process)
+    try {
+        return ivec_read_body(a, dst);
+    } catch (const std::bad_alloc&) {
+        pk_set_error("pk_ivec_read: out of memory for the staging buffer");
+        return 2;
+    } catch (...) {
+        pk_set_error("pk_ivec_read: unexpected exception");
+        return 2;
+    }
+}
+static int ivec_read_body(pk_ark* a, int32_t* dst) {
     PK_REQUIRE(a != nullptr && a->kind == 'I', "pk_ivec_read: no pending vector (call pk_ivec_next first)");
     const int64_t n = a->rows;
     a->kind = 0;
@@ -144,7 +193,19 @@ extern "C" int pk_ivec_read(pk_ark* a, int32_t* dst) {
 }
 
 // The matrix announced by pk_ark_next -> dst[rows*cols] (row-major float32).
+static int ark_read_body(pk_ark* a, float* dst);
 extern "C" int pk_ark_read(pk_ark* a, float* dst) {
+    try {
+        return ark_read_body(a, dst);
+    } catch (const std::bad_alloc&) {
+        pk_set_error("pk_ark_read: out of memory for the staging buffer");
+        return 2;
+    } catch (...) {
+        pk_set_error("pk_ark_read: unexpected exception");
+        return 2;
+    }
+}
+static int ark_read_body(pk_ark* a, float* dst) {
     PK_REQUIRE(a != nullptr && a->kind != 0 && a->kind != 'I', "pk_ark_read: no pending matrix (call pk_ark_next first)");
     const int64_t R = a->rows, C = a->cols, n = R * C;
     const char kind = a->kind;
@@ -211,7 +272,16 @@ extern "C" int pk_context_window(const float* x, int64_t rows, int64_t cols, int
 }
 
 // x <- (x - mean) / std per column (population std, as np.std), accumulated in double like the reference's float64 chunk
+static int mean_var_norm_body(float* x, int64_t rows, int64_t cols);
 extern "C" int pk_mean_var_norm(float* x, int64_t rows, int64_t cols) {
+    try {
+        return mean_var_norm_body(x, rows, cols);
+    } catch (...) {
+        pk_set_error("pk_mean_var_norm: out of memory");
+        return 2;
+    }
+}
+static int mean_var_norm_body(float* x, int64_t rows, int64_t cols) {
     PK_REQUIRE(rows > 0 && cols > 0, "pk_mean_var_norm: empty chunk");
     std::vector<double> mean((size_t)cols, 0.0), m2((size_t)cols, 0.0);
     for (int64_t r = 0; r < rows; ++r)

@@ -83,7 +83,9 @@ class GradReducer:
             flat = flats[name] if flats else None
             params = [p for p in mod.parameters() if p.requires_grad]
             if flat is not None:
-                order = sorted(zip(flat.offsets, flat.params), key=lambda t: -t[0])
+                # (the never-used parameters sit behind n_active with a zero gradient: nothing to exchange)
+                order = sorted(((o, p) for o, p, u in zip(flat.offsets, flat.params, flat.unused) if not u),
+                               key=lambda t: -t[0])
                 cur, cur_hi = [], None
                 for off, p in order:
                     if cur_hi is None:

@@ -148,6 +148,17 @@ class MLP(nn.Module):
             cur = self.dnn_lay[i]
         self.out_dim = cur
 
+    def pk_unused_parameters(self):
+        """Parameters forward never touches (the reference creates ln / bn for every layer and calls what the flags
+        select, :139-148): torch leaves their .grad None and its optimizers skip them; optim.FlatParams does the same."""
+        out = []
+        for i in range(self.N_dnn_lay):
+            if not self.dnn_use_laynorm[i]:
+                out += list(self.ln[i].parameters())
+            if not self.dnn_use_batchnorm[i]:
+                out += list(self.bn[i].parameters())
+        return out
+
     def forward(self, x):
         if self.dnn_use_laynorm_inp:
             x = self.ln0(x)
@@ -228,6 +239,17 @@ class _Recurrent(nn.Module):
             self.ln.append(LayerNorm(lay[i]))
             cur = 2 * lay[i] if self.bidir else lay[i]
         self.out_dim = lay[-1] + self.bidir * lay[-1]
+
+    def pk_unused_parameters(self):
+        """ln / bn_* of a layer whose flag is off (18 of 62 tensors in the shipped Li-GRU recipe)."""
+        out = []
+        for i in range(self._n_lay):
+            if not self._use_ln[i]:
+                out += list(self.ln[i].parameters())
+            if not self._use_bn[i]:
+                for (_, _, b) in self._gates:
+                    out += list(getattr(self, b)[i].parameters())
+        return out
 
     def _drop_mask(self, i, batch, device):
         """Bernoulli(1-p) mask (rows, H) of layer i, unscaled and constant over time (:1102-1107), or
@@ -453,6 +475,15 @@ class _ConvStack(nn.Module):
                 self.conv.append(nn.Conv1d(self._n_filt[i - 1], n_filt, len_filt))
             cur = pooled
         self.out_dim = cur * self._n_filt[-1]
+
+    def pk_unused_parameters(self):
+        out = []
+        for i in range(self._n_lay):
+            if not self._use_ln[i]:
+                out += list(self.ln[i].parameters())
+            if not self._use_bn[i]:
+                out += list(self.bn[i].parameters())
+        return out
 
     def _conv_pool(self, i, x):
         c = self.conv[i]

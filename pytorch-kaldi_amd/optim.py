@@ -10,9 +10,11 @@ same buffer with no packing copies.
 Semantics follow ``torch.optim.RMSprop`` / ``SGD`` / ``Adam`` exactly as
 ``utils.optimizer_init`` configures them (utils.py:2106-2164).  Parameters the
 reference leaves without a gradient (its unused ``ln``/``bn`` sub-modules,
-SURVEY.md 7.2) keep a zero gradient here; for momentum-free RMSprop/SGD without
-weight decay a zero gradient leaves the parameter unchanged, which is what
-torch's "skip grad=None" does.
+SURVEY.md 7.2; a module lists them in ``pk_unused_parameters()``) are laid out
+BEHIND the active ones: the fused step covers the active range only, so they are
+never touched - also with weight decay, momentum or Adam, where a zero gradient
+would still move them - and ``state_dict()`` has no entry for them, exactly like
+torch's "skip grad=None".
 """
 import ctypes
 
@@ -28,13 +30,19 @@ def _stream():
 class FlatParams:
     def __init__(self, module, align=64):
         self.module = module
-        self.params = [p for p in module.parameters()]
+        self.params = [p for p in module.parameters()]  # registration order: what indexes torch optimizer state
         dev = self.params[0].device  # the flat layout itself is device-agnostic (CPU in the gloo tests)
-        self.offsets = []
+        unused = {id(p) for p in module.pk_unused_parameters()} if hasattr(module, "pk_unused_parameters") else set()
+        self.unused = [id(p) in unused for p in self.params]
+        self.offsets = [0] * len(self.params)
         off = 0
-        for p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + align - 1) // align * align
+        for want_unused in (False, True):  # active parameters first, the never-used ones behind them
+            if want_unused:
+                self.n_active = off
+            for i, p in enumerate(self.params):
+                if self.unused[i] == want_unused:
+                    self.offsets[i] = off
+                    off += (p.numel() + align - 1) // align * align
         self.numel = off
         self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
@@ -106,14 +114,14 @@ class FusedOptimizer:
         f = self.flat
         ptr = lambda k: self.bufs[k].data_ptr() if k in self.bufs else None
         if self.kind == "rmsprop":
-            rc = lib.pk_rmsprop_step(_stream(), f.flat.data_ptr(), f.grad.data_ptr(), ptr("square_avg"), f.numel, lr,
+            rc = lib.pk_rmsprop_step(_stream(), f.flat.data_ptr(), f.grad.data_ptr(), ptr("square_avg"), f.n_active, lr,
                                      self.alpha, self.eps, self.weight_decay)
         elif self.kind == "sgd":
-            rc = lib.pk_sgd_step(_stream(), f.flat.data_ptr(), f.grad.data_ptr(), ptr("momentum_buffer"), f.numel, lr,
+            rc = lib.pk_sgd_step(_stream(), f.flat.data_ptr(), f.grad.data_ptr(), ptr("momentum_buffer"), f.n_active, lr,
                                  self.momentum, self.weight_decay, int(self.steps == 0))
         else:
             rc = lib.pk_adam_step(_stream(), f.flat.data_ptr(), f.grad.data_ptr(), ptr("exp_avg"), ptr("exp_avg_sq"),
-                                  ptr("max_exp_avg_sq"), f.numel, lr, self.betas[0], self.betas[1], self.eps,
+                                  ptr("max_exp_avg_sq"), f.n_active, lr, self.betas[0], self.betas[1], self.eps,
                                   self.weight_decay, self.steps + 1)
         _lib.check(rc, "fused optimizer step")
         self.steps += 1
@@ -135,6 +143,8 @@ class FusedOptimizer:
         state = {}
         if self.steps > 0:
             for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets)):
+                if self.flat.unused[i]:  # torch never steps a parameter whose grad stays None: no state entry
+                    continue
                 ent = {k: b[o:o + p.numel()].view(p.shape).clone() for k, b in self.bufs.items()}
                 if self.kind != "sgd":
                     ent["step"] = torch.tensor(float(self.steps))

@@ -232,6 +232,43 @@ def test_optimizers_match_torch():
         assert rel_err(pe, pr) < 1e-6
 
 
+@pytest.mark.parametrize("kind,kw", [("rmsprop", {"weight_decay": 0.05}), ("sgd", {"momentum": 0.9, "weight_decay": 0.05}),
+                                     ("adam", {"weight_decay": 0.05})])
+def test_fused_optimizer_skips_never_used_parameters_like_torch(kind, kw):
+    """The reference's classes carry ln / bn sub-modules forward never calls; torch leaves their .grad None and its
+    optimizers skip them - with weight decay / momentum / Adam a ZERO gradient would still move them.  The fused
+    optimizers keep them behind the active range: untouched, and without a state entry in state_dict()."""
+    optim_ = importlib.import_module("pytorch-kaldi_amd.optim")
+    nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
+    opts = {"ligru_lay": "24,16", "ligru_drop": "0.0,0.0", "ligru_use_laynorm_inp": "False", "ligru_use_batchnorm_inp": "False",
+            "ligru_use_laynorm": "False,True", "ligru_use_batchnorm": "True,False", "ligru_bidir": "True",
+            "ligru_act": "relu,relu", "ligru_orthinit": "True", "use_cuda": "True", "to_do": "train"}
+    torch.manual_seed(3)
+    net_e = nn_amd.liGRU(dict(opts), 9).cuda().train()
+    net_t = nn_amd.liGRU(dict(opts), 9).cuda().train()
+    net_t.load_state_dict(net_e.state_dict())
+    x = torch.randn(7, 3, 9, generator=torch.Generator().manual_seed(1)).cuda()
+    mk = {"rmsprop": torch.optim.RMSprop, "sgd": torch.optim.SGD, "adam": torch.optim.Adam}[kind]
+    lr = 0.01
+    opt_t = mk(net_t.parameters(), lr=lr, **kw)
+    opt_e = optim_.FusedOptimizer(optim_.FlatParams(net_e), kind, lr, **kw)
+    unused = {n for n, p in net_e.named_parameters() if any(p is q for q in net_e.pk_unused_parameters())}
+    assert unused == {"ln.0.gamma", "ln.0.beta", "bn_wh.1.weight", "bn_wh.1.bias", "bn_wz.1.weight", "bn_wz.1.bias"}
+    before = {n: p.detach().clone() for n, p in net_e.named_parameters()}
+    for _ in range(3):
+        for net, opt in ((net_t, opt_t), (net_e, opt_e)):
+            opt.zero_grad()
+            net(x).square().mean().backward()
+            opt.step()
+    torch.cuda.synchronize()
+    for (n, pe), (_, pt) in zip(net_e.named_parameters(), net_t.named_parameters()):
+        if n in unused:
+            assert pt.grad is None and torch.equal(pe, before[n]) and torch.equal(pt, before[n]), n
+        else:
+            assert rel_err(pe, pt) < 1e-5, n
+    assert sorted(opt_e.state_dict()["state"]) == sorted(opt_t.state_dict()["state"])
+
+
 @pytest.mark.parametrize("kind", ["rmsprop", "sgd", "adam"])
 def test_fused_optimizer_continues_a_torch_checkpoint(kind):
     """optimizer_par written by torch.optim (the reference, core.py:708-722) -> fused optimizer -> same next steps,

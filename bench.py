@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--mask-rng", default="device", choices=["device", "reference"],
                     help="recurrent drop masks: GPU RNG (default) or the reference's CPU torch.bernoulli stream")
-    ap.add_argument("--overlap", action="store_true",
-                    help="N > 1: launch the gradient all-reduce bucket by bucket from backward hooks instead of after backward")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false",
+                    help="N > 1: reduce every gradient bucket after backward instead of behind the layer that produced it")
+    ap.set_defaults(overlap=True)
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim instead of the fused flat optimizers")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step as one HIP graph (auto: the launch-bound non-sequence recipes on one GPU)")

@@ -161,7 +161,9 @@ def make_reducer(nns, optimizers, world):
     """Gradient all-reduce over the flat buckets of the fused optimizers (None on one rank)."""
     if world <= 1:
         return None
-    return _dp.GradReducer({k: nns[k] for k in nns}, flats={k: optimizers[k].flat for k in nns}, overlap=False)
+    # bucket by bucket, behind the layer that produced it (PK_DP_OVERLAP=0: everything after backward)
+    return _dp.GradReducer({k: nns[k] for k in nns}, flats={k: optimizers[k].flat for k in nns}, bucket_bytes=8 << 20,
+                           overlap=os.environ.get("PK_DP_OVERLAP", "1") != "0")
 
 
 def mean_over_ranks(loss_sum, err_sum, world):

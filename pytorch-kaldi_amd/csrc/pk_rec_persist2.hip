@@ -598,6 +598,24 @@ int pk_rec2_host_setup(R2Args& a, bool backward) {
     a.empty_step = g2_empty_step;
     return 0;
 }
+int pk_rec2_check_residency(const void* kernel, int threads, size_t lds, int grid, const char* who) {
+    struct Entry { const void* k; size_t lds; int threads; int cap; };
+    static Entry cache[64];
+    static int n_cache = 0;
+    int cap = -1;
+    for (int i = 0; i < n_cache; ++i)
+        if (cache[i].k == kernel && cache[i].lds == lds && cache[i].threads == threads) cap = cache[i].cap;
+    if (cap < 0) {
+        int per_cu = 0;
+        PK_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds));
+        cap = per_cu * pk_num_cu();
+        if (n_cache < 64) cache[n_cache++] = Entry{kernel, lds, threads, cap};
+    }
+    PK_REQUIRE(grid <= cap, "%s: a grid of %d workgroups cannot be co-resident on this device (%d fit): the persistent "
+               "recurrence would dead-lock into spin time-outs", who, grid, cap);
+    return 0;
+}
+
 int pk_rec2_reset_handshake(hipStream_t st) {
     PK_CHECK_HIP(hipMemsetAsync(g2_xcd_tab, 0xFF, XCD_TAB_BYTES, st));
     return 0;
@@ -675,6 +693,8 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
+        rc = pk_rec2_check_residency((const void*)pick_fwd(cell, act), 256, lds, pl.C * pl.Pn, "pk_rec_fwd_bf16");
+        if (rc) return rc;
         hipLaunchKernelGGL(pick_fwd(cell, act), grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }
@@ -721,6 +741,8 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
+        rc = pk_rec2_check_residency((const void*)pick_bwd(cell, act), 256, lds, pl.C * pl.Pn, "pk_rec_bwd_bf16");
+        if (rc) return rc;
         hipLaunchKernelGGL(pick_bwd(cell, act), grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }

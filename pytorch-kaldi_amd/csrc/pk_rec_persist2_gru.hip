@@ -569,6 +569,8 @@ extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, 
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
+        rc = pk_rec2_check_residency((const void*)fn, 256, lds, pl.C * pl.Pn, "pk_rec2p_*_bf16");
+        if (rc) return rc;
         hipLaunchKernelGGL(fn, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }
@@ -610,6 +612,8 @@ extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, 
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
+        rc = pk_rec2_check_residency((const void*)fn, 256, lds, pl.C * pl.Pn, "pk_rec2p_*_bf16");
+        if (rc) return rc;
         hipLaunchKernelGGL(fn, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }

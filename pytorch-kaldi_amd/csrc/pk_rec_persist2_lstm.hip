@@ -671,6 +671,8 @@ int pk_rec2l_launch(hipStream_t st, R2Args& a, const Plan2& pl, int act, bool ba
         int rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(512);
+        rc = pk_rec2_check_residency((const void*)k, 512, lds, pl.C * pl.Pn, "pk_rec_*_bf16 (LSTM, eight waves)");
+        if (rc) return rc;
         hipLaunchKernelGGL(k, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }

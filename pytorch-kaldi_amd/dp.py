@@ -61,24 +61,30 @@ class GradReducer:
     not fire, e.g. parameters that received no gradient this step).
     """
 
-    def __init__(self, modules, bucket_bytes=32 << 20, flats=None, group=None, overlap=True):
-        """overlap=False: no hooks, every bucket is reduced in finish() (after backward).  At the recipes' sizes
-        (27-63 MB of gradients) the exchange is 1-2 % of a step either way; the serial form keeps
-        RCCL's kernels from competing for CUs with the persistent recurrent kernels, which want their whole
-        grid resident."""
+    def __init__(self, modules, bucket_bytes=32 << 20, flats=None, group=None, overlap=True, force=False):
+        """overlap=True (default): a bucket's all-reduce is launched as soon as every gradient in it has been produced,
+        while BPTT of the lower layers still runs.  Gradients arrive two ways: through autograd (BatchNorm / bias
+        gradients: post-accumulate-grad hooks) and - in perf mode - from the weight-gradient GEMMs that
+        functional.side_launch runs on the side stream and that accumulate straight into the flat .grad buffer
+        (functional.set_side_listener reports them).  The all-reduce is enqueued from the SIDE stream, behind those
+        GEMMs, so the main stream (the backward dependency chain) never waits for a weight gradient.
+        overlap=False: every bucket is reduced in finish(), after backward.  force: build buckets on one rank too
+        (tests: the whole path runs over a one-rank RCCL communicator)."""
         self.group = group
         self.overlap = overlap
-        if overlap:
-            # buckets launched from gradient hooks must not race gradients that arrive outside autograd
-            from . import functional as _F
-            _F.settings.wgrad_side = False
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._by_param = {}
         self.flats = flats  # dict name -> FlatParams or None
         self.buckets = []   # each: dict(params=[...], flat=tensor or None, pending=int)
         self.handles = []
         self._hooks = []
-        if self.world == 1:
+        self.active = False
+        if self.world == 1 and not force:
             return
+        self.active = True
+        if overlap:
+            from . import functional as _F
+            _F.set_side_listener(self._side_done)
         for name, mod in modules.items():
             flat = flats[name] if flats else None
             params = [p for p in mod.parameters() if p.requires_grad]
@@ -114,9 +120,19 @@ class GradReducer:
         b = {"params": list(params), "flat": flat_slice, "pending": len(params), "fired": False, "seen": set(),
              "expect": None}
         self.buckets.append(b)
+        for p in params:
+            self._by_param[id(p)] = b
         if self.overlap:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, b=b: self._ready(b, _p)))
+
+    def _side_done(self, params):
+        """functional.side_launch: the GEMMs that accumulate into these parameters' .grad are enqueued on the side
+        stream (a bucket launched now, from that stream, runs behind them)."""
+        for p in params:
+            b = self._by_param.get(id(p))
+            if b is not None:
+                self._ready(b, p)
 
     def _ready(self, b, p):
         if b["expect"] is None:
@@ -135,18 +151,31 @@ class GradReducer:
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b["params"]]
             buf = torch.cat([g.reshape(-1) for g in grads])
             b["packed"] = (buf, grads)
-        buf.div_(self.world)
-        self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), b))
+        side = None
+        if buf.is_cuda:
+            from . import functional as _F
+            side = _F._Side.stream if _F._Side.pending else None
+        if side is not None:
+            # behind the weight-gradient GEMMs of this bucket (side stream) AND behind the gradients autograd has
+            # accumulated so far (main stream); the main stream itself does not wait
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                buf.div_(self.world)
+                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            buf.div_(self.world)
+            h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.handles.append((h, b))
 
     def finish(self):
         """Call after backward(): completes every bucket and re-arms for the next step."""
-        if self.world == 1:
+        if not self.active:
             return
-        from .functional import join_side
-        join_side()  # weight gradients accumulated from the side stream must be in the buckets
         for b in self.buckets:
             if not b["fired"]:
                 self._launch(b)
+        from .functional import join_side
+        join_side()  # the side stream's weight gradients (and the reductions enqueued behind them) before anything reads .grad
         for h, b in self.handles:
             h.wait()
             if b["flat"] is None:

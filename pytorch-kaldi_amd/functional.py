@@ -229,6 +229,11 @@ def bf16_mode():
 class _Side:
     stream = None
     pending = False
+    listener = None  # dp.GradReducer (overlap mode): told which parameters' gradients were just enqueued on the side stream
+
+
+def set_side_listener(fn):
+    _Side.listener = fn
 
 
 def side_targets_ok(params):
@@ -239,9 +244,10 @@ def side_targets_ok(params):
             and all(getattr(q, "_pk_flat", False) and q.grad is not None for q in params))
 
 
-def side_launch(fn, keep):
+def side_launch(fn, keep, params=None):
     """Run fn() on the side stream after everything enqueued so far on the current stream; `keep` are the tensors
-    fn reads or writes that autograd may free before the side stream is done."""
+    fn reads or writes that autograd may free before the side stream is done; `params`: the parameters whose .grad fn
+    accumulates into (the data-parallel reducer launches a bucket's all-reduce behind them, on this stream)."""
     main = torch.cuda.current_stream()
     if _Side.stream is None:
         _Side.stream = torch.cuda.Stream()
@@ -253,6 +259,8 @@ def side_launch(fn, keep):
         if t is not None:
             t.record_stream(side)
     _Side.pending = True
+    if _Side.listener is not None and params:
+        _Side.listener(params)
 
 
 def join_side():
@@ -327,7 +335,7 @@ class LinearFn(torch.autograd.Function):
                 if M >= 4096 and wp is not None and wp.is_contiguous() and side_targets_ok([wp]):
                     # off the dependency chain: accumulate into the flat .grad on the side stream (beta = 1)
                     side_launch(lambda: gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0,
-                                                  splitk=_splitk_bf(_tiles_bf(N, K), M)), (dyb, xb))
+                                                  splitk=_splitk_bf(_tiles_bf(N, K), M)), (dyb, xb), [wp])
                 else:
                     dw = _new(N, K, like=dy2)
                     gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K,
@@ -929,7 +937,7 @@ class RecLayerPerfFn(torch.autograd.Function):
                 _accumulate_rows(ctx.uparams, [dU[g * H:(g + 1) * H] for g in range(G)])
 
         if side_u:
-            side_launch(do_dU, (Y, S, Yb, dGb, Xb, dU))
+            side_launch(do_dU, (Y, S, Yb, dGb, Xb, dU), ctx.uparams)
         else:
             do_dU()
         # BatchNorm backward (or plain sum of the two directions) straight from dGb -> bf16 projection gradient
@@ -965,7 +973,7 @@ class RecLayerPerfFn(torch.autograd.Function):
                 _accumulate_rows(ctx.wparams, [dW[g * H:(g + 1) * H] for g in range(G)])
 
         if side_w:
-            side_launch(do_dW, (dPb, xb, dWp))
+            side_launch(do_dW, (dPb, xb, dWp), ctx.wparams)
         dx = None
         if ctx.needs_input_grad[0]:  # dx[m,d] = sum_n dP[m,n] W[n,d]: A k-contiguous, B = W (plain pitch) k-major
             Wb2 = Wb if xseg is None else cvt_bf16(Wcat)

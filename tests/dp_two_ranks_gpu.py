@@ -54,10 +54,40 @@ def main():
     ap.add_argument("--overlap", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--reference", action="store_true")
+    ap.add_argument("--solo", default="", help="one rank: '' | 'plain' (no reducer) | 'nccl' (one-rank RCCL communicator, forced buckets)")
     a = ap.parse_args()
     DP = importlib.import_module("pytorch-kaldi_amd.dp")
     _lib = importlib.import_module("pytorch-kaldi_amd._lib")
     world = 2
+    if a.solo:
+        # the whole data-parallel path - buckets over the flat gradient buffer, hooks + side-stream notifications, async
+        # all_reduce on RCCL's stream, finish() - on ONE rank, where the result must equal the plain loop bit for bit
+        if a.solo == "nccl":
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            torch.cuda.set_device(0)
+            torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        F_, nns, opts = build(a.prec)
+        red = None
+        if a.solo == "nccl":
+            red = DP.GradReducer(nns, flats={k: o.flat for k, o in opts.items()}, bucket_bytes=64 << 10,
+                                 overlap=bool(a.overlap), force=True)
+            assert red.active and len(red.buckets) > 1
+        for step in range(a.steps):
+            x, lab = batch(step)
+            for o in opts.values():
+                o.zero_grad()
+            loss_of(nns, x, lab).backward()
+            if red is not None:
+                red.finish()
+            for o in opts.values():
+                o.step()
+        torch.cuda.synchronize()
+        _lib.raise_if_persist_failed()
+        torch.save({"params": {k: o.flat.flat.cpu() for k, o in opts.items()}}, a.out)
+        if a.solo == "nccl":
+            torch.distributed.destroy_process_group()
+        return
     if a.reference:
         F_, nns, opts = build(a.prec)
         g0 = None

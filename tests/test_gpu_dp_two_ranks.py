@@ -75,3 +75,21 @@ def test_two_ranks_on_one_gpu_equal_the_shard_average(tmp_path, prec, overlap):
         e = err(got["params"][k], ref["params"][k])
         print("parameters after 3 steps", k, "%.2e" % e)
         assert e < 2e-4, (k, e, used)
+
+
+@pytest.mark.parametrize("prec,overlap", [("bf16", 1), ("bf16", 0), ("fp32", 1)])
+def test_one_rank_rccl_communicator_runs_the_bucket_path(tmp_path, prec, overlap):
+    """backend="nccl" (RCCL) executed on the hardware there is: a ONE-rank communicator with the buckets forced.  The
+    reducer's whole machinery runs - flat-buffer buckets, gradient hooks + side-stream notifications, async all_reduce
+    on RCCL's stream next to the persistent recurrent kernels and the side-stream GEMMs, finish() - and, a one-rank
+    sum being the identity, three optimizer steps must end bit-identical to the plain loop."""
+    outs = {}
+    for solo in ("plain", "nccl"):
+        out = str(tmp_path / (solo + ".pt"))
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+        r = subprocess.run([sys.executable, WORKER, "--solo", solo, "--out", out, "--prec", prec, "--overlap", str(overlap)],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout[-4000:]
+        outs[solo] = torch.load(out)["params"]
+    for k in outs["plain"]:
+        assert torch.equal(outs["plain"][k], outs["nccl"][k]), k

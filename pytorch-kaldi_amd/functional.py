@@ -829,6 +829,7 @@ class RecLayerPerfFn(torch.autograd.Function):
         lib = _lib.load()
         cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar, xseg = cfg[:10]
         ctx.wparams, ctx.uparams = (cfg[10], cfg[11]) if len(cfg) > 10 else (None, None)
+        ctx.side_w, ctx.side_u = (bool(cfg[12]), bool(cfg[13])) if len(cfg) > 13 else (False, False)
         T, B, D = x.shape
         G = lib.pk_rec_num_gates(CELL[cell])
         NS = lib.pk_rec_num_saved(CELL[cell])
@@ -925,8 +926,7 @@ class RecLayerPerfFn(torch.autograd.Function):
             _lib.check(rc, "pk_rec_bwd_bf16")
         # weight gradients are off the dependency chain (the next thing on it is the layer below's recurrent
         # backward): with flat-bucket parameters they run on the side stream and accumulate straight into .grad
-        side_u = side_targets_ok(ctx.uparams)
-        side_w = side_targets_ok(ctx.wparams)
+        side_u, side_w = ctx.side_u, ctx.side_w  # decided in forward: those weights were handed over detached
         Xb = ctx.Xb
         ctx.Xb = None
         dU = _new(GH, H, like=dY)

@@ -329,8 +329,19 @@ class _Recurrent(nn.Module):
                                  % (tuple(x.shape),))
             cfg = (self.KIND, self._act[i], H, bool(self.bidir), use_bn, self.training, 1e-5, 0.05, scalar_i)
             if F_.perf_path_ok(self.KIND, H, bool(self._use_ln[i]), use_bn, self.training):
-                y, bmean, bvar, xb = F_.RecLayerPerfFn.apply(x, xb, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, mask_i,
-                                                           cfg + (xseg, [m.weight for m in Ws], [m.weight for m in Us]))
+                wps, ups = [m.weight for m in Ws], [m.weight for m in Us]
+                # weight gradients that go to the flat .grad buffer from the side stream do not pass through autograd:
+                # the concatenated weights are handed over detached (otherwise cat's backward materialises a zero
+                # gradient per gate and adds it to .grad on the main stream - launches, and a write that would race
+                # a data-parallel bucket already being reduced)
+                # (some other input must still carry the autograd edge that makes backward run at all: the BatchNorm
+                # affine or the bias - one of the two always exists, neural_networks.py:1052-1055 - or x itself)
+                edge = torch.is_grad_enabled() and (use_bn or bcat is not None or x.requires_grad)
+                side_w = edge and F_.side_targets_ok(wps)
+                side_u = edge and F_.side_targets_ok(ups)
+                y, bmean, bvar, xb = F_.RecLayerPerfFn.apply(x, xb, Wcat.detach() if side_w else Wcat, bcat,
+                                                           Ucat.detach() if side_u else Ucat, gamma, beta, rmean, rvar,
+                                                           mask_i, cfg + (xseg, wps, ups, side_w, side_u))
                 xseg = (2 if self.bidir else 1, H, (H + 7) // 8 * 8)
             else:
                 lng = self.ln[i].gamma if self._use_ln[i] else None

@@ -295,15 +295,20 @@ def _read_alignments(rspec):
     return out
 
 
-def load_chunk(fea_rspec, lab_rspec, left, right, max_sequence_length, fea_only=False):
+def load_chunk(fea_rspec, lab_rspec, left, right, max_sequence_length, fea_only=False, device=None):
     """The reference's load_chunk (data_io.py:244-274) for tables that already exist on disk: `fea_rspec` is a feature
     scp ("key file:offset" lines) or ark, `lab_rspec` an integer-vector ark of pdf-ids (plain, .gz, or a folder of
     ali*.gz) - i.e. what `copy-feats scp:... ark:- | <fea_opts>` and `gunzip -c ali*.gz | ali-to-pdf ...` would deliver.
-    Returns [data_name, data_set (float32, features + one label column), end_index_fea]."""
+    Returns [data_name, data_set (float32, features + one label column), end_index_fea].  `device`: splice and
+    normalise on that device (finish_chunk_device: the un-spliced features cross PCIe) and return data_set as a tensor
+    resident there."""
     fea = _read_features(fea_rspec)
     lab = {} if fea_only else _read_alignments(lab_rspec)
     names, data_set, data_lab, end_index_fea, _ = load_dataset(fea, lab, max_sequence_length, fea_only)
-    data_set, end_index_fea = finish_chunk(data_set, data_lab, end_index_fea, left, right)
+    if device is not None:
+        data_set, end_index_fea = finish_chunk_device(data_set, data_lab, end_index_fea, left, right, device)
+    else:
+        data_set, end_index_fea = finish_chunk(data_set, data_lab, end_index_fea, left, right)
     return [names, data_set, end_index_fea]
 
 
@@ -352,7 +357,11 @@ def read_lab_fea(cfg_file, fea_only, shared_list, output_folder=None):
     ranges appended to fea_dict (:590-592, :601-604), label columns follow (:622-627); non-sequence training chunks are
     shuffled with the global numpy RNG (:633-635).  `fea_opts` / `lab_opts` must be empty (or `lab_opts = pdf-ids`):
     a pipeline needs Kaldi and stays with the reference's reader.  data_set is float32 (the reference hands float64 to
-    run_nn, which converts it)."""
+    run_nn, which converts it).  PK_CHUNK_DEVICE=cuda: the chunk is finished ON the device (context windows spliced and
+    the chunk normalised there, finish_chunk_device) and data_set is a tensor resident there - run_nn_dp's batch
+    assembly gathers from it without a second copy."""
+    dev = os.environ.get("PK_CHUNK_DEVICE") or None
+    stack = (lambda cols: torch.cat([c if c.dim() == 2 else c[:, None] for c in cols], 1)) if dev else np.column_stack
     if not os.path.exists(cfg_file):
         raise IOError("The config file %s does not exist!" % cfg_file)
     config = configparser.ConfigParser()
@@ -384,7 +393,7 @@ def read_lab_fea(cfg_file, fea_only, shared_list, output_folder=None):
                 if lab_opts.strip() not in ("", "pdf-ids"):
                     raise ValueError("read_lab_fea: lab_opts of %s is %r; store pdf-ids (ali-to-pdf run once) and set "
                                      "lab_opts = pdf-ids, or use the reference's reader" % (lab, lab_opts))
-            name_fea, set_fea, end_fea = load_chunk(fea_scp, lab_folder, cw_left, cw_right, max_seq_length, fea_only)
+            name_fea, set_fea, end_fea = load_chunk(fea_scp, lab_folder, cw_left, cw_right, max_seq_length, fea_only, dev)
             lo, hi = cw_left_max - cw_left, set_fea.shape[0] - (cw_right_max - cw_right)
             labs_fea, set_fea = set_fea[lo:hi, -1], set_fea[lo:hi, 0:-1]
             end_fea = end_fea - lo
@@ -393,9 +402,9 @@ def read_lab_fea(cfg_file, fea_only, shared_list, output_folder=None):
                 data_set, labs, data_end_index, data_name = set_fea, labs_fea, end_fea, name_fea
             else:
                 if cnt_fea == 0:
-                    labs = np.column_stack((labs, labs_fea))
+                    labs = stack((labs, labs_fea))
                 if cnt_lab == 0:
-                    data_set = np.column_stack((data_set, set_fea))
+                    data_set = stack((data_set, set_fea))
                 if data_name != name_fea:
                     raise ValueError("different sentence ids are detected for the different features. Please check "
                                      "again input feature lists")
@@ -409,8 +418,13 @@ def read_lab_fea(cfg_file, fea_only, shared_list, output_folder=None):
     if not fea_only:
         for cnt_lab, lab in enumerate(lab_dict):
             lab_dict[lab].append(data_set.shape[1] + cnt_lab)
-    data_set = np.column_stack((data_set, labs))
+    data_set = stack((data_set, labs))
     seq_model = any(arch_dict[a][2] for a in arch_dict)
     if not seq_model and to_do != "forward":
-        np.random.shuffle(data_set)
+        if dev:  # np.random.shuffle draws the same swaps whatever the rows hold: shuffle an index with it, gather on the device
+            perm = np.arange(data_set.shape[0])
+            np.random.shuffle(perm)
+            data_set = data_set[torch.as_tensor(perm, device=data_set.device)]
+        else:
+            np.random.shuffle(data_set)
     shared_list.extend([data_name, data_end_index, fea_dict, lab_dict, arch_dict, data_set])

@@ -5,6 +5,7 @@ import importlib
 import struct
 
 import numpy as np
+import torch
 import pytest
 
 from golden_util import Golden
@@ -347,3 +348,113 @@ def test_reader_edge_cases(tmp_path):
         list(dio.read_mat_ark(str(p)))
     with pytest.raises(IOError):
         list(dio.read_mat_ark(str(tmp_path / "missing.ark")))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# on the device (SURVEY.md 8f-4 on the GPU box): finish_chunk_device, the reader with PK_CHUNK_DEVICE=cuda, and a
+# chunk trained by run_nn_dp straight from tables on disk (PK_READER=tables)
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("left,right", [(0, 0), (3, 2), (5, 5)])
+def test_finish_chunk_device_matches_the_host_path(left, right):
+    rng = np.random.RandomState(4)
+    x = (rng.randn(300, 13) * rng.rand(13) * 3 + rng.randn(13)).astype(np.float32)
+    lab = rng.randint(2, 40, 300)
+    end = np.array([90, 200, 300])
+    want, want_end = dio.finish_chunk(x.copy(), lab, end, left, right)
+    got, got_end = dio.finish_chunk_device(x.copy(), lab, end, left, right, "cuda")
+    assert got.is_cuda and tuple(got.shape) == want.shape and np.array_equal(got_end, want_end)
+    assert np.array_equal(got[:, -1].cpu().numpy(), want[:, -1])            # labels exact
+    assert np.allclose(got[:, :-1].cpu().numpy(), want[:, :-1], rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("run", ["train_mlp_two_streams", "train_seq_split", "valid_mlp_one_stream", "forward_production"])
+def test_read_lab_fea_on_the_device_matches_reference(reader_tables, run, monkeypatch):
+    """The reference's read_lab_fea fixture again, with the chunk finished on the GPU (PK_CHUNK_DEVICE=cuda): two
+    feature streams with different context windows, two label sets, the shuffle of non-sequence training chunks."""
+    monkeypatch.setenv("PK_CHUNK_DEVICE", "cuda")
+    g, tmp = reader_tables
+    m = g.meta["runs"][run]
+    cfg = tmp / (run + ".cfg")
+    cfg.write_text(m["cfg"].replace("{TMP}", str(tmp)).replace("lab_opts=ali-to-pdf", "lab_opts=pdf-ids"))
+    np.random.seed(m["np_seed"])
+    shared = []
+    dio.read_lab_fea(str(cfg), m["fea_only"], shared, str(tmp))
+    data_name, end_index, fea_dict, lab_dict, arch_dict, data_set = shared
+    assert torch.is_tensor(data_set) and data_set.is_cuda and data_set.dtype == torch.float32
+    assert data_name == m["names"] and np.array_equal(end_index, g.arrays[run + "/end_index"])
+    ref = g.arrays[run + "/data_set"]
+    nfea = max(v[6] for v in m["fea_dict"].values())
+    got = data_set.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, nfea:], ref[:, nfea:].astype(np.float32))
+    assert np.allclose(got[:, :nfea], ref[:, :nfea], rtol=0, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk_device", ["", "cuda"])
+def test_run_nn_dp_trains_a_chunk_from_tables_on_disk(reader_tables, tmp_path, monkeypatch, chunk_device):
+    """run_nn_dp with PK_READER=tables: a training chunk read from Kaldi tables on disk by this package's reader (no
+    Kaldi binary, no reference reader), assembled into padded batches on the device and trained on the engine.  The
+    engine run must equal the same chunk trained by the CPU oracle batch for batch (loss of the .info file)."""
+    import configparser
+    import random
+
+    import pk_oracle as O
+
+    core = importlib.import_module("pytorch-kaldi_amd.core")
+    g, tmp = reader_tables
+    gc = Golden("chunk_ligru_run_nn")
+    monkeypatch.setenv("PK_READER", "tables")
+    if chunk_device:
+        monkeypatch.setenv("PK_CHUNK_DEVICE", chunk_device)
+    ref = g.arrays["train_seq_split/data_set"]
+    n_mono, n_cd = int(ref[:, 5].max()) + 1, int(ref[:, 6].max()) + 1
+    cp = configparser.ConfigParser()
+    cp.read_string(gc.meta["cfgs"]["ck0"].replace("{OUT}", str(tmp_path)).replace("arch_library = neural_networks",
+                                                                                "arch_library = pytorch-kaldi_amd.nn")
+                   .replace("use_cuda = False", "use_cuda = True"))
+    rd = configparser.ConfigParser()
+    rd.read_string(g.meta["runs"]["train_seq_split"]["cfg"].replace("{TMP}", str(tmp)).replace("lab_opts=ali-to-pdf", "lab_opts=pdf-ids"))
+    cp["data_chunk"] = dict(rd["data_chunk"])
+    cp["batches"]["max_seq_length_train"] = rd["batches"]["max_seq_length_train"]
+    cp["batches"]["batch_size_train"] = "4"
+    cp["model"]["model"] = cp["model"]["model"].replace("fmllr", "fbank")
+    cp["architecture2"]["dnn_lay"], cp["architecture3"]["dnn_lay"] = str(n_cd), str(n_mono)
+    cfg = tmp_path / "chunk.cfg"
+    with open(cfg, "w") as f:
+        cp.write(f)
+    nxt = core.run_nn_dp(None, None, None, None, None, None, str(cfg), True, str(cfg))
+    assert nxt[1].is_cuda and tuple(nxt[1].shape) == ref.shape   # the next chunk, read by the prefetch thread
+    info = configparser.ConfigParser()
+    info.read(tmp_path / "ck0.info")
+    loss_engine = float(info["results"]["loss"])
+    # ---- the same chunk through the CPU oracle: same seed -> same initialisation and padding, drop masks off
+    seed = int(cp["exp"]["seed"])
+    torch.manual_seed(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+    nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
+    a1, a2, a3 = (dict(cp["architecture%d" % i], use_cuda="False", to_do="train") for i in (1, 2, 3))
+    nets = [nn_amd.liGRU(a1, 5)]
+    nets += [nn_amd.MLP(a2, nets[0].out_dim), nn_amd.MLP(a3, nets[0].out_dim)]
+    sds = [{k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in n.state_dict().items()}
+           for n in nets]
+    opts = [torch.optim.RMSprop([v for v in sd.values() if v.requires_grad], lr=float(a["arch_lr"]), alpha=float(a["opt_alpha"]),
+                                eps=float(a["opt_eps"])) for sd, a in zip(sds, (a1, a2, a3))]
+    data = torch.from_numpy(ref.astype(np.float32))
+    end = g.arrays["train_seq_split/end_index"]
+    asm = core.BatchAssembler(data, end, torch.device("cpu"))
+    losses = []
+    for b in range(len(end) // 4):
+        T_, inp = asm.batch(4 * b, 4)
+        out1 = O.recurrent_forward("liGRU", a1, sds[0], inp[:, :, :5])
+        loss, _, _, _ = O.two_head_loss(out1, sds[1], a2, sds[2], a3, inp[:, :, 6].reshape(-1).long(), inp[:, :, 5].reshape(-1).long())
+        for o in opts:
+            o.zero_grad()
+        loss.backward()
+        for o in opts:
+            o.step()
+        losses.append(float(loss.detach()))
+    assert abs(loss_engine - np.mean(losses)) < 1e-4 * abs(np.mean(losses)), (loss_engine, np.mean(losses))

@@ -518,16 +518,22 @@ int check_common(const char* who, int algo, int prec, int cell, int act, int T, 
 extern "C" int pk_rec_num_saved(int cell) { return pk_cell_saved(cell); }
 extern "C" int pk_rec_num_gates(int cell) { return pk_cell_gates(cell); }
 
-extern "C" int64_t pk_rec_work_floats(int cell, int T, int B, int bidir, int H) {
+// scratch of the step-wise algorithm and of the deferred dU GEMMs (every algorithm); a multiple of 64 floats
+int64_t pk_rec_work_base_floats(int cell, int B, int bidir, int H) {
     const long R = (long)B * (1 + bidir), G = pk_cell_gates(cell);
-    (void)T;
     long n = 6 * ((R * H + 63) / 64 * 64) + 2 * ((R * G * H + 63) / 64 * 64);
     n += (long)DU_SPLITK * G * H * H + 64;
     // per-step LayerNorm backward: dh, two accumulators, column-sum partials
     n += 3 * ((R * H + 63) / 64 * 64) + pk_bn_partial_floats(R, H);
     // slack
     n += 4096;
-    return n;
+    return (n + 63) / 64 * 64;
+}
+int64_t pk_rec2f_exchange_floats(int cell, int T, int B, int bidir, int H);  // pk_rec_persist2_f32.hip
+
+extern "C" int64_t pk_rec_work_floats(int cell, int T, int B, int bidir, int H) {
+    // + the fp32 exchange buffer of the exact-fp32 persistent kernels (liGRU / RNN), placed behind the base scratch
+    return pk_rec_work_base_floats(cell, B, bidir, H) + pk_rec2f_exchange_floats(cell, T, B, bidir, H);
 }
 
 extern "C" int pk_rec_fwd(void* stream, int algo, int prec, int cell, int act, int T, int B, int bidir, int H,

@@ -2,7 +2,9 @@
 // (pk_rec_persist2.hip: liGRU / RNN / LSTM; pk_rec_persist2_gru.hip: GRU / minimalGRU).
 // See pk_rec_persist2.hip for the design notes.
 #pragma once
+#ifndef PK_REC2_PRECISE       // (pk_rec_persist2_f32.hip: the exact-fp32 twin keeps the precise exp / division)
 #define PK_CELL_FAST_MATH 1  // perf mode: hardware-rate exp / reciprocal in the gate math
+#endif
 #include "pk_cell.h"
 
 struct R2Args {
@@ -19,6 +21,8 @@ struct R2Args {
     float* dP2;
     unsigned short* dGb;
     int Gpitch;  // elements per row of dGb; gate g starts at g*Hp
+    float* Yx;   // exact-fp32 kernels (pk_rec_persist2_f32.hip): fp32 exchange buffers with the same geometry as Yb / dGb
+    float* dGx;  //   (pitches in floats; a chunk = 16 bytes = 4 units)
     unsigned* err;
     int spin_limit;
     float* trash;               // >= 64 bytes per lane-group of write-only scratch for masked-off stores

@@ -28,6 +28,8 @@
 //
 // Cells: liGRU, RNN, LSTM (single GEMM phase per step).  GRU / minimalGRU need
 // two phases per step and use the step-wise algorithm.
+#include <stdlib.h>
+
 #include "pk_cell.h"
 
 namespace {
@@ -619,10 +621,30 @@ extern "C" void pk_persist_error_reset(void) {
     if (g_err_host) *g_err_host = 0u;
 }
 
+// second-generation exact-fp32 kernels (pk_rec_persist2_f32.hip): liGRU / RNN; their exchange buffer lives in `work`
+int pk_rec2f_covers(int cell, int H);
+int64_t pk_rec_work_base_floats(int cell, int B, int bidir, int H);
+int pk_rec2f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int H, const float* P, const float* pscale,
+                 const float* pshift, const float* U, const float* mask, float mask_scalar, float* Y, float* S, float* Yx);
+int pk_rec2f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
+                 float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, float* dGx);
+static bool use_gen2_f32(int prec, int cell, int H) {
+    static int off = -1;
+    if (off < 0) {
+        const char* e = getenv("PK_REC_F32_GEN");  // 1 = keep the first-generation kernels (A/B measurements)
+        off = (e && e[0] == '1') ? 1 : 0;
+    }
+    return !off && prec == PK_PREC_F32 && pk_rec2f_covers(cell, H);
+}
+
 int pk_rec_fwd_persistent(hipStream_t st, int prec, int cell, int act, int T, int B, int bidir, int H, const float* P,
                           const float* pscale, const float* pshift, const float* U, const float* mask,
                           float mask_scalar, float* Y, float* S, float* work) {
-    (void)work;
+    if (use_gen2_f32(prec, cell, H)) {
+        PK_REQUIRE(work != nullptr, "pk_rec_fwd: work buffer missing");
+        return pk_rec2f_fwd(st, cell, act, T, B, bidir, H, P, pscale, pshift, U, mask, mask_scalar, Y, S,
+                            work + pk_rec_work_base_floats(cell, B, bidir, H));
+    }
     int rc = check_persist("pk_rec_fwd", cell, H);
     if (rc) return rc;
     rc = ensure_err();
@@ -646,7 +668,11 @@ int pk_rec_fwd_persistent(hipStream_t st, int prec, int cell, int act, int T, in
 int pk_rec_bwd_persistent(hipStream_t st, int prec, int cell, int act, int T, int B, int bidir, int H, const float* U,
                           const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
                           float* dP2, float* work) {
-    (void)work;
+    if (use_gen2_f32(prec, cell, H)) {
+        PK_REQUIRE(work != nullptr, "pk_rec_bwd: work buffer missing");
+        return pk_rec2f_bwd(st, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dP2,
+                            work + pk_rec_work_base_floats(cell, B, bidir, H));
+    }
     int rc = check_persist("pk_rec_bwd", cell, H);
     if (rc) return rc;
     rc = ensure_err();

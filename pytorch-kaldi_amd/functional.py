@@ -549,7 +549,7 @@ def log_softmax(x):
 def choose_rec_algo(cell, H, use_ln):
     want = settings.rec_algo
     ok = cell in ("liGRU", "RNN", "LSTM") and H <= 576 and not use_ln
-    if not bf16_mode():  # the exact-fp32 persistent kernels exchange pairs of fp32 values
+    if not bf16_mode() and cell == "LSTM":  # its (first-generation) exact-fp32 kernels exchange pairs of fp32 values
         ok = ok and H % 2 == 0
     if want == "persistent":
         if not ok:

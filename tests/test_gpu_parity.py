@@ -41,8 +41,8 @@ def _check_case(case, algo):
            for s in v.split(",")) and m["arch_class"] in PERSISTENT_OK + ("GRU", "minimalGRU") and algo == "persistent":
         pytest.skip("per-step LayerNorm runs in the step-wise algorithm")
     pre = {"liGRU": "ligru", "LSTM": "lstm", "GRU": "gru", "minimalGRU": "minimalgru", "RNN": "rnn"}.get(m["arch_class"])
-    if algo == "persistent" and pre and any(int(h) % 2 for h in m["options"][pre + "_lay"].split(",")):
-        pytest.skip("the exact-fp32 persistent kernels exchange pairs of fp32 values: odd layer widths run step-wise")
+    if algo == "persistent" and m["arch_class"] == "LSTM" and any(int(h) % 2 for h in m["options"][pre + "_lay"].split(",")):
+        pytest.skip("LSTM's exact-fp32 persistent kernels exchange pairs of fp32 values: odd layer widths run step-wise")
     F_amd.set_rec_algo(algo)
     net = build_engine(m, g.group("sd/"))
     has_bwd = "dx" in g.arrays

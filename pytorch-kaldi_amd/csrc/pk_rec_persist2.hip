@@ -40,7 +40,7 @@ template <int CELL, int ACT, bool TR>
 __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
-    constexpr int LDA = KPAD + 8;                 // bf16 elements per A-tile row (1168 B: odd multiple of 16 B)
+    constexpr int LDA = pk_r2_lda_bf16(KPAD);      // bf16 elements per A-tile row (1312 B: conflict-free b128 reads)
     constexpr int ATILE = RMAX * LDA * 2;         // bytes
     constexpr int NCH = (RMAX * (KPAD / 8) + 255) / 256;  // 16-byte chunks polled per lane (5)
     constexpr int WAVE_LDS = (G + 1 + NS) * 1024 + 512;   // P stage | Y | S slots | bf16 publish patch
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
     constexpr bool LSTM = (CELL == PK_CELL_LSTM);
-    constexpr int LDA = G * KPAD + 8;
+    constexpr int LDA = pk_r2_lda_bf16(G * KPAD);
     constexpr int ATILE = RMAX * LDA * 2;
     constexpr int NBUF = (2 * ATILE > 96 * 1024) ? 1 : 2;  // LSTM: one A tile (74 KB) + an extra barrier per step
     constexpr int NCH = (RMAX * G * (KPAD / 8) + 255) / 256;
@@ -678,7 +678,7 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     if (cell == PK_CELL_LSTM && pk_rec2l_enabled()) return pk_rec2l_launch(st, a, pl, act, false);
     const int G = pk_cell_gates(cell);
-    const size_t lds = 2 * (size_t)RMAX * (KPAD + 8) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024 + 512) + 16;
+    const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024 + 512) + 16;
     {   // dynamic LDS above the 64 KB default needs the opt-in (exact size: the kernels also hold a little static LDS)
         static size_t granted[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
         const int slot = cell == PK_CELL_LIGRU ? 0 : cell == PK_CELL_RNN ? 1 : 2;
@@ -724,7 +724,7 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     if (rc) return rc;
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
     if (cell == PK_CELL_LSTM && pk_rec2l_enabled()) return pk_rec2l_launch(st, a, pl, act, true);
-    const size_t atile = (size_t)RMAX * (G * KPAD + 8) * 2;
+    const size_t atile = (size_t)RMAX * pk_r2_lda_bf16(G * KPAD) * 2;
     const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0);
     const size_t lds = (2 * atile > 96 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(nin + G) * 1024 + (size_t)G * 512) + 16;
     {

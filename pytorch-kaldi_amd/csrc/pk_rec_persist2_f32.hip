@@ -44,7 +44,7 @@ template <int CELL, int ACT>
 __global__ __launch_bounds__(256, 1) void rec2f_fwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
-    constexpr int LDA = KPAD + 4;                  // floats per A-tile row (2320 B: 16 rows x 16-byte reads hit 64 banks)
+    constexpr int LDA = pk_r2_lda_f32(KPAD);       // floats per A-tile row (conflict-free b128 reads, pk_rec2_common.h)
     constexpr int ATILE = RMAX * LDA * 4;          // bytes
     constexpr int NCH = (RMAX * (KPAD / 4) + 255) / 256;  // 16-byte chunks polled per lane (9)
     constexpr int WAVE_LDS = (G + 1 + NS) * 1024;  // P stage | Y | S slots
@@ -237,7 +237,7 @@ template <int CELL, int ACT>
 __global__ __launch_bounds__(256, 1) void rec2f_bwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
-    constexpr int LDA = G * KPAD + 4;              // floats per A-tile row
+    constexpr int LDA = pk_r2_lda_f32(G * KPAD);   // floats per A-tile row
     constexpr int ATILE = RMAX * LDA * 4;
     constexpr int NBUF = (2 * ATILE > 100 * 1024) ? 1 : 2;  // two gates: one 74 KB tile + an extra barrier per step
     constexpr int NCH = (RMAX * G * (KPAD / 4) + 255) / 256;  // 9 per gate
@@ -490,7 +490,7 @@ int pk_rec2f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     if (rc) return rc;
     PK_CHECK_HIP(hipMemsetAsync(Yx, 0xFF, (size_t)T * B * y_pitch * 4, st));  // the mailbox: every dword "not written yet"
     const int G = pk_cell_gates(cell);
-    const size_t lds = 2 * (size_t)RMAX * (KPAD + 4) * 4 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024) + 16;
+    const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_f32(KPAD) * 4 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024) + 16;
     const Rec2fKernel k = cell == PK_CELL_LIGRU ? pickf_fwd<PK_CELL_LIGRU>(act) : pickf_fwd<PK_CELL_RNN>(act);
     rc = grant_lds(k, lds);
     if (rc) return rc;
@@ -527,7 +527,7 @@ int pk_rec2f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     rc = pk_rec2_host_setup(a, true);
     if (rc) return rc;
     PK_CHECK_HIP(hipMemsetAsync(dGx, 0xFF, (size_t)ndir * T * B * g_pitch * 4, st));
-    const size_t atile = (size_t)RMAX * (G * KPAD + 4) * 4;
+    const size_t atile = (size_t)RMAX * pk_r2_lda_f32(G * KPAD) * 4;
     const size_t lds = (2 * atile > 100 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(pk_cell_saved(cell) + 2 + G) * 1024) + 16;
     const Rec2fKernel k = cell == PK_CELL_LIGRU ? pickf_bwd<PK_CELL_LIGRU>(act) : pickf_bwd<PK_CELL_RNN>(act);
     rc = grant_lds(k, lds);

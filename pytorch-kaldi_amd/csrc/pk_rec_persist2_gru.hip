@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
     constexpr bool TR = false;  // no phase trace in the two-phase kernels
     constexpr int G = pk_cell_gates(CELL), G1 = G - 1, NS = pk_cell_saved(CELL);
     constexpr bool GRU = (CELL == PK_CELL_GRU);
-    constexpr int LDA = KPAD + 8;
+    constexpr int LDA = pk_r2_lda_bf16(KPAD);
     constexpr int ATILE = RMAX * LDA * 2;
     constexpr int NCH = (RMAX * (KPAD / 8) + 255) / 256;
     constexpr int WAVE_LDS = (G + 1 + G) * 1024 + 512;  // P stage | Y | saved z(,r),a | bf16 publish patch
@@ -278,8 +278,8 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
     constexpr bool TR = false;  // no phase trace in the two-phase kernels
     constexpr int G = pk_cell_gates(CELL), G1 = G - 1, NS = pk_cell_saved(CELL);
     constexpr bool GRU = (CELL == PK_CELL_GRU);
-    constexpr int LDB = G1 * KPAD + 8;           // tile of [dz(,dr)]_{t+1}
-    constexpr int LDA = KPAD + 8;                // tile of da_t
+    constexpr int LDB = pk_r2_lda_bf16(G1 * KPAD);  // tile of [dz(,dr)]_{t+1}
+    constexpr int LDA = pk_r2_lda_bf16(KPAD);       // tile of da_t
     constexpr int BTILE = RMAX * LDB * 2, ATILE = RMAX * LDA * 2;
     constexpr int NCHB = (RMAX * G1 * (KPAD / 8) + 255) / 256;
     constexpr int NCHA = (RMAX * (KPAD / 8) + 255) / 256;
@@ -557,7 +557,7 @@ extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, 
     if (rc) return rc;
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Xb, 0xFF, (size_t)T * B * y_pitch * 2, st));
-    const size_t lds = 2 * (size_t)RMAX * (KPAD + 8) * 2 + 4 * ((size_t)(2 * G + 1) * 1024 + 512) + 16;
+    const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(2 * G + 1) * 1024 + 512) + 16;
     const int slot = cell == PK_CELL_GRU ? 0 : 1;
     const Rec2gKernel fn = cell == PK_CELL_GRU ? pick_fwd<PK_CELL_GRU>(act) : pick_fwd<PK_CELL_MINGRU>(act);
     if (granted_lds[0][slot][act_slot(act)] < lds) {
@@ -599,7 +599,7 @@ extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, 
     rc = pk_rec2_host_setup(a, true);
     if (rc) return rc;
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
-    const size_t lds = (size_t)RMAX * (G1 * KPAD + 8) * 2 + (size_t)RMAX * (KPAD + 8) * 2 +
+    const size_t lds = (size_t)RMAX * pk_r2_lda_bf16(G1 * KPAD) * 2 + (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 +
                        4 * ((size_t)(G + 2) * 1024 + (size_t)G * 512) + 16;
     const int slot = cell == PK_CELL_GRU ? 0 : 1;
     const Rec2gKernel fn = cell == PK_CELL_GRU ? pick_bwd<PK_CELL_GRU>(act) : pick_bwd<PK_CELL_MINGRU>(act);

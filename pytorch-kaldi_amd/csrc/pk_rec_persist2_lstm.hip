@@ -72,7 +72,7 @@ __device__ __forceinline__ bool poll_to_lds_tab(__amdgpu_buffer_rsrc_t rs, const
 template <int ACT>
 __global__ __launch_bounds__(512, 1) void rec2l_fwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
-    constexpr int LDA = KPAD + 8;
+    constexpr int LDA = pk_r2_lda_bf16(KPAD);
     constexpr int ATILE = RMAX * LDA * 2;
     constexpr int NCH = (RMAX * (KPAD / 8) + 511) / 512;   // 16-byte chunks polled per lane (3)
     constexpr int WAVE_LDS = (GW + 1 + 3) * 1024 + 512;    // P stage (2 gates) | Y | up to 3 S slots | bf16 publish patch
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512, 1) void rec2l_fwd_kernel(R2Args a) {
 template <int ACT>
 __global__ __launch_bounds__(512, 1) void rec2l_bwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
-    constexpr int LDA = LG * KPAD + 8;
+    constexpr int LDA = pk_r2_lda_bf16(LG * KPAD);
     constexpr int ATILE = RMAX * LDA * 2;                        // one tile (74 KB): barrier B of a step frees it
     constexpr int NCH = (RMAX * LG * (KPAD / 8) + 511) / 512;    // 9
     constexpr int NIN = LNS + 3;                                 // f, i, o, g, c | h_{t-1}, dY, c_{t-1}
@@ -652,9 +652,9 @@ int pk_rec2l_launch(hipStream_t st, R2Args& a, const Plan2& pl, int act, bool ba
     a.helper_delay = pk_rec2l_helper_delay();
     size_t lds;
     if (!backward) {
-        lds = 2 * (size_t)RMAX * (KPAD + 8) * 2 + NWV * ((size_t)(GW + 1 + 3) * 1024 + 512) + 4 * GW * 1024 + 16;
+        lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + NWV * ((size_t)(GW + 1 + 3) * 1024 + 512) + 4 * GW * 1024 + 16;
     } else {
-        lds = (size_t)RMAX * (LG * KPAD + 8) * 2 + 4 * ((size_t)(LNS + 3 + LG) * 1024 + LG * 512) + 4 * 1024 +
+        lds = (size_t)RMAX * pk_r2_lda_bf16(LG * KPAD) * 2 + 4 * ((size_t)(LNS + 3 + LG) * 1024 + LG * 512) + 4 * 1024 +
               (size_t)((RMAX * LG * (KPAD / 8) + 511) / 512) * 512 * 4 + 16;
     }
     Rec2Kernel k = backward ? pick_bwd(act) : pick_fwd(act);

@@ -323,18 +323,25 @@ def roofline_of(tr, args, summ, prec):
     roof.update({"kernel": dom, "achieved": round(ach, 3), "frac": round(ach / roof["peak"], 5),
                  "avg_launch_ms": round(d["avg_ms"], 4), "launches_per_step": d["calls_per_step"], "flops_per_launch": fl})
     if "rec" in dom and tr.rcp["seq"]:
-        # a recurrent launch is T strictly dependent steps: neither roofline binds it, the per-step latency does.  The
-        # floor of a step is one cross-CU hand-off (handoff-1to1 of MI355X_MICROARCH.md's price list: 0.8-1.0 us idle;
-        # profiles/r02_rec_step_floor.json holds this kernel's own empty-step measurement when it has been taken)
+        # A recurrent launch is T strictly dependent steps: neither roofline binds it, the per-step latency does.  Two
+        # floors, both measured with this library's own traced kernels (profiles/r02_rec_step_floor.json,
+        # tools/trace_rec2.py): `hop_floor_us` = one cross-CU hand-off (publish of the slowest member -> data in
+        # registers; the chip's handoff-1to1 price, 0.8-1.0 us) and `step_floor_us` = a step of THIS kernel structure with
+        # its MFMA block and gate math removed (EMPTY=1: poll + barrier + flush / prefetch issue + patches + publish).
         roof["dependent_steps_per_launch"] = tr.T
         roof["us_per_step"] = round(d["avg_ms"] * 1e3 / tr.T, 3)
-        floor = 0.9
+        hop, floor = 0.9, None
         try:
-            floor = float(json.load(open(os.path.join(ROOT, "profiles", "r02_rec_step_floor.json")))["floor_us"])
+            fl_ = json.load(open(os.path.join(ROOT, "profiles", "r02_rec_step_floor.json")))
+            side_ = "bwd" if "bwd" in dom else "fwd"
+            hop, floor = float(fl_["hop_us"][side_]), float(fl_["floor_us_" + side_])
         except (OSError, ValueError, KeyError):
             pass
-        roof["step_floor_us"] = floor
-        roof["latency_frac"] = round(floor / roof["us_per_step"], 4)
+        roof["hop_floor_us"] = hop
+        roof["latency_frac"] = round(hop / roof["us_per_step"], 4)
+        if floor is not None and dom in ("pk_rec_fwd_bf16", "pk_rec_bwd_bf16") and tr.rcp["cfg"]["architecture1"]["arch_class"] == "liGRU":
+            roof["step_floor_us"] = floor
+            roof["structure_frac"] = round(floor / roof["us_per_step"], 4)
     # algorithmic HBM bytes of one recurrent launch and the PMC-measured traffic
     # of the same launch at this geometry (null for any other geometry)
     rb = rec_launch_bytes(tr.rcp, tr.T, tr.B, dom)

@@ -1,4 +1,4 @@
-"""The committed bench lines (profiles/r01_*.json, printed by bench.py on an MI355X) carry every field of the driver's
+"""The committed bench lines (profiles/r0N_*.json, printed by bench.py on an MI355X) carry every field of the driver's
 contract, name BASELINE.json's metric and workload, and are internally consistent (value = frames / time, roofline
 fraction = achieved / peak)."""
 import json
@@ -8,7 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BASE = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-LINES = ["profiles/r01_bench_bf16.json", "profiles/r01_bench_fp32_with_cpu_baseline.json",
+LINES = ["profiles/r02_bench_bf16.json", "profiles/r01_bench_bf16.json", "profiles/r01_bench_fp32_with_cpu_baseline.json",
          "profiles/r01_timit_lstm_8wave_bench.json", "profiles/r01_timit_lstm_4wave_bench.json"]
 
 
@@ -46,3 +46,20 @@ def test_headline_line_names_the_baseline_workload():
         assert k in c, k
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1
     assert d["roofline"]["traffic"] is not None          # PMC-measured HBM bytes of the dominant launch
+
+
+def test_round2_line_carries_the_parity_mode_and_every_baseline_configuration():
+    """The default single-GPU run also reports the same workload in the exact-fp32 (1e-4-grade) mode and the other four
+    BASELINE.json configurations."""
+    d = _line("profiles/r02_bench_bf16.json")
+    pm = d["parity_mode"]
+    assert pm["dtype"] == "fp32" and pm["unit"] == "frames/s" and pm["roofline"]["peak"] == 157.3
+    assert abs(pm["value"] - 128 * 500 / (pm["ms_per_step"] * 1e-3)) < 0.01 * pm["value"]
+    got = {o["recipe"]: o for o in d["other_configs"]}
+    assert sorted(got) == ["libri_gru", "timit_lstm", "timit_mlp", "timit_sincnet"]
+    for name, o in got.items():
+        assert "error" not in o, (name, o.get("error"))
+        assert o["ms_per_step"] > 0 and o["value"] > 0 and "workload" in o["config"] and "kernel" in o["roofline"]
+    r = d["roofline"]
+    assert r["dependent_steps_per_launch"] == 500 and 0 < r["latency_frac"] < 1 and 0 < r["structure_frac"] <= 1
+    assert "r02_pmc_traffic" in r["traffic_source"]

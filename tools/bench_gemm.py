@@ -23,6 +23,11 @@ SHAPES = [
 ]
 
 
+if os.environ.get("SHAPES"):  # "M:N:K:a_kc:b_kc;..." replaces the list above
+    SHAPES = [("%sx%sx%s %s%s" % tuple(f.split(":")),) + tuple(int(v) for v in f.split(":"))
+              for f in os.environ["SHAPES"].split(";")]
+
+
 def up(n, m):
     return (n + m - 1) // m * m
 
@@ -34,11 +39,12 @@ for tile, (name, M, N, K, akc, bkc) in [(t, sh) for sh in SHAPES for t in TILES]
     _lib.load().pk_gemm_bf16_set_tile(tile)
     A = torch.randn((M, up(K, 64)) if akc else (K, up(M, 64)), device="cuda").to(torch.bfloat16)
     B = torch.randn((N, up(K, 64)) if bkc else (K, up(N, 64)), device="cuda").to(torch.bfloat16)
-    C = torch.empty(M, N, device="cuda")
+    ldc = up(N, int(os.environ.get("LDC_ALIGN", "1")))  # row pitch of the fp32 output (floats)
+    C = torch.empty(M, ldc, device="cuda")
     sk = F_._splitk_bf(F_._tiles_bf(M, N), K) if not akc else 1
 
     def run():
-        F_.gemm_bf16(M, N, K, A, A.shape[1], akc, B, B.shape[1], bkc, C, N, splitk=sk)
+        F_.gemm_bf16(M, N, K, A, A.shape[1], akc, B, B.shape[1], bkc, C, ldc, splitk=sk)
 
     for _ in range(3):
         run()
@@ -51,4 +57,4 @@ for tile, (name, M, N, K, akc, bkc) in [(t, sh) for sh in SHAPES for t in TILES]
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    print("%s  tile %3d  M=%6d N=%5d K=%6d splitk=%2d  %.3f ms  %.0f TFLOP/s" % (name, tile, M, N, K, sk, ms, 2.0 * M * N * K / ms / 1e9))
+    print("%s  tile %3d  ldc %5d  M=%6d N=%5d K=%6d splitk=%2d  %.3f ms  %.0f TFLOP/s" % (name, tile, ldc, M, N, K, sk, ms, 2.0 * M * N * K / ms / 1e9))

@@ -157,6 +157,19 @@ int pk_logsoftmax_fwd_ld(void* stream, const float* x, int64_t ldx, int64_t rows
 int64_t pk_logsoftmax_bwd_bf16_partial_floats(int64_t rows, int64_t N);
 int pk_logsoftmax_bwd_bf16(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, uint16_t* dxb,
                            int64_t ldb, float* partial, float* colsum);
+/* The cost lines on such a head (utils.py:2361-2367: loss = NLLLoss()(out, lab), err = mean(argmax(out, 1) != lab))
+ * in one pass over the log-posteriors y [rows][N], N <= 2048, labels int64 on the device.
+ * out4 (device) = { mean of -y[r][lab[r]] over the rows whose label is not ignore_index, error rate over all rows,
+ * number of counted rows, number of labels outside [0, N) (the caller raises on it) }.
+ * partial: pk_nll_err_partial_floats(rows) floats. */
+int64_t pk_nll_err_partial_floats(int64_t rows);
+int pk_nll_err_fwd(void* stream, const float* y, const int64_t* lab, int64_t ignore_index, int64_t rows, int64_t N,
+                   float* partial, float* out4);
+/* ... and its backward joined with the LogSoftmax backward: the one-hot gradient of the mean NLL is never written;
+ * dz = (dloss / count) * (exp(y) - onehot(lab)) as bf16 plus its column sums.  dloss, count: device scalars. */
+int pk_nll_logsoftmax_bwd_bf16(void* stream, const float* y, const int64_t* lab, const float* dloss, const float* count,
+                               int64_t ignore_index, int64_t rows, int64_t N, uint16_t* dxb, int64_t ldb, float* partial,
+                               float* colsum);
 
 /* ---- recurrent layers (LSTM / GRU / liGRU / minimalGRU / RNN time loops):
  * neural_networks.py:457-469, 629-641, 1130-1141, 1291-1302, 1438-1447, with

@@ -29,6 +29,7 @@ import torch
 
 from . import _lib
 from . import dp as _dp
+from . import functional as F_
 from ._lib import PkError
 from .graphs import GraphedStep
 from .optim import fused_optimizer_init
@@ -346,6 +347,7 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
     # a bounded-spin time-out of a persistent recurrent kernel invalidates that launch's results: it must surface
     # BEFORE this chunk's .pkl / .info are written (the counter is host-mapped, read after the sync above)
     _lib.raise_if_persist_failed()
+    F_.raise_if_bad_labels()
     elapsed_time_chunk = time.time() - start_time
     loss_tot = loss_sum / max(N_batches, 1)
     err_tot = err_sum / max(N_batches, 1)

@@ -37,16 +37,14 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 #define PK_WAVE 64
 
-__device__ __forceinline__ unsigned short pk_f2bf(float f) {
-    // round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+// round-to-nearest-even fp32 -> bf16: the gfx950 conversion instruction (v_cvt_pk_bf16_f32; NaN stays a quiet NaN)
+typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned short pk_f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float pk_bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned pk_pack_bf2(float lo, float hi) {
-    return (unsigned)pk_f2bf(lo) | ((unsigned)pk_f2bf(hi) << 16);
+    const pk_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pk_bf16x2));
 }
 
 __device__ __forceinline__ float pk_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }

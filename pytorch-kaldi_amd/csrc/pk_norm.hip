@@ -479,27 +479,44 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_wave_kernel(const float* _
 // operand the dX / dW GEMMs read (row pitch ldb, pad columns zero), and its column sums (the bias gradient, taken from
 // the fp32 values before rounding) are accumulated in registers over the rows a wave owns: the fp32 dz matrix, its
 // conversion pass and the column-sum pass never exist (64 000 x 1938: 2.7 GB of HBM traffic -> 1.25 GB).
-template <int NPL>
+// ONEHOT: the incoming gradient is that of NLLLoss(reduction = mean) on this output (utils.py:2361) and is never
+// materialised: dy[r][c] = -scale at c = lab[r] and zero elsewhere, scale = dloss / count (both read on the device).
+template <int NPL, bool ONEHOT>
 __global__ __launch_bounds__(256) void logsoftmax_bwd_bf16_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                   const long* __restrict__ lab,
+                                                                   const float* __restrict__ dloss,
+                                                                   const float* __restrict__ count, long ignore_index,
                                                                    long rows, long N, unsigned short* __restrict__ dxb,
                                                                    long ldb, float* __restrict__ partial) {
     __shared__ float sh[3][64 * NPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long wid = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
+    float scale = 0.f;
+    if (ONEHOT) {
+        const float cnt = count[0];
+        scale = cnt > 0.f ? dloss[0] / cnt : 0.f;
+    }
     float acc[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) acc[i] = 0.f;
     for (long r = wid; r < rows; r += nw) {
         float g[NPL], e[NPL];
         float sum = 0.f;
+        long lr = -1;
+        if (ONEHOT) {
+            lr = lab[r];
+            if (lr == ignore_index || lr < 0 || lr >= N) lr = -1;  // (an out-of-range label is counted by the forward pass)
+            sum = lr >= 0 ? -scale : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             const long c = lane + 64 * i;
-            g[i] = c < N ? dy[r * N + c] : 0.f;
+            if (ONEHOT) g[i] = c == lr ? -scale : 0.f;
+            else g[i] = c < N ? dy[r * N + c] : 0.f;
             e[i] = c < N ? y[r * N + c] : -INFINITY;
-            sum += g[i];
+            if (!ONEHOT) sum += g[i];
         }
-        sum = pk_wave_sum(sum);
+        if (!ONEHOT) sum = pk_wave_sum(sum);
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             const long c = lane + 64 * i;
@@ -524,6 +541,74 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_bf16_kernel(const float* _
                 o[1] = 0.f;
             }
         }
+    }
+}
+
+// NLLLoss(reduction = mean, ignore_index) and the frame error rate of the reference's cost_nll / cost_err lines
+// (utils.py:2361-2367: loss = NLLLoss()(out, lab); err = mean(argmax(out, 1) != lab)) in ONE pass over the
+// log-posteriors: a wave per row keeps the row in registers, finds its arg-max (first index on ties) and the entry at
+// the label.  partial: [waves][4] = (sum of -y[r][lab], rows whose arg-max misses the label, counted rows, bad labels).
+template <int NPL>
+__global__ __launch_bounds__(256) void nll_err_partial_kernel(const float* __restrict__ y, const long* __restrict__ lab,
+                                                               long ignore_index, long rows, long N,
+                                                               float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+    float loss = 0.f, err = 0.f, cnt = 0.f, bad = 0.f;
+    for (long r = wid; r < rows; r += nw) {
+        const long lr = lab[r];
+        const bool ignored = lr == ignore_index;
+        const bool in_range = lr >= 0 && lr < N;
+        float best = -INFINITY, at_lab = 0.f;
+        long besti = N;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const long c = lane + 64 * i;
+            const float v = c < N ? y[r * N + c] : -INFINITY;
+            if (c < N && (v > best || (v == best && c < besti) || besti == N)) best = v, besti = c;  // NaN rows: index of the first column
+            if (c == lr) at_lab = v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off);
+            const long oi = __shfl_xor(besti, off);
+            if (ob > best || (ob == best && oi < besti)) best = ob, besti = oi;
+            at_lab += __shfl_xor(at_lab, off);
+        }
+        err += besti != lr ? 1.f : 0.f;
+        if (!ignored && in_range) loss -= at_lab, cnt += 1.f;
+        if (!ignored && !in_range) bad += 1.f;
+    }
+    if (lane == 0) {
+        float* o = partial + wid * 4;
+        o[0] = loss, o[1] = err, o[2] = cnt, o[3] = bad;
+    }
+}
+
+// out[0] = mean loss over the counted rows, out[1] = error rate over all rows, out[2] = counted rows, out[3] = bad labels
+__global__ __launch_bounds__(256) void nll_err_final_kernel(const float* __restrict__ partial, long nw, long rows,
+                                                             float* __restrict__ out) {
+    __shared__ float sh[4][4];
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long w = threadIdx.x; w < nw; w += 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += partial[w * 4 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = pk_wave_sum(a[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh[threadIdx.x >> 6][k] = a[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
+        out[0] = t[0] / t[2];  // 0/0 = NaN when every row is ignored, as torch
+        out[1] = t[1] / (float)rows;
+        out[2] = t[2];
+        out[3] = t[3];
     }
 }
 
@@ -691,23 +776,74 @@ static inline long lsm_bf16_blocks(int64_t rows) {
 
 extern "C" int64_t pk_logsoftmax_bwd_bf16_partial_floats(int64_t rows, int64_t N) { return lsm_bf16_blocks(rows) * N * 2; }
 
+static int lsm_bwd_bf16_launch(hipStream_t st, bool onehot, const float* dy, const float* y, const long* lab,
+                               const float* dloss, const float* count, long ignore_index, int64_t rows, int64_t N,
+                               uint16_t* dxb, int64_t ldb, float* partial, float* colsum) {
+    const long blocks = lsm_bf16_blocks(rows);
+    const dim3 grid((unsigned)blocks);
+    unsigned short* o = (unsigned short*)dxb;
+#define PK_LSMB(NPL)                                                                                                      \
+    do {                                                                                                                  \
+        if (onehot) hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<NPL, true>), grid, dim3(256), 0, st, dy, y, lab, dloss, \
+                                       count, ignore_index, (long)rows, (long)N, o, (long)ldb, partial);                  \
+        else hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<NPL, false>), grid, dim3(256), 0, st, dy, y, lab, dloss,       \
+                                count, ignore_index, (long)rows, (long)N, o, (long)ldb, partial);                         \
+    } while (0)
+    if (ldb <= 64) PK_LSMB(1);
+    else if (ldb <= 256) PK_LSMB(4);
+    else if (ldb <= 1024) PK_LSMB(16);
+    else PK_LSMB(32);
+#undef PK_LSMB
+    PK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st,
+                       partial, (int)blocks, (long)N, colsum, (float*)nullptr);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int pk_logsoftmax_bwd_bf16(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, uint16_t* dxb,
                                       int64_t ldb, float* partial, float* colsum) {
     if (rows == 0) return 0;
     PK_REQUIRE(N >= 1 && N <= 2048, "pk_logsoftmax_bwd_bf16: rows of 1..2048 columns (longer rows: pk_logsoftmax_bwd + pk_cvt_bf16)");
     PK_REQUIRE(ldb >= N && ldb <= 2048 && (ldb % 8) == 0, "pk_logsoftmax_bwd_bf16: bad bf16 pitch");
     PK_REQUIRE(partial && colsum, "pk_logsoftmax_bwd_bf16: null workspace");
+    return lsm_bwd_bf16_launch(pk_stream(stream), false, dy, y, nullptr, nullptr, nullptr, 0, rows, N, dxb, ldb, partial, colsum);
+}
+
+extern "C" int pk_nll_logsoftmax_bwd_bf16(void* stream, const float* y, const int64_t* lab, const float* dloss,
+                                          const float* count, int64_t ignore_index, int64_t rows, int64_t N, uint16_t* dxb,
+                                          int64_t ldb, float* partial, float* colsum) {
+    if (rows == 0) return 0;
+    PK_REQUIRE(N >= 1 && N <= 2048, "pk_nll_logsoftmax_bwd_bf16: rows of 1..2048 columns");
+    PK_REQUIRE(ldb >= N && ldb <= 2048 && (ldb % 8) == 0, "pk_nll_logsoftmax_bwd_bf16: bad bf16 pitch");
+    PK_REQUIRE(y && lab && dloss && count && partial && colsum, "pk_nll_logsoftmax_bwd_bf16: null argument");
+    return lsm_bwd_bf16_launch(pk_stream(stream), true, nullptr, y, (const long*)lab, dloss, count, (long)ignore_index, rows, N,
+                               dxb, ldb, partial, colsum);
+}
+
+static inline long nll_err_blocks(int64_t rows) {
+    long b = (rows + 31) / 32;  // >= 8 rows per wave
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return b;
+}
+
+extern "C" int64_t pk_nll_err_partial_floats(int64_t rows) { return nll_err_blocks(rows) * 4 * 4; }
+
+extern "C" int pk_nll_err_fwd(void* stream, const float* y, const int64_t* lab, int64_t ignore_index, int64_t rows, int64_t N,
+                              float* partial, float* out4) {
+    PK_REQUIRE(rows > 0 && N >= 1 && N <= 2048, "pk_nll_err_fwd: needs rows of 1..2048 columns");
+    PK_REQUIRE(y && lab && partial && out4, "pk_nll_err_fwd: null argument");
     hipStream_t st = pk_stream(stream);
-    const long blocks = lsm_bf16_blocks(rows);
+    const long blocks = nll_err_blocks(rows);
     const dim3 grid((unsigned)blocks);
-    unsigned short* o = (unsigned short*)dxb;
-    if (ldb <= 64) hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<1>), grid, dim3(256), 0, st, dy, y, (long)rows, (long)N, o, (long)ldb, partial);
-    else if (ldb <= 256) hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<4>), grid, dim3(256), 0, st, dy, y, (long)rows, (long)N, o, (long)ldb, partial);
-    else if (ldb <= 1024) hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<16>), grid, dim3(256), 0, st, dy, y, (long)rows, (long)N, o, (long)ldb, partial);
-    else hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<32>), grid, dim3(256), 0, st, dy, y, (long)rows, (long)N, o, (long)ldb, partial);
+    const long* l = (const long*)lab;
+    if (N <= 64) hipLaunchKernelGGL((nll_err_partial_kernel<1>), grid, dim3(256), 0, st, y, l, (long)ignore_index, (long)rows, (long)N, partial);
+    else if (N <= 256) hipLaunchKernelGGL((nll_err_partial_kernel<4>), grid, dim3(256), 0, st, y, l, (long)ignore_index, (long)rows, (long)N, partial);
+    else if (N <= 1024) hipLaunchKernelGGL((nll_err_partial_kernel<16>), grid, dim3(256), 0, st, y, l, (long)ignore_index, (long)rows, (long)N, partial);
+    else hipLaunchKernelGGL((nll_err_partial_kernel<32>), grid, dim3(256), 0, st, y, l, (long)ignore_index, (long)rows, (long)N, partial);
     PK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st,
-                       partial, (int)blocks, (long)N, colsum, (float*)nullptr);
+    hipLaunchKernelGGL(nll_err_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks * 4, (long)rows, out4);
     PK_LAUNCH_CHECK();
     return 0;
 }
@@ -735,8 +871,7 @@ extern "C" int pk_logsoftmax_bwd(void* stream, const float* dy, const float* y, 
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int BC_COLS = 16;  // chunks (of 8 columns) per block
-constexpr int BC_ROWL = 16;  // row lanes per block
+// A block is BC_COLS chunks (of 8 columns) wide and BC_ROWL row lanes deep (BC_COLS * BC_ROWL <= 256 threads).
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned 16-byte access
 __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
@@ -753,77 +888,120 @@ __device__ __forceinline__ void bf8_to_f32(uint4 v, float (&f)[8]) {
     }
 }
 
+// Both passes are written so that the compiler can keep every load of an iteration in flight together: two rows per
+// thread and iteration (the second one clamped to the first when the strip ends: no branch around a load), the fp32
+// projection through a range-checked buffer load based at the block's first row (the 8 floats of a chunk that hangs
+// over the end of a gate may run past the end of the matrix: those lanes read 0), per-column constants gathered with
+// clamped indices.  The first version branched around each load (second direction? whole chunk? aligned?) and hipcc
+// serialised them behind s_waitcnt vmcnt(0): three dependent HBM round trips per row and 3.3 TB/s.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bnb_rsrc(const void* p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes), 0x00020000);
+}
+__device__ __forceinline__ void bnb_ldx(__amdgpu_buffer_rsrc_t rs, unsigned off, float (&f)[8]) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+    f[0] = __uint_as_float(a[0]); f[1] = __uint_as_float(a[1]); f[2] = __uint_as_float(a[2]); f[3] = __uint_as_float(a[3]);
+    f[4] = __uint_as_float(b[0]); f[5] = __uint_as_float(b[1]); f[6] = __uint_as_float(b[2]); f[7] = __uint_as_float(b[3]);
+}
+
 // MODE 0: per-column sums of g and g*xhat (BatchNorm); MODE 1: sum of g only (bias gradient, no BatchNorm)
-template <int MODE>
+template <int MODE, bool TWO, int BC_COLS, int BC_ROWL>
 __global__ __launch_bounds__(256) void bnb_reduce_kernel(const unsigned short* __restrict__ g0,
                                                           const unsigned short* __restrict__ g1, long gpitch, int G, int H,
                                                           int Hp, const float* __restrict__ x, long ldx, long M,
                                                           const float* __restrict__ mean, const float* __restrict__ var,
                                                           float eps, float* __restrict__ partial) {
-    const int cl = threadIdx.x & (BC_COLS - 1), rl = threadIdx.x / BC_COLS;
+    const int cl = threadIdx.x % BC_COLS, rl = threadIdx.x / BC_COLS;
     const int chunk = blockIdx.x * BC_COLS + cl;  // chunk index in the padded layout
     const int cpg = Hp >> 3;
     const int g = chunk / cpg, j0 = (chunk - g * cpg) * 8;
-    const bool cok = g < G;
+    const bool cok = g < G && rl < BC_ROWL;
     const int rb = gridDim.y;
     const long rows_per = (M + rb - 1) / rb;
     const long r0 = (long)blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    const int nvalid = cok ? ((H - j0) < 8 ? (H - j0) : 8) : 0;
     float s0[8], s1[8], mu[8], inv[8];
+    {
+        float vm[8], vv[8];
+        const long nb = cok ? (long)g * H + j0 : 0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        s0[e] = s1[e] = 0.f;
-        const int j = j0 + e;
-        const bool ok = cok && j < H;
-        mu[e] = (MODE == 0 && ok) ? mean[g * H + j] : 0.f;
-        inv[e] = (MODE == 0 && ok) ? 1.0f / sqrtf(var[g * H + j] + eps) : 0.f;
+        for (int e = 0; e < 8; ++e) {
+            const long n = nb + (e < nvalid ? e : 0);  // clamped: every load in range, all in flight together
+            vm[e] = MODE == 0 ? mean[n] : 0.f;
+            vv[e] = MODE == 0 ? var[n] : 1.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s0[e] = s1[e] = 0.f;
+            const bool ok = e < nvalid;
+            mu[e] = (MODE == 0 && ok) ? vm[e] : 0.f;
+            inv[e] = (MODE == 0 && ok) ? 1.0f / sqrtf(vv[e] + eps) : 0.f;  // inv = 0 beyond H
+        }
     }
-    if (cok) {
+    if (cok && r0 < r1) {
         const long goff = (long)g * Hp + j0;
-        const bool full = j0 + 8 <= H;  // (the last chunk of a gate may hang over H: element-wise there)
-#pragma unroll 2
-        for (long r = r0 + rl; r < r1; r += BC_ROWL) {
-            float a[8], b[8], xv[8];
-            bf8_to_f32(*reinterpret_cast<const uint4*>(g0 + r * gpitch + goff), a);
-            if (g1) {
-                bf8_to_f32(*reinterpret_cast<const uint4*>(g1 + r * gpitch + goff), b);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] += b[e];
+        const __amdgpu_buffer_rsrc_t rsx = bnb_rsrc(x + r0 * ldx, (r1 - r0) * ldx * 4);
+        const unsigned xoff = (unsigned)(((long)g * H + j0) * 4), xrow = (unsigned)(ldx * 4);
+        for (long r = r0 + rl; r < r1; r += 2 * BC_ROWL) {
+            const bool second = r + BC_ROWL < r1;
+            const long rs = second ? r + BC_ROWL : r;
+            const uint4 qa0 = *reinterpret_cast<const uint4*>(g0 + r * gpitch + goff);
+            const uint4 qb0 = *reinterpret_cast<const uint4*>(g0 + rs * gpitch + goff);
+            uint4 qa1 = make_uint4(0, 0, 0, 0), qb1 = make_uint4(0, 0, 0, 0);
+            if (TWO) {
+                qa1 = *reinterpret_cast<const uint4*>(g1 + r * gpitch + goff);
+                qb1 = *reinterpret_cast<const uint4*>(g1 + rs * gpitch + goff);
             }
+            float xa[8], xb[8];
             if (MODE == 0) {
-                const float* xr = x + r * ldx + (long)g * H + j0;
-                if (full) {
-                    ld8f(xr, xv);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xv[e] = (j0 + e < H) ? xr[e] : 0.f;
-                }
+                bnb_ldx(rsx, (unsigned)(r - r0) * xrow + xoff, xa);
+                bnb_ldx(rsx, (unsigned)(rs - r0) * xrow + xoff, xb);
             }
+            __builtin_amdgcn_sched_barrier(0);  // both rows' loads are issued before anything waits for the first
+            float a[8], b[8], t[8];
+            bf8_to_f32(qa0, a);
+            bf8_to_f32(qb0, b);
+            if (TWO) {
+                bf8_to_f32(qa1, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += t[e];
+                bf8_to_f32(qb1, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b[e] += t[e];
+            }
+            const float w = second ? 1.f : 0.f;  // the clamped second row counts for nothing
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 s0[e] += a[e];
-                if (MODE == 0) s1[e] += a[e] * ((xv[e] - mu[e]) * inv[e]);  // inv = 0 beyond H
+                if (MODE == 0) s1[e] += a[e] * ((xa[e] - mu[e]) * inv[e]);
+                s0[e] += w * b[e];
+                if (MODE == 0) s1[e] += w * (b[e] * ((xb[e] - mu[e]) * inv[e]));
             }
         }
     }
-    __shared__ float sh[BC_ROWL][BC_COLS][16];
+    __shared__ float sh[BC_ROWL][BC_COLS][17];
+    if (rl < BC_ROWL) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        sh[rl][cl][e] = s0[e];
-        sh[rl][cl][8 + e] = s1[e];
+        for (int e = 0; e < 8; ++e) {
+            sh[rl][cl][e] = s0[e];
+            sh[rl][cl][8 + e] = s1[e];
+        }
     }
     __syncthreads();
-    // 256 threads: one (chunk, element, kind) each
-    const int oc = threadIdx.x >> 4, oe = threadIdx.x & 15;
-    float t = 0.f;
+    // one (chunk, element, kind) per thread and round
+    for (int o = threadIdx.x; o < BC_COLS * 16; o += 256) {
+        const int oc = o >> 4, oe = o & 15;
+        float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < BC_ROWL; ++k) t += sh[k][oc][oe];
-    const int ochunk = blockIdx.x * BC_COLS + oc;
-    const int og = ochunk / cpg, oj = (ochunk - og * cpg) * 8 + (oe & 7);
-    if (og < G && oj < H) partial[((long)blockIdx.y * ((long)G * H) + (long)og * H + oj) * 2 + (oe >> 3)] = t;
+        for (int k = 0; k < BC_ROWL; ++k) t += sh[k][oc][oe];
+        const int ochunk = blockIdx.x * BC_COLS + oc;
+        const int og = ochunk / cpg, oj = (ochunk - og * cpg) * 8 + (oe & 7);
+        if (og < G && oj < H) partial[((long)blockIdx.y * ((long)G * H) + (long)og * H + oj) * 2 + (oe >> 3)] = t;
+    }
 }
 
 // dx = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count) as bf16 (MODE 0), or dx = g (MODE 1)
-template <int MODE>
+template <int MODE, bool TWO, int BC_COLS, int BC_ROWL>
 __global__ __launch_bounds__(256) void bnb_apply_kernel(const unsigned short* __restrict__ g0,
                                                          const unsigned short* __restrict__ g1, long gpitch, int G, int H,
                                                          int Hp, const float* __restrict__ x, long ldx, long M,
@@ -831,68 +1009,91 @@ __global__ __launch_bounds__(256) void bnb_apply_kernel(const unsigned short* __
                                                          float eps, const float* __restrict__ gamma,
                                                          const float* __restrict__ sum_g, const float* __restrict__ sum_gx,
                                                          float inv_count, unsigned short* __restrict__ out, long opitch) {
-    const int cl = threadIdx.x & (BC_COLS - 1), rl = threadIdx.x / BC_COLS;
+    const int cl = threadIdx.x % BC_COLS, rl = threadIdx.x / BC_COLS;
     const int chunk = blockIdx.x * BC_COLS + cl;
     const int cpg = Hp >> 3;
     const int g = chunk / cpg, j0 = (chunk - g * cpg) * 8;
-    if (g >= G) return;
+    if (g >= G || rl >= BC_ROWL) return;
     const int rb = gridDim.y;
     const long rows_per = (M + rb - 1) / rb;
     const long r0 = (long)blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    if (r0 >= r1) return;
+    const int nvalid = (H - j0) < 8 ? (H - j0) : 8;
     float mu[8], sc[8], c0[8], c1[8];
+    {
+        float vm[8], vv[8], vg[8], v0[8], v1[8];
+        const long nb = (long)g * H + j0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int n = g * H + j0 + e;
-        const bool ok = j0 + e < H;
-        if (MODE == 0 && ok) {
-            const float inv = 1.0f / sqrtf(var[n] + eps);
-            mu[e] = mean[n];
-            sc[e] = (gamma ? gamma[n] : 1.f) * inv;
-            c0[e] = sum_g[n] * inv_count;
-            c1[e] = sum_gx[n] * inv_count * inv;  // xhat*c1' with xhat = (x-mu)*inv folded: (x-mu)*inv*sum_gx/count
-        } else {
-            mu[e] = 0.f; sc[e] = ok ? 1.f : 0.f; c0[e] = 0.f; c1[e] = 0.f;
+        for (int e = 0; e < 8; ++e) {
+            const long n = nb + (e < nvalid ? e : 0);
+            vm[e] = MODE == 0 ? mean[n] : 0.f;
+            vv[e] = MODE == 0 ? var[n] : 1.f;
+            vg[e] = (MODE == 0 && gamma) ? gamma[n] : 1.f;
+            v0[e] = MODE == 0 ? sum_g[n] : 0.f;
+            v1[e] = MODE == 0 ? sum_gx[n] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = e < nvalid;
+            if (MODE == 0) {
+                const float inv = 1.0f / sqrtf(vv[e] + eps);
+                mu[e] = vm[e];
+                sc[e] = ok ? vg[e] * inv : 0.f;
+                c0[e] = v0[e] * inv_count;
+                c1[e] = v1[e] * inv_count * inv;  // xhat*c1' with xhat = (x-mu)*inv folded: (x-mu)*inv*sum_gx/count
+            } else {
+                mu[e] = 0.f; sc[e] = ok ? 1.f : 0.f; c0[e] = 0.f; c1[e] = 0.f;
+            }
         }
     }
     const long goff = (long)g * Hp + j0;
-    const int nvalid = (H - j0) < 8 ? (H - j0) : 8;
-#pragma unroll 2
-    for (long r = r0 + rl; r < r1; r += BC_ROWL) {
-        float a[8], b[8];
-        bf8_to_f32(*reinterpret_cast<const uint4*>(g0 + r * gpitch + goff), a);
-        if (g1) {
-            bf8_to_f32(*reinterpret_cast<const uint4*>(g1 + r * gpitch + goff), b);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] += b[e];
+    const __amdgpu_buffer_rsrc_t rsx = bnb_rsrc(x + r0 * ldx, MODE == 0 ? (r1 - r0) * ldx * 4 : 0);
+    const unsigned xoff = (unsigned)(((long)g * H + j0) * 4), xrow = (unsigned)(ldx * 4);
+    const bool pairs = ((((long)g * H + j0) & 1) == 0) && ((opitch & 1) == 0);  // 4-byte aligned bf16 pairs
+    for (long r = r0 + rl; r < r1; r += 2 * BC_ROWL) {
+        const bool second = r + BC_ROWL < r1;
+        const long rs = second ? r + BC_ROWL : r;
+        const uint4 qa0 = *reinterpret_cast<const uint4*>(g0 + r * gpitch + goff);
+        const uint4 qb0 = *reinterpret_cast<const uint4*>(g0 + rs * gpitch + goff);
+        uint4 qa1 = make_uint4(0, 0, 0, 0), qb1 = make_uint4(0, 0, 0, 0);
+        if (TWO) {
+            qa1 = *reinterpret_cast<const uint4*>(g1 + r * gpitch + goff);
+            qb1 = *reinterpret_cast<const uint4*>(g1 + rs * gpitch + goff);
         }
-        float o[8];
+        float xa[8], xb[8];
         if (MODE == 0) {
-            const float* xr = x + r * ldx + (long)g * H + j0;
-            float xv[8];
-            if (nvalid == 8) {
-                ld8f(xr, xv);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = (e < nvalid) ? xr[e] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (e < nvalid) ? sc[e] * (a[e] - c0[e] - (xv[e] - mu[e]) * c1[e]) : 0.f;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (e < nvalid) ? a[e] : 0.f;
+            bnb_ldx(rsx, (unsigned)(r - r0) * xrow + xoff, xa);
+            bnb_ldx(rsx, (unsigned)(rs - r0) * xrow + xoff, xb);
         }
-        // plain layout: column g*H + j0 (+e); 4-byte aligned pairs (H even) or single elements
-        unsigned short* op = out + r * opitch + (long)g * H + j0;
-        if ((((long)g * H + j0) & 1) == 0) {
+        __builtin_amdgcn_sched_barrier(0);  // both rows' loads are issued before anything waits for the first
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                if (e + 1 < nvalid) *reinterpret_cast<unsigned*>(op + e) = pk_pack_bf2(o[e], o[e + 1]);
-                else if (e < nvalid) op[e] = pk_f2bf(o[e]);
+        for (int half = 0; half < 2; ++half) {
+            if (half == 1 && !second) break;
+            float a[8], t[8], o[8];
+            bf8_to_f32(half ? qb0 : qa0, a);
+            if (TWO) {
+                bf8_to_f32(half ? qb1 : qa1, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] += t[e];
             }
-        } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (e < nvalid) op[e] = pk_f2bf(o[e]);
+            for (int e = 0; e < 8; ++e) {
+                const float xv = half ? xb[e] : xa[e];
+                o[e] = MODE == 0 ? sc[e] * (a[e] - c0[e] - (xv - mu[e]) * c1[e]) : sc[e] * a[e];  // sc = 0 beyond H
+            }
+            // plain layout: column g*H + j0 (+e): 4-byte aligned pairs (H even), or single elements
+            unsigned short* op = out + (half ? rs : r) * opitch + (long)g * H + j0;
+            if (pairs && nvalid == 8) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) *reinterpret_cast<unsigned*>(op + e) = pk_pack_bf2(o[e], o[e + 1]);
+            } else {
+                unsigned short hb[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hb[e] = pk_f2bf(o[e]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (e < nvalid) op[e] = hb[e];
+            }
         }
     }
 }
@@ -920,19 +1121,44 @@ extern "C" int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* 
     hipStream_t st = pk_stream(stream);
     const int Hp = (H + 7) & ~7;
     const int chunks = G * (Hp >> 3);
-    const int rb = row_blocks(M);
-    dim3 grid((chunks + BC_COLS - 1) / BC_COLS, rb);
+    int rb = row_blocks(M);
+    static int k_rbr = -1, k_rba = -1, k_cw = 0;  // development knobs (tools/bench_bnb.py): row blocks of the two passes, block width
+    if (k_rbr < 0) {
+        const char* e = getenv("PK_BNB_RBR"); k_rbr = e ? atoi(e) : 0;
+        e = getenv("PK_BNB_RBA"); k_rba = e ? atoi(e) : 0;
+        e = getenv("PK_BNB_CW"); k_cw = e ? atoi(e) : 0;
+    }
+    if (k_rbr > 0) rb = k_rbr;
+    PK_REQUIRE(((M + rb - 1) / rb) * ldx * 4 < 0x7fffffffL, "pk_bn_bwd_bf16: a row strip of the projection exceeds 2 GB");
+    const int CW = k_cw == 16 ? 16 : 48;
+    dim3 grid((chunks + CW - 1) / CW, rb);
+    dim3 grid_a((chunks + CW - 1) / CW, k_rba > 0 ? k_rba : rb);
     const long N = (long)G * H;
     const bool use_bn = mean != nullptr;
-    if (use_bn) hipLaunchKernelGGL((bnb_reduce_kernel<0>), grid, dim3(256), 0, st, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x, (long)ldx, (long)M, mean, var, eps, partial);
-    else hipLaunchKernelGGL((bnb_reduce_kernel<1>), grid, dim3(256), 0, st, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x, (long)ldx, (long)M, mean, var, eps, partial);
+#define PK_BNB_LAUNCH2(KERNEL, GRID, C, R, ...)                                                                           \
+    do {                                                                                                                  \
+        if (use_bn && g1) hipLaunchKernelGGL((KERNEL<0, true, C, R>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
+        else if (use_bn) hipLaunchKernelGGL((KERNEL<0, false, C, R>), GRID, dim3(256), 0, st, __VA_ARGS__);               \
+        else if (g1) hipLaunchKernelGGL((KERNEL<1, true, C, R>), GRID, dim3(256), 0, st, __VA_ARGS__);                    \
+        else hipLaunchKernelGGL((KERNEL<1, false, C, R>), GRID, dim3(256), 0, st, __VA_ARGS__);                           \
+    } while (0)
+#define PK_BNB_LAUNCH(KERNEL, GRID, ...)                                  \
+    do {                                                                  \
+        if (CW == 16) PK_BNB_LAUNCH2(KERNEL, GRID, 16, 16, __VA_ARGS__);  \
+        else PK_BNB_LAUNCH2(KERNEL, GRID, 48, 5, __VA_ARGS__);            \
+    } while (0)
+    PK_BNB_LAUNCH(bnb_reduce_kernel, grid, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x,
+                  (long)ldx, (long)M, mean, var, eps, partial);
     PK_LAUNCH_CHECK();
     hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st, partial, rb, N, sum_g,
                        use_bn ? sum_gx : (float*)nullptr);
     PK_LAUNCH_CHECK();
-    if (use_bn) hipLaunchKernelGGL((bnb_apply_kernel<0>), grid, dim3(256), 0, st, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x, (long)ldx, (long)M, mean, var, eps, gamma, sum_g, sum_gx, (float)(1.0 / count), (unsigned short*)out, (long)out_pitch);
-    else hipLaunchKernelGGL((bnb_apply_kernel<1>), grid, dim3(256), 0, st, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x, (long)ldx, (long)M, mean, var, eps, gamma, sum_g, sum_gx, 0.f, (unsigned short*)out, (long)out_pitch);
+    PK_BNB_LAUNCH(bnb_apply_kernel, grid_a, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x,
+                  (long)ldx, (long)M, mean, var, eps, gamma, sum_g, sum_gx, use_bn ? (float)(1.0 / count) : 0.f,
+                  (unsigned short*)out, (long)out_pitch);
     PK_LAUNCH_CHECK();
+#undef PK_BNB_LAUNCH
+#undef PK_BNB_LAUNCH2
     if (out_pitch > N) {
         const long total = M * (out_pitch - N);
         long blocks = (total + 255) / 256;

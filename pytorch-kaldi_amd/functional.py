@@ -370,17 +370,16 @@ class LinearLogSoftmaxFn(torch.autograd.Function):
       backward  dz = dy - exp(y) rowsum(dy) is produced directly as the bf16 operand of the dX / dW GEMMs, with its
                 column sums (the bias gradient) taken on the way (pk_logsoftmax_bwd_bf16).
     Same arithmetic as LinearFn + LogSoftmaxFn in perf mode (operands rounded to bf16 once, fp32 accumulation, bias
-    gradient from the unrounded dz)."""
+    gradient from the unrounded dz).  xb / wb: the bf16 copies of x / weight (made by the caller, shared with
+    HeadNllFn)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, xb, wb):
         _need_gpu(x, weight, bias)
         lib = _lib.load()
         x2 = _rows2d(x)
-        weight = weight.contiguous()
         M, K = x2.shape
         N = weight.shape[0]
-        xb, wb = _cvt_bf16_shared(x2), cvt_bf16(weight)
         ldz = _up(N, 32)
         z = torch.empty(M, ldz, device=x2.device, dtype=torch.float32)
         gemm_bf16(M, N, K, xb, xb.shape[1], 1, wb, wb.shape[1], 1, z, ldz, bias=bias)
@@ -406,7 +405,7 @@ class LinearLogSoftmaxFn(torch.autograd.Function):
         _lib.check(lib.pk_logsoftmax_bwd_bf16(_stream(), _p(dy2), _p(y), M, N, _p(dzb), ldb, _p(part), _p(db)),
                    "pk_logsoftmax_bwd_bf16")
         dx, dw = _linear_bwd_bf16(ctx, dzb, xb, wb, y)
-        return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None)
+        return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None
 
 
 def linear_log_softmax_ok(x, weight):
@@ -415,7 +414,57 @@ def linear_log_softmax_ok(x, weight):
 
 
 def linear_log_softmax(x, weight, bias=None):
-    return LinearLogSoftmaxFn.apply(x, weight, bias)
+    """-> log-posteriors y.  y carries what head_nll needs to put the mean-NLL cost of the recipe directly behind
+    (x, weight, bias): `y._pk_head`."""
+    with torch.no_grad():
+        w = weight.contiguous()
+        xb, wb = _cvt_bf16_shared(_rows2d(x)), cvt_bf16(w)
+    y = LinearLogSoftmaxFn.apply(x, weight if weight.is_contiguous() else w, bias, xb, wb)
+    y._pk_head = (x, weight, bias, xb, wb, y._version)
+    return y
+
+
+class HeadNllFn(torch.autograd.Function):
+    """loss = NLLLoss()(y, lab) for y = linear_log_softmax(x, weight, bias) (utils.py:2361; core.py:631-642), as a node
+    whose inputs are (x, weight, bias): the log-posteriors are the ones the head already computed (nothing is
+    recomputed), and backward goes from the scalar straight to dz = (dloss / count) (exp(y) - onehot(lab)) in bf16 -
+    the dense one-hot gradient of the cost (a 496 MB zero fill, a scatter and a second read at the BASELINE shape) is
+    never formed.  Autograd runs y's own node only if something else back-propagates through y; the two paths then add
+    up in (x, weight, bias) as they should.  The same forward pass counts the frame errors of the cost_err line."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, y, lab, xb, wb, ignore_index):
+        lib = _lib.load()
+        M, N = y.shape
+        lab = lab.contiguous()
+        out4 = _new(4, like=y)
+        part = _new(int(lib.pk_nll_err_partial_floats(M)), like=y)
+        _lib.check(lib.pk_nll_err_fwd(_stream(), _p(y), _p(lab), int(ignore_index), M, N, _p(part), _p(out4)),
+                   "pk_nll_err_fwd")
+        ctx.save_for_backward(xb, wb, y, lab, out4)
+        ctx.dims = (M, N, x.shape[-1])
+        ctx.has_bias = bias is not None
+        ctx.in_shape = x.shape
+        ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None
+        ctx.ignore_index = int(ignore_index)
+        ctx.mark_non_differentiable(out4)
+        return out4[0].clone(), out4
+
+    @staticmethod
+    def backward(ctx, dloss, _d4):
+        lib = _lib.load()
+        xb, wb, y, lab, out4 = ctx.saved_tensors
+        M, N, K = ctx.dims
+        dl = dloss.contiguous().float()
+        ldb = _up(N, 64)
+        dzb = torch.empty(M, ldb, device=y.device, dtype=torch.bfloat16)
+        part = _new(int(lib.pk_logsoftmax_bwd_bf16_partial_floats(M, N)), like=y)
+        db = _new(N, like=y)
+        cnt = ctypes.c_void_p(out4.data_ptr() + 8)
+        _lib.check(lib.pk_nll_logsoftmax_bwd_bf16(_stream(), _p(y), _p(lab), _p(dl), cnt, ctx.ignore_index, M, N, _p(dzb),
+                                                  ldb, _p(part), _p(db)), "pk_nll_logsoftmax_bwd_bf16")
+        dx, dw = _linear_bwd_bf16(ctx, dzb, xb, wb, y)
+        return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None, None, None, None
 
 
 def linear(x, weight, bias=None):
@@ -429,6 +478,37 @@ def colsum(g, g2=None):
     part = _new(int(lib.pk_bn_partial_floats(M, N)), like=g)
     _lib.check(lib.pk_colsum(_stream(), _p(g), _p(g2), g.stride(0), M, N, _p(part), _p(out)), "pk_colsum")
     return out
+
+
+class _LabelCheck:
+    bad = None  # device scalar: labels outside [0, classes) seen by head_nll since the last raise_if_bad_labels()
+
+
+def note_label_check(stats):
+    """Accumulate the bad-label count of one head_nll call (no host sync here: torch's nll_loss would trip a device-side
+    assert on such a label; the engine reports it at the next point where the host waits for the GPU anyway)."""
+    with torch.no_grad():
+        _LabelCheck.bad = stats[3].clone() if _LabelCheck.bad is None else _LabelCheck.bad + stats[3]
+
+
+def raise_if_bad_labels():
+    """Call after a host sync (core.run_nn_dp: once per chunk)."""
+    bad, _LabelCheck.bad = _LabelCheck.bad, None
+    if bad is not None and float(bad) > 0:
+        raise _lib.PkError("cost_nll: %d label(s) outside [0, classes) in this chunk" % int(float(bad)))
+
+
+def head_nll(y, lab, ignore_index=-100):
+    """(loss, stats) of the mean-NLL cost on the output y of linear_log_softmax, or None when y is not one (any more).
+    stats (device, 4 floats): loss, frame error rate, counted rows, labels outside [0, classes)."""
+    head = getattr(y, "_pk_head", None)
+    if head is None or y.dim() != 2 or lab.dim() != 1 or lab.shape[0] != y.shape[0] or lab.dtype != torch.int64:
+        return None
+    x, weight, bias, xb, wb, version = head
+    if y._version != version or not lab.is_cuda:
+        return None
+    loss, out4 = HeadNllFn.apply(x, weight, bias, y.detach(), lab, xb, wb, ignore_index)
+    return loss, out4
 
 
 # ----------------------------------------------------------------------------

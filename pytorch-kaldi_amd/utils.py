@@ -17,6 +17,8 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
+F_ = importlib.import_module(__package__ + ".functional")
+
 _LINE = re.compile(r"(.*)=(.*)\((.*),(.*)\)")
 
 
@@ -137,11 +139,28 @@ def forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out
             outs[out_name] = nns[inp1](x)
         elif op == "cost_nll":
             if to_do != "forward":
-                outs[out_name] = costs[out_name](flat(outs[inp1]), labels(inp2))
+                y, lab, cost = flat(outs[inp1]), labels(inp2), costs[out_name]
+                fused = None
+                if (type(cost) is nn.NLLLoss and cost.weight is None and cost.reduction == "mean"
+                        and getattr(y, "_pk_head", None) is not None):
+                    # perf-mode output layer: the cost goes straight behind the head's inputs (functional.HeadNllFn);
+                    # the same pass counts the frame errors a cost_err line on the same pair asks for
+                    fused = F_.head_nll(y, lab, cost.ignore_index)
+                if fused is not None:
+                    outs[out_name], stats = fused
+                    y._pk_nll_stats = (inp2, stats)
+                    F_.note_label_check(stats)
+                else:
+                    outs[out_name] = cost(y, lab)
         elif op == "cost_err":
             if to_do != "forward":
-                pred = torch.max(flat(outs[inp1]), dim=1)[1]
-                outs[out_name] = torch.mean((pred != labels(inp2)).float())
+                y = flat(outs[inp1])
+                stats = getattr(y, "_pk_nll_stats", None)
+                if stats is not None and stats[0] == inp2:
+                    outs[out_name] = stats[1][1]
+                else:
+                    pred = torch.max(y, dim=1)[1]
+                    outs[out_name] = torch.mean((pred != labels(inp2)).float())
         elif op == "concatenate":
             outs[out_name] = torch.cat((outs[inp1], outs[inp2]), outs[inp1].dim() - 1)
         elif op == "mult":

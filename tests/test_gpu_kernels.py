@@ -457,3 +457,68 @@ def test_fused_output_layer_matches_the_two_nodes(rows, K, N):
     assert rel_err(y1, yr) < 1e-5
     assert rel_err(db1, br.grad) < 1e-5
     assert rel_err(dx1, xr.grad) < 1e-2 and rel_err(dw1, wr.grad) < 1e-2  # dz rounded to bf16 for the two GEMMs
+
+
+@pytest.mark.parametrize("rows,K,N,ignored", [(6, 24, 1, 0), (70, 40, 48, 3), (300, 330, 1938, 0), (64 * 40 + 3, 64, 2048, 40),
+                                               (9, 16, 200, 9)])
+def test_head_nll_matches_nll_loss_behind_the_head(rows, K, N, ignored):
+    """functional.head_nll (cost straight behind the head's inputs, one-hot gradient never formed, frame errors counted
+    in the same pass) against torch's nll_loss / argmax on the same head output: loss to summation order, error rate
+    exactly, dX / dW bit for bit (same dz bits into the same GEMMs), bias gradient to summation order."""
+    g = torch.Generator().manual_seed(rows * 3 + N)
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(N, K, generator=g) / (K ** 0.5)
+    b = torch.randn(N, generator=g)
+    lab = torch.randint(0, N, (rows,), generator=g)
+    lab[:ignored] = -100
+    F_.set_precision("bf16")
+    try:
+        res = []
+        for fused in (True, False):
+            xe, we, be = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+            y = F_.linear_log_softmax(xe, we, be)
+            if fused:
+                loss, stats = F_.head_nll(y, lab.cuda())
+                err = stats[1]
+                assert float(stats[2]) == rows - ignored and float(stats[3]) == 0
+            else:
+                loss = TF.nll_loss(y, lab.cuda())
+                err = (y.argmax(1) != lab.cuda()).float().mean()
+            (loss * 1.7).backward()
+            torch.cuda.synchronize()
+            res.append((loss.detach(), err, xe.grad, we.grad, be.grad))
+    finally:
+        F_.set_precision("fp32")
+    (l1, e1, dx1, dw1, db1), (l2, e2, dx2, dw2, db2) = res
+    if ignored == rows:
+        assert torch.isnan(l1) and torch.isnan(l2)
+        assert float(dx1.abs().max()) == 0.0  # torch: 0 * nan-free zeros; the engine: scale 0
+        return
+    assert abs(float(l1) - float(l2)) <= 2e-6 * abs(float(l2))
+    assert float(e1) == pytest.approx(float(e2), abs=1e-7)
+    assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2)
+    assert rel_err(db1, db2) < 1e-5
+
+
+def test_head_nll_declines_what_it_does_not_cover():
+    F_.set_precision("bf16")
+    try:
+        x = torch.randn(8, 16, device="cuda", requires_grad=True)
+        w = torch.randn(5, 16, device="cuda", requires_grad=True)
+        y = F_.linear_log_softmax(x, w, None)
+        lab = torch.randint(0, 5, (8,), device="cuda")
+        assert F_.head_nll(F_.log_softmax(F_.linear(x, w, None)), lab) is None     # not a fused head
+        assert F_.head_nll(y, lab.int()) is None                                    # labels must be int64
+        assert F_.head_nll(y, lab[:4]) is None
+        bad = lab.clone()
+        bad[2] = 7
+        loss, stats = F_.head_nll(y, bad)
+        F_.note_label_check(stats)
+        with pytest.raises(_lib.PkError):
+            F_.raise_if_bad_labels()
+        y2 = F_.linear_log_softmax(x, w, None)
+        with torch.no_grad():
+            y2.add_(1.0)
+        assert F_.head_nll(y2, lab) is None                                         # modified in place since
+    finally:
+        F_.set_precision("fp32")

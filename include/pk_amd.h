@@ -81,6 +81,15 @@ void pk_gemm_bf16_set_tile(int tile);
 int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
                  const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc, const float* bias,
                  int splitk, float* workspace);
+/* The projection of a BatchNorm-ed layer (neural_networks.py:1114-1124: bn_wh(wh(x)), bn_wz(wz(x)) over all T*B
+ * rows): C = alpha * A.B + bias with the per-column statistics of C taken in the GEMM epilogue instead of by a second
+ * pass over C.  Shapes that run on the 256-tile produce them: *row_blocks = number of 256-row tiles and
+ * stats[row_blocks][N][3] = (rows, mean, M2); fold with pk_bn_stats_merge.  Other shapes: *row_blocks = 0, plain GEMM,
+ * the caller runs pk_bn_stats.  stats: pk_gemm_bf16_stats_floats(M, N) floats. */
+int64_t pk_gemm_bf16_stats_floats(int M, int N);
+int pk_gemm_bf16_stats(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
+                       const uint16_t* B, int64_t ldb, int b_kc, float* C, int64_t ldc, const float* bias, float* stats,
+                       int* row_blocks);
 /* fp32 [rows][ld_src] -> bf16 [rows][ld_dst].  The source columns are nseg segments of seglen values;
  * segment s lands at destination column s*segpad (e.g. the two direction halves of a layer output,
  * 550 -> 576, so that each half starts 16-byte aligned); all other destination elements are zero. */
@@ -96,6 +105,8 @@ int pk_cvt_bf16(void* stream, const float* src, int64_t ld_src, int64_t rows, in
 int64_t pk_bn_partial_floats(int64_t M, int64_t N);
 int pk_bn_stats(void* stream, const float* x, int64_t ldx, int64_t M, int64_t N, float* partial, float* mean,
                 float* var);
+/* the second half of pk_bn_stats on its own: fold rb rows of (rows, mean, M2) partials per column */
+int pk_bn_stats_merge(void* stream, const float* partial, int rb, int64_t N, float* mean, float* var);
 /* scale = gamma * rsqrt(var+eps), shift = beta - mean*scale (gamma/beta NULL = 1/0);
  * if running_mean != NULL also updates running stats with `momentum` and the
  * unbiased factor count/(count-1) (count = rows that the reference would have

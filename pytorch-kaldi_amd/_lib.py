@@ -32,6 +32,9 @@ SIGNATURES = {
     "pk_gemm_bf16_set_tile": (None, [c_int]),
     "pk_gemm_bf16": (c_int, [P, c_int, c_int, c_int, c_float, P, c_int64, c_int, P, c_int64, c_int, c_float, P, c_int64, P,
                              c_int, P]),
+    "pk_gemm_bf16_stats_floats": (c_int64, [c_int, c_int]),
+    "pk_gemm_bf16_stats": (c_int, [P, c_int, c_int, c_int, c_float, P, c_int64, c_int, P, c_int64, c_int, P, c_int64, P, P, P]),
+    "pk_bn_stats_merge": (c_int, [P, P, c_int, c_int64, P, P]),
     "pk_cvt_bf16": (c_int, [P, P, c_int64, c_int64, c_int, c_int, c_int, P, c_int64]),
     "pk_bn_partial_floats": (c_int64, [c_int64, c_int64]),
     "pk_bn_stats": (c_int, [P, P, c_int64, c_int64, c_int64, P, P, P]),

@@ -48,6 +48,7 @@ struct BArgs {
     int tiles_m, tiles_n;
     int items, per_xcd;  // work items = splits x tiles_m x tiles_n, and ceil(items / 8)
     const unsigned short* zeros;  // >= 16 bytes of zeros
+    float* stats;  // 256-tile, no split-K: per (m-tile, column) (rows, mean, M2) of the output, [tiles_m][N][3], or null
 };
 
 __device__ unsigned short g_zero_page[64];
@@ -393,6 +394,73 @@ __device__ __forceinline__ void store_frag(const BArgs& p, const f32x4 v, int ro
     }
 }
 
+// Column statistics of one 256 x 256 output tile, taken from the accumulators before they are stored (BatchNorm of a
+// projection: neural_networks.py:1114-1124 normalises w*(x) over all T*B rows; the separate statistics pass re-read
+// the 282 MB projection).  Two passes over the registers - sum, then squared deviations from the tile's own mean - so
+// nothing cancels; lanes that share a column (the 16 rows of a fragment) fold with xor-shuffles, the two row halves
+// of the workgroup through LDS.  Output: (rows, mean, M2) per column, the partial format of pk_bn_stats' merge.
+__device__ __forceinline__ void tile_colstats(const BArgs& p, const f32x4 (&acc)[2][2][4][2], int m0, int n0, int tm, int wm,
+                                              int wn, int lane, float* sh) {
+    const int nrows = (p.M - m0) < 256 ? (p.M - m0) : 256;
+    __syncthreads();  // every wave is past its last fragment read: the staging buffers are free
+    float part[2][2][4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float mu[2][2][4];
+        if (pass == 1) {
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int cl = bh * 128 + wn * 32 + j * 16 + (lane >> 4) * 4 + r;
+                        mu[bh][j][r] = (sh[cl] + sh[256 + cl]) / (float)nrows;
+                    }
+        }
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool in = ah * 128 + wm * 64 + i * 16 + (lane & 15) < nrows;
+                            const float v = acc[ah][bh][i][j][r];
+                            const float d = pass == 0 ? v : v - mu[bh][j][r];
+                            t += in ? (pass == 0 ? d : d * d) : 0.f;
+                        }
+#pragma unroll
+                    for (int off = 1; off < 16; off <<= 1) t += __shfl_xor(t, off);
+                    part[bh][j][r] = t;
+                }
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        sh[pass * 512 + wm * 256 + bh * 128 + wn * 32 + j * 16 + (lane >> 4) * 4 + r] = part[bh][j][r];
+        }
+        __syncthreads();
+    }
+    // 256 columns, 512 threads: thread c < 256 writes column c
+    const int c = threadIdx.x;
+    if (c < 256 && n0 + c < p.N) {
+        const float mean_v = (sh[c] + sh[256 + c]) / (float)nrows;
+        const float m2_v = sh[512 + c] + sh[768 + c];
+        float* o = p.stats + ((long)tm * p.N + n0 + c) * 3;
+        o[0] = (float)nrows;
+        o[1] = p.alpha * mean_v + (p.bias ? p.bias[n0 + c] : 0.f);
+        o[2] = p.alpha * p.alpha * m2_v;
+    }
+}
+
 #define PK_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 template <bool A_KC, bool B_KC>
@@ -515,6 +583,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(BArgs p) {
 #undef PK_END_L
     if (wm == 0) __builtin_amdgcn_s_barrier();  // pairs with the extra barrier the other group took before the loop
     PK_VMCNT(0);  // the zero-page DMAs of the two k-tiles past the end
+    if constexpr (A_KC && B_KC) {  // (projections: both operands k-contiguous; the other instantiations stay as they were)
+        if (p.stats != nullptr) tile_colstats(p, acc, m0, n0, tm, wm, wn, lane, reinterpret_cast<float*>(smem));
+    }
     const bool vec_ok = (((uintptr_t)(p.ws ? p.ws : p.C) & 15) == 0) && (((p.ws ? (long)p.N : p.ldc) & 3) == 0);
     const bool interior = m0 + 256 <= p.M && n0 + 256 <= p.N;
     if (vec_ok && interior && (p.ws != nullptr || p.beta == 0.f)) {
@@ -668,9 +739,9 @@ extern "C" int pk_gemm_bf16_auto_splitk(int M, int N, int K) {
     return (int)s;
 }
 
-extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
-                            const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc,
-                            const float* bias, int splitk, float* workspace) {
+static int gemm_bf16_impl(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
+                          const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc, const float* bias,
+                          int splitk, float* workspace, float* stats) {
     if (M <= 0 || N <= 0) return 0;
     PK_REQUIRE(K >= 0, "pk_gemm_bf16: negative K");
     PK_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0 && ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0,
@@ -685,7 +756,9 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
     p.alpha = alpha; p.beta = beta;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.bias = bias;
+    p.stats = stats;
     const int tile = gemm_tile_for(M, N, a_kc, b_kc);
+    PK_REQUIRE(stats == nullptr || (tile == 256 && a_kc && b_kc && splitk <= 1 && beta == 0.f), "pk_gemm_bf16_stats: internal: shape not covered");
     p.tiles_m = (M + tile - 1) / tile;
     p.tiles_n = (N + tile - 1) / tile;
     static void* zp = nullptr;  // looked up once (also keeps the call out of a HIP-graph capture)
@@ -769,3 +842,25 @@ extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, cons
     }
     return 0;
 }
+
+extern "C" int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
+                            const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc,
+                            const float* bias, int splitk, float* workspace) {
+    return gemm_bf16_impl(stream, M, N, K, alpha, A, lda, a_kc, B, ldb, b_kc, beta, C, ldc, bias, splitk, workspace, nullptr);
+}
+
+// C = alpha * A.B + bias with the column statistics of C taken in the epilogue (shapes that run on the 256-tile; others:
+// *row_blocks = 0 and the caller runs pk_bn_stats on C).  stats: pk_gemm_bf16_stats_floats(M, N) floats,
+// [*row_blocks][N][3] = (rows, mean, M2) per 256-row tile and column - what pk_bn_stats_merge folds.
+extern "C" int64_t pk_gemm_bf16_stats_floats(int M, int N) { return (int64_t)((M + 255) / 256) * N * 3; }
+
+extern "C" int pk_gemm_bf16_stats(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
+                                  const uint16_t* B, int64_t ldb, int b_kc, float* C, int64_t ldc, const float* bias,
+                                  float* stats, int* row_blocks) {
+    PK_REQUIRE(row_blocks != nullptr, "pk_gemm_bf16_stats: null row_blocks");
+    const bool fused = stats != nullptr && M > 0 && N > 0 && K > 0 && a_kc && b_kc && gemm_tile_for(M, N, a_kc, b_kc) == 256;
+    *row_blocks = fused ? (M + 255) / 256 : 0;
+    return gemm_bf16_impl(stream, M, N, K, alpha, A, lda, a_kc, B, ldb, b_kc, 0.f, C, ldc, bias, 1, nullptr,
+                          fused ? stats : nullptr);
+}
+

@@ -264,25 +264,35 @@ __global__ __launch_bounds__(256) void col_reduce_partial_kernel(const float* __
     }
 }
 
-__global__ __launch_bounds__(FIN_COLS* FIN_GROUPS) void col_reduce_final_kernel(const float* __restrict__ partial, int rb, long N,
-                                                                               float* __restrict__ out0,
-                                                                               float* __restrict__ out1) {
-    __shared__ float sh[FIN_GROUPS][FIN_COLS][2];
-    const int cx = threadIdx.x & (FIN_COLS - 1), q = threadIdx.x / FIN_COLS;
-    const long c = (long)blockIdx.x * FIN_COLS + cx;
+// Final column sums of [rb][N][2] partials: a block is 16 columns x 16 row-groups (N / 16 blocks: 69 at N = 1100 - with 32
+// columns per block the 35 blocks of the first version took 40 us per call, seven calls per training step); a thread
+// keeps eight partial rows in flight; fixed reduction order, deterministic run to run.
+constexpr int CF_COLS = 16, CF_GROUPS = 16;
+__global__ __launch_bounds__(CF_COLS* CF_GROUPS) void col_reduce_final_kernel(const float* __restrict__ partial, int rb, long N,
+                                                                             float* __restrict__ out0,
+                                                                             float* __restrict__ out1) {
+    __shared__ float sh[CF_GROUPS][CF_COLS][2];
+    const int cx = threadIdx.x & (CF_COLS - 1), q = threadIdx.x / CF_COLS;
+    const long c = (long)blockIdx.x * CF_COLS + cx;
     float a0 = 0.f, a1 = 0.f;
     if (c < N) {
-#pragma unroll 4
-        for (int k = q; k < rb; k += FIN_GROUPS) {
-            const float* o = partial + ((long)k * N + c) * 2;
-            a0 += o[0];
-            a1 += o[1];
+        int k = q;
+        for (; k + 7 * CF_GROUPS < rb; k += 8 * CF_GROUPS) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(partial + ((long)(k + u * CF_GROUPS) * N + c) * 2);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a0 += v[u].x, a1 += v[u].y;
+        }
+        for (; k < rb; k += CF_GROUPS) {
+            const float2 v = *reinterpret_cast<const float2*>(partial + ((long)k * N + c) * 2);
+            a0 += v.x, a1 += v.y;
         }
     }
     sh[q][cx][0] = a0, sh[q][cx][1] = a1;
     __syncthreads();
     if (q == 0 && c < N) {
-        for (int g = 1; g < FIN_GROUPS; ++g) a0 += sh[g][cx][0], a1 += sh[g][cx][1];
+        for (int g = 1; g < CF_GROUPS; ++g) a0 += sh[g][cx][0], a1 += sh[g][cx][1];
         out0[c] = a0;
         if (out1) out1[c] = a1;
     }
@@ -679,7 +689,7 @@ extern "C" int pk_bn_bwd_reduce(void* stream, const float* g, const float* g2, i
     hipLaunchKernelGGL(col_reduce_partial_kernel<0>, grid, dim3(256), 0, st, g, g2, (long)ldg, x, (long)ldx, (long)M,
                        (long)N, mean, var, eps, partial);
     PK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st, partial, rb, (long)N,
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_GROUPS), 0, st, partial, rb, (long)N,
                        sum_g, sum_gx);
     PK_LAUNCH_CHECK();
     return 0;
@@ -703,7 +713,7 @@ extern "C" int pk_colsum(void* stream, const float* g, const float* g2, int64_t 
     hipLaunchKernelGGL(col_reduce_partial_kernel<1>, grid, dim3(256), 0, st, g, g2, (long)ldg, (const float*)nullptr, 0L,
                        (long)M, (long)N, (const float*)nullptr, (const float*)nullptr, 0.f, partial);
     PK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st, partial, rb, (long)N,
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_GROUPS), 0, st, partial, rb, (long)N,
                        out, (float*)nullptr);
     PK_LAUNCH_CHECK();
     return 0;
@@ -734,6 +744,15 @@ extern "C" int pk_layernorm_bwd(void* stream, const float* dy, const float* x, i
     int blocks = (int)(rows < 4096 ? rows : 4096);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, pk_stream(stream), dy, x, (long)rows, (long)F,
                        gamma, mean, rinv, eps, dx, dgx);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+// fold [rb][N][3] (rows, mean, M2) partials (pk_bn_stats' own, or the ones pk_gemm_bf16_stats' epilogue wrote)
+extern "C" int pk_bn_stats_merge(void* stream, const float* partial, int rb, int64_t N, float* mean, float* var) {
+    PK_REQUIRE(rb > 0 && N > 0 && partial && mean && var, "pk_bn_stats_merge: bad arguments");
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0,
+                       pk_stream(stream), partial, rb, (long)N, mean, var);
     PK_LAUNCH_CHECK();
     return 0;
 }
@@ -769,7 +788,7 @@ extern "C" int pk_logsoftmax_fwd(void* stream, const float* x, int64_t rows, int
 // blocks of the fused backward: every wave keeps the column sums of its rows in registers, so few, long-lived waves
 static inline long lsm_bf16_blocks(int64_t rows) {
     long b = (rows + 63) / 64;  // >= 16 rows per wave
-    if (b > 1024) b = 1024;
+    if (b > 512) b = 512;
     if (b < 1) b = 1;
     return b;
 }
@@ -795,7 +814,7 @@ static int lsm_bwd_bf16_launch(hipStream_t st, bool onehot, const float* dy, con
     else PK_LSMB(32);
 #undef PK_LSMB
     PK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st,
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_GROUPS), 0, st,
                        partial, (int)blocks, (long)N, colsum, (float*)nullptr);
     PK_LAUNCH_CHECK();
     return 0;
@@ -1150,7 +1169,7 @@ extern "C" int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* 
     PK_BNB_LAUNCH(bnb_reduce_kernel, grid, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x,
                   (long)ldx, (long)M, mean, var, eps, partial);
     PK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0, st, partial, rb, N, sum_g,
+    hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_GROUPS), 0, st, partial, rb, N, sum_g,
                        use_bn ? sum_gx : (float*)nullptr);
     PK_LAUNCH_CHECK();
     PK_BNB_LAUNCH(bnb_apply_kernel, grid_a, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x,

@@ -211,6 +211,26 @@ def gemm_bf16(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, alpha=1.0, beta=0.0, 
     return C
 
 
+def gemm_bf16_bn_stats(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, bias=None):
+    """C = A.B (+ bias) on bf16 operands together with the BatchNorm statistics of C's columns (biased variance):
+    taken in the GEMM epilogue where the shape runs on the 256-tile (pk_gemm_bf16_stats), by pk_bn_stats otherwise.
+    -> (mean, var)"""
+    lib = _lib.load()
+    if os.environ.get("PK_GEMM_STATS", "1") == "0":  # A/B switch: statistics by a second pass over C
+        gemm_bf16(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, bias=bias)
+        return bn_stats(C if ldc == N else C.as_strided((M, N), (ldc, 1)))
+    stats = torch.empty(int(lib.pk_gemm_bf16_stats_floats(M, N)), device=C.device, dtype=torch.float32)
+    rb = ctypes.c_int(0)
+    rc = lib.pk_gemm_bf16_stats(_stream(), M, N, K, 1.0, _p(A), lda, int(a_kc), _p(B), ldb, int(b_kc), _p(C), ldc, _p(bias),
+                                _p(stats), ctypes.byref(rb))
+    _lib.check(rc, "pk_gemm_bf16_stats")
+    if rb.value == 0:
+        return bn_stats(C if ldc == N else C.as_strided((M, N), (ldc, 1)))
+    mean, var = torch.empty(N, device=C.device), torch.empty(N, device=C.device)
+    _lib.check(lib.pk_bn_stats_merge(_stream(), _p(stats), rb.value, N, _p(mean), _p(var)), "pk_bn_stats_merge")
+    return mean, var
+
+
 def _splitk_bf(out_tiles, K):
     """Split the reduction of the dW / dU shapes (few output tiles, K = T*B rows) over the chip.  `out_tiles` is an
     (M, N) pair: the library knows which block tile the shape takes."""
@@ -1001,11 +1021,13 @@ class RecLayerPerfFn(torch.autograd.Function):
         fill = _Prefill()
         fill.start(Yb, Xb, dGb)
         P = _new(TB, GH, like=Wcat)
-        gemm_bf16(TB, GH, K, xb, xb.shape[1], 1, Wb, Wb.shape[1], 1, P, GH)
         mean = var = None
+        if use_bn and training:  # the statistics come out of the projection GEMM's epilogue
+            mean, var = gemm_bf16_bn_stats(TB, GH, K, xb, xb.shape[1], 1, Wb, Wb.shape[1], 1, P, GH)
+        else:
+            gemm_bf16(TB, GH, K, xb, xb.shape[1], 1, Wb, Wb.shape[1], 1, P, GH)
         if use_bn:
             if training:
-                mean, var = bn_stats(P)
                 pscale, pshift = bn_finalize(mean, var, gamma, beta, eps, running_mean, running_var, momentum, ndir * TB)
             else:
                 mean, var = running_mean, running_var

@@ -522,3 +522,24 @@ def test_head_nll_declines_what_it_does_not_cover():
         assert F_.head_nll(y2, lab) is None                                         # modified in place since
     finally:
         F_.set_precision("fp32")
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(16384 + 100, 1100, 200, False), (16384, 1024, 72, True), (300, 1100, 64, False)])
+def test_projection_gemm_with_batchnorm_statistics(M, N, K, bias):
+    """pk_gemm_bf16_stats: the BatchNorm statistics of the projection taken in the GEMM epilogue (256-tile shapes; the
+    third shape takes the fallback: plain GEMM + pk_bn_stats) against torch on the very matrix the GEMM wrote."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) + 0.3).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = (torch.randn(N, generator=g) * 3).cuda() if bias else None
+    xb, wb = F_.cvt_bf16(x), F_.cvt_bf16(w)
+    C = torch.empty(M, N, device="cuda")
+    mean, var = F_.gemm_bf16_bn_stats(M, N, K, xb, xb.shape[1], 1, wb, wb.shape[1], 1, C, N, bias=b)
+    torch.cuda.synchronize()
+    ref = x.to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().t()
+    if bias:
+        ref = ref + b.double()
+    assert rel_err(C, ref) < 1e-5
+    Cd = C.double()
+    assert rel_err(mean, Cd.mean(0)) < 1e-5
+    assert rel_err(var, Cd.var(0, unbiased=False)) < 1e-5

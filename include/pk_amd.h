@@ -233,6 +233,11 @@ int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, int T, int B
  * slabs are then not written: pk_bn_bwd_bf16 works from dGb).  * prefilled != 0: the caller has already filled the exchange buffer(s) (Yb, Xb / dGb) with 0xFF bytes - e.g. on
  * another stream, next to the projection GEMM - and the entry point skips its own hipMemsetAsync.
  */
+/* prefilled (both entry points below): 1 = the caller stored the 0xFF "not written yet" pattern in the whole exchange
+ * buffer, 0 = the library does it in front of the launch, 2 = the kernel does it on the way where it can
+ * (pk_rec_self_fill(cell) == 1: every chunk is patterned by the lane that later publishes it, a few steps ahead; other
+ * cells: as 0). */
+int pk_rec_self_fill(int cell);
 int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
                     const float* pscale, const float* pshift, const float* U, const float* mask, float mask_scalar,
                     float* Y, float* S, uint16_t* Yb, int64_t y_pitch, int prefilled);

@@ -7,6 +7,12 @@
 #endif
 #include "pk_cell.h"
 
+// Self-filling exchange (liGRU / RNN / 4-wave LSTM kernels of pk_rec_persist2.hip): the lane that publishes a chunk of
+// step t also stores the 0xFF pattern into the same chunk of step t + PK_R2_FILL_AHEAD (same lane, same address, program
+// order: the pattern can never overtake the data), and the first PK_R2_FILL_AHEAD slabs before the placement handshake
+// (write-through, drained with vmcnt(0): every member's pattern is in place before any member polls).  Replaces the
+// whole-buffer fill (141 + 295 MB per layer and step) - the pattern now meets its data in L2 a few microseconds later.
+#define PK_R2_FILL_AHEAD 4
 struct R2Args {
     int T, B, R, H, Hp, YH, act;
     int C, Pn, rpc, row0;  // clusters, workgroups per cluster, rows per cluster, first row of this launch
@@ -31,6 +37,7 @@ struct R2Args {
     unsigned* xcd_tab;          // [C][16] placement handshake words (0xFFFFFFFF before the launch)
     unsigned long long* trace;  // optional [T][8] phase time stamps of (cluster 0, member 0, wave 0); null = off
     int helper_delay;           // eight-wave LSTM kernels: extra s_sleep units before the second wave of a pair polls
+    int self_fill;              // 1 = the kernel writes the "not written yet" pattern itself, PK_R2_FILL_AHEAD steps ahead of its publishes
     int empty_step;             // diagnostics (traced kernels only): skip the MFMA block and the gate math - what is left
                                 // of a step is the hand-off itself (poll, barrier, flush / prefetch issue, publish)
 };

@@ -170,6 +170,12 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     };
 #define PK_LP0(E) load_proj(0, E)
     PK_EDGE_DISPATCH(PK_LP0);
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (a.self_fill) {  // my chunks of the first slabs, visible everywhere before the handshake lets anyone poll
+        for (int tt = 0; tt < PK_R2_FILL_AHEAD && tt < T; ++tt)
+            pub_store<false>(rs, pbase + (pk_ok ? (unsigned)(pdir ? (T - 1 - tt) : tt) * TS : 0u), sentinel);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     bool dead = false;
@@ -213,6 +219,11 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
         if (t + 1 < T) {
 #define PK_LP1(E) load_proj(t + 1, E)
             PK_EDGE_DISPATCH_S(PK_LP1);
+        }
+        if (a.self_fill && t + PK_R2_FILL_AHEAD < T) {
+            const unsigned off = pbase + (pk_ok ? (unsigned)(pdir ? (T - 1 - (t + PK_R2_FILL_AHEAD)) : (t + PK_R2_FILL_AHEAD)) * TS : 0u);
+            if (fast) pub_store<true>(rs, off, sentinel);
+            else pub_store<false>(rs, off, sentinel);
         }
         const bool empty = TR && a.empty_step != 0;  // diagnostics: the step without its arithmetic
         if (t > 0 && !empty) {
@@ -422,6 +433,16 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
         PK_EDGE_DISPATCH_S(PK_FOB);
     };
     load_step(T - 1, BoolC<-1>());
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    auto fill_slab = [&](int tt, auto FASTC) {  // my G chunks of the slab that step tt will publish
+        const unsigned off = pbase + (pk_ok ? (unsigned)(pdir ? (T - 1 - tt) : tt) * TS : 0u);
+#pragma unroll
+        for (int g = 0; g < G; ++g) pub_store<decltype(FASTC)::value != 0>(rs, off + (pk_ok ? (unsigned)(g * Hp) * 2u : 0u), sentinel);
+    };
+    if (a.self_fill) {  // the first slabs (the steps run T-1, T-2, ...), in place before the handshake lets anyone poll
+        for (int k = 0; k < PK_R2_FILL_AHEAD && k < T; ++k) fill_slab(T - 1 - k, BoolC<0>());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     bool dead = false;
@@ -456,6 +477,10 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
         // the saved tensors of the next one
         if (t < T - 1) flush_outputs(t + 1, SEC);
         if (t > 0) load_step(t - 1, SEC);
+        if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) {
+            if (fast) fill_slab(t - PK_R2_FILL_AHEAD, BoolC<1>());
+            else fill_slab(t - PK_R2_FILL_AHEAD, BoolC<0>());
+        }
         const bool empty = TR && a.empty_step != 0;
         if (t < T - 1 && !empty) {
             const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
@@ -596,6 +621,7 @@ int pk_rec2_host_setup(R2Args& a, bool backward) {
     a.trash = g2_trash; a.poll_delay = g2_poll_delay >= 0 ? g2_poll_delay : default_poll_delay(backward);
     a.helper_delay = 0;
     a.empty_step = g2_empty_step;
+    a.self_fill = 0;
     return 0;
 }
 int pk_rec2_check_residency(const void* kernel, int threads, size_t lds, int grid, const char* who) {
@@ -618,6 +644,13 @@ int pk_rec2_check_residency(const void* kernel, int threads, size_t lds, int gri
 
 int pk_rec2_reset_handshake(hipStream_t st) {
     PK_CHECK_HIP(hipMemsetAsync(g2_xcd_tab, 0xFF, XCD_TAB_BYTES, st));
+    return 0;
+}
+
+// Does the bf16 persistent kernel of this cell keep its exchange buffer filled by itself (prefilled = 2)?
+extern "C" int pk_rec_self_fill(int cell) {
+    if (cell == PK_CELL_LIGRU || cell == PK_CELL_RNN) return 1;
+    if (cell == PK_CELL_LSTM) return pk_rec2l_enabled() ? 0 : 1;
     return 0;
 }
 
@@ -674,9 +707,12 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.dY = nullptr; a.dP2 = nullptr; a.dGb = nullptr; a.Gpitch = 0;
     rc = pk_rec2_host_setup(a, false);
     if (rc) return rc;
-    // the bf16 layer output is the mailbox: poison it with the sentinel
-    if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
-    if (cell == PK_CELL_LSTM && pk_rec2l_enabled()) return pk_rec2l_launch(st, a, pl, act, false);
+    // the bf16 layer output is the mailbox: it must hold the sentinel wherever a poll can arrive before its data.
+    // prefilled: 1 = the caller filled it, 2 = fill it on the way if this kernel can (pk_rec_self_fill), 0 = fill here
+    const bool lstm8 = cell == PK_CELL_LSTM && pk_rec2l_enabled();
+    a.self_fill = (prefilled == 2 && !lstm8) ? 1 : 0;
+    if (prefilled != 1 && !a.self_fill) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
+    if (lstm8) return pk_rec2l_launch(st, a, pl, act, false);
     const int G = pk_cell_gates(cell);
     const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024 + 512) + 16;
     {   // dynamic LDS above the 64 KB default needs the opt-in (exact size: the kernels also hold a little static LDS)
@@ -722,8 +758,10 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.dY = dY; a.dP2 = dP2; a.dGb = (unsigned short*)dGb; a.Gpitch = (int)g_pitch;
     rc = pk_rec2_host_setup(a, true);
     if (rc) return rc;
-    if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
-    if (cell == PK_CELL_LSTM && pk_rec2l_enabled()) return pk_rec2l_launch(st, a, pl, act, true);
+    const bool lstm8 = cell == PK_CELL_LSTM && pk_rec2l_enabled();
+    a.self_fill = (prefilled == 2 && !lstm8) ? 1 : 0;
+    if (prefilled != 1 && !a.self_fill) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
+    if (lstm8) return pk_rec2l_launch(st, a, pl, act, true);
     const size_t atile = (size_t)RMAX * pk_r2_lda_bf16(G * KPAD) * 2;
     const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0);
     const size_t lds = (2 * atile > 96 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(nin + G) * 1024 + (size_t)G * 512) + 16;

@@ -39,6 +39,8 @@ class _Settings:
         # the following layer's recurrent backward, and accumulate straight into the parameters' flat .grad buffer
         # (only for parameters owned by optim.FlatParams; see side_launch / join_side)
         self.wgrad_side = os.environ.get("PK_WGRAD_SIDE", "1") != "0"
+        # the liGRU / RNN persistent kernels keep their exchange buffers filled themselves (0 = whole-buffer fill on a third stream)
+        self.self_fill = os.environ.get("PK_REC_SELF_FILL", "1") != "0"
         assert self.precision in PREC, self.precision
         assert self.rec_algo in ("auto", "stepwise", "persistent"), self.rec_algo
 
@@ -829,7 +831,7 @@ class RecLayerFn(torch.autograd.Function):
             Hp = _up(H, 8)
             Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
             rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
-                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1], 0)
+                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1], 2)
             _lib.check(rc, "pk_rec_fwd_bf16")
         else:
             rc = lib.pk_rec_fwd(_stream(), algo, prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
@@ -874,7 +876,7 @@ class RecLayerFn(torch.autograd.Function):
             Hp = _up(H, 8)
             dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16)
             rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
-                                     float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dP2), _p(dGb), dGb.shape[1], 0)
+                                     float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dP2), _p(dGb), dGb.shape[1], 2)
             _lib.check(rc, "pk_rec_bwd_bf16")
         else:
             rc = lib.pk_rec_bwd(_stream(), ctx.algo, ctx.prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat),
@@ -1013,13 +1015,16 @@ class RecLayerPerfFn(torch.autograd.Function):
         # one, dGb, too: 295 MB that would otherwise be filled on the critical path of backward)
         Hp = _up(H, 8)
         Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
-        dGb = None
-        if any(ctx.needs_input_grad):  # a backward pass will follow
-            dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=x.device, dtype=torch.bfloat16)
         two_phase = cell in ("GRU", "minimalGRU")
+        # (the liGRU / RNN kernels write the pattern themselves, a few steps ahead of their own publishes: prefilled = 2)
+        self_fill = (not two_phase and settings.self_fill and lib.pk_rec_self_fill(CELL[cell]) == 1)
+        dGb = None
+        if any(ctx.needs_input_grad) and not self_fill:  # a backward pass will follow: its exchange buffer is filled now
+            dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=x.device, dtype=torch.bfloat16)
         Xb = torch.empty_like(Yb) if two_phase else None  # two exchanges per step: h and r*h (z*h)
         fill = _Prefill()
-        fill.start(Yb, Xb, dGb)
+        if not self_fill:
+            fill.start(Yb, Xb, dGb)
         P = _new(TB, GH, like=Wcat)
         mean = var = None
         if use_bn and training:  # the statistics come out of the projection GEMM's epilogue
@@ -1046,9 +1051,11 @@ class RecLayerPerfFn(torch.autograd.Function):
             _lib.check(rc, "pk_rec2p_fwd_bf16")
         else:
             rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
-                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1], fill.done)
+                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1],
+                                     2 if self_fill else fill.done)
             _lib.check(rc, "pk_rec_fwd_bf16")
         _force_kinks(S, cell, T, B, ndir, H)
+        ctx.self_fill = self_fill
         ctx.dGb = dGb if fill.done else None
         ctx.Xb = Xb
         ctx.save_for_backward(xb, Wb, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, Yb)
@@ -1079,7 +1086,8 @@ class RecLayerPerfFn(torch.autograd.Function):
         dGb, prefilled = ctx.dGb, 1  # filled with the "not written" pattern during forward (third stream)
         ctx.dGb = None
         if dGb is None:
-            dGb, prefilled = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16), 0
+            dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16)
+            prefilled = 2 if ctx.self_fill else 0
         Gp = dGb.shape[1]
         if ctx.Xb is not None:
             rc = lib.pk_rec2p_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),

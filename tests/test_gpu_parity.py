@@ -284,6 +284,55 @@ def test_bf16_persistent_matches_bf16_stepwise(kind, pre, act, H, T, B, bidir, s
         assert rel_err(res["persistent"][2][k], v) < 2e-2, k
 
 
+@pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("RNN", "rnn", "tanh")])
+@pytest.mark.parametrize("H,T,B,bidir", [(550, 40, 9, True), (72, 3, 4, True), (40, 64, 3, False), (24, 9, 300, True)])
+@pytest.mark.parametrize("safe", [0, 1])
+def test_self_filled_exchange_on_a_dirty_buffer(kind, pre, act, H, T, B, bidir, safe):
+    """The liGRU / RNN persistent kernels write the "not written yet" pattern of their exchange buffers themselves, a few
+    steps ahead of their own publishes (prefilled = 2).  Run twice in a row on different inputs, so that the second
+    run's buffers are the allocator's recycled blocks holding the FIRST run's perfectly valid-looking data: outputs and
+    gradients must equal, bit for bit, what the whole-buffer fill (PK_REC_SELF_FILL=0 path) gives on the second input -
+    a poll that accepted a stale chunk would show up here."""
+    from engine_util import F_amd, nn_amd
+
+    opts = _rec_opts(pre, [H, H], act, bidir=bidir)
+    torch.manual_seed(5)
+    net = getattr(nn_amd, kind)(opts, 23).cuda().train()
+    g = torch.Generator().manual_seed(17)
+    xs = [torch.randn(T, B, 23, generator=g).cuda() for _ in range(2)]
+    masks = O.make_drop_masks(kind, opts, B, "train", generator=g)
+    cot = torch.randn(T, B, net.out_dim, generator=g).cuda()
+    lib = importlib.import_module("pytorch-kaldi_amd._lib").load()
+    assert lib.pk_rec_self_fill(F_amd.CELL[kind]) == 1
+    F_amd.set_precision("bf16")
+    F_amd.set_rec_algo("persistent")
+    lib.pk_persist2_set_mode(safe)
+    res = {}
+    try:
+        for self_fill in (True, False):
+            F_amd.settings.self_fill = self_fill
+            for x in (xs if self_fill else xs[1:]):  # the self-filled run sees a dirty allocator
+                net.zero_grad()
+                xe = x.clone().requires_grad_(True)
+                y = net(xe, drop_masks=masks)
+                (y * cot).sum().backward()
+                torch.cuda.synchronize()
+                out = (y.detach().clone(), xe.grad.clone(),
+                       {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None})
+                del y, xe
+            res[self_fill] = out
+    finally:
+        F_amd.settings.self_fill = True
+        F_amd.set_rec_algo("auto")
+        F_amd.set_precision("fp32")
+        lib.pk_persist2_set_mode(0)
+    assert lib.pk_persist2_error_count() == 0
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
+    for k, v in res[False][2].items():
+        assert torch.equal(res[True][2][k], v), k
+
+
 # --------------------------------------------------------------------------------
 # BASELINE configs[1] at FULL size (Li-GRU 5x550 bidirectional + 1938/48 heads, T=500, B=128):
 # the oracle needs ~400 s and 37 GB per step there (SURVEY.md 7.2), so parity is checked through

@@ -649,9 +649,8 @@ int pk_rec2_reset_handshake(hipStream_t st) {
 
 // Does the bf16 persistent kernel of this cell keep its exchange buffer filled by itself (prefilled = 2)?
 extern "C" int pk_rec_self_fill(int cell) {
-    if (cell == PK_CELL_LIGRU || cell == PK_CELL_RNN) return 1;
-    if (cell == PK_CELL_LSTM) return pk_rec2l_enabled() ? 0 : 1;
-    return 0;
+    (void)cell;
+    return 1;  // every bf16 persistent kernel (liGRU / RNN / LSTM: pk_rec_*_bf16; GRU / minimalGRU: pk_rec2p_*_bf16)
 }
 
 extern "C" void pk_persist2_set_mode(int force_safe) { g2_force_safe = force_safe ? 1 : 0; }
@@ -710,7 +709,7 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     // the bf16 layer output is the mailbox: it must hold the sentinel wherever a poll can arrive before its data.
     // prefilled: 1 = the caller filled it, 2 = fill it on the way if this kernel can (pk_rec_self_fill), 0 = fill here
     const bool lstm8 = cell == PK_CELL_LSTM && pk_rec2l_enabled();
-    a.self_fill = (prefilled == 2 && !lstm8) ? 1 : 0;
+    a.self_fill = prefilled == 2 ? 1 : 0;
     if (prefilled != 1 && !a.self_fill) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     if (lstm8) return pk_rec2l_launch(st, a, pl, act, false);
     const int G = pk_cell_gates(cell);
@@ -759,7 +758,7 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     rc = pk_rec2_host_setup(a, true);
     if (rc) return rc;
     const bool lstm8 = cell == PK_CELL_LSTM && pk_rec2l_enabled();
-    a.self_fill = (prefilled == 2 && !lstm8) ? 1 : 0;
+    a.self_fill = prefilled == 2 ? 1 : 0;
     if (prefilled != 1 && !a.self_fill) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
     if (lstm8) return pk_rec2l_launch(st, a, pl, act, true);
     const size_t atile = (size_t)RMAX * pk_r2_lda_bf16(G * KPAD) * 2;

@@ -152,6 +152,16 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
     };
 #define PKG_LP0(E) load_proj(0, E)
     PK_EDGE_DISPATCH(PKG_LP0);
+    // self-filling exchange (pk_rec2_common.h), both mailboxes: h in Yb, r*h (z*h) in Xb
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (a.self_fill) {
+        for (int tt = 0; tt < PK_R2_FILL_AHEAD && tt < T; ++tt) {
+            const unsigned off = pbase + (pk_ok ? (unsigned)(pdir ? (T - 1 - tt) : tt) * TS : 0u);
+            pub_store<false>(rsY, off, sentinel);
+            pub_store<false>(rsX, off, sentinel);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     bool dead = false;
@@ -190,6 +200,11 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
         if (t + 1 < T) {
 #define PKG_LP1(E) load_proj(t + 1, E)
             PK_EDGE_DISPATCH_S(PKG_LP1);
+        }
+        if (a.self_fill && t + PK_R2_FILL_AHEAD < T) {
+            const unsigned off = pbase + (pk_ok ? (unsigned)(pdir ? (T - 1 - (t + PK_R2_FILL_AHEAD)) : (t + PK_R2_FILL_AHEAD)) * TS : 0u);
+            pub_store<fast>(rsY, off, sentinel);
+            pub_store<fast>(rsX, off, sentinel);
         }
         if (t > 0) {
             const unsigned char* Ar = A0 + (lane & 15) * (LDA * 2) + kq * 16;
@@ -408,6 +423,16 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
         PK_EDGE_DISPATCH(PKG_LS);
     };
     load_step(T - 1);
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    auto fill_slab = [&](int tt, auto FASTC) {  // my G chunks of the slab that step tt will publish
+        const unsigned off = pbase + (pk_ok ? (unsigned)(pdir ? (T - 1 - tt) : tt) * TS : 0u);
+#pragma unroll
+        for (int g = 0; g < G; ++g) pub_store<decltype(FASTC)::value != 0>(rs, off + (pk_ok ? (unsigned)(g * Hp) * 2u : 0u), sentinel);
+    };
+    if (a.self_fill) {
+        for (int k = 0; k < PK_R2_FILL_AHEAD && k < T; ++k) fill_slab(T - 1 - k, BoolC<0>());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     bool dead = false;
@@ -433,6 +458,10 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
         if (t < T - 1) PK_BARRIER_LDS();
         else PK_LDS_ORDER();
         if (t > 0) load_step(t - 1);
+        if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) {
+            if (fast) fill_slab(t - PK_R2_FILL_AHEAD, BoolC<1>());
+            else fill_slab(t - PK_R2_FILL_AHEAD, BoolC<0>());
+        }
         if (t < T - 1) {
             const unsigned char* Ar = smem + (lane & 15) * (LDB * 2) + kq * 16;
 #pragma unroll
@@ -555,6 +584,7 @@ extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, 
     a.dY = nullptr; a.dP2 = nullptr; a.dGb = nullptr; a.Gpitch = 0;
     rc = pk_rec2_host_setup(a, false);
     if (rc) return rc;
+    a.self_fill = prefilled == 2 ? 1 : 0;  // (prefilled: see pk_rec_fwd_bf16)
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Xb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(2 * G + 1) * 1024 + 512) + 16;
@@ -598,6 +628,7 @@ extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, 
     a.dY = dY; a.dP2 = nullptr; a.dGb = (unsigned short*)dGb; a.Gpitch = (int)g_pitch;
     rc = pk_rec2_host_setup(a, true);
     if (rc) return rc;
+    a.self_fill = prefilled == 2 ? 1 : 0;
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
     const size_t lds = (size_t)RMAX * pk_r2_lda_bf16(G1 * KPAD) * 2 + (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 +
                        4 * ((size_t)(G + 2) * 1024 + (size_t)G * 512) + 16;

@@ -217,6 +217,13 @@ __global__ __launch_bounds__(512, 1) void rec2l_fwd_kernel(R2Args a) {
     };
 #define PK_LLP0(E) load_proj(0, E)
     PK_EDGE_DISPATCH(PK_LLP0);
+    // self-filling exchange (pk_rec2_common.h): the publishing lanes (first wave of a pair) pattern their own chunks
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (a.self_fill && half == 0) {
+        for (int tt = 0; tt < PK_R2_FILL_AHEAD && tt < T; ++tt)
+            pub_store<false>(rs, pbase + (pk_ok ? (unsigned)(pdir ? (T - 1 - tt) : tt) * TS : 0u), sentinel);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     bool dead = false;
@@ -253,6 +260,10 @@ __global__ __launch_bounds__(512, 1) void rec2l_fwd_kernel(R2Args a) {
         if (t + 1 < T) {
 #define PK_LLP1(E) load_proj(t + 1, E)
             PK_EDGE_DISPATCH_S(PK_LLP1);
+        }
+        if constexpr (HALF == 0) {
+            if (a.self_fill && t + PK_R2_FILL_AHEAD < T)
+                pub_store<fast>(rs, pbase + (pk_ok ? (unsigned)(pdir ? (T - 1 - (t + PK_R2_FILL_AHEAD)) : (t + PK_R2_FILL_AHEAD)) * TS : 0u), sentinel);
         }
         if (t > 0) {
             const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
@@ -506,6 +517,19 @@ __global__ __launch_bounds__(512, 1) void rec2l_bwd_kernel(R2Args a) {
 #define PK_LLS1(E) load_step_e(T - 1, E, BoolC<1>())
         PK_EDGE_DISPATCH(PK_LLS1);
     }
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    auto fill_slab = [&](int tt, auto FASTC) {  // my pieces of the slab that step tt will publish
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = (plds[j] >> 29) & 1;
+            const int pdir = (plds[j] >> 30) & 1;
+            pub_store<decltype(FASTC)::value != 0>(rs, pbase[j] + (ok ? (unsigned)(pdir ? (T - 1 - tt) : tt) * TS : 0u), sentinel);
+        }
+    };
+    if (a.self_fill && half == 0) {
+        for (int k = 0; k < PK_R2_FILL_AHEAD && k < T; ++k) fill_slab(T - 1 - k, BoolC<0>());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     int* ltab = reinterpret_cast<int*>(smem + LTAB) + tid;
 #pragma unroll
@@ -534,6 +558,12 @@ __global__ __launch_bounds__(512, 1) void rec2l_bwd_kernel(R2Args a) {
         PK_BARRIER_LDS();  // A: the polled dgates_{t+1} tile and the pair's input patches are complete
         // off the dependency chain: fp32 gate gradients of the previous step (if wanted)
         if (t < T - 1) flush_outputs(t + 1);
+        if constexpr (HALF == 0) {
+            if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) {
+                if (fast) fill_slab(t - PK_R2_FILL_AHEAD, BoolC<1>());
+                else fill_slab(t - PK_R2_FILL_AHEAD, BoolC<0>());
+            }
+        }
         if (t < T - 1) {
             const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
 #pragma unroll

@@ -1017,7 +1017,7 @@ class RecLayerPerfFn(torch.autograd.Function):
         Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
         two_phase = cell in ("GRU", "minimalGRU")
         # (the liGRU / RNN kernels write the pattern themselves, a few steps ahead of their own publishes: prefilled = 2)
-        self_fill = (not two_phase and settings.self_fill and lib.pk_rec_self_fill(CELL[cell]) == 1)
+        self_fill = settings.self_fill and lib.pk_rec_self_fill(CELL[cell]) == 1
         dGb = None
         if any(ctx.needs_input_grad) and not self_fill:  # a backward pass will follow: its exchange buffer is filled now
             dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=x.device, dtype=torch.bfloat16)
@@ -1047,7 +1047,7 @@ class RecLayerPerfFn(torch.autograd.Function):
         if two_phase:
             rc = lib.pk_rec2p_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
                                        _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), _p(Xb),
-                                       Yb.shape[1], fill.done)
+                                       Yb.shape[1], 2 if self_fill else fill.done)
             _lib.check(rc, "pk_rec2p_fwd_bf16")
         else:
             rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),

@@ -284,11 +284,12 @@ def test_bf16_persistent_matches_bf16_stepwise(kind, pre, act, H, T, B, bidir, s
         assert rel_err(res["persistent"][2][k], v) < 2e-2, k
 
 
-@pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("RNN", "rnn", "tanh")])
+@pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("RNN", "rnn", "tanh"), ("LSTM", "lstm", "tanh"),
+                                          ("GRU", "gru", "tanh"), ("minimalGRU", "minimalgru", "relu")])
 @pytest.mark.parametrize("H,T,B,bidir", [(550, 40, 9, True), (72, 3, 4, True), (40, 64, 3, False), (24, 9, 300, True)])
 @pytest.mark.parametrize("safe", [0, 1])
 def test_self_filled_exchange_on_a_dirty_buffer(kind, pre, act, H, T, B, bidir, safe):
-    """The liGRU / RNN persistent kernels write the "not written yet" pattern of their exchange buffers themselves, a few
+    """The bf16 persistent kernels write the "not written yet" pattern of their exchange buffers themselves, a few
     steps ahead of their own publishes (prefilled = 2).  Run twice in a row on different inputs, so that the second
     run's buffers are the allocator's recycled blocks holding the FIRST run's perfectly valid-looking data: outputs and
     gradients must equal, bit for bit, what the whole-buffer fill (PK_REC_SELF_FILL=0 path) gives on the second input -

@@ -114,6 +114,12 @@ int pk_bn_stats_merge(void* stream, const float* partial, int rb, int64_t N, flo
 int pk_bn_finalize(void* stream, int64_t N, const float* mean, const float* var, const float* gamma,
                    const float* beta, float eps, float* scale, float* shift, float* running_mean,
                    float* running_var, float momentum, double count);
+/* the same over the G <= 4 concatenated gates of a recurrent layer (columns [g*H, (g+1)*H) belong to gate g) whose
+ * running statistics sit in one BatchNorm1d per gate (neural_networks.py:1052-1055): running_mean / running_var /
+ * num_batches are host arrays of G device pointers (num_batches or its entries may be NULL); always updates. */
+int pk_bn_finalize_gates(void* stream, int G, int H, const float* mean, const float* var, const float* gamma,
+                         const float* beta, float eps, float* scale, float* shift, float* const* running_mean,
+                         float* const* running_var, int64_t* const* num_batches, float momentum, double count);
 /* y = dropmask * act(x*scale[n] + shift[n]); scale/shift NULL = identity;
  * mask NULL = no dropout (mask holds 0 or 1/(1-p)).  In-place allowed. */
 int pk_affine_act_fwd(void* stream, const float* x, int64_t ldx, int64_t M, int64_t N, const float* scale,

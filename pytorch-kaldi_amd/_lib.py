@@ -39,6 +39,7 @@ SIGNATURES = {
     "pk_bn_partial_floats": (c_int64, [c_int64, c_int64]),
     "pk_bn_stats": (c_int, [P, P, c_int64, c_int64, c_int64, P, P, P]),
     "pk_bn_finalize": (c_int, [P, c_int64, P, P, P, P, c_float, P, P, P, P, c_float, c_double]),
+    "pk_bn_finalize_gates": (c_int, [P, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, c_float, c_double]),
     "pk_affine_act_fwd": (c_int, [P, P, c_int64, c_int64, c_int64, P, P, c_int, P, P, c_int64]),
     "pk_act_bwd": (c_int, [P, P, P, P, c_int, c_int64, P]),
     "pk_bn_bwd_reduce": (c_int, [P, P, P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_float, P, P, P]),

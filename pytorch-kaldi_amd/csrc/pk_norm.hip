@@ -194,6 +194,33 @@ __global__ void bn_finalize_kernel(long N, const float* __restrict__ mean, const
     }
 }
 
+// The same for the concatenated gates of a recurrent layer, whose running statistics live in one BatchNorm1d module
+// per gate (neural_networks.py:1052-1055: bn_wh, bn_wz, ...): gate g owns columns [g*H, (g+1)*H).
+struct BnGateBufs {
+    float* rmean[4];
+    float* rvar[4];
+    long long* batches[4];
+};
+__global__ void bn_finalize_gates_kernel(int G, int H, const float* __restrict__ mean, const float* __restrict__ var,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                         float* __restrict__ scale, float* __restrict__ shift, BnGateBufs bufs,
+                                         float momentum, float unbias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= G * H) return;
+    const int g = c / H, j = c - g * H;
+    const float m = mean[c], v = var[c];
+    const float inv = 1.0f / sqrtf(v + eps);
+    const float ga = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = ga * inv;
+    scale[c] = sc;
+    shift[c] = b - m * sc;
+    float* rm = bufs.rmean[g];
+    float* rv = bufs.rvar[g];
+    rm[j] = (1.f - momentum) * rm[j] + momentum * m;
+    rv[j] = (1.f - momentum) * rv[j] + momentum * (v * unbias);
+    if (j == 0 && bufs.batches[g] != nullptr) bufs.batches[g][0] += 1;  // num_batches_tracked
+}
+
 // ---- y = mask * act(x*scale + shift) ----------------------------------------
 __global__ void affine_act_fwd_kernel(const float* __restrict__ x, long ldx, long M, long N,
                                       const float* __restrict__ scale, const float* __restrict__ shift, int act,
@@ -659,6 +686,25 @@ extern "C" int pk_bn_finalize(void* stream, int64_t N, const float* mean, const 
     const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.0f;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (long)N, mean, var, gamma,
                        beta, eps, scale, shift, running_mean, running_var, momentum, unbias);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_bn_finalize_gates(void* stream, int G, int H, const float* mean, const float* var, const float* gamma,
+                                    const float* beta, float eps, float* scale, float* shift, float* const* running_mean,
+                                    float* const* running_var, int64_t* const* num_batches, float momentum, double count) {
+    PK_REQUIRE(G >= 1 && G <= 4 && H >= 1, "pk_bn_finalize_gates: 1..4 gates");
+    PK_REQUIRE(running_mean != nullptr && running_var != nullptr, "pk_bn_finalize_gates: null running-statistics tables");
+    BnGateBufs bufs;
+    for (int g = 0; g < 4; ++g) {
+        bufs.rmean[g] = g < G ? running_mean[g] : nullptr;
+        bufs.rvar[g] = g < G ? running_var[g] : nullptr;
+        bufs.batches[g] = (g < G && num_batches != nullptr) ? (long long*)num_batches[g] : nullptr;
+        PK_REQUIRE(g >= G || (bufs.rmean[g] && bufs.rvar[g]), "pk_bn_finalize_gates: null running statistics of a gate");
+    }
+    const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.0f;
+    hipLaunchKernelGGL(bn_finalize_gates_kernel, dim3((unsigned)((G * H + 255) / 256)), dim3(256), 0, pk_stream(stream), G, H,
+                       mean, var, gamma, beta, eps, scale, shift, bufs, momentum, unbias);
     PK_LAUNCH_CHECK();
     return 0;
 }

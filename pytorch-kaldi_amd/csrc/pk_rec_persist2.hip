@@ -580,6 +580,19 @@ int pk_rec2_make_plan(int R, int H, Plan2& pl) {
                ncu);
     if (C > 256) C = 256;
     if (C >= 8) C -= C % 8;  // members of one cluster congruent mod 8: one XCD under round-robin dispatch (speed only)
+    {   // no more clusters than full 16-row MFMA tiles need (rounded up to the XCD count): a step costs the same for 11
+        // rows as for 16, and the CUs left over go to the weight-gradient GEMMs of the side stream (256 rows: 16 clusters
+        // instead of 24, 19.09 -> 18.99 ms per step; a count that is not a multiple of 8 straddles XCDs: 23.6 ms).
+        // PK_REC_CLUSTERS overrides the cap.
+        static int cap = -1;
+        if (cap < 0) {
+            const char* e = getenv("PK_REC_CLUSTERS");
+            cap = e ? atoi(e) : 0;
+        }
+        const int full = (((R + RMAX - 1) / RMAX) + 7) & ~7;
+        const int want = cap > 0 ? cap : full;
+        if (want < C) C = want;
+    }
     int rpc = (R + C - 1) / C;
     if (rpc > RMAX) rpc = RMAX;
     if (rpc < 1) rpc = 1;

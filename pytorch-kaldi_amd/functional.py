@@ -363,8 +363,11 @@ class LinearFn(torch.autograd.Function):
 
 
 def _linear_bwd_bf16(ctx, dyb, xb, wb, like):
-    """dX and dW of a perf-mode Linear from the bf16 copy of the output gradient (ctx: dims, in_shape, wparam)."""
+    """dX and dW of a perf-mode Linear from the bf16 copy of the output gradient (ctx: dims, in_shape, wparam, and
+    xseg = (nseg, seglen, segpad) when xb is a re-pitched twin of the input: wb is then the plain-pitch weight copy)."""
     M, N, K = ctx.dims
+    xseg = getattr(ctx, "xseg", None)
+    Kx = K if xseg is None else xseg[0] * xseg[2]  # columns of xb that carry data (pad columns are zero)
     dx = dw = None
     if ctx.needs_input_grad[0]:  # dx[m,k] = sum_n dy[m,n] W[n,k]: A k-contiguous, B = W is k-major
         dx = _new(M, K, like=like)
@@ -372,15 +375,44 @@ def _linear_bwd_bf16(ctx, dyb, xb, wb, like):
         dx = dx.view(ctx.in_shape)
     if ctx.needs_input_grad[1]:  # dw[n,k] = sum_m dy[m,n] x[m,k]: both operands k-major
         wp = ctx.wparam
-        if M >= 4096 and wp is not None and wp.is_contiguous() and side_targets_ok([wp]):
-            # off the dependency chain: accumulate into the flat .grad on the side stream (beta = 1)
-            side_launch(lambda: gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0,
-                                          splitk=_splitk_bf(_tiles_bf(N, K), M)), (dyb, xb), [wp])
-        else:
-            dw = _new(N, K, like=like)
-            gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K,
-                      splitk=_splitk_bf(_tiles_bf(N, K), M))
+        side = M >= 4096 and wp is not None and wp.is_contiguous() and side_targets_ok([wp])
+        sk = _splitk_bf(_tiles_bf(N, Kx), M)
+        if xseg is None:
+            if side:  # off the dependency chain: accumulate into the flat .grad on the side stream (beta = 1)
+                side_launch(lambda: gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0,
+                                              splitk=sk), (dyb, xb), [wp])
+            else:
+                dw = _new(N, K, like=like)
+                gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K, splitk=sk)
+        else:  # the product comes out with the input's segment pitch: its segments are copied / added back
+            nseg, seglen, segpad = xseg
+            dwp = _new(N, Kx, like=like)
+
+            def run():
+                gemm_bf16(N, Kx, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dwp, Kx, splitk=sk)
+                if side:
+                    with torch.no_grad():
+                        for s_ in range(nseg):
+                            wp.grad[:, s_ * seglen:(s_ + 1) * seglen].add_(dwp[:, s_ * segpad:s_ * segpad + seglen])
+
+            if side:
+                side_launch(run, (dyb, xb, dwp), [wp])
+            else:
+                run()
+                dw = torch.cat([dwp[:, s_ * segpad:s_ * segpad + seglen] for s_ in range(nseg)], 1)
     return dx, dw
+
+
+def input_twin(x2):
+    """(xb, xseg) when the 2-D Linear input x2 still carries the bf16 copy its producer published (a recurrent layer's
+    exchange buffer: direction halves at a pitch of Hp), else None."""
+    tw = getattr(x2, "_pk_twin", None)
+    if tw is None:
+        return None
+    xb, xseg, version = tw
+    if x2._version != version or x2.dim() != 2 or xb.shape[0] != x2.shape[0] or xseg[0] * xseg[1] != x2.shape[1]:
+        return None
+    return xb, xseg
 
 
 class LinearLogSoftmaxFn(torch.autograd.Function):
@@ -396,7 +428,7 @@ class LinearLogSoftmaxFn(torch.autograd.Function):
     HeadNllFn)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, xb, wb):
+    def forward(ctx, x, weight, bias, xb, wb, wb_plain, xseg):
         _need_gpu(x, weight, bias)
         lib = _lib.load()
         x2 = _rows2d(x)
@@ -404,10 +436,12 @@ class LinearLogSoftmaxFn(torch.autograd.Function):
         N = weight.shape[0]
         ldz = _up(N, 32)
         z = torch.empty(M, ldz, device=x2.device, dtype=torch.float32)
-        gemm_bf16(M, N, K, xb, xb.shape[1], 1, wb, wb.shape[1], 1, z, ldz, bias=bias)
+        Kx = K if xseg is None else xseg[0] * xseg[2]
+        gemm_bf16(M, N, Kx, xb, xb.shape[1], 1, wb, wb.shape[1], 1, z, ldz, bias=bias)
         y = _new(M, N, like=x2)
         _lib.check(lib.pk_logsoftmax_fwd_ld(_stream(), _p(z), ldz, M, N, _p(y)), "pk_logsoftmax_fwd_ld")
-        ctx.save_for_backward(xb, wb, y)
+        ctx.save_for_backward(xb, wb_plain, y)
+        ctx.xseg = xseg
         ctx.dims = (M, N, K)
         ctx.has_bias = bias is not None
         ctx.in_shape = x.shape
@@ -427,7 +461,7 @@ class LinearLogSoftmaxFn(torch.autograd.Function):
         _lib.check(lib.pk_logsoftmax_bwd_bf16(_stream(), _p(dy2), _p(y), M, N, _p(dzb), ldb, _p(part), _p(db)),
                    "pk_logsoftmax_bwd_bf16")
         dx, dw = _linear_bwd_bf16(ctx, dzb, xb, wb, y)
-        return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None
+        return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None, None, None
 
 
 def linear_log_softmax_ok(x, weight):
@@ -437,12 +471,22 @@ def linear_log_softmax_ok(x, weight):
 
 def linear_log_softmax(x, weight, bias=None):
     """-> log-posteriors y.  y carries what head_nll needs to put the mean-NLL cost of the recipe directly behind
-    (x, weight, bias): `y._pk_head`."""
+    (x, weight, bias): `y._pk_head`.  When x is the output of a perf-mode recurrent layer, the bf16 copy that layer
+    published is the GEMM operand (the weight copy is re-pitched to match): the 282 MB activation is not converted
+    again."""
     with torch.no_grad():
         w = weight.contiguous()
-        xb, wb = _cvt_bf16_shared(_rows2d(x)), cvt_bf16(w)
-    y = LinearLogSoftmaxFn.apply(x, weight if weight.is_contiguous() else w, bias, xb, wb)
-    y._pk_head = (x, weight, bias, xb, wb, y._version)
+        x2 = _rows2d(x)
+        tw = input_twin(x2)
+        wb_plain = cvt_bf16(w)
+        if tw is None:
+            xb, xseg, wb = _cvt_bf16_shared(x2), None, wb_plain
+        else:
+            xb, xseg = tw
+            wb = cvt_bf16(w, *xseg)
+            assert wb.shape[1] == xb.shape[1]
+    y = LinearLogSoftmaxFn.apply(x, weight if weight.is_contiguous() else w, bias, xb, wb, wb_plain, xseg)
+    y._pk_head = (x, weight, bias, xb, wb_plain, xseg, y._version)
     return y
 
 
@@ -455,8 +499,9 @@ class HeadNllFn(torch.autograd.Function):
     up in (x, weight, bias) as they should.  The same forward pass counts the frame errors of the cost_err line."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, y, lab, xb, wb, ignore_index):
+    def forward(ctx, x, weight, bias, y, lab, xb, wb, xseg, ignore_index):
         lib = _lib.load()
+        ctx.xseg = xseg
         M, N = y.shape
         lab = lab.contiguous()
         out4 = _new(4, like=y)
@@ -486,7 +531,7 @@ class HeadNllFn(torch.autograd.Function):
         _lib.check(lib.pk_nll_logsoftmax_bwd_bf16(_stream(), _p(y), _p(lab), _p(dl), cnt, ctx.ignore_index, M, N, _p(dzb),
                                                   ldb, _p(part), _p(db)), "pk_nll_logsoftmax_bwd_bf16")
         dx, dw = _linear_bwd_bf16(ctx, dzb, xb, wb, y)
-        return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None, None, None, None
+        return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None, None, None, None, None
 
 
 def linear(x, weight, bias=None):
@@ -526,10 +571,10 @@ def head_nll(y, lab, ignore_index=-100):
     head = getattr(y, "_pk_head", None)
     if head is None or y.dim() != 2 or lab.dim() != 1 or lab.shape[0] != y.shape[0] or lab.dtype != torch.int64:
         return None
-    x, weight, bias, xb, wb, version = head
+    x, weight, bias, xb, wb, xseg, version = head
     if y._version != version or not lab.is_cuda:
         return None
-    loss, out4 = HeadNllFn.apply(x, weight, bias, y.detach(), lab, xb, wb, ignore_index)
+    loss, out4 = HeadNllFn.apply(x, weight, bias, y.detach(), lab, xb, wb, xseg, ignore_index)
     return loss, out4
 
 
@@ -552,6 +597,19 @@ def bn_finalize(mean, var, gamma, beta, eps, running_mean=None, running_var=None
     scale, shift = torch.empty_like(mean), torch.empty_like(mean)
     _lib.check(lib.pk_bn_finalize(_stream(), N, _p(mean), _p(var), _p(gamma), _p(beta), eps, _p(scale), _p(shift),
                                   _p(running_mean), _p(running_var), momentum, float(count)), "pk_bn_finalize")
+    return scale, shift
+
+
+def bn_finalize_gates(mean, var, gamma, beta, eps, H, running_means, running_vars, batches, momentum, count):
+    """bn_finalize for the concatenated gates of a recurrent layer in training mode: scale / shift, and the
+    running statistics + num_batches_tracked of every gate's own BatchNorm1d updated by the same launch."""
+    lib = _lib.load()
+    G = len(running_means)
+    scale, shift = torch.empty_like(mean), torch.empty_like(mean)
+    arr = lambda ts: (ctypes.c_void_p * G)(*[t.data_ptr() for t in ts])
+    rm, rv, nb = arr(running_means), arr(running_vars), arr(batches)
+    _lib.check(lib.pk_bn_finalize_gates(_stream(), G, H, _p(mean), _p(var), _p(gamma), _p(beta), eps, _p(scale), _p(shift),
+                                        rm, rv, nb, momentum, float(count)), "pk_bn_finalize_gates")
     return scale, shift
 
 
@@ -1031,8 +1089,12 @@ class RecLayerPerfFn(torch.autograd.Function):
             mean, var = gemm_bf16_bn_stats(TB, GH, K, xb, xb.shape[1], 1, Wb, Wb.shape[1], 1, P, GH)
         else:
             gemm_bf16(TB, GH, K, xb, xb.shape[1], 1, Wb, Wb.shape[1], 1, P, GH)
+        bn_bufs = cfg[14] if len(cfg) > 14 else None  # per-gate (running_mean, running_var, num_batches_tracked) lists
         if use_bn:
-            if training:
+            if training and bn_bufs is not None:
+                pscale, pshift = bn_finalize_gates(mean, var, gamma, beta, eps, H, bn_bufs[0], bn_bufs[1], bn_bufs[2],
+                                                   momentum, ndir * TB)
+            elif training:
                 pscale, pshift = bn_finalize(mean, var, gamma, beta, eps, running_mean, running_var, momentum, ndir * TB)
             else:
                 mean, var = running_mean, running_var

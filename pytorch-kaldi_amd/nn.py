@@ -344,10 +344,18 @@ class _Recurrent(nn.Module):
                 edge = torch.is_grad_enabled() and (use_bn or bcat is not None or x.requires_grad)
                 side_w = edge and F_.side_targets_ok(wps)
                 side_u = edge and F_.side_targets_ok(ups)
+                # training-mode BatchNorm: the running statistics of every gate's module are updated by the launch that
+                # turns the batch statistics into scale / shift (pk_bn_finalize_gates)
+                stats_in_kernel = use_bn and self.training
+                bn_bufs = ([b.running_mean for b in bns], [b.running_var for b in bns],
+                           [b.num_batches_tracked for b in bns]) if stats_in_kernel else None
                 y, bmean, bvar, xb = F_.RecLayerPerfFn.apply(x, xb, Wcat.detach() if side_w else Wcat, bcat,
                                                            Ucat.detach() if side_u else Ucat, gamma, beta, rmean, rvar,
-                                                           mask_i, cfg + (xseg, wps, ups, side_w, side_u))
+                                                           mask_i, cfg + (xseg, wps, ups, side_w, side_u, bn_bufs))
                 xseg = (2 if self.bidir else 1, H, (H + 7) // 8 * 8)
+                if stats_in_kernel:
+                    x = y
+                    continue
             else:
                 lng = self.ln[i].gamma if self._use_ln[i] else None
                 lnb = self.ln[i].beta if self._use_ln[i] else None
@@ -362,6 +370,8 @@ class _Recurrent(nn.Module):
                     torch._foreach_add_(vars_, [bvar[k * H:(k + 1) * H] for k in range(len(bns))], alpha=0.05 * n / (n - 1))
                     torch._foreach_add_([b.num_batches_tracked for b in bns], 1)
             x = y
+        if xb is not None:  # the bf16 copy the last layer published: a perf-mode Linear behind it uses it as its operand
+            x._pk_twin = (xb, xseg, x._version)
         return x
 
 

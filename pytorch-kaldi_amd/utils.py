@@ -133,7 +133,10 @@ def forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out
             else:
                 x = outs[inp2]
                 if not seq_arch and x.dim() == 3:
+                    twin = getattr(x, "_pk_twin", None)  # (the rows of the bf16 copy are already the flattened rows)
                     x = outs[inp2] = x.reshape(max_len * batch_size, -1)
+                    if twin is not None:
+                        x._pk_twin = (twin[0], twin[1], x._version)
                 if seq_arch and x.dim() == 2:
                     x = outs[inp2] = x.reshape(max_len, batch_size, -1)
             outs[out_name] = nns[inp1](x)

@@ -543,3 +543,33 @@ def test_projection_gemm_with_batchnorm_statistics(M, N, K, bias):
     Cd = C.double()
     assert rel_err(mean, Cd.mean(0)) < 1e-5
     assert rel_err(var, Cd.var(0, unbiased=False)) < 1e-5
+
+
+def test_output_layer_on_the_published_bf16_twin():
+    """A perf-mode output layer behind a recurrent layer reads the bf16 copy that layer published (direction halves at
+    a pitch of Hp, weight copy re-pitched to match) instead of converting the fp32 activation again: same operands, the
+    reduction merely walks the zero pad columns too -> results equal to summation order; gradients likewise."""
+    g = torch.Generator().manual_seed(77)
+    rows, H, N = 4200, 70, 130  # two direction halves of 70 units at a pitch of 72
+    x = torch.randn(rows, 2 * H, generator=g)
+    w = torch.randn(N, 2 * H, generator=g) / 12
+    b = torch.randn(N, generator=g)
+    lab = torch.randint(0, N, (rows,), generator=g).cuda()
+    F_.set_precision("bf16")
+    try:
+        res = []
+        for twin in (True, False):
+            xe, we, be = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+            if twin:
+                xb = F_.cvt_bf16(xe.detach(), 2, H, 72)
+                xe._pk_twin = (xb, (2, H, 72), xe._version)
+            y = F_.linear_log_softmax(xe, we, be)
+            loss, _ = F_.head_nll(y, lab)
+            loss.backward()
+            torch.cuda.synchronize()
+            res.append((y.detach(), xe.grad, we.grad, be.grad))
+        assert F_.input_twin(torch.zeros(3, 4, device="cuda")) is None
+    finally:
+        F_.set_precision("fp32")
+    for a, r in zip(*res):
+        assert rel_err(a, r) < 1e-5

@@ -41,6 +41,10 @@ class _Settings:
         self.wgrad_side = os.environ.get("PK_WGRAD_SIDE", "1") != "0"
         # the liGRU / RNN persistent kernels keep their exchange buffers filled themselves (0 = whole-buffer fill on a third stream)
         self.self_fill = os.environ.get("PK_REC_SELF_FILL", "1") != "0"
+        # weight-gradient GEMMs of a recurrent layer go to the side stream behind the layer's LAST main-stream kernel
+        # (its dX GEMM), so that they run next to the layer below's latency-bound recurrence and not next to this
+        # layer's bandwidth-bound BatchNorm backward / dX GEMM (0 = as soon as their operands exist)
+        self.side_late = os.environ.get("PK_SIDE_LATE", "1") != "0"
         assert self.precision in PREC, self.precision
         assert self.rec_algo in ("auto", "stepwise", "persistent"), self.rec_algo
 
@@ -266,6 +270,9 @@ def side_targets_ok(params):
             and all(getattr(q, "_pk_flat", False) and q.grad is not None for q in params))
 
 
+_DEBUG_SKIP_SIDE = os.environ.get("PK_DEBUG_SKIP_SIDE", "0") == "1"  # timing experiments only: drops the weight-gradient work
+
+
 def side_launch(fn, keep, params=None):
     """Run fn() on the side stream after everything enqueued so far on the current stream; `keep` are the tensors
     fn reads or writes that autograd may free before the side stream is done; `params`: the parameters whose .grad fn
@@ -276,7 +283,8 @@ def side_launch(fn, keep, params=None):
     side = _Side.stream
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        fn()
+        if not _DEBUG_SKIP_SIDE:
+            fn()
     for t in keep:
         if t is not None:
             t.record_stream(side)
@@ -1171,9 +1179,10 @@ class RecLayerPerfFn(torch.autograd.Function):
             if side_u:
                 _accumulate_rows(ctx.uparams, [dU[g * H:(g + 1) * H] for g in range(G)])
 
-        if side_u:
+        late = settings.side_late
+        if side_u and not late:
             side_launch(do_dU, (Y, S, Yb, dGb, Xb, dU), ctx.uparams)
-        else:
+        elif not side_u:
             do_dU()
         # BatchNorm backward (or plain sum of the two directions) straight from dGb -> bf16 projection gradient
         dPb = torch.empty(TB, _up(GH, 64), device=dY.device, dtype=torch.bfloat16)
@@ -1207,7 +1216,7 @@ class RecLayerPerfFn(torch.autograd.Function):
             if side_w:
                 _accumulate_rows(ctx.wparams, [dW[g * H:(g + 1) * H] for g in range(G)])
 
-        if side_w:
+        if side_w and not late:
             side_launch(do_dW, (dPb, xb, dWp), ctx.wparams)
         dx = None
         if ctx.needs_input_grad[0]:  # dx[m,d] = sum_n dP[m,n] W[n,d]: A k-contiguous, B = W (plain pitch) k-major
@@ -1215,6 +1224,11 @@ class RecLayerPerfFn(torch.autograd.Function):
             dx = _new(TB, D, like=dY)
             gemm_bf16(TB, D, GH, dPb, dPb.shape[1], 1, Wb2, Wb2.shape[1], 0, dx, D)
             dx = dx.view(T, B, D)
+        if late:  # behind the dX GEMM: next on the main stream is the recurrence of the layer below
+            if side_u:
+                side_launch(do_dU, (Y, S, Yb, dGb, Xb, dU), ctx.uparams)
+            if side_w:
+                side_launch(do_dW, (dPb, xb, dWp), ctx.wparams)
         if not side_w:
             do_dW()
         return dx, None, (None if side_w else dW), dbias, (None if side_u else dU), dgamma, dbeta, None, None, None, None

@@ -831,20 +831,23 @@ extern "C" int pk_logsoftmax_fwd(void* stream, const float* x, int64_t rows, int
     return pk_logsoftmax_fwd_ld(stream, x, N, rows, N, y);
 }
 
-// blocks of the fused backward: every wave keeps the column sums of its rows in registers, so few, long-lived waves
-static inline long lsm_bf16_blocks(int64_t rows) {
-    long b = (rows + 63) / 64;  // >= 16 rows per wave
-    if (b > 512) b = 512;
+// blocks of the fused backward: every wave keeps the column sums of its rows in registers, so the waves are long-lived -
+// but a wave walks its rows one dependent HBM round trip after the other, so short rows (a 48-class head: one load per
+// lane and row) need many waves to hide that: 64 000 x 48 took 284 us with 31 rows per wave, ~20 us with 4
+static inline long lsm_bf16_blocks(int64_t rows, int64_t N) {
+    const long rows_per_wave = N <= 64 ? 4 : N <= 256 ? 8 : N <= 1024 ? 16 : 31;
+    long b = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+    if (b > 4096) b = 4096;
     if (b < 1) b = 1;
     return b;
 }
 
-extern "C" int64_t pk_logsoftmax_bwd_bf16_partial_floats(int64_t rows, int64_t N) { return lsm_bf16_blocks(rows) * N * 2; }
+extern "C" int64_t pk_logsoftmax_bwd_bf16_partial_floats(int64_t rows, int64_t N) { return lsm_bf16_blocks(rows, N) * N * 2; }
 
 static int lsm_bwd_bf16_launch(hipStream_t st, bool onehot, const float* dy, const float* y, const long* lab,
                                const float* dloss, const float* count, long ignore_index, int64_t rows, int64_t N,
                                uint16_t* dxb, int64_t ldb, float* partial, float* colsum) {
-    const long blocks = lsm_bf16_blocks(rows);
+    const long blocks = lsm_bf16_blocks(rows, N);
     const dim3 grid((unsigned)blocks);
     unsigned short* o = (unsigned short*)dxb;
 #define PK_LSMB(NPL)                                                                                                      \

@@ -1179,7 +1179,9 @@ class RecLayerPerfFn(torch.autograd.Function):
             if side_u:
                 _accumulate_rows(ctx.uparams, [dU[g * H:(g + 1) * H] for g in range(G)])
 
-        late = settings.side_late
+        # (the bottom layer has no dX GEMM and nothing below it to hide behind: its dU starts at once, next to its own
+        # BatchNorm backward, and only the short dW is left for the tail of the step)
+        late = settings.side_late and bool(ctx.needs_input_grad[0])
         if side_u and not late:
             side_launch(do_dU, (Y, S, Yb, dGb, Xb, dU), ctx.uparams)
         elif not side_u:

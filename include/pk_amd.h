@@ -77,6 +77,8 @@ int pk_gemm_bf16_tile_m(int M);
 /* the split-K factor the library recommends for a k-major x k-major product of this shape (1 for short reductions) */
 int pk_gemm_bf16_auto_splitk(int M, int N, int K);
 /* tests / tools: 128 or 256 forces that block tile for every shape, 0 = automatic (also PK_GEMM_TILE) */
+/* split-K factor for a k-major x k-major product that will only get `cus` CUs (0 = the whole device) */
+int pk_gemm_bf16_auto_splitk_cus(int M, int N, int K, int cus);
 void pk_gemm_bf16_set_tile(int tile);
 int pk_gemm_bf16(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
                  const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc, const float* bias,
@@ -243,6 +245,8 @@ int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, int T, int B
  * buffer, 0 = the library does it in front of the launch, 2 = the kernel does it on the way where it can
  * (pk_rec_self_fill(cell) == 1: every chunk is patterned by the lane that later publishes it, a few steps ahead; other
  * cells: as 0). */
+/* CUs the bf16 persistent recurrence over R = B * (1 + bidir) rows of H units occupies (0: not covered) */
+int pk_rec_plan_cus(int R, int H);
 int pk_rec_self_fill(int cell);
 int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
                     const float* pscale, const float* pshift, const float* U, const float* mask, float mask_scalar,

@@ -67,6 +67,8 @@ SIGNATURES = {
     "pk_rec_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P,
                            P, P, P, P]),
     "pk_rec_self_fill": (c_int, [c_int]),
+    "pk_rec_plan_cus": (c_int, [c_int, c_int]),
+    "pk_gemm_bf16_auto_splitk_cus": (c_int, [c_int, c_int, c_int, c_int]),
     "pk_rec_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, P, c_int64, c_int]),
     "pk_rec_bwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int64, c_int]),
     "pk_rec2p_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, P, P, c_int64, c_int]),

@@ -726,11 +726,14 @@ extern "C" int pk_gemm_bf16_tile_m(int M) {
 // Split-K factor the library recommends for a k-major x k-major product C[M,N] = A^T.B over K (the dW / dU shapes: few
 // output tiles, K = T*B rows): the reduction is cut so that the grid covers the chip about twice (128-tiles, several
 // workgroups per CU) or once (256-tiles, one workgroup per CU), never below 512 k per slice.
-extern "C" int pk_gemm_bf16_auto_splitk(int M, int N, int K) {
+// cus: the CUs the product will actually get (a weight-gradient GEMM on the side stream runs next to a persistent
+// recurrence that holds 144 of the 256 CUs: sized for the whole chip its 250 items took three rounds on the 112 free ones)
+extern "C" int pk_gemm_bf16_auto_splitk_cus(int M, int N, int K, int cus) {
     if (K < 2048 || M <= 0 || N <= 0) return 1;
     const int t = gemm_tile_for(M, N, 0, 0);
     const long tiles = (long)((M + t - 1) / t) * ((N + t - 1) / t);
-    const long ncu = pk_num_cu();
+    long ncu = pk_num_cu();
+    if (cus > 0 && cus < ncu) ncu = cus;
     long s = (t == 256 ? ncu : 2 * ncu) / (tiles > 0 ? tiles : 1);
     if (s < 1) s = 1;
     if (s > 32) s = 32;
@@ -738,6 +741,7 @@ extern "C" int pk_gemm_bf16_auto_splitk(int M, int N, int K) {
     if (s > kmax) s = kmax;
     return (int)s;
 }
+extern "C" int pk_gemm_bf16_auto_splitk(int M, int N, int K) { return pk_gemm_bf16_auto_splitk_cus(M, N, K, 0); }
 
 static int gemm_bf16_impl(void* stream, int M, int N, int K, float alpha, const uint16_t* A, int64_t lda, int a_kc,
                           const uint16_t* B, int64_t ldb, int b_kc, float beta, float* C, int64_t ldc, const float* bias,

@@ -666,6 +666,14 @@ extern "C" int pk_rec_self_fill(int cell) {
     return 1;  // every bf16 persistent kernel (liGRU / RNN / LSTM: pk_rec_*_bf16; GRU / minimalGRU: pk_rec2p_*_bf16)
 }
 
+// CUs a bf16 persistent recurrence over R rows of H units occupies (one workgroup per CU): what is left is what a
+// kernel on another stream can get while it runs
+extern "C" int pk_rec_plan_cus(int R, int H) {
+    Plan2 pl;
+    if (R <= 0 || H <= 0 || H > KPAD || pk_rec2_make_plan(R, H, pl) != 0) return 0;
+    return pl.C * pl.Pn;
+}
+
 extern "C" void pk_persist2_set_mode(int force_safe) { g2_force_safe = force_safe ? 1 : 0; }
 extern "C" void pk_persist2_set_poll_delay(int units) { g2_poll_delay = units; }  // < 0: back to the per-pass defaults
 extern "C" void pk_persist2_set_trace(void* dev_buf) { g2_trace = (unsigned long long*)dev_buf; }

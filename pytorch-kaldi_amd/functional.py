@@ -45,6 +45,8 @@ class _Settings:
         # (its dX GEMM), so that they run next to the layer below's latency-bound recurrence and not next to this
         # layer's bandwidth-bound BatchNorm backward / dX GEMM (0 = as soon as their operands exist)
         self.side_late = os.environ.get("PK_SIDE_LATE", "1") != "0"
+        # ... and size their split-K grids for the CUs that recurrence leaves free (0 = for the whole device)
+        self.side_cus = os.environ.get("PK_SIDE_CUS", "0") != "0"
         assert self.precision in PREC, self.precision
         assert self.rec_algo in ("auto", "stepwise", "persistent"), self.rec_algo
 
@@ -241,7 +243,25 @@ def _splitk_bf(out_tiles, K):
     """Split the reduction of the dW / dU shapes (few output tiles, K = T*B rows) over the chip.  `out_tiles` is an
     (M, N) pair: the library knows which block tile the shape takes."""
     M, N = out_tiles
-    return int(_lib.load().pk_gemm_bf16_auto_splitk(int(M), int(N), int(K)))
+    return int(_lib.load().pk_gemm_bf16_auto_splitk_cus(int(M), int(N), int(K), int(_SideCus.cus)))
+
+
+class _SideCus:
+    """CUs a split-K GEMM should size its grid for (0 = the whole device).  The weight-gradient GEMMs of a recurrent
+    layer run on the side stream next to the recurrence of the layer below, which holds C x Pn CUs for its whole
+    launch (pk_rec_plan_cus): sized for the whole chip, their 250 (dW) / 500 (dU) work items took three / two rounds
+    on the CUs that are left."""
+    cus = 0
+
+
+def _sized_for(cus, fn):
+    def run():
+        old, _SideCus.cus = _SideCus.cus, cus
+        try:
+            fn()
+        finally:
+            _SideCus.cus = old
+    return run
 
 
 def bf16_mode():
@@ -273,13 +293,19 @@ def side_targets_ok(params):
 _DEBUG_SKIP_SIDE = os.environ.get("PK_DEBUG_SKIP_SIDE", "0") == "1"  # timing experiments only: drops the weight-gradient work
 
 
+def _make_side_stream():
+    # (hardware queue priorities were tried both ways - side stream lowest, main stream highest - to let a recurrence
+    # launched into a chip full of weight-gradient workgroups take the CUs first: no effect on the step time)
+    return torch.cuda.Stream()
+
+
 def side_launch(fn, keep, params=None):
     """Run fn() on the side stream after everything enqueued so far on the current stream; `keep` are the tensors
     fn reads or writes that autograd may free before the side stream is done; `params`: the parameters whose .grad fn
     accumulates into (the data-parallel reducer launches a bucket's all-reduce behind them, on this stream)."""
     main = torch.cuda.current_stream()
     if _Side.stream is None:
-        _Side.stream = torch.cuda.Stream()
+        _Side.stream = _make_side_stream()
     side = _Side.stream
     side.wait_stream(main)
     with torch.cuda.stream(side):
@@ -1227,10 +1253,14 @@ class RecLayerPerfFn(torch.autograd.Function):
             gemm_bf16(TB, D, GH, dPb, dPb.shape[1], 1, Wb2, Wb2.shape[1], 0, dx, D)
             dx = dx.view(T, B, D)
         if late:  # behind the dX GEMM: next on the main stream is the recurrence of the layer below
+            free = 0
+            if settings.side_cus:
+                held = int(lib.pk_rec_plan_cus(ndir * B, H))
+                free = max(int(lib.pk_num_cu()) - held, 0) if held > 0 else 0
             if side_u:
-                side_launch(do_dU, (Y, S, Yb, dGb, Xb, dU), ctx.uparams)
+                side_launch(_sized_for(free, do_dU), (Y, S, Yb, dGb, Xb, dU), ctx.uparams)
             if side_w:
-                side_launch(do_dW, (dPb, xb, dWp), ctx.wparams)
+                side_launch(_sized_for(free, do_dW), (dPb, xb, dWp), ctx.wparams)
         if not side_w:
             do_dW()
         return dx, None, (None if side_w else dW), dbias, (None if side_u else dU), dgamma, dbeta, None, None, None, None

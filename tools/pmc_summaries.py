@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""profiles/r02_pmc_traffic.json and profiles/r02_pmc_mfma_busy.json from the PMC summaries tools/rocpd_pmc.py wrote
+(profiles/r02_pmc_fetch_size.csv, r02_pmc_write_size.csv, r02_pmc_sq.csv):  python tools/pmc_summaries.py [dir]
+
+HBM traffic per launch = 2 x FETCH_SIZE (KB; MI355X_MICROARCH.md: gfx950's rocprofv3 reports half of a 16-byte-per-lane
+streaming read) + WRITE_SIZE (as reported; it matches the algorithmic write volume of rec2_fwd_kernel).
+Matrix-pipe busy share = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)."""
+import csv
+import json
+import os
+import sys
+
+d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+
+
+def table(name):
+    out = {}
+    for r in csv.DictReader(open(os.path.join(d, name))):
+        out.setdefault(r["Kernel"], {})[r["Counter"]] = (float(r["MeanValue"]), int(r["Dispatches"]), float(r["MeanDurationNs"]))
+    return out
+
+
+fetch, write, sq = table("r02_pmc_fetch_size.csv"), table("r02_pmc_write_size.csv"), table("r02_pmc_sq.csv")
+ENTRY = {"pk_rec_bwd_bf16": "rec2_bwd_kernel<0, 1", "pk_rec_fwd_bf16": "rec2_fwd_kernel<0, 1"}
+traffic = {"_note": "HBM bytes per launch from rocprofv3 --pmc (separate passes for FETCH_SIZE and WRITE_SIZE, bench.py --steps 2 "
+           "--warmup 1; profiles/r02_pmc_fetch_size.csv, profiles/r02_pmc_write_size.csv, values in KB). FETCH_SIZE is doubled "
+           "as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads on gfx950; WRITE_SIZE is used as reported. "
+           "Written by tools/pmc_summaries.py."}
+for entry, prefix in ENTRY.items():
+    kf = [k for k in fetch if k.startswith(prefix)]
+    kw = [k for k in write if k.startswith(prefix)]
+    if not kf or not kw:
+        continue
+    f, w = fetch[kf[0]]["FETCH_SIZE"][0], write[kw[0]]["WRITE_SIZE"][0]
+    traffic[entry] = {"kernel": prefix, "fetch_kb_reported": round(f, 3), "write_kb_reported": round(w, 3),
+                      "traffic_bytes": int(round((2.0 * f + w) * 1024.0))}
+json.dump(traffic, open(os.path.join(d, "r02_pmc_traffic.json"), "w"), indent=1)
+busy = {"_note": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+        "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -- python bench.py --steps 2 --warmup 1 "
+        "(profiles/r02_pmc_sq.csv). Shares are of SQ_WAVE_CYCLES (quad-cycles): wait_any = parked in s_waitcnt / s_barrier, "
+        "wait_inst = issue stalls, active = issuing. mfma_busy_frac_per_simd = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / "
+        "(GRBM_GUI_ACTIVE / 8 XCDs): the fraction of the launch during which a SIMD's matrix pipe was busy = MFMA "
+        "utilisation. Written by tools/pmc_summaries.py.", "kernels": {}}
+rows = sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", (0, 0, 0))[0] * kv[1].get("SQ_WAVE_CYCLES", (0, 1, 0))[1])
+for k, c in rows[:14]:
+    if "SQ_WAVE_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:
+        continue
+    wc = c["SQ_WAVE_CYCLES"][0] or 1.0
+    busy["kernels"][k] = {
+        "dispatches": c["SQ_WAVE_CYCLES"][1], "mean_duration_us": round(c["SQ_WAVE_CYCLES"][2] / 1e3, 1),
+        "wait_any_share": round(c.get("SQ_WAIT_ANY", (0,))[0] / wc, 3),
+        "wait_inst_share": round(c.get("SQ_WAIT_INST_ANY", (0,))[0] / wc, 3),
+        "active_inst_share": round(c.get("SQ_ACTIVE_INST_ANY", (0,))[0] / wc, 3),
+        "mfma_busy_frac_per_simd": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", (0,))[0] / 1024.0 / (c["GRBM_GUI_ACTIVE"][0] / 8.0), 4),
+        "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT", (0,))[0]}
+json.dump(busy, open(os.path.join(d, "r02_pmc_mfma_busy.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1)[:900])
+for k, v in list(busy["kernels"].items())[:8]:
+    print("%-60s %s" % (k[:60], v))

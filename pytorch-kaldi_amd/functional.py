@@ -326,9 +326,35 @@ def join_side():
         _Side.pending = False
 
 
+def adjacent_view(ts):
+    """The row-wise concatenation of `ts` as a VIEW, when the tensors sit back to back in one storage (the gates of a
+    recurrent layer after optim.FlatParams packed them: pk_flat_groups), else None.  No autograd history."""
+    if not ts:
+        return None
+    base = ts[0]
+    if len(ts) == 1:
+        return base.detach() if base.is_contiguous() else None
+    ptr, rows = base.data_ptr(), 0
+    for t in ts:
+        if (not t.is_contiguous() or t.dtype != base.dtype or t.shape[1:] != base.shape[1:] or t.data_ptr() != ptr
+                or t.untyped_storage().data_ptr() != base.untyped_storage().data_ptr()):
+            return None
+        ptr += t.numel() * t.element_size()
+        rows += t.shape[0]
+    if base.data_ptr() % 16 != 0:
+        return None
+    return base.detach().as_strided((rows,) + tuple(base.shape[1:]), base.stride())
+
+
 def _accumulate_rows(params, rows):
-    """params[i].grad += rows[i] (row blocks of a concatenated weight gradient)."""
+    """params[i].grad += rows[i] (row blocks of a concatenated weight gradient); one launch when the gradients sit back
+    to back in the flat buffer and the row blocks are slices of one matrix."""
     with torch.no_grad():
+        gview = adjacent_view([q.grad for q in params])
+        whole = adjacent_view(list(rows)) if gview is not None else None
+        if whole is not None and whole.shape == gview.shape:
+            gview.add_(whole)
+            return
         for q, r in zip(params, rows):
             q.grad.add_(r)
 
@@ -1234,8 +1260,18 @@ class RecLayerPerfFn(torch.autograd.Function):
 
         def do_dW():
             nonlocal dW
-            gemm_bf16(GH, Kx, TB, dPb, dPb.shape[1], 0, xb, xb.shape[1], 0, dWp, Kx,
-                      splitk=_splitk_bf(_tiles_bf(GH, Kx), TB))
+            gview = adjacent_view([q.grad for q in ctx.wparams]) if side_w else None
+            sk = _splitk_bf(_tiles_bf(GH, Kx), TB)
+            if gview is not None and xseg is None:  # straight into the flat gradient of the layer's gates (beta = 1)
+                gemm_bf16(GH, Kx, TB, dPb, dPb.shape[1], 0, xb, xb.shape[1], 0, gview, Kx, beta=1.0, splitk=sk)
+                return
+            gemm_bf16(GH, Kx, TB, dPb, dPb.shape[1], 0, xb, xb.shape[1], 0, dWp, Kx, splitk=sk)
+            if gview is not None:  # re-pitched input: one add per direction segment, all gates at once
+                nseg, seglen, segpad = xseg
+                with torch.no_grad():
+                    for s_ in range(nseg):
+                        gview[:, s_ * seglen:(s_ + 1) * seglen].add_(dWp[:, s_ * segpad:s_ * segpad + seglen])
+                return
             if xseg is None:
                 dW = dWp
             else:

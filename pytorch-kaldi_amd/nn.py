@@ -159,6 +159,20 @@ class MLP(nn.Module):
                 out += list(self.bn[i].parameters())
         return out
 
+    def pk_flat_groups(self):
+        """optim.FlatParams layout: layer by layer (registration order is kind by kind - all wx, then all bn, ... -
+        which makes every gradient bucket of dp.GradReducer wait for the FIRST layer's backward)."""
+        out = []
+        if self.dnn_use_laynorm_inp:
+            out.append(list(self.ln0.parameters()))
+        if self.dnn_use_batchnorm_inp:
+            out.append(list(self.bn0.parameters()))
+        for i in range(self.N_dnn_lay):
+            out.append(list(self.wx[i].parameters()))
+            out.append(list(self.ln[i].parameters()))
+            out.append(list(self.bn[i].parameters()))
+        return out
+
     def forward(self, x):
         if self.dnn_use_laynorm_inp:
             x = self.ln0(x)
@@ -294,6 +308,28 @@ class _Recurrent(nn.Module):
         self._pin_k[i] = 1 - k
         return d
 
+    def pk_flat_groups(self):
+        """optim.FlatParams layout: layer by layer, and inside a layer the gates of the input weights (of the recurrent
+        weights, of the BatchNorm scales / shifts, of the biases) back to back in the order forward concatenates them -
+        the concatenation is then a view of the flat buffer (functional.adjacent_view), and the weight-gradient GEMM
+        accumulates into the matching view of the flat gradient."""
+        out = []
+        if self._use_ln_inp:
+            out.append(list(self.ln0.parameters()))
+        if self._use_bn_inp:
+            out.append(list(self.bn0.parameters()))
+        for i in range(self._n_lay):
+            Ws = [getattr(self, w)[i] for (w, _, _) in self._gates]
+            Us = [getattr(self, u)[i] for (_, u, _) in self._gates]
+            bns = [getattr(self, b)[i] for (_, _, b) in self._gates]
+            out.append([m.weight for m in Ws])
+            out.append([m.weight for m in Us])
+            out.append([m.bias for m in Ws if m.bias is not None])
+            out.append([b.weight for b in bns])
+            out.append([b.bias for b in bns])
+            out.append(list(self.ln[i].parameters()))
+        return out
+
     def forward(self, x, drop_masks=None):
         if not x.is_cuda:
             raise PkError("pytorch-kaldi_amd.nn.%s runs on the GPU only: set use_cuda=True" % self.KIND)
@@ -314,8 +350,7 @@ class _Recurrent(nn.Module):
             H = self._lay[i]
             Ws = [getattr(self, w)[i] for (w, _, _) in self._gates]
             Us = [getattr(self, u)[i] for (_, u, _) in self._gates]
-            Wcat = torch.cat([m.weight for m in Ws], 0) if len(Ws) > 1 else Ws[0].weight
-            Ucat = torch.cat([m.weight for m in Us], 0) if len(Us) > 1 else Us[0].weight
+            Wcat = Ucat = None  # (concatenated below; on the perf path possibly as views of the flat parameter buffer)
             bcat = None
             if Ws[0].bias is not None:
                 bcat = torch.cat([m.bias for m in Ws], 0) if len(Ws) > 1 else Ws[0].bias
@@ -344,6 +379,15 @@ class _Recurrent(nn.Module):
                 edge = torch.is_grad_enabled() and (use_bn or bcat is not None or x.requires_grad)
                 side_w = edge and F_.side_targets_ok(wps)
                 side_u = edge and F_.side_targets_ok(ups)
+                # detached weights: the concatenation is a view when optim.FlatParams packed the gates back to back
+                if side_w or not torch.is_grad_enabled():
+                    Wcat = F_.adjacent_view([w.detach() for w in wps])
+                if side_u or not torch.is_grad_enabled():
+                    Ucat = F_.adjacent_view([u.detach() for u in ups])
+                if Wcat is None:
+                    Wcat = torch.cat(wps, 0) if len(wps) > 1 else wps[0]
+                if Ucat is None:
+                    Ucat = torch.cat(ups, 0) if len(ups) > 1 else ups[0]
                 # training-mode BatchNorm: the running statistics of every gate's module are updated by the launch that
                 # turns the batch statistics into scale / shift (pk_bn_finalize_gates)
                 stats_in_kernel = use_bn and self.training
@@ -357,6 +401,8 @@ class _Recurrent(nn.Module):
                     x = y
                     continue
             else:
+                Wcat = torch.cat([m.weight for m in Ws], 0) if len(Ws) > 1 else Ws[0].weight
+                Ucat = torch.cat([m.weight for m in Us], 0) if len(Us) > 1 else Us[0].weight
                 lng = self.ln[i].gamma if self._use_ln[i] else None
                 lnb = self.ln[i].beta if self._use_ln[i] else None
                 y, bmean, bvar = F_.RecLayerFn.apply(x, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, mask_i, lng, lnb, cfg)

@@ -18,6 +18,8 @@ torch's "skip grad=None".
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -29,20 +31,42 @@ def _stream():
 
 class FlatParams:
     def __init__(self, module, align=64):
+        """Layout of the flat buffer: the parameters forward actually uses first, the never-used ones behind them
+        (`n_active`).  A module may state a layout for its active parameters through ``pk_flat_groups()`` - a list of
+        parameter lists in buffer order: the members of a group are packed back to back (the gates of a recurrent layer:
+        their concatenation is then a VIEW of the buffer, and so is the gradient the weight-gradient GEMM accumulates
+        into), groups follow each other in the given order (layer-major: the buckets of dp.GradReducer, which walk the
+        buffer from the top, then complete in the order backward produces gradients).  torch-format optimizer state
+        is indexed by registration order and does not see the layout."""
         self.module = module
         self.params = [p for p in module.parameters()]  # registration order: what indexes torch optimizer state
         dev = self.params[0].device  # the flat layout itself is device-agnostic (CPU in the gloo tests)
         unused = {id(p) for p in module.pk_unused_parameters()} if hasattr(module, "pk_unused_parameters") else set()
         self.unused = [id(p) in unused for p in self.params]
+        index = {id(p): i for i, p in enumerate(self.params)}
+        units, placed = [], set()
+        if hasattr(module, "pk_flat_groups") and os.environ.get("PK_FLAT_GROUPS", "1") != "0":
+            for grp in module.pk_flat_groups():
+                ids = [index[id(q)] for q in grp if id(q) in index and id(q) not in unused and index[id(q)] not in placed]
+                if ids:
+                    units.append(ids)
+                    placed.update(ids)
+        for i in range(len(self.params)):  # everything the module did not place: registration order, one by one
+            if not self.unused[i] and i not in placed:
+                units.append([i])
         self.offsets = [0] * len(self.params)
         off = 0
-        for want_unused in (False, True):  # active parameters first, the never-used ones behind them
-            if want_unused:
-                self.n_active = off
-            for i, p in enumerate(self.params):
-                if self.unused[i] == want_unused:
-                    self.offsets[i] = off
-                    off += (p.numel() + align - 1) // align * align
+        for ids in units:
+            off = (off + align - 1) // align * align
+            for i in ids:
+                self.offsets[i] = off
+                off += self.params[i].numel()
+        off = (off + align - 1) // align * align
+        self.n_active = off
+        for i, p in enumerate(self.params):  # the never-used ones behind the active range
+            if self.unused[i]:
+                self.offsets[i] = off
+                off += (p.numel() + align - 1) // align * align
         self.numel = off
         self.flat = torch.zeros(off, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(off, device=dev, dtype=torch.float32)

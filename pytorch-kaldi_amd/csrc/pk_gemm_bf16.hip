@@ -707,7 +707,7 @@ static int gemm_tile_for(int M, int N, int a_kc, int b_kc) {
     if (forced) return forced;
     // row-streaming shapes (projection, dX, output layers: M = T*B rows, k-contiguous A, N >= 1024): the 256-tile is worth
     // 3-10 % on the current kernel (652 vs 603, 775 vs 695 TFLOP/s: profiles/r02_gemm_tiles.txt) and 0.22 ms of the
-    // 21.1 ms training step (A/B on one box, tools/gpu_ab.sh); PK_GEMM_TILE_ROWS=0 keeps them on the 128-tile
+    // 21.1 ms training step (A/B on one box, tools/gpu_ab3.sh); PK_GEMM_TILE_ROWS=0 keeps them on the 128-tile
     static int rows256 = -1;
     if (rows256 < 0) {
         const char* e = getenv("PK_GEMM_TILE_ROWS");

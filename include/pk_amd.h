@@ -238,8 +238,7 @@ int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, int T, int B
  * padded) and dGb [ndir*T*B][g_pitch] bf16 gate gradients (gate g at column g*Hp) are laid out as the
  * k-major operands pk_gemm_bf16 needs for dU / dW.  Columns beyond ndir*Hp (G*Hp) of a row are left
  * undefined.  Pitches are multiples of 8 elements; H <= 576.  dP2 may be NULL (the fp32 gate-gradient
- * slabs are then not written: pk_bn_bwd_bf16 works from dGb).  * prefilled != 0: the caller has already filled the exchange buffer(s) (Yb, Xb / dGb) with 0xFF bytes - e.g. on
- * another stream, next to the projection GEMM - and the entry point skips its own hipMemsetAsync.
+ * slabs are then not written: pk_bn_bwd_bf16 works from dGb).
  */
 /* prefilled (both entry points below): 1 = the caller stored the 0xFF "not written yet" pattern in the whole exchange
  * buffer, 0 = the library does it in front of the launch, 2 = the kernel does it on the way where it can

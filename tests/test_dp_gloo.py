@@ -29,6 +29,13 @@ def _batch():
     return torch.randn(7, 8, 6, generator=g), torch.randn(7, 8, 3, generator=g)
 
 
+def _grouped(net):
+    """A layout statement like the recurrent modules make (pk_flat_groups): layer by layer from the input up, a layer's
+    weight and bias back to back - the reducer's buckets then complete in backward order."""
+    net.pk_flat_groups = lambda: [[net[0].weight, net[0].bias], [net[2].weight, net[2].bias], [net[4].weight, net[4].bias]]
+    return net
+
+
 def _worker(rank, world, port, use_flat, bucket_bytes, out, overlap=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -39,7 +46,15 @@ def _worker(rank, world, port, use_flat, bucket_bytes, out, overlap=True):
     net = _model(0)
     # an unused parameter, like the reference's never-called ln/bn sub-modules (grad stays None / zero)
     net.unused = torch.nn.Parameter(torch.ones(4))
+    if use_flat == "grouped":
+        _grouped(net)
     flats = {"net": OPT.FlatParams(net)} if use_flat else None
+    if use_flat == "grouped":  # weight and bias of a layer are neighbours in the flat buffer, layers in order
+        f = flats["net"]
+        off = {id(p): o for p, o in zip(f.params, f.offsets)}
+        for i in (0, 2, 4):
+            assert off[id(net[i].bias)] == off[id(net[i].weight)] + net[i].weight.numel()
+        assert off[id(net[0].weight)] < off[id(net[2].weight)] < off[id(net[4].weight)] < off[id(net.unused)] < f.n_active
     red = DP.GradReducer({"net": net}, bucket_bytes=bucket_bytes, flats=flats, overlap=overlap)
     x, y = _batch()
     for step in range(2):  # two steps: buckets must re-arm
@@ -58,7 +73,8 @@ def _worker(rank, world, port, use_flat, bucket_bytes, out, overlap=True):
 
 
 @pytest.mark.parametrize("use_flat,bucket_bytes,overlap", [(False, 1 << 20, True), (False, 64, True), (True, 1 << 20, True),
-                                                           (True, 128, True), (True, 128, False)])
+                                                           (True, 128, True), (True, 128, False),
+                                                           ("grouped", 128, True), ("grouped", 1 << 20, False)])
 def test_two_rank_allreduce_equals_shard_average(tmp_path, use_flat, bucket_bytes, overlap):
     world = 2
     out = str(tmp_path / "g.pt")

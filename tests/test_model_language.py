@@ -65,3 +65,75 @@ def test_forward_pass_stops_at_the_last_requested_output():
     assert sorted(outs) == m["forward_keys"]           # nothing after out_dnn3, no costs
     for k in m["forward_keys"]:
         assert rel_err(outs[k], g.t("forward/" + k)) < 2e-6, k
+
+
+def test_cost_lines_on_a_fused_head_take_the_joined_path(monkeypatch):
+    """Host logic of the perf-mode fusion across the plug-in boundary (no GPU: functional.head_nll is replaced by a torch
+    stand-in): a cost_nll line on an output that carries `_pk_head` goes through head_nll, the cost_err line on the same
+    (output, label) pair reads the error rate the same pass produced, a cost on an ordinary output and a cost object that is
+    not a plain NLLLoss() take torch's path - and every value still equals the reference's."""
+    g, m, inp_out_dict, nns, costs = _setup("train")
+    calls = []
+
+    def fake_head_nll(y, lab, ignore_index=-100):
+        loss = torch.nn.functional.nll_loss(y, lab, ignore_index=ignore_index)
+        err = (y.detach().argmax(1) != lab).float().mean()
+        calls.append((tuple(y.shape), int(ignore_index)))
+        return loss, torch.stack([loss.detach(), err, torch.tensor(float(lab.numel())), torch.tensor(0.0)])
+
+    noted = []
+    monkeypatch.setattr(U.F_, "head_nll", fake_head_nll)
+    monkeypatch.setattr(U.F_, "note_label_check", lambda stats: noted.append(stats))
+    head = nns["head_cd"]
+    plain_forward = head.forward
+
+    def tagged(x):  # what nn.MLP does for a perf-mode output layer: the output carries the head's inputs
+        y = plain_forward(x)
+        y._pk_head = ("stand-in",)
+        return y
+
+    monkeypatch.setattr(head, "forward", tagged)
+    outs = U.forward_model(m["fea_dict"], m["lab_dict"], m["arch_dict"], m["model"], nns, costs, g.t("inp"), inp_out_dict,
+                           m["T"], m["B"], "train", [])
+    assert len(calls) == 1 and calls[0][1] == -100 and len(noted) == 1   # loss_cd only: out_dnn4 is an ordinary output
+    for k in ("loss_cd", "loss_mono", "loss_final", "err_final"):
+        ref = g.t("train/" + k)
+        assert abs(float(outs[k].detach()) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref))), k
+    assert outs["err_final"] is noted[0][1] or float(outs["err_final"]) == float(noted[0][1])
+    # a weighted NLLLoss is not what head_nll implements: torch's path, no call
+    calls.clear()
+    costs["loss_cd"] = torch.nn.NLLLoss(weight=torch.ones(outs["out_dnn3"].shape[1]))
+    U.forward_model(m["fea_dict"], m["lab_dict"], m["arch_dict"], m["model"], nns, costs, g.t("inp"), inp_out_dict,
+                    m["T"], m["B"], "train", [])
+    assert calls == []
+
+
+def test_the_published_twin_follows_the_flattening_reshape(monkeypatch):
+    """A sequence network's output that carries `_pk_twin` (the bf16 copy a perf-mode recurrent stack published) keeps it
+    across the (T, B, F) -> (T*B, F) reshape forward_model does in front of a non-sequence network."""
+    seen = {}
+
+    class Seq(torch.nn.Module):
+        def forward(self, x):
+            y = x * 2.0
+            y._pk_twin = ("xb", (2, 3, 8), y._version)
+            return y
+
+    class Flat(torch.nn.Module):
+        def forward(self, x):
+            seen["twin"] = getattr(x, "_pk_twin", None)
+            seen["shape"] = tuple(x.shape)
+            return x.sum(1, keepdim=True)
+
+    T, B, F = 5, 3, 6
+    inp = torch.randn(T, B, F + 1)
+    fea_dict = {"fea": ["fea", "lst", "opts", "cw_l", "cw_r", 0, F]}
+    lab_dict = {"lab": ["lab", "folder", "opts", F]}
+    arch_dict = {"rec": ["architecture1", "rec", True], "head": ["architecture2", "head", False]}
+    model = ["out1=compute(rec,fea)", "out2=compute(head,out1)"]
+    inp_out_dict = {"fea": ["a", "b", "c", "d", "e", 0, F, F], "out1": [F], "out2": [1]}
+    outs = U.forward_model(fea_dict, lab_dict, arch_dict, model, {"rec": Seq(), "head": Flat()}, {}, inp, inp_out_dict,
+                           T, B, "train", [])
+    assert seen["shape"] == (T * B, F)
+    assert seen["twin"] is not None and seen["twin"][0] == "xb" and seen["twin"][1] == (2, 3, 8)
+    assert outs["out2"].shape == (T * B, 1)

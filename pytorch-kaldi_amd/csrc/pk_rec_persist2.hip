@@ -624,7 +624,9 @@ static int default_poll_delay(bool backward) {
         e = v ? atoi(v) : -1;
     }
     if (e >= 0) return e;
-    return backward ? 1 : 2;
+    // (end of round 2, 16 clusters + self-filling exchange, whole training step on one box: backward 1 -> 18.47 ms,
+    // 0 -> 18.36, 2 -> 18.24; forward 1 vs 2: 18.45 vs 18.47)
+    return 2;
 }
 
 int pk_rec2_host_setup(R2Args& a, bool backward) {

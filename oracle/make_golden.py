@@ -360,6 +360,124 @@ def scale_case(name, seed, T=500, B=4):
     print("  loss_final %.6f err_final %.4f" % (float(outs["loss_final"]), float(outs["err_final"])))
 
 
+class _DropoutTap:
+    """Recovers the masks nn.Dropout drew in the (unmodified) reference: forward hooks on every nn.Dropout module with
+    p > 0 compare input and output (y = x * m / (1 - p)): m = (y != 0) wherever x != 0; where x == 0 the mask can be
+    seen neither in the output nor - behind a ReLU, the only place the shipped recipes put dropout - in any gradient,
+    and is recorded as 1."""
+
+    def __init__(self, nets):
+        self.masks, self.tags, self._hooks, self._nets = [], [], [], nets
+
+    def __enter__(self):
+        for an, net in self._nets.items():
+            for mn, mod in net.named_modules():
+                if isinstance(mod, torch.nn.Dropout) and mod.p > 0.0:
+                    def hook(m, inp, out, tag="%s/%s" % (an, mn)):
+                        if m.training:
+                            self.masks.append(torch.where(inp[0] != 0, out != 0, torch.ones_like(out, dtype=torch.bool)))
+                            self.tags.append(tag)
+                    self._hooks.append(mod.register_forward_hook(hook))
+        return self
+
+    def __exit__(self, *exc):
+        for h in self._hooks:
+            h.remove()
+
+
+def recipe_scale_case(name, cfg_rel, seed, T, B, nfea, fea_name, n_cd, n_mono, x_scale=1.0, out_cap=65536):
+    """Config-scale goldens of the other BASELINE configurations: a SHIPPED cfg file, unscaled, through the reference's
+    own utils.model_init / forward_model + loss_final.backward() (what core.run_nn does per batch, core.py:616-634).
+
+      timit_lstm     cfg/TIMIT_baselines/TIMIT_LSTM_fmllr.cfg:131-217      LSTM 4 x 550 bidirectional, T = 500
+      libri_gru      cfg/Librispeech_baselines/libri_GRU_fmllr.cfg:76-146  GRU 5 x 550 + 3400-way head, T = 500
+      timit_sincnet  cfg/TIMIT_baselines/TIMIT_SincNet_raw.cfg:87-211      SincNet [128,60,60,60] on 3200 samples -> MLP
+      timit_mlp      cfg/TIMIT_baselines/TIMIT_MLP_fmllr.cfg:131-214       MLP 440 -> 1024 x 5 -> 1938 / 48
+
+    Like scale_case the parameters are not stored (they are what torch.manual_seed(seed) + model_init gives; per-tensor
+    checksums are).  Stored: the input batch, the recurrent drop masks (torch.bernoulli tap) and the nn.Dropout masks
+    (_DropoutTap), loss / err, row samples + norm + projections of every out_* tensor and of every parameter gradient."""
+    import utils as ref_utils
+
+    torch.set_num_threads(8)
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(REF, cfg_rel))
+    cfg["exp"]["to_do"] = "train"
+    cfg["exp"]["use_cuda"] = "False"
+    secs = [s for s in cfg.sections() if s.startswith("architecture")]
+    for s in secs:  # utils.py:707-722 resolves the placeholders with hmm-info; the counts are BASELINE's
+        if cfg[s].get("dnn_lay") == "N_out_lab_cd":
+            cfg[s]["dnn_lay"] = str(n_cd)
+        if cfg[s].get("dnn_lay") == "N_out_lab_mono":
+            cfg[s]["dnn_lay"] = str(n_mono)
+    model = [m.strip() for m in cfg["model"]["model"].split("\n")]
+    seq = T is not None
+    fea_dict = {fea_name: [fea_name, "lst", "opts", "0", "0", 0, nfea, nfea]}
+    lab_dict = {"lab_cd": ["lab_cd", "f", "o", nfea]}
+    uses_mono = any("lab_mono" in m for m in model)
+    if uses_mono:
+        lab_dict["lab_mono"] = ["lab_mono", "f", "o", nfea + 1]
+    arch_dict = {cfg[s]["arch_name"]: [s, cfg[s]["arch_name"], cfg[s]["arch_seq_model"].strip() == "True"] for s in secs}
+    inp_out_dict = {fea_name: fea_dict[fea_name][5:]}
+    torch.manual_seed(seed)
+    nns, costs = ref_utils.model_init(inp_out_dict, model, cfg, arch_dict, False, False, "train")
+    g = torch.Generator().manual_seed(seed + 2)
+    shape = (T, B) if seq else (B,)
+    inp = torch.randn(*shape, nfea + (2 if uses_mono else 1), generator=g)
+    inp[..., :nfea] *= x_scale
+    inp[..., nfea] = torch.randint(0, n_cd, shape, generator=g).float()
+    if uses_mono:
+        inp[..., nfea + 1] = torch.randint(0, n_mono, shape, generator=g).float()
+    arrays, meta_ck = {"inp": inp}, {}
+    for n, net in nns.items():
+        for k, v in net.state_dict().items():
+            if v.is_floating_point():
+                arrays["init_ck/%s/%s" % (n, k)] = np.concatenate(([float(v.double().norm())], _projections(v, 7)))
+    torch.manual_seed(seed + 3)
+    Tm, Bm = (T, B) if seq else (B, 1)  # forward_model's max_len / batch_size only reshape (utils.py:2323-2337)
+    with _MaskTap() as tap, _DropoutTap(nns) as dtap:
+        outs = ref_utils.forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out_dict,
+                                       Tm, Bm, "train", [])
+    outs["loss_final"].backward()
+    arrays["loss_final"], arrays["err_final"] = outs["loss_final"], outs["err_final"]
+    out_keys = sorted(k for k in outs if k.startswith("out_"))
+    for k in out_keys:
+        o = outs[k].detach()
+        o = o.reshape(-1, o.shape[-1])
+        smp, stride = _rows_sample(o, out_cap)
+        arrays["out/%s/rows" % k], meta_ck["out/%s/stride" % k] = smp, stride
+        arrays["out/%s/ck" % k] = np.concatenate(([float(o.double().norm())], _projections(o, 11)))
+    for n, net in nns.items():
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                continue
+            smp, stride = _rows_sample(p.grad, 8192)
+            arrays["grad/%s/%s/rows" % (n, k)], meta_ck["grad/%s/%s/stride" % (n, k)] = smp, stride
+            arrays["grad/%s/%s/ck" % (n, k)] = np.concatenate(([float(p.grad.double().norm())], _projections(p.grad, 13)))
+    for i, m in enumerate(tap.masks):
+        arrays["mask/%d" % i] = m.to(torch.uint8)
+    dshapes = []
+    for i, m in enumerate(dtap.masks):  # bit-packed, in call order; shapes and owners in the meta block
+        arrays["dmask/%d" % i] = np.packbits(m.numpy().reshape(-1))
+        dshapes.append([dtap.tags[i], list(m.shape)])
+    opts = {sec: dict(cfg[sec]) for sec in secs}
+    meta = {"options": opts, "model": model, "nfea": nfea, "T": T, "B": B, "seed": seed, "n_masks": len(tap.masks),
+            "n_dmasks": len(dtap.masks), "dmasks": dshapes, "strides": meta_ck, "fea_dict": fea_dict, "lab_dict": lab_dict,
+            "arch_dict": arch_dict, "n_cd": n_cd, "n_mono": n_mono if uses_mono else 0, "out_keys": out_keys,
+            "cfg_file": cfg_rel, "seq": seq}
+    _save(name, meta, arrays)
+    print("  loss_final %.6f err_final %.4f" % (float(outs["loss_final"]), float(outs["err_final"])))
+
+
+def config_scale_cases():
+    recipe_scale_case("scale_lstm_T500", "cfg/TIMIT_baselines/TIMIT_LSTM_fmllr.cfg", 5234, 500, 4, 40, "fmllr", 1938, 48)
+    recipe_scale_case("scale_gru_libri_T500", "cfg/Librispeech_baselines/libri_GRU_fmllr.cfg", 1234, 500, 4, 40, "fmllr",
+                      3400, 0)
+    recipe_scale_case("scale_sincnet_3200", "cfg/TIMIT_baselines/TIMIT_SincNet_raw.cfg", 2234, None, 32, 3200, "raw",
+                      1938, 48, x_scale=0.05)
+    recipe_scale_case("scale_mlp_440", "cfg/TIMIT_baselines/TIMIT_MLP_fmllr.cfg", 3234, None, 128, 440, "fmllr", 1938, 48)
+
+
 def chunk_case(name, seed):
     """Drive the reference's own chunk loop, core.run_nn (core.py:439-753), on an in-memory synthetic chunk: train a
     tiny Li-GRU recipe for one chunk from scratch (checkpoint ck0), continue for a second chunk from ck0 (-> ck1 +
@@ -840,6 +958,9 @@ def main():
     if os.environ.get("PK_GOLDEN_ONLY") == "scale":
         scale_case("scale_ligru_T500", 4234)
         return
+    if os.environ.get("PK_GOLDEN_ONLY") == "config_scale":
+        config_scale_cases()
+        return
     if os.environ.get("PK_GOLDEN_ONLY") == "oracle_extra":
         oracle_extra_cases()
         return
@@ -897,6 +1018,7 @@ def main():
     model_lang_case("e2e_model_language", 333)
     train_case("train_ligru_30steps", 4100, lr=0.004)   # CE-loss trajectory over 30 optimizer steps
     scale_case("scale_ligru_T500", 4234)      # the unscaled recipe at T = 500 (minutes of CPU time)
+    config_scale_cases()                      # the other four BASELINE configurations, unscaled
 
     # --- two levels up: the chunk loop core.run_nn (train from scratch, continue, validate, forward) ---
     chunk_case("chunk_ligru_run_nn", 1234)

@@ -467,3 +467,82 @@ def two_head_loss(rec_out, sd_cd, opt_cd, sd_mono, opt_mono, lab_cd, lab_mono, m
     loss = loss_cd + loss_mono * mono_weight
     err = torch.mean((torch.max(out_cd, dim=1)[1] != lab_cd).float())
     return loss, err, out_cd, out_mono
+
+
+def recipe_forward(model, options, arch_dict, sds, inp, fea_dict, lab_dict, rec_masks=None, drop_masks=None,
+                   kinks=None, training=True, to_do="train"):
+    """A whole [model] section on one batch, as utils.forward_model evaluates it (utils.py:2296-2420), over this
+    oracle's arch functions - the generic form of two_head_loss, for the shipped recipes of the other BASELINE
+    configurations (LSTM / GRU / SincNet + MLP / MLP).
+
+    model      the [model] lines; options[section] the cfg sections (strings); arch_dict[name] = [section, name, seq]
+    sds        {arch name: parameter dict}
+    inp        (T, B, feat + labels) or (N, feat + labels); label columns are float, cast with .long() (:2352)
+    rec_masks  recurrent drop masks, consumed layer by layer in call order (torch.bernoulli tap of the reference run)
+    drop_masks {"<arch>/drop.<i>": 0/1 mask} of the nn.Dropout modules (unscaled; scaled by 1/(1-p) here)
+    kinks      per-layer ReLU patterns of the FIRST recurrent architecture (kink-forced mode)
+    -> dict of every named result (out_*, loss_*, err_*)
+    """
+    import re
+
+    outs = {}
+    rec_masks = list(rec_masks) if rec_masks is not None else None
+    T = inp.shape[0] if inp.dim() == 3 else None
+    for fea, spec in fea_dict.items():
+        outs[fea] = inp[..., spec[5]:spec[6]]
+
+    def labels(name):
+        return inp[..., lab_dict[name][3]].reshape(-1).long()
+
+    def flat(t):
+        return t.reshape(-1, t.shape[-1]) if t.dim() == 3 else t
+
+    for line in model:
+        out_name, op, a, b = [s.strip() for s in re.findall(r"(.*)=(.*)\((.*),(.*)\)", line)[0]]
+        if op == "compute":
+            sec, name, seq = arch_dict[a]
+            o = options[sec]
+            cls = o["arch_class"]
+            x = outs[b]
+            if not seq and x.dim() == 3:
+                x = x.reshape(-1, x.shape[-1])
+            if seq and x.dim() == 2:
+                x = x.reshape(T, -1, x.shape[-1])
+            if cls in _REC:
+                n_lay = len(_ints(_opt(o, _REC[cls][0] + "_lay")))
+                m = None
+                if rec_masks is not None:
+                    m, rec_masks = rec_masks[:n_lay], rec_masks[n_lay:]
+                outs[out_name] = recurrent_forward(cls, o, sds[name], x, training, to_do, m, kinks=kinks)
+                kinks = None
+            else:
+                pre = {"MLP": "dnn", "CNN": "cnn", "SincNet": "sinc"}[cls]
+                drops = _floats(_opt(o, pre + "_drop"))
+                dm = None
+                if drop_masks is not None and training and any(p > 0 for p in drops):
+                    dm = []
+                    for i, p in enumerate(drops):
+                        mk = drop_masks.get("%s/drop.%d" % (name, i))
+                        dm.append(None if mk is None else mk.to(x.dtype) / (1.0 - p))
+                outs[out_name] = arch_forward(cls, o, sds[name], x, training, to_do, dm)
+        elif op == "cost_nll":
+            outs[out_name] = F.nll_loss(flat(outs[a]), labels(b))
+        elif op == "cost_err":
+            outs[out_name] = torch.mean((torch.max(flat(outs[a]), dim=1)[1] != labels(b)).float())
+        elif op == "concatenate":
+            outs[out_name] = torch.cat((outs[a], outs[b]), outs[a].dim() - 1)
+        elif op == "mult":
+            outs[out_name] = outs[a] * outs[b]
+        elif op == "sum":
+            outs[out_name] = outs[a] + outs[b]
+        elif op == "mult_constant":
+            outs[out_name] = outs[a] * float(b)
+        elif op == "sum_constant":
+            outs[out_name] = outs[a] + float(b)
+        elif op == "avg":
+            outs[out_name] = (outs[a] + outs[b]) / 2
+        elif op == "mse":
+            outs[out_name] = torch.mean((outs[a] - outs[b]) ** 2)
+        else:
+            raise ValueError("unknown [model] operation " + op)
+    return outs

@@ -117,6 +117,31 @@ def _force_kinks(S, cell, T, B, ndir, H):
 
 
 # ----------------------------------------------------------------------------
+# Injected nn.Dropout masks (test infrastructure, like the kink patterns above): the reference draws the masks of its
+# nn.Dropout modules (MLP :139-148, CNN / SincNet :1546-1552, :1655-1661) from torch's dropout RNG; a config-scale
+# comparison with a reference run needs the very masks that run drew (tests/golden/scale_*: recovered by forward hooks,
+# oracle/make_golden.py::_DropoutTap).  Off unless set_forced_dropout() is called.
+# ----------------------------------------------------------------------------
+class _Drops:
+    queue = None
+
+
+def set_forced_dropout(masks):
+    """masks: list of 0/1 tensors, one per dropout call with p > 0 in forward order, or None to switch off."""
+    _Drops.queue = None if masks is None else list(masks)
+
+
+def dropout_mask(like, p):
+    """The Bernoulli(1-p) / (1-p) mask of one nn.Dropout call on a tensor shaped `like` (device RNG)."""
+    if _Drops.queue is not None:
+        m = _Drops.queue.pop(0)
+        if tuple(m.shape) != tuple(like.shape):
+            raise _lib.PkError("forced dropout mask %s for a %s tensor" % (tuple(m.shape), tuple(like.shape)))
+        return m.to(device=like.device, dtype=torch.float32) / (1.0 - p)
+    return torch.empty_like(like).bernoulli_(1.0 - p).div_(1.0 - p)
+
+
+# ----------------------------------------------------------------------------
 # small helpers
 # ----------------------------------------------------------------------------
 def _p(t):

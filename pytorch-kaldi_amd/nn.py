@@ -103,7 +103,7 @@ def _apply_act_drop(x2, bn, use_bn, training, act, drop_p, eps=None):
     """drop(act(bn(x))) on a 2-D tensor; 'softmax' is LogSoftmax(dim=1)."""
     mask = None
     if training and drop_p > 0.0:
-        mask = torch.empty_like(x2).bernoulli_(1.0 - drop_p).div_(1.0 - drop_p)
+        mask = F_.dropout_mask(x2, drop_p)
     if act == "softmax":
         y = F_.norm_act_drop(x2, bn, use_bn, training, "linear", None, eps) if use_bn else x2
         y = F_.log_softmax(y)
@@ -567,7 +567,7 @@ class _ConvStack(nn.Module):
         B, C, L = z.shape
         mask = None
         if self.training and self._drop[i] > 0.0:
-            mask = torch.empty_like(z).bernoulli_(1.0 - self._drop[i]).div_(1.0 - self._drop[i])
+            mask = F_.dropout_mask(z, self._drop[i])
         act = self._act[i]
         if act == "softmax":
             raise PkError("softmax activation inside a conv stack is not supported")

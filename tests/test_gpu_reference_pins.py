@@ -79,6 +79,7 @@ def _restore_mode():
     F_.set_precision("fp32")
     F_.set_rec_algo("auto")
     F_.set_forced_kinks(None)
+    F_.set_forced_dropout(None)
 
 
 def _two_step(name, got, model, ref, tight, total=None):
@@ -430,3 +431,71 @@ def test_config_scale_golden(prec):
     print("\nconfig-scale golden [bf16]: outputs (engine-vs-model, model-vs-ref, engine-vs-ref) %s; worst kink-forced "
           "gradient %s; share of ReLU pre-activations whose sign bf16 rounding changed: %.2e"
           % ({k: tuple("%.1e" % x for x in v) for k, v in rep.items()}, tuple("%.1e" % x for x in worst), flipped))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# config-scale goldens of the other four BASELINE configurations (shipped cfg files, unscaled, run by the reference)
+# --------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", ["scale_lstm_T500", "scale_gru_libri_T500", "scale_sincnet_3200", "scale_mlp_440"])
+def test_recipe_scale_golden(case, prec):
+    """LSTM 4 x 550 (cfg/TIMIT_baselines/TIMIT_LSTM_fmllr.cfg:131-217) and GRU 5 x 550 + 3400-way head
+    (cfg/Librispeech_baselines/libri_GRU_fmllr.cfg:76-146) at T = 500, SincNet [128,60,60,60] / [129,5,5,3] on 3200
+    samples + MLP + heads (TIMIT_SincNet_raw.cfg:87-211), MLP 440 -> 1024 x 5 + heads at batch 128
+    (TIMIT_MLP_fmllr.cfg:131-214): parameters from the seed (initialisation checked against the reference's checksums),
+    the reference run's recurrent drop masks and nn.Dropout masks injected.
+    fp32: posteriors, loss, every parameter gradient at 1e-4 against the reference's own run (tanh cells: nothing is
+    kink-forced).  bf16: the two-step grading against the bf16-operand model run here on the host CPU."""
+    import pk_oracle as O
+    import scale_util as SU
+    from engine_util import F_amd
+
+    g = Golden(case)
+    m = g.meta
+    F_amd.set_precision(prec)
+    U, cfg, iod, nns, costs = SU.build(g, True)
+    init = SU.oracle_params(nns) if prec == "bf16" else None
+    rmasks = [mk.cuda() for mk in SU.rec_masks(g)]
+    restore = []
+    for name, net in nns.items():  # the recurrent architecture takes the reference run's masks, layer by layer
+        if type(net).__name__ in REC:
+            n = len(net._lay)
+            orig, net.forward = _with_masks(net, rmasks[:n])
+            rmasks = rmasks[n:]
+            restore.append((net, orig))
+    F_amd.set_forced_dropout([mk for _, mk in SU.dropout_masks(g)])
+    inp = g.t("inp").cuda()
+    Tm, Bm = (m["T"], m["B"]) if m["seq"] else (m["B"], 1)
+    try:
+        outs = U.forward_model(m["fea_dict"], m["lab_dict"], m["arch_dict"], m["model"], nns, costs, inp, iod, Tm, Bm,
+                               "train", [])
+        outs["loss_final"].backward()
+        torch.cuda.synchronize()
+    finally:
+        F_amd.set_forced_dropout(None)
+        for net, orig in restore:
+            net.forward = orig
+    grads_of = lambda name: [(k, q.grad) for k, q in nns[name].named_parameters()]  # noqa: E731
+    if prec == "fp32":
+        worst = SU.check_fp32(g, outs, grads_of, tol=1e-4, tol_grad=1e-4)
+        print("\n%s [fp32]: worst gradient row-sample error %.2e (%s)" % (case, worst[0], worst[1]))
+        return
+    oouts = SU.oracle_run(O, g, init, emulate=True)
+    st = m["strides"]
+    rep = {}
+    for k in m["out_keys"]:
+        s_ = st["out/%s/stride" % k]
+        rep[k] = _two_step(k, SU.rows(outs[k].reshape(-1, outs[k].shape[-1]), s_),
+                           SU.rows(oouts[k].detach().reshape(-1, oouts[k].shape[-1]), s_), g.t("out/%s/rows" % k), TIGHT_OUT)
+    lref, lo = float(g.t("loss_final")), float(oouts["loss_final"].detach())
+    assert abs(float(outs["loss_final"]) - lo) < TIGHT_OUT * lref
+    assert abs(float(outs["loss_final"]) - lref) < model_bound(abs(lo - lref) / lref) * lref
+    gtot = SU.grad_total(g)
+    worst = (0.0, 0.0, 0.0)
+    for name, k, key, gr, ref_rows, ref_ck in SU.grad_items(g, grads_of):
+        s_ = st[key + "/stride"]
+        frac = float(ref_rows.double().norm()) / ref_ck[0]
+        worst = max(worst, _two_step((name, k), SU.rows(gr, s_), SU.rows(init[name][k].grad, s_), ref_rows, TIGHT_GRAD,
+                                     gtot * frac), key=lambda t: t[2])
+    print("\n%s [bf16]: outputs (engine-vs-model, model-vs-ref, engine-vs-ref) %s; worst gradient %s"
+          % (case, {k: tuple("%.1e" % x for x in v) for k, v in rep.items()}, tuple("%.1e" % x for x in worst)))

@@ -187,3 +187,21 @@ def test_oracle_config_scale_golden():
             ref = g.t(key + "/rows")
             if float(ref.norm()) > 1e-9:
                 assert rel_err(rows, ref) < 5e-5, (n, k)
+
+
+@pytest.mark.parametrize("case", ["scale_lstm_T500", "scale_gru_libri_T500", "scale_sincnet_3200", "scale_mlp_440"])
+def test_oracle_recipe_scale_golden(case):
+    """The other four BASELINE configurations, UNSCALED, against the reference's own run of the shipped cfg file
+    (oracle/make_golden.py::recipe_scale_case): LSTM 4 x 550 and GRU 5 x 550 + 3400-way head at T = 500, SincNet
+    [128,60,60,60] on 3200 samples + MLP + heads, MLP 440 -> 1024 x 5 + heads at batch 128.  Parameters from the seed,
+    the recurrent drop masks and the nn.Dropout masks of that run injected; no ReLU recurrence here (tanh cells; the
+    ReLUs of the MLP / SincNet stacks sit in feed-forward layers), so nothing is kink-forced."""
+    import scale_util as SU
+
+    g = Golden(case)
+    _, _, _, nns, _ = SU.build(g, False)
+    sds = SU.oracle_params(nns)
+    outs = SU.oracle_run(O, g, sds)
+    worst = SU.check_fp32(g, outs, lambda name: [(k, v.grad) for k, v in sds[name].items() if v.requires_grad],
+                          tol=TOL, tol_grad=5e-5)
+    print("\n%s: oracle vs reference, worst gradient row-sample error %.2e (%s)" % (case, worst[0], worst[1]))

@@ -261,7 +261,7 @@ def _act_kink_forced(name, a, pattern):
 
 
 def recurrent_forward(kind, options, sd, x, training=True, to_do="train", drop_masks=None,
-                      index_like_reference=False, return_all=False, kinks=None):
+                      index_like_reference=False, return_all=False, kinks=None, kink_log=None):
     """Forward of LSTM/GRU/liGRU/minimalGRU/RNN exactly as the reference orders
     it: pack bidirectional on the batch axis, per-gate Linear over all steps,
     per-gate BatchNorm over the T*rows rows, python time loop from h=0, stack,
@@ -270,6 +270,9 @@ def recurrent_forward(kind, options, sd, x, training=True, to_do="train", drop_m
     ``kinks``: optional list (one per layer) of (T, rows, H) bool tensors = the pattern (a_t > 0) of another run; the
     candidate's ReLU then takes its derivative from that pattern (test mode for long sequences, see
     _act_kink_forced).
+
+    ``kink_log``: optional list; receives one (T, rows, H) bool tensor per layer, this run's own pattern (a_t > 0) -
+    what a second implementation is given as ``kinks`` to differentiate the same linear pieces.
 
     ``index_like_reference=True`` indexes the projections with ``w_out[k]`` inside
     the loop as the reference does (this is what makes its backward O(T^2));
@@ -311,7 +314,11 @@ def recurrent_forward(kind, options, sd, x, training=True, to_do="train", drop_m
         def U(name, h):
             return _mm(h, sd["%s.%d.weight" % (name, i)])
 
+        seen = []
+
         def cand(at, k):
+            if kink_log is not None:
+                seen.append(at.detach() > 0)
             if kinks is not None:
                 return _act_kink_forced(acts[i], at, kinks[i][k])
             return activation(acts[i], at)
@@ -351,6 +358,8 @@ def recurrent_forward(kind, options, sd, x, training=True, to_do="train", drop_m
                 ht = layer_norm(ht, sd["ln.%d.gamma" % i], sd["ln.%d.beta" % i])
             hs.append(ht)
         h = torch.stack(hs)
+        if kink_log is not None:
+            kink_log.append(torch.stack(seen) if seen else None)
         if bidir:
             B = R // 2
             h = torch.cat([h[:, :B], flip_time(h[:, B:].contiguous())], 2)

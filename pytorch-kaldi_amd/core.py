@@ -146,7 +146,10 @@ class BatchAssembler:
             it = torch.from_numpy(idx.reshape(-1))
         out = self.src.index_select(0, it).view(max_len, ncol, -1)
         if out.device != self.device:
-            out = out.pin_memory().to(self.device, non_blocking=True) if self.device.type == "cuda" else out.to(self.device)
+            if self.device.type == "cuda" and not out.is_cuda:
+                out = out.pin_memory().to(self.device, non_blocking=True)
+            else:  # (a chunk resident on another GPU: device-to-device copy; pin_memory() is for host tensors only)
+                out = out.to(self.device)
         return max_len, out
 
 
@@ -191,6 +194,17 @@ def _default_reader():
     return data_io.read_lab_fea
 
 
+def _on_device(read, device):
+    """The reader as a thread target that first binds the thread to this rank's GPU: the HIP current device is
+    THREAD-local and a fresh thread starts on device 0, so without this every rank of a node would finish its chunk
+    (PK_CHUNK_DEVICE=cuda: 1.9 GB fp32 + temporaries) on GPU 0."""
+    def run(*args):
+        if device.type == "cuda":
+            torch.cuda.set_device(device)
+        return read(*args)
+    return run
+
+
 def _to_tensor(data_set, save_gpumem, use_cuda):
     t = torch.from_numpy(data_set).float() if isinstance(data_set, np.ndarray) else data_set.float()
     return t.cuda() if (use_cuda and not save_gpumem) else t
@@ -233,13 +247,13 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
 
     if processed_first:
         shared_list = []
-        p = threading.Thread(target=read, args=(cfg_file, is_production, shared_list, output_folder))
+        p = threading.Thread(target=_on_device(read, device), args=(cfg_file, is_production, shared_list, output_folder))
         p.start()
         p.join()
         data_name, data_end_index, fea_dict, lab_dict, arch_dict, data_set = shared_list[:6]
         data_set = _to_tensor(data_set, save_gpumem, use_cuda)
     shared_list = []
-    p = threading.Thread(target=read, args=(next_config_file, is_production, shared_list, output_folder))
+    p = threading.Thread(target=_on_device(read, device), args=(next_config_file, is_production, shared_list, output_folder))
     p.start()
 
     inp_out_dict = fea_dict

@@ -642,7 +642,10 @@ __global__ __launch_bounds__(256) void nll_err_final_kernel(const float* __restr
         float t[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
-        out[0] = t[0] / t[2];  // 0/0 = NaN when every row is ignored, as torch
+        // 0/0 = NaN when every row is ignored, as torch.  A label outside [0, classes) trips a device-side assert in
+        // torch's nll_loss; here it POISONS the loss (NaN): loud without a host sync, whoever the caller is (the count
+        // in out[3] is what core.run_nn_dp turns into an exception at its next sync point)
+        out[0] = t[3] > 0.f ? __builtin_nanf("") : t[0] / t[2];
         out[1] = t[1] / (float)rows;
         out[2] = t[2];
         out[3] = t[3];

@@ -361,6 +361,8 @@ def read_lab_fea(cfg_file, fea_only, shared_list, output_folder=None):
     the chunk normalised there, finish_chunk_device) and data_set is a tensor resident there - run_nn_dp's batch
     assembly gathers from it without a second copy."""
     dev = os.environ.get("PK_CHUNK_DEVICE") or None
+    if dev == "cuda":  # "cuda" = THIS thread's current device (core.run_nn_dp binds its reader thread to the rank's GPU)
+        dev = torch.device("cuda", torch.cuda.current_device())
     stack = (lambda cols: torch.cat([c if c.dim() == 2 else c[:, None] for c in cols], 1)) if dev else np.column_stack
     if not os.path.exists(cfg_file):
         raise IOError("The config file %s does not exist!" % cfg_file)

@@ -114,11 +114,13 @@ class GradReducer:
                     self._add_bucket(cur, None)
 
     def _add_bucket(self, params, flat_slice):
-        # "expect" = parameters that actually receive a gradient.  The reference always creates ln / bn sub-modules
-        # it never calls (18 of 62 tensors in the Li-GRU recipe): their hooks never fire, so after
-        # the first step a bucket is launched as soon as every parameter that fired in step 1 has fired again.
-        b = {"params": list(params), "flat": flat_slice, "pending": len(params), "fired": False, "seen": set(),
-             "expect": None}
+        # "expect" = how many ready-signals each parameter gives per step.  The reference always creates ln / bn
+        # sub-modules it never calls (18 of 62 tensors in the Li-GRU recipe): their hooks never fire.
+        # A module applied twice in one [model] (shared architecture) has its weight-gradient GEMM side-launched twice.
+        # Step 1 therefore only COUNTS the signals per parameter (its buckets are reduced in finish()); from step 2 on
+        # a bucket is launched when every parameter that signalled in step 1 has signalled as often again.
+        b = {"params": list(params), "flat": flat_slice, "pending": len(params), "fired": False, "seen": {},
+             "expect": None, "got": {}}
         self.buckets.append(b)
         for p in params:
             self._by_param[id(p)] = b
@@ -135,13 +137,28 @@ class GradReducer:
                 self._ready(b, p)
 
     def _ready(self, b, p):
-        if b["expect"] is None:
-            b["seen"].add(id(p))
-        elif id(p) not in b["expect"]:
+        """One gradient contribution of p is enqueued (autograd: once per backward; side stream: once per
+        side_launch).  Which path a Linear takes (functional: M >= 4096 rows -> side stream) depends on the shard
+        shape only, and shards are equal on every rank (shard_batch), so all ranks signal - and launch their
+        collectives - in the same order."""
+        k = id(p)
+        if b["expect"] is None:  # step 1: learn the pattern, reduce in finish()
+            b["seen"][k] = b["seen"].get(k, 0) + 1
+            return
+        if b["fired"]:
+            raise RuntimeError("data parallel: a gradient of a %s parameter arrived after its bucket had been handed to "
+                               "the all-reduce (the step produced more gradient contributions than the first step of "
+                               "this run did); build the GradReducer with overlap=False for graphs that change from "
+                               "step to step" % (tuple(p.shape),))
+        want = b["expect"].get(k)
+        if want is None:
             return  # a parameter that was silent in step 1 fired now: it is still covered by finish()
-        b["pending"] -= 1
-        if b["pending"] == 0 and not b["fired"]:
-            self._launch(b)
+        got = b["got"].get(k, 0) + 1
+        b["got"][k] = got
+        if got == want:
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                self._launch(b)
 
     def _launch(self, b):
         b["fired"] = True
@@ -191,6 +208,8 @@ class GradReducer:
         self.handles = []
         for b in self.buckets:
             if b["expect"] is None:
-                b["expect"] = set(b["seen"])
-            b["pending"] = len(b["expect"]) if b["expect"] else len(b["params"])
+                b["expect"] = dict(b["seen"])
+            # (a bucket none of whose parameters signalled in step 1 never reaches 0: finish() reduces it)
+            b["pending"] = len(b["expect"]) if b["expect"] else len(b["params"]) + 1
+            b["got"] = {}
             b["fired"] = False

@@ -312,7 +312,7 @@ def side_targets_ok(params):
     view of an optim.FlatParams buffer (its consumers - fused optimizer step, gradient all-reduce, zero_grad -
     call join_side() first)."""
     return (settings.wgrad_side and bf16_mode() and params is not None and len(params) > 0
-            and all(getattr(q, "_pk_flat", False) and q.grad is not None for q in params))
+            and all(getattr(q, "_pk_flat", False) and q.grad is not None and q.requires_grad for q in params))
 
 
 _DEBUG_SKIP_SIDE = os.environ.get("PK_DEBUG_SKIP_SIDE", "0") == "1"  # timing experiments only: drops the weight-gradient work
@@ -633,21 +633,34 @@ def colsum(g, g2=None):
 
 
 class _LabelCheck:
-    bad = None  # device scalar: labels outside [0, classes) seen by head_nll since the last raise_if_bad_labels()
+    bad = {}  # device -> persistent scalar: labels outside [0, classes) seen by head_nll since the last raise_if_bad_labels()
+
+
+def label_check_counter(device):
+    """The persistent per-device counter (allocate it BEFORE a HIP-graph capture: the captured in-place add then
+    accumulates on every replay)."""
+    dev = torch.empty(0, device=device).device
+    if dev not in _LabelCheck.bad:
+        _LabelCheck.bad[dev] = torch.zeros((), device=dev)
+    return _LabelCheck.bad[dev]
 
 
 def note_label_check(stats):
-    """Accumulate the bad-label count of one head_nll call (no host sync here: torch's nll_loss would trip a device-side
-    assert on such a label; the engine reports it at the next point where the host waits for the GPU anyway)."""
+    """Accumulate the bad-label count of one head_nll call IN PLACE into the persistent device scalar (no host sync
+    here; the loss of such a batch is NaN - pk_nll_err_fwd - and the count is reported at the next point where the host
+    waits for the GPU anyway).  In place, so that a HIP-graph replay of the step keeps counting."""
     with torch.no_grad():
-        _LabelCheck.bad = stats[3].clone() if _LabelCheck.bad is None else _LabelCheck.bad + stats[3]
+        label_check_counter(stats.device).add_(stats[3])
 
 
 def raise_if_bad_labels():
     """Call after a host sync (core.run_nn_dp: once per chunk)."""
-    bad, _LabelCheck.bad = _LabelCheck.bad, None
-    if bad is not None and float(bad) > 0:
-        raise _lib.PkError("cost_nll: %d label(s) outside [0, classes) in this chunk" % int(float(bad)))
+    n = 0
+    for c in _LabelCheck.bad.values():
+        n += int(float(c))
+        c.zero_()
+    if n > 0:
+        raise _lib.PkError("cost_nll: %d label(s) outside [0, classes) in this chunk" % n)
 
 
 def head_nll(y, lab, ignore_index=-100):
@@ -857,7 +870,9 @@ def log_softmax(x):
 def choose_rec_algo(cell, H, use_ln):
     want = settings.rec_algo
     ok = cell in ("liGRU", "RNN", "LSTM") and H <= 576 and not use_ln
-    if not bf16_mode() and cell == "LSTM":  # its (first-generation) exact-fp32 kernels exchange pairs of fp32 values
+    # the first-generation exact-fp32 kernels exchange pairs of fp32 values: LSTM always, liGRU / RNN when
+    # PK_REC_F32_GEN=1 keeps them (the library reads the same switch, pk_rec_persist.hip::use_gen2_f32)
+    if not bf16_mode() and (cell == "LSTM" or os.environ.get("PK_REC_F32_GEN", "")[:1] == "1"):
         ok = ok and H % 2 == 0
     if want == "persistent":
         if not ok:
@@ -974,7 +989,8 @@ class RecLayerFn(torch.autograd.Function):
             Hp = _up(H, 8)
             Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
             rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
-                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1], 2)
+                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1],
+                                     2 if settings.self_fill else 0)
             _lib.check(rc, "pk_rec_fwd_bf16")
         else:
             rc = lib.pk_rec_fwd(_stream(), algo, prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
@@ -1019,7 +1035,8 @@ class RecLayerFn(torch.autograd.Function):
             Hp = _up(H, 8)
             dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16)
             rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
-                                     float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dP2), _p(dGb), dGb.shape[1], 2)
+                                     float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dP2), _p(dGb), dGb.shape[1],
+                                     2 if settings.self_fill else 0)
             _lib.check(rc, "pk_rec_bwd_bf16")
         else:
             rc = lib.pk_rec_bwd(_stream(), ctx.algo, ctx.prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat),

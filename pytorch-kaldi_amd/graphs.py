@@ -36,6 +36,8 @@ class GraphedStep:
 
     def capture(self, inp):
         self.static_inp = inp.clone()
+        from . import functional as F_
+        F_.label_check_counter(inp.device)  # the bad-label counter must exist before the capture that adds into it
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         steps0 = [getattr(o, "steps", 0) for o in self.optimizers]

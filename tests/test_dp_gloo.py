@@ -156,3 +156,44 @@ def test_run_nn_dp_plumbing_two_ranks(tmp_path):
     for k in ref:
         assert torch.allclose(got["grads"][k], ref[k], atol=1e-6), k
     assert abs(float(got["loss"]) - sum(losses) / 2) < 1e-6 and abs(float(got["err"]) - 0.5) < 1e-6
+
+
+def test_bucket_waits_for_every_contribution_of_a_parameter_used_twice():
+    """A module applied twice in one [model] (shared architecture) has its weight-gradient GEMM side-launched twice
+    per step: the bucket must not leave for the all-reduce after the first one (dp.GradReducer counts, in step 1, how
+    many signals each parameter gives, and only reduces in finish() during that step)."""
+    DP = importlib.import_module("pytorch-kaldi_amd.dp")
+    net = torch.nn.Linear(3, 2)
+    red = DP.GradReducer({"net": net}, bucket_bytes=1 << 20, overlap=False, force=True)
+    assert len(red.buckets) == 1
+    b = red.buckets[0]
+    launched = []
+
+    def fake_launch(bk):
+        bk["fired"] = True
+        launched.append(dict(bk["got"]))
+
+    red._launch = fake_launch
+    w, bias = net.weight, net.bias
+    # step 1: the weight signals twice, the bias once - nothing leaves before finish()
+    for p in (w, bias, w):
+        red._ready(b, p)
+    assert launched == []
+    red.finish()
+    assert len(launched) == 1 and b["expect"] == {id(w): 2, id(bias): 1}
+    # step 2: after (weight, bias) the bucket is NOT complete; the second weight signal completes it
+    red._ready(b, w)
+    red._ready(b, bias)
+    assert len(launched) == 1
+    red._ready(b, w)
+    assert len(launched) == 2
+    # a contribution that arrives after the bucket left is an error, not a silent race
+    with pytest.raises(RuntimeError):
+        red._ready(b, w)
+    red.handles = []
+    red.finish()
+    # step 3: fewer signals than learnt -> the bucket is reduced by finish()
+    red._ready(b, w)
+    assert len(launched) == 2
+    red.finish()
+    assert len(launched) == 3

@@ -513,9 +513,14 @@ def test_head_nll_declines_what_it_does_not_cover():
         bad = lab.clone()
         bad[2] = 7
         loss, stats = F_.head_nll(y, bad)
+        assert bool(torch.isnan(loss))   # a label outside [0, classes) poisons the loss (torch: device-side assert) ...
         F_.note_label_check(stats)
+        F_.note_label_check(stats)       # ... and is counted in place (a HIP-graph replay keeps counting)
+        assert float(F_.label_check_counter("cuda")) == 2.0
         with pytest.raises(_lib.PkError):
             F_.raise_if_bad_labels()
+        assert float(F_.label_check_counter("cuda")) == 0.0
+        F_.raise_if_bad_labels()
         y2 = F_.linear_log_softmax(x, w, None)
         with torch.no_grad():
             y2.add_(1.0)
@@ -573,3 +578,67 @@ def test_output_layer_on_the_published_bf16_twin():
         F_.set_precision("fp32")
     for a, r in zip(*res):
         assert rel_err(a, r) < 1e-5
+
+
+# --------------------------------------------------------------------------------
+# the GEMM shapes the timed step actually launches (BASELINE configs[1]: T*B = 64 000 rows, H = 550, 1938 / 48 classes)
+# --------------------------------------------------------------------------------
+BASELINE_GEMMS = [
+    # name, M, N, K, a_kc, b_kc, split-K (0 = the library's own choice for the shape)
+    ("projection", 64000, 1100, 1104, 1, 1, 1),
+    ("projection_layer0", 64000, 1100, 40, 1, 1, 1),
+    ("dX", 64000, 1100, 1100, 1, 0, 1),
+    ("head_1938", 64000, 1938, 1104, 1, 1, 1),
+    ("head_48", 64000, 48, 1104, 1, 1, 1),
+    ("dW", 1100, 1104, 64000, 0, 0, 0),
+    ("dW_layer0", 1100, 40, 64000, 0, 0, 0),
+    ("dU", 1104, 550, 63872, 0, 0, 0),
+    ("head_dW_1938", 1938, 1100, 64000, 0, 0, 0),
+    ("head_dW_48", 48, 1100, 64000, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize("name,M,N,K,a_kc,b_kc,splitk", BASELINE_GEMMS)
+def test_gemm_bf16_baseline_shapes(name, M, N, K, a_kc, b_kc, splitk):
+    """pk_gemm_bf16 on the shapes of the benchmarked step, with the tile and split-K the library picks for them (the
+    256-tile for the row-streaming and weight-gradient shapes, split-K 4-28 over the 64 000-row reductions).  The fp64
+    reference is evaluated on a sample of output rows (every 61st) plus the column sums of the whole output - a
+    checksum that sees every row."""
+    g = torch.Generator().manual_seed(len(name) * 1000 + M % 977 + N)
+    A = torch.randn(M, K, generator=g) / 8
+    B = torch.randn(K, N, generator=g) / 8
+    Ab = F_.cvt_bf16((A if a_kc else A.t().contiguous()).cuda())
+    Bb = F_.cvt_bf16((B.t().contiguous() if b_kc else B).cuda())
+    C = torch.full((M, N), float("nan"), device="cuda")
+    sk = splitk or F_._splitk_bf(F_._tiles_bf(M, N), K)
+    F_.gemm_bf16(M, N, K, Ab, Ab.shape[1], a_kc, Bb, Bb.shape[1], b_kc, C, N, splitk=sk)
+    torch.cuda.synchronize()
+    Ar, Br = _bf_round(A), _bf_round(B)
+    idx = torch.arange(0, M, 61)
+    ref_rows = Ar[idx] @ Br
+    assert rel_err(C[idx.cuda()], ref_rows) < 2e-5, (name, sk)
+    ref_colsum = Ar.sum(0, keepdim=True) @ Br
+    got = C.double().sum(0, keepdim=True)
+    scale = float((Ar.abs().sum(0, keepdim=True) @ Br.abs()).norm())  # the size of what cancels in a column sum
+    assert float((got.cpu() - ref_colsum).norm()) < 2e-6 * scale, (name, sk)
+    assert bool(torch.isfinite(C).all())
+
+
+@pytest.mark.parametrize("K", [1104, 40])
+def test_projection_statistics_at_250_row_blocks(K):
+    """pk_gemm_bf16_stats at the benchmarked projection shape: 64 000 rows = 250 row blocks of the 256-tile, 1100
+    columns, merged by pk_bn_stats_merge - mean / biased variance of every column against fp64 on the matrix the GEMM
+    wrote, and that matrix against fp64 on sampled rows."""
+    M, N = 64000, 1100
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(M, K, generator=g) + 0.25
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    xb, wb = F_.cvt_bf16(x.cuda()), F_.cvt_bf16(w.cuda())
+    C = torch.empty(M, N, device="cuda")
+    mean, var = F_.gemm_bf16_bn_stats(M, N, K, xb, xb.shape[1], 1, wb, wb.shape[1], 1, C, N)
+    torch.cuda.synchronize()
+    idx = torch.arange(0, M, 61)
+    assert rel_err(C[idx.cuda()], _bf_round(x[idx]) @ _bf_round(w).t()) < 2e-5
+    Cd = C.double()
+    assert rel_err(mean, Cd.mean(0)) < 1e-5
+    assert rel_err(var, Cd.var(0, unbiased=False)) < 1e-5

@@ -300,7 +300,7 @@ def test_self_filled_exchange_on_a_dirty_buffer(kind, pre, act, H, T, B, bidir, 
     torch.manual_seed(5)
     net = getattr(nn_amd, kind)(opts, 23).cuda().train()
     g = torch.Generator().manual_seed(17)
-    xs = [torch.randn(T, B, 23, generator=g).cuda() for _ in range(2)]
+    xs = [torch.randn(T, B, 23, generator=g).cuda() for _ in range(4)]  # the same recycled blocks, step after step
     masks = O.make_drop_masks(kind, opts, B, "train", generator=g)
     cot = torch.randn(T, B, net.out_dim, generator=g).cuda()
     lib = importlib.import_module("pytorch-kaldi_amd._lib").load()
@@ -312,7 +312,7 @@ def test_self_filled_exchange_on_a_dirty_buffer(kind, pre, act, H, T, B, bidir, 
     try:
         for self_fill in (True, False):
             F_amd.settings.self_fill = self_fill
-            for x in (xs if self_fill else xs[1:]):  # the self-filled run sees a dirty allocator
+            for x in (xs if self_fill else xs[-1:]):  # the self-filled run sees a dirty allocator
                 net.zero_grad()
                 xe = x.clone().requires_grad_(True)
                 y = net(xe, drop_masks=masks)
@@ -536,3 +536,60 @@ def test_bf16_eval_forward_is_close(kind, pre, act):
         with torch.no_grad():
             outs[prec] = net(x).cpu()
     assert rel_err(outs["bf16"], outs["fp32"]) < 3e-2
+
+
+# --------------------------------------------------------------------------------
+# the FULL launch geometry, value for value: 2B = 256 rows x H = 550 (16 clusters live), both precisions
+# --------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("T", [20, 50])
+@pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("LSTM", "lstm", "tanh"), ("GRU", "gru", "tanh")])
+def test_full_geometry_value_for_value(kind, pre, act, T, prec):
+    """The recurrent kernels at the geometry bench.py times - batch 128 bidirectional = 256 rows, H = 550, every one of
+    the 16 clusters live, two layers so that the layer-to-layer hand-over of the bf16 copy is on the path too - compared
+    VALUE FOR VALUE with the oracle on the host CPU: fp32 mode against the fp32 oracle at 1e-4, bf16 mode (the
+    persistent bf16 kernels: liGRU, the 8-wave LSTM, the two-phase GRU) against the oracle's bf16-operand model at
+    5e-3 (outputs) / 2e-2 (gradients).  The Li-GRU's ReLU recurrence is differentiated on the oracle run's own kink
+    pattern on both sides (kink-forced backward), so that the gradient comparison measures arithmetic at any T."""
+    import contextlib
+
+    from engine_util import F_amd, nn_amd
+
+    B, D, H = 128, 40, 550
+    opts = _rec_opts(pre, [H, H], act)
+    torch.manual_seed(4321)
+    net = getattr(nn_amd, kind)(opts, D)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(T, B, D, generator=g)
+    masks = O.make_drop_masks(kind, opts, B, "train", generator=g)
+    cot = torch.randn(T, B, net.out_dim, generator=g)
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    log = [] if act == "relu" else None
+    with (O.bf16_operands() if prec == "bf16" else contextlib.nullcontext()):
+        yo = O.recurrent_forward(kind, opts, osd, xo, training=True, to_do="train", drop_masks=masks, kink_log=log)
+        (yo * cot).sum().backward()
+    F_amd.set_precision(prec)
+    F_amd.set_rec_algo("auto")
+    report = F_amd.set_forced_kinks(log) if log is not None else None
+    try:
+        net.cuda().train()
+        xe = x.clone().cuda().requires_grad_(True)
+        ye = net(xe, drop_masks=masks)
+        (ye * cot.cuda()).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        F_amd.set_forced_kinks(None)
+    otol, gtol = (TOL, TOL) if prec == "fp32" else (5e-3, 2e-2)
+    e_y, e_x = rel_err(ye, yo), rel_err(xe.grad, xo.grad)
+    ref = {k: v.grad for k, v in osd.items() if v.requires_grad and v.grad is not None}
+    got = {k: (p.grad.detach().cpu() if p.grad is not None else None) for k, p in net.named_parameters()}
+    worst = check_grads(got, ref, None, gtol)
+    print("\nfull geometry %s T=%d %s: y %.2e, dx %.2e, worst parameter gradient %.2e%s"
+          % (kind, T, prec, e_y, e_x, worst, "" if report is None else "; kink report %s" % (report,)))
+    assert e_y < otol, e_y
+    assert e_x < gtol, e_x
+    if report is not None:  # the engine's own pattern differs from the oracle's only where a_t is rounding noise
+        for flipped, total, worst_a in report:
+            assert flipped < (2e-4 if prec == "fp32" else 2e-2) * total, report

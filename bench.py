@@ -54,7 +54,21 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the parity_mode (fp32) and other_configs sub-records of the default single-GPU run")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    ap.add_argument("--cpu-T", type=int, default=500, help="sequence length of the CPU baseline sample (batch 8)")
+    ap.add_argument("--cpu-T", type=int, default=100, help="sequence length of the CPU baseline sample")
+    ap.add_argument("--cpu-B", type=int, default=128, help="batch of the CPU baseline sample (the metric's: 128)")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="CPU baseline only: ONE step at the metric's full shape (T, B of --T / --B; minutes of CPU time), "
+                         "printed as JSON - the source of profiles/r03_cpu_full_shape.json")
+    ap.add_argument("--repeats", type=int, default=1, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--unfused-cost", action="store_true",
+                    help="cost lines through torch's NLLLoss on the log-posteriors (what the reference's own forward_model does)")
+    ap.add_argument("--sync-every-step", action="store_true", help="read the loss back after every step (core.py:689)")
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="one GPU: run the whole data-parallel path anyway - a ONE-rank RCCL communicator, the bucketed "
+                         "reducer forced on (a one-rank sum is the identity: losses must equal the plain run bit for bit)")
+    ap.add_argument("--dump-losses", default=None, help="write the loss of every timed step to this file (JSON list)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: every rank joins, one all-reduce, rank 0 prints {\"n_gpus\": world} (tests)")
     return ap.parse_args()
 
 
@@ -70,6 +84,7 @@ class Trainer:
         F_.set_precision(args.prec)
         F_.set_rec_algo(args.algo)
         F_.set_mask_rng(args.mask_rng)
+        F_.settings.fused_cost = not args.unfused_cost
         self.args, self.rank, self.world = args, rank, world
         self.rcp = rcp = self.R.recipe(args.recipe, n_lay=args.layers)
         self.inp_out_dict = {"fea": rcp["fea_dict"]["fea"][5:]}
@@ -83,7 +98,8 @@ class Trainer:
             self.opts = self.OPT.fused_optimizer_init(self.nns, rcp["cfg"], rcp["arch_dict"])
             flats = {k: o.flat for k, o in self.opts.items()}
         # 8 MB buckets: the recurrent stack's 31.7 MB of gradients leave in 4 pieces while BPTT of the lower layers runs
-        self.reducer = self.DP.GradReducer(self.nns, flats=flats, bucket_bytes=8 << 20, overlap=args.overlap)
+        self.reducer = self.DP.GradReducer(self.nns, flats=flats, bucket_bytes=8 << 20, overlap=args.overlap,
+                                           force=bool(getattr(args, "force_reducer", False)))
         # one resident synthetic batch per rank (different seeds per rank = different shards)
         self.T, self.B = (args.T, args.B) if rcp["seq"] else (1, args.B)
         self.batches = [self.R.synthetic_batch(rcp, self.T, self.B, 4234 + 17 * rank + i, "cuda") for i in range(2)]
@@ -112,6 +128,8 @@ class Trainer:
         self.reducer.finish()
         for o in self.opts.values():
             o.step()
+        if self.args.sync_every_step:  # the reference's progress bar reads the running loss once per batch (core.py:689)
+            return float(outs["loss_final"].detach().cpu())
         return outs["loss_final"].detach()
 
 
@@ -210,9 +228,14 @@ def log(msg):
 T_START = time.time()
 
 
-def cpu_baseline(args, rcp_name):
-    """The CPU oracle (a torch-CPU port of the reference path; kind = "port") timed on this host's
-    cores on a bounded sample of the same workload: same network, shorter/narrower batch."""
+def cpu_baseline(args, rcp_name, full=False):
+    """The CPU oracle (a torch-CPU port of the reference path; kind = "port") timed on this host's cores on a bounded
+    sample of the same workload: same network, the metric's batch (128 sequences), a shorter sequence so that the
+    default run stays within ~20 s of CPU time.  The reference's autograd cost per frame GROWS with T (its backward
+    zero-fills a (T, 2B, H) tensor per step and gate, SURVEY.md 3.3 - the port indexes the projections inside the time
+    loop the same way), so the short sample FLATTERS the CPU; the full-shape number (one step at T = 500, B = 128,
+    minutes of CPU time: `bench.py --cpu-full`) is measured once per round on the GPU box's host and quoted from
+    profiles/r03_cpu_full_shape.json."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pk_oracle as O
 
@@ -243,12 +266,14 @@ def cpu_baseline(args, rcp_name):
             opts.append(torch.optim.SGD(leaves, lr=float(cfg[k]["arch_lr"])))
         else:
             opts.append(torch.optim.RMSprop(leaves, lr=float(cfg[k]["arch_lr"]), alpha=0.95, eps=1e-8))
-    # sequence recipes: the metric's sequence length (the reference's autograd cost per frame GROWS with T, SURVEY.md
-    # 3.3), a batch of 8 so that a step is seconds of CPU work
-    T, B = (args.cpu_T, 8) if rcp["seq"] else (1, 128)
+    if full:
+        T, B = (args.T, args.B) if rcp["seq"] else (1, args.B)
+    else:
+        T, B = (args.cpu_T, args.cpu_B) if rcp["seq"] else (1, 128)
 
-    def one_step(seed):
-        inp = R.synthetic_batch(rcp, T, B, seed)
+    def one_step(seed, T_=None):
+        Ts = T_ or T
+        inp = R.synthetic_batch(rcp, Ts, B, seed)
         x = inp[..., :rcp["nfea"]]
         lab_cd = inp[..., rcp["nfea"]].reshape(-1).long()
         if rcp["seq"]:
@@ -256,7 +281,7 @@ def cpu_baseline(args, rcp_name):
             # (neural_networks.py:1133-1134) - that is what makes its backward O(T^2), and with it the port runs
             # within 4-11 % of the reference's own speed (profiles/r02_cpu_port_vs_reference.json)
             h = O.recurrent_forward(kind, dict(a1), sds["architecture1"], x, index_like_reference=True)
-            h = h.reshape(T * B, -1)
+            h = h.reshape(Ts * B, -1)
         else:
             h = O.arch_forward(kind, dict(a1), sds["architecture1"], x)
             if trunk:
@@ -271,13 +296,13 @@ def cpu_baseline(args, rcp_name):
         for opt in opts:
             opt.step()
 
-    one_step(1)  # warm-up
+    one_step(1, 8 if rcp["seq"] else None)  # warm-up (thread pool, allocator) on a short sequence
     t0 = time.time()
     n = 0
     while True:
         one_step(2 + n)
         n += 1
-        if time.time() - t0 > args.cpu_budget_s or n >= 50:
+        if full or time.time() - t0 > args.cpu_budget_s or n >= 50:
             break
     dt = time.time() - t0
     model = ""
@@ -288,11 +313,19 @@ def cpu_baseline(args, rcp_name):
                 break
     except OSError:
         pass
-    return {"value": round(n * T * B / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of the same network (fwd+bwd+the cfg optimizers) at T=%d, B=%d on %s, torch-CPU oracle fp32, "
-                      "projections indexed in the time loop like the reference; the reference's own classes run 1.04x "
-                      "(T=500) / 1.11x (T=50) slower than this port on the build host (profiles/r02_cpu_port_vs_reference.json)"
-                      % (n, T, B, model or "host CPU")}
+    rec = {"value": round(n * T * B / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "%d step(s) of the same network (fwd+bwd+the cfg optimizers) at T=%d, B=%d on %s, torch-CPU oracle fp32, "
+                     "projections indexed in the time loop like the reference; the reference's own classes run 1.04x "
+                     "(T=500) / 1.11x (T=50) slower than this port on the build host (profiles/r02_cpu_port_vs_reference.json)"
+                     % (n, T, B, model or "host CPU"), "T": T, "B": B, "seconds": round(dt, 2)}
+    if not full:
+        try:  # the same port at the metric's FULL shape, measured once on the GPU box's host (bench.py --cpu-full)
+            fs = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_full_shape.json")))
+            if fs.get("recipe", "timit_ligru") == rcp_name:
+                rec["full_shape"] = {k: fs[k] for k in ("value", "unit", "cores", "T", "B", "seconds", "sample") if k in fs}
+        except (OSError, ValueError):
+            pass
+    return rec
 
 
 def roofline_of(tr, args, summ, prec):
@@ -322,34 +355,48 @@ def roofline_of(tr, args, summ, prec):
     ach = fl / (d["avg_ms"] * 1e-3) / 1e12 if d["avg_ms"] > 0 else 0.0
     roof.update({"kernel": dom, "achieved": round(ach, 3), "frac": round(ach / roof["peak"], 5),
                  "avg_launch_ms": round(d["avg_ms"], 4), "launches_per_step": d["calls_per_step"], "flops_per_launch": fl})
+    # algorithmic HBM bytes of one recurrent launch: which roof is the NEARER one follows from the
+    # launch's arithmetic intensity against the ridge (peak FLOP/s / peak B/s = 312 FLOP/B in bf16)
+    rb = rec_launch_bytes(tr.rcp, tr.T, tr.B, dom)
+    if rb:
+        gbps = rb / (d["avg_ms"] * 1e-3) / 1e9
+        roof["algorithmic_bytes_per_launch"] = rb
+        roof["arithmetic_intensity"] = round(fl / rb, 1)
+        roof["ridge"] = round(roof["peak"] * 1e12 / (HBM_PEAK * 1e9), 1)
+        roof["mfma"] = {"achieved": round(ach, 3), "peak": roof["peak"], "unit": "TFLOP/s", "frac": round(ach / roof["peak"], 5)}
+        roof["hbm"] = {"achieved": round(gbps, 1), "peak": HBM_PEAK, "unit": "GB/s", "frac": round(gbps / HBM_PEAK, 5)}
+        if fl / rb < roof["ridge"]:  # below the ridge: the HBM roof is the one this launch would hit first
+            roof.update({"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK, "unit": "GB/s",
+                         "frac": round(gbps / HBM_PEAK, 5)})
     if "rec" in dom and tr.rcp["seq"]:
         # A recurrent launch is T strictly dependent steps: neither roofline binds it, the per-step latency does.  Two
-        # floors, both measured with this library's own traced kernels (profiles/r02_rec_step_floor.json,
+        # floors, both measured with this library's own traced kernels (profiles/r0N_rec_step_floor.json,
         # tools/trace_rec2.py): `hop_floor_us` = one cross-CU hand-off (publish of the slowest member -> data in
         # registers; the chip's handoff-1to1 price, 0.8-1.0 us) and `step_floor_us` = a step of THIS kernel structure with
         # its MFMA block and gate math removed (EMPTY=1: poll + barrier + flush / prefetch issue + patches + publish).
-        roof["dependent_steps_per_launch"] = tr.T
-        roof["us_per_step"] = round(d["avg_ms"] * 1e3 / tr.T, 3)
-        hop, floor = 0.9, None
-        try:
-            fl_ = json.load(open(os.path.join(ROOT, "profiles", "r02_rec_step_floor.json")))
-            side_ = "bwd" if "bwd" in dom else "fwd"
-            hop, floor = float(fl_["hop_us"][side_]), float(fl_["floor_us_" + side_])
-        except (OSError, ValueError, KeyError):
-            pass
-        roof["hop_floor_us"] = hop
-        roof["latency_frac"] = round(hop / roof["us_per_step"], 4)
+        lat = {"bound": "latency", "dependent_steps_per_launch": tr.T, "us_per_step": round(d["avg_ms"] * 1e3 / tr.T, 3)}
+        hop, floor, src_ = 0.9, None, None
+        for cand in ("r03_rec_step_floor.json", "r02_rec_step_floor.json"):
+            try:
+                fl_ = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                side_ = "bwd" if "bwd" in dom else "fwd"
+                hop, floor, src_ = float(fl_["hop_us"][side_]), float(fl_["floor_us_" + side_]), cand
+                break
+            except (OSError, ValueError, KeyError):
+                pass
+        lat["hop_floor_us"] = hop
+        lat["frac"] = round(hop / lat["us_per_step"], 4)  # 1.0 = every step costs exactly one cross-CU hop
         if floor is not None and dom in ("pk_rec_fwd_bf16", "pk_rec_bwd_bf16") and tr.rcp["cfg"]["architecture1"]["arch_class"] == "liGRU":
-            roof["step_floor_us"] = floor
-            roof["structure_frac"] = round(floor / roof["us_per_step"], 4)
-    # algorithmic HBM bytes of one recurrent launch and the PMC-measured traffic
-    # of the same launch at this geometry (null for any other geometry)
-    rb = rec_launch_bytes(tr.rcp, tr.T, tr.B, dom)
-    if rb:
-        roof["algorithmic_bytes_per_launch"] = rb
-        roof["hbm_gbps"] = round(rb / (d["avg_ms"] * 1e-3) / 1e9, 1)
-        roof["hbm_frac"] = round(rb / (d["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK, 5)
-    for src in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            lat["step_floor_us"] = floor
+            lat["structure_frac"] = round(floor / lat["us_per_step"], 4)
+            lat["floor_source"] = "profiles/" + src_
+        roof["latency"] = lat
+        # (kept at the top level too: earlier rounds' readers look for them there)
+        roof["dependent_steps_per_launch"], roof["us_per_step"] = tr.T, lat["us_per_step"]
+        roof["hop_floor_us"], roof["latency_frac"] = hop, lat["frac"]
+        if "structure_frac" in lat:
+            roof["step_floor_us"], roof["structure_frac"] = lat["step_floor_us"], lat["structure_frac"]
+    for src in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", src)))
             if dom in pm and args.recipe == "timit_ligru" and (tr.T, tr.B) == (500, 128) and args.layers is None:
@@ -390,18 +437,25 @@ def measure(args, rank, world, steps, warmup):
             tr.step(0)  # lazy one-time initialisation must not land inside the capture
         tr.enable_graph()
         tr.step(0)      # first replay (graph upload) outside the timed region
-    barrier()
-    t0 = time.perf_counter()
+    regions = []
     loss = None
-    for i in range(steps):
-        loss = tr.step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    log("%s/%s timed region done: %.3f s" % (args.recipe, args.prec, dt))
-    if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    losses = [] if getattr(args, "dump_losses", None) else None
+    for _ in range(max(1, getattr(args, "repeats", 1))):  # every region: EXACTLY `steps` steps between two barriers
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = tr.step(i)
+            if losses is not None:
+                losses.append(loss)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        regions.append(dt)
+    dt = sorted(regions)[len(regions) // 2]  # the median region (one region: that one)
+    log("%s/%s timed region(s) done: %s s" % (args.recipe, args.prec, ["%.3f" % r for r in regions]))
     _lib = importlib.import_module("pytorch-kaldi_amd._lib")
     _lib.raise_if_persist_failed()
     frames = steps * tr.T * tr.B * world
@@ -418,6 +472,19 @@ def measure(args, rank, world, steps, warmup):
                    "params": tr.n_params},
         "loss_final": round(float(loss), 5),
     }
+    if losses is not None and rank == 0:
+        with open(args.dump_losses, "w") as f:
+            json.dump([float(v) for v in losses], f)
+    if tr.reducer.active:
+        out["config"]["reducer"] = "%d buckets, %s" % (len(tr.reducer.buckets), "forced on one rank" if world == 1 else "RCCL")
+        if tr.reducer.trace and rank == 0:
+            out["allreduce_timeline"] = tr.reducer.timeline()[-3:]
+    if len(regions) > 1:
+        out["regions_ms_per_step"] = [round(1e3 * r / steps, 3) for r in regions]
+        out["config"]["timing"] = "median of %d regions of %d steps" % (len(regions), steps)
+    if args.unfused_cost or args.sync_every_step:
+        out["config"]["cost"] = "nn.NLLLoss on the log-posteriors" if args.unfused_cost else "fused"
+        out["config"]["host_sync"] = "every step" if args.sync_every_step else "end of region"
     if tr.rcp["cfg"]["architecture1"]["arch_class"] == "LSTM":
         out["config"]["lstm_waves"] = int(_lib.load().pk_persist2_get_lstm_waves())  # DESIGN.md 6.1 (PK_LSTM_WAVES)
     # roofline of the dominant kernel class, measured live with HIP events (every rank runs the two extra steps:
@@ -441,15 +508,137 @@ def release(tr):
 
 
 # the other BASELINE.json configurations (parity-test cases, reported beside the headline): recipe, steps, warmup
-OTHER_CONFIGS = [("timit_mlp", 400, 5), ("timit_lstm", 10, 2), ("libri_gru", 10, 2), ("timit_sincnet", 100, 5)]
+# (each: median of 3 timed regions of `steps` steps)
+OTHER_CONFIGS = [("timit_mlp", 400, 5), ("timit_lstm", 50, 5), ("libri_gru", 50, 5), ("timit_sincnet", 100, 5)]
+
+
+def through_run_nn(args, n_batches=12):
+    """The same workload THROUGH the chunk loop (`elapsed_time_chunk`, core.py:567-701): a synthetic
+    chunk of n_batches x B sentences of T frames resident in HBM, handed to pytorch-kaldi_amd.core.run_nn_dp with a
+    chunk cfg on disk - batch assembly (the zero-padding gather), forward_model, backward, fused optimizers, ONE host
+    sync per chunk, checkpoint + .info written afterwards.  Two chunks: the first warms up, the second is reported from
+    its own .info file (`elapsed_time_chunk`, which brackets the batch loop exactly as the reference's does)."""
+    import configparser
+    import tempfile
+
+    import numpy as np
+
+    core = importlib.import_module("pytorch-kaldi_amd.core")
+    R = importlib.import_module("pytorch-kaldi_amd.recipes")
+    F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+    F_.set_precision(args.prec)
+    rcp = R.recipe(args.recipe, n_lay=args.layers)
+    T, B = args.T, args.B
+    n_snt = n_batches * B
+    g = torch.Generator().manual_seed(99)
+    nlab = 2 if rcp["n_mono"] else 1
+    data = torch.randn(n_snt * T, rcp["nfea"] + nlab, generator=g)
+    data[:, rcp["nfea"]] = torch.randint(0, rcp["n_cd"], (n_snt * T,), generator=g).float()
+    if rcp["n_mono"]:
+        data[:, rcp["nfea"] + 1] = torch.randint(0, rcp["n_mono"], (n_snt * T,), generator=g).float()
+    end = np.arange(1, n_snt + 1, dtype=np.int64) * T  # equal-length sentences: the metric's (T, B) batch every time
+    names = ["utt%05d" % i for i in range(n_snt)]
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = configparser.ConfigParser()
+        for sec in rcp["cfg"].sections():
+            cfg[sec] = dict(rcp["cfg"][sec])
+        cfg["exp"].update({"seed": "1234", "out_folder": tmp, "save_gpumem": "False", "production": "False",
+                           "out_info": os.path.join(tmp, "chunk.info")})
+        cfg["model"] = {"model": "\n".join(rcp["model"])}
+        cfg["forward"] = {"forward_out": "out_dnn2", "normalize_posteriors": "False", "normalize_with_counts_from": "none",
+                          "require_decoding": "False"}
+        cfg["batches"] = {"batch_size_train": str(B), "batch_size_valid": str(B)}
+        path = os.path.join(tmp, "chunk.cfg")
+        with open(path, "w") as f:
+            cfg.write(f)
+
+        def reader(cfg_file, is_production, shared_list, output_folder):
+            return None  # no next chunk
+
+        fea_dict = {k: list(v) for k, v in rcp["fea_dict"].items()}
+        times = []
+        for rep in range(2):
+            core.run_nn_dp(names, data.cuda(), end, {k: list(v) for k, v in fea_dict.items()}, rcp["lab_dict"],
+                           rcp["arch_dict"], path, False, path, reader=reader)
+            info = configparser.ConfigParser()
+            info.read(os.path.join(tmp, "chunk.info"))
+            times.append(float(info["results"]["elapsed_time_chunk"]))
+        dt = times[-1]
+        out = {"value": round(n_batches * T * B / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_batches, 3),
+               "batches": n_batches, "elapsed_time_chunk_s": round(dt, 4), "warmup_chunk_s": round(times[0], 4),
+               "note": "pytorch-kaldi_amd.core.run_nn_dp on a resident synthetic chunk (%d sentences of %d frames): batch "
+                       "assembly + forward_model + backward + fused optimizers, one host sync per chunk; the time is the "
+                       ".info file's elapsed_time_chunk (core.py:567, 701)" % (n_snt, T)}
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no rendezvous in the environment: start N ranks of this very command under
+    torch.distributed.run (one process per GPU, RCCL) and pass their exit code on.  Under the driver's own
+    `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE is set and this is skipped."""
+    import socket
+    import subprocess
+
+    if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus and not args.launch_check:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible\n" % (args.gpus, torch.cuda.device_count()))
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def launch_check(rank, world):
+    """Rendezvous test (CPU: gloo): every rank contributes its rank + 1 to one all-reduce."""
+    import torch.distributed as dist
+
+    t = torch.tensor([float(rank + 1)], device="cuda" if torch.cuda.is_available() else "cpu")
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "launch_check": True, "sum_of_ranks_plus_1": float(t)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def sub_record(rec, extra=()):
+    keep = ("dtype", "ms_per_step", "value", "unit", "steps", "warmup", "roofline", "entry_points_ms_per_step",
+            "whole_step_tflops", "regions_ms_per_step") + tuple(extra)
+    return {k: rec[k] for k in keep if k in rec}
 
 
 def main():
     import copy
 
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        self_launch(args)
+    if args.cpu_full:
+        rec = cpu_baseline(args, args.recipe, full=True)
+        rec["recipe"] = args.recipe
+        print(json.dumps(rec), flush=True)
+        return
     DP = importlib.import_module("pytorch-kaldi_amd.dp")
+    if args.force_reducer and "WORLD_SIZE" not in os.environ:
+        import socket
+        import torch.distributed as dist
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]))
+        s_.close()
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     rank, world, _ = DP.init_from_env()
+    if args.launch_check:
+        launch_check(rank, world)
+        return
     if world != args.gpus and world > 1:
         args.gpus = world
     out, tr = measure(args, rank, world, args.steps, args.warmup)
@@ -459,39 +648,65 @@ def main():
                                     "region overlaps the weight-gradient GEMMs with the recurrences on a second stream")
     release(tr)
     if rank == 0 and world == 1 and headline and not args.no_extras:
+        F_ = importlib.import_module("pytorch-kaldi_amd.functional")
         # (1) the 1e-4-grade mode of the SAME workload: exact-fp32 MFMA, what tests/test_gpu_parity.py grades
         a2 = copy.copy(args)
-        a2.prec = "fp32"
+        a2.prec, a2.repeats = "fp32", 1
         rec, tr2 = measure(a2, rank, world, 3, 1)
-        out["parity_mode"] = {k: rec[k] for k in ("dtype", "ms_per_step", "value", "unit", "steps", "warmup", "roofline",
-                                                  "entry_points_ms_per_step", "whole_step_tflops")}
+        out["parity_mode"] = sub_record(rec)
         out["parity_mode"]["note"] = ("same network, batch and sequence length in the engine's exact-fp32 mode (fp32 MFMA, "
                                       "157.3 TFLOP/s peak): the mode the 1e-4 parity tests run in")
         release(tr2)
-        # (2) the other BASELINE configurations, batch 128 per GPU
+        # (2) the same workload through the chunk loop, and as the reference's own caller would drive these classes
+        try:
+            out["through_run_nn"] = through_run_nn(args)
+        except Exception as e:
+            out["through_run_nn"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            a4 = copy.copy(args)
+            a4.torch_optim, a4.unfused_cost, a4.sync_every_step, a4.repeats = True, True, True, 1
+            rec, tr4 = measure(a4, rank, world, 30, 3)
+            out["reference_caller"] = sub_record(rec, ("config",))
+            out["reference_caller"]["note"] = ("what a recipe gets that ONLY switches arch_library: torch.optim optimizers "
+                                               "(utils.py:2106-2164), the cost through nn.NLLLoss on the log-posteriors "
+                                               "(utils.py:2361), one loss read-back per batch (core.py:689)")
+            release(tr4)
+        except Exception as e:
+            out["reference_caller"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            F_.settings.fused_cost = True
+        # (3) the other BASELINE configurations, batch 128 per GPU: perf mode (median of 3 regions) and parity mode
         out["other_configs"] = []
         for recipe, steps, warmup in OTHER_CONFIGS:
             a3 = copy.copy(args)
-            a3.recipe, a3.prec = recipe, "bf16"
+            a3.recipe, a3.prec, a3.repeats = recipe, "bf16", 3
             try:
                 rec, tr3 = measure(a3, rank, world, steps, warmup)
-                out["other_configs"].append({"recipe": recipe, "config": rec["config"], "dtype": rec["dtype"],
-                                             "ms_per_step": rec["ms_per_step"], "value": rec["value"], "unit":
-                                             "frames/s" if tr3.rcp["seq"] or recipe == "timit_mlp" else "chunks/s",
-                                             "steps": steps, "warmup": warmup, "roofline": rec["roofline"],
-                                             "entry_points_ms_per_step": dict(list(rec["entry_points_ms_per_step"].items())[:4])})
+                ent = {"recipe": recipe, "config": rec["config"], "dtype": rec["dtype"],
+                       "ms_per_step": rec["ms_per_step"], "value": rec["value"], "unit":
+                       "frames/s" if tr3.rcp["seq"] or recipe == "timit_mlp" else "chunks/s",
+                       "steps": steps, "warmup": warmup, "regions_ms_per_step": rec.get("regions_ms_per_step"),
+                       "roofline": rec["roofline"],
+                       "entry_points_ms_per_step": dict(list(rec["entry_points_ms_per_step"].items())[:4])}
                 release(tr3)
+                if recipe in ("timit_lstm", "libri_gru"):
+                    a5 = copy.copy(a3)
+                    a5.prec, a5.repeats = "fp32", 1
+                    rec5, tr5 = measure(a5, rank, world, 2, 1)
+                    ent["parity_mode"] = {k: rec5[k] for k in ("dtype", "ms_per_step", "value", "steps", "warmup")}
+                    ent["parity_mode"]["entry_points_ms_per_step"] = dict(list(rec5["entry_points_ms_per_step"].items())[:3])
+                    release(tr5)
+                out["other_configs"].append(ent)
             except Exception as e:  # a recipe that fails must not take the headline line with it
                 out["other_configs"].append({"recipe": recipe, "error": "%s: %s" % (type(e).__name__, e)})
-        F_ = importlib.import_module("pytorch-kaldi_amd.functional")
         F_.set_precision(args.prec)
     if rank == 0:
         log("roofline leg done")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.recipe)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -79,6 +79,11 @@ class GradReducer:
         self.handles = []
         self._hooks = []
         self.active = False
+        # PK_DP_TRACE=1: HIP events at every bucket's hand-over to the all-reduce and around finish(): timeline() then
+        # says how far ahead of the end of backward each bucket left and how much of the exchange finish() still waited for
+        self.trace = os.environ.get("PK_DP_TRACE", "0") == "1"
+        self._ev = []
+        self._timelines = []
         if self.world == 1 and not force:
             return
         self.active = True
@@ -120,7 +125,7 @@ class GradReducer:
         # Step 1 therefore only COUNTS the signals per parameter (its buckets are reduced in finish()); from step 2 on
         # a bucket is launched when every parameter that signalled in step 1 has signalled as often again.
         b = {"params": list(params), "flat": flat_slice, "pending": len(params), "fired": False, "seen": {},
-             "expect": None, "got": {}}
+             "expect": None, "got": {}, "idx": len(self.buckets)}
         self.buckets.append(b)
         for p in params:
             self._by_param[id(p)] = b
@@ -160,6 +165,17 @@ class GradReducer:
             if b["pending"] == 0:
                 self._launch(b)
 
+    def _mark(self, tag, stream=None):
+        if self.trace and torch.cuda.is_available():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            self._ev.append((tag, ev))
+
+    def timeline(self):
+        """PK_DP_TRACE=1: per finished step a dict {"buckets": [(index, bytes, ms of the hand-over relative to the start
+        of finish(): negative = while backward was still running)], "exposed_ms": what finish() waited for}."""
+        return list(self._timelines)
+
     def _launch(self, b):
         b["fired"] = True
         if b["flat"] is not None:
@@ -177,9 +193,11 @@ class GradReducer:
             # accumulated so far (main stream); the main stream itself does not wait
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                self._mark(("bucket", b["idx"], buf.numel() * buf.element_size()), side)
                 buf.div_(self.world)
                 h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
+            self._mark(("bucket", b["idx"], buf.numel() * buf.element_size()))
             buf.div_(self.world)
             h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.handles.append((h, b))
@@ -188,6 +206,7 @@ class GradReducer:
         """Call after backward(): completes every bucket and re-arms for the next step."""
         if not self.active:
             return
+        self._mark(("finish",))
         for b in self.buckets:
             if not b["fired"]:
                 self._launch(b)
@@ -206,6 +225,14 @@ class GradReducer:
                         p.grad.copy_(buf[o:o + n].view_as(p))
                     o += n
         self.handles = []
+        if self.trace and self._ev:
+            self._mark(("done",))
+            torch.cuda.current_stream().synchronize()  # (tracing only: the events are read back per step)
+            t0 = next(ev for tag, ev in self._ev if tag[0] == "finish")
+            rec = {"buckets": [(tag[1], tag[2], round(t0.elapsed_time(ev), 3)) for tag, ev in self._ev if tag[0] == "bucket"],
+                   "exposed_ms": round(t0.elapsed_time(self._ev[-1][1]), 3)}
+            self._timelines.append(rec)
+            self._ev = []
         for b in self.buckets:
             if b["expect"] is None:
                 b["expect"] = dict(b["seen"])

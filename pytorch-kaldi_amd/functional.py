@@ -47,6 +47,10 @@ class _Settings:
         self.side_late = os.environ.get("PK_SIDE_LATE", "1") != "0"
         # ... and size their split-K grids for the CUs that recurrence leaves free (0 = for the whole device)
         self.side_cus = os.environ.get("PK_SIDE_CUS", "0") != "0"
+        # perf mode: a cost_nll line directly behind a fused output layer is computed by head_nll (one pass, no dense
+        # one-hot gradient); 0 = through the caller's nn.NLLLoss on the log-posteriors, which is what the reference's
+        # own forward_model does with this package's classes (utils.py:2361)
+        self.fused_cost = os.environ.get("PK_FUSED_COST", "1") != "0"
         assert self.precision in PREC, self.precision
         assert self.rec_algo in ("auto", "stepwise", "persistent"), self.rec_algo
 

@@ -144,8 +144,8 @@ def forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out
             if to_do != "forward":
                 y, lab, cost = flat(outs[inp1]), labels(inp2), costs[out_name]
                 fused = None
-                if (type(cost) is nn.NLLLoss and cost.weight is None and cost.reduction == "mean"
-                        and getattr(y, "_pk_head", None) is not None):
+                if (F_.settings.fused_cost and type(cost) is nn.NLLLoss and cost.weight is None
+                        and cost.reduction == "mean" and getattr(y, "_pk_head", None) is not None):
                     # perf-mode output layer: the cost goes straight behind the head's inputs (functional.HeadNllFn);
                     # the same pass counts the frame errors a cost_err line on the same pair asks for
                     fused = F_.head_nll(y, lab, cost.ignore_index)

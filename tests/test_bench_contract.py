@@ -63,3 +63,20 @@ def test_round2_line_carries_the_parity_mode_and_every_baseline_configuration():
     r = d["roofline"]
     assert r["dependent_steps_per_launch"] == 500 and 0 < r["latency_frac"] < 1 and 0 < r["structure_frac"] <= 1
     assert "r02_pmc_traffic" in r["traffic_source"]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no rendezvous in the environment re-executes itself under torch.distributed.run
+    with N ranks (here on CPU over gloo; on a GPU node the same path gives N RCCL ranks): rank 0 reports n_gpus = N and
+    an all-reduce over all ranks' (rank + 1)."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["sum_of_ranks_plus_1"] == 3.0

@@ -93,3 +93,38 @@ def test_one_rank_rccl_communicator_runs_the_bucket_path(tmp_path, prec, overlap
         outs[solo] = torch.load(out)["params"]
     for k in outs["plain"]:
         assert torch.equal(outs["plain"][k], outs["nccl"][k]), k
+
+
+def test_benchmarked_step_with_the_reducer_forced_on_for_50_steps(tmp_path):
+    """The FULL benchmarked workload (Li-GRU 5 x 550, T = 500, B = 128, bf16) for 50 steps with the data-parallel path
+    forced on over a one-rank RCCL communicator: 8 MB buckets of the flat gradient buffer handed to async all_reduce from
+    the side stream, behind the weight-gradient GEMMs, while the persistent recurrences of the lower layers spin on
+    their exchange buffers.  A one-rank sum is the identity, so every one of the 50 losses must equal the plain run's
+    bit for bit; a persistent kernel that lost its co-residency to an RCCL kernel would show up as a spin time-out
+    (bench.py raises on the error word) or as a different loss."""
+    import json
+
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    losses = {}
+    for mode in ("plain", "forced"):
+        out = str(tmp_path / (mode + ".json"))
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PK_DP_TRACE="1" if mode == "forced" else "0")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, bench, "--steps", "50", "--warmup", "2", "--no-extras", "--no-cpu-baseline", "--dump-losses", out]
+        if mode == "forced":
+            cmd.append("--force-reducer")
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-4000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        losses[mode] = json.load(open(out))
+        if mode == "forced":
+            assert "forced on one rank" in line["config"]["reducer"]
+            tl = line["allreduce_timeline"]
+            early = [b for step in tl for b in step["buckets"] if b[2] < 0]
+            print("forced reducer: %.2f ms/step; buckets handed over before the end of backward: %d of %d; finish() "
+                  "waited %.3f ms" % (line["ms_per_step"], len(early), sum(len(s["buckets"]) for s in tl), tl[-1]["exposed_ms"]))
+            assert early, "no bucket left before the end of backward: the overlap is not happening"
+        else:
+            print("plain: %.2f ms/step" % line["ms_per_step"])
+    assert len(losses["plain"]) == 50 and losses["plain"] == losses["forced"]

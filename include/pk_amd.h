@@ -317,6 +317,9 @@ void pk_persist_error_reset(void);
 /* ---- self tests (tests/ only): MFMA fragment-layout check on the device.
  * Writes 0 to *h_bad_count if every layout assumption holds. */
 int pk_selftest_mfma(void* stream, int* h_bad_count);
+/* v_permlane16_swap_b32 lane mapping the third-generation persistent recurrences rely on when they assemble a 16-byte
+ * publish chunk from two lanes (pk_rec_persist3.hip) */
+int pk_selftest_permlane(void* stream, int* h_bad_count);
 
 /* ---- chunk loader pieces (next row): binary Kaldi matrix tables and the whole-chunk transforms
  * of data_io.load_chunk.  Host memory; plain files (the reference reads through Kaldi pipes, which stay outside).

@@ -385,6 +385,40 @@ class _DropoutTap:
             h.remove()
 
 
+class _DecisionTap:
+    """The discrete decisions of the feed-forward stacks in the (unmodified) reference run, recorded by forward hooks:
+    ReLU patterns (input > 0) of every nn.ReLU inside MLP / CNN / SincNet modules, and the arg-max offsets of the
+    max-pools of the conv stacks (F.max_pool1d is a functional call in the reference: the hook sits on the conv module
+    and repeats the pooling on the tensor the reference pooled, with return_indices).  A second implementation given
+    these differentiates the same piecewise-linear function (extended to pooling)."""
+
+    def __init__(self, nets):
+        self.relu, self.pool, self._hooks, self._nets = [], [], [], nets
+
+    def __enter__(self):
+        for an, net in self._nets.items():
+            cls = type(net).__name__
+            if cls not in ("MLP", "CNN", "SincNet"):
+                continue
+            for i, mod in enumerate(net.act):
+                if isinstance(mod, torch.nn.ReLU):
+                    self._hooks.append(mod.register_forward_hook(
+                        lambda m, inp, out, tag="%s/act.%d" % (an, i): self.relu.append((tag, (inp[0].detach() > 0)))))
+            if cls in ("CNN", "SincNet"):
+                pools = net.sinc_max_pool_len if cls == "SincNet" else net.cnn_max_pool_len
+                for i, mod in enumerate(net.conv):
+                    def hook(m, inp, out, tag="%s/conv.%d" % (an, i), pool=int(pools[i])):
+                        _, idx = torch.nn.functional.max_pool1d(out.detach(), pool, return_indices=True)
+                        base = torch.arange(idx.shape[-1]) * pool
+                        self.pool.append((tag, pool, (idx - base).to(torch.uint8)))
+                    self._hooks.append(mod.register_forward_hook(hook))
+        return self
+
+    def __exit__(self, *exc):
+        for h in self._hooks:
+            h.remove()
+
+
 def recipe_scale_case(name, cfg_rel, seed, T, B, nfea, fea_name, n_cd, n_mono, x_scale=1.0, out_cap=65536):
     """Config-scale goldens of the other BASELINE configurations: a SHIPPED cfg file, unscaled, through the reference's
     own utils.model_init / forward_model + loss_final.backward() (what core.run_nn does per batch, core.py:616-634).
@@ -435,7 +469,7 @@ def recipe_scale_case(name, cfg_rel, seed, T, B, nfea, fea_name, n_cd, n_mono, x
                 arrays["init_ck/%s/%s" % (n, k)] = np.concatenate(([float(v.double().norm())], _projections(v, 7)))
     torch.manual_seed(seed + 3)
     Tm, Bm = (T, B) if seq else (B, 1)  # forward_model's max_len / batch_size only reshape (utils.py:2323-2337)
-    with _MaskTap() as tap, _DropoutTap(nns) as dtap:
+    with _MaskTap() as tap, _DropoutTap(nns) as dtap, _DecisionTap(nns) as dec:
         outs = ref_utils.forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out_dict,
                                        Tm, Bm, "train", [])
     outs["loss_final"].backward()
@@ -460,9 +494,16 @@ def recipe_scale_case(name, cfg_rel, seed, T, B, nfea, fea_name, n_cd, n_mono, x
     for i, m in enumerate(dtap.masks):  # bit-packed, in call order; shapes and owners in the meta block
         arrays["dmask/%d" % i] = np.packbits(m.numpy().reshape(-1))
         dshapes.append([dtap.tags[i], list(m.shape)])
+    relus, pools = [], []
+    for i, (tag, pat) in enumerate(dec.relu):  # call order; bit-packed
+        arrays["relu/%d" % i] = np.packbits(pat.numpy().reshape(-1))
+        relus.append([tag, list(pat.shape)])
+    for i, (tag, pool, off) in enumerate(dec.pool):  # offset of the arg-max inside its pooling window
+        arrays["pool/%d" % i] = off.numpy()
+        pools.append([tag, pool, list(off.shape)])
     opts = {sec: dict(cfg[sec]) for sec in secs}
     meta = {"options": opts, "model": model, "nfea": nfea, "T": T, "B": B, "seed": seed, "n_masks": len(tap.masks),
-            "n_dmasks": len(dtap.masks), "dmasks": dshapes, "strides": meta_ck, "fea_dict": fea_dict, "lab_dict": lab_dict,
+            "n_dmasks": len(dtap.masks), "dmasks": dshapes, "relus": relus, "pools": pools, "strides": meta_ck, "fea_dict": fea_dict, "lab_dict": lab_dict,
             "arch_dict": arch_dict, "n_cd": n_cd, "n_mono": n_mono if uses_mono else 0, "out_keys": out_keys,
             "cfg_file": cfg_rel, "seq": seq}
     _save(name, meta, arrays)

@@ -194,9 +194,17 @@ def _dropout(x, p, training, mask):
 # ----------------------------------------------------------------------------
 # MLP
 # ----------------------------------------------------------------------------
-def mlp_forward(options, sd, x, training=True, drop_masks=None):
+def _act_maybe_forced(name, z, pattern):
+    """activation(name, z), differentiated on another run's ReLU pattern when one is given (see _act_kink_forced)."""
+    if pattern is not None and name == "relu":
+        return _act_kink_forced(name, z, pattern.reshape(z.shape))
+    return activation(name, z)
+
+
+def mlp_forward(options, sd, x, training=True, drop_masks=None, kinks=None):
     """neural_networks.py:126-150.  ``drop_masks[i]`` (already scaled by
-    1/(1-p)) replaces nn.Dropout of layer i when given."""
+    1/(1-p)) replaces nn.Dropout of layer i when given; ``kinks[i]``: the ReLU pattern
+    (z > 0) of another run of layer i (kink-forced derivative, test mode)."""
     lay = _ints(_opt(options, "dnn_lay"))
     drop = _floats(_opt(options, "dnn_drop"))
     use_bn = _bools(_opt(options, "dnn_use_batchnorm"))
@@ -212,7 +220,7 @@ def mlp_forward(options, sd, x, training=True, drop_masks=None):
             z = layer_norm(z, sd["ln.%d.gamma" % i], sd["ln.%d.beta" % i])
         if use_bn[i]:
             z = batch_norm(z, sd, "bn.%d" % i, training)
-        z = activation(acts[i], z)
+        z = _act_maybe_forced(acts[i], z, None if kinks is None else kinks[i])
         m = None if drop_masks is None else drop_masks[i]
         x = _dropout(z, drop[i], training, m)
     return x
@@ -399,7 +407,15 @@ def sinc_filters(low_hz_, band_hz_, kernel_size, sample_rate, min_low_hz, min_ba
     return (bp * window).view(low_hz_.shape[0], 1, K)
 
 
-def conv_stack_forward(kind, options, sd, x, training=True, drop_masks=None):
+def _max_pool(v, pool, forced_idx):
+    """F.max_pool1d(v, pool); with ``forced_idx`` (another run's arg-max positions, absolute indices into v's last
+    axis) the pooled value is gathered from THOSE positions, so that both runs route the gradient identically."""
+    if forced_idx is None:
+        return F.max_pool1d(v, pool)
+    return v.gather(2, forced_idx.to(torch.int64))
+
+
+def conv_stack_forward(kind, options, sd, x, training=True, drop_masks=None, kinks=None, pool_idx=None):
     """CNN.forward (:1530-1556) / SincNet.forward (:1639-1665).  Note the
     reference constructs its BatchNorm1d with eps = pooled length (positional
     slip at :1515-1517 / :1615-1617) and runs the block twice when both
@@ -432,18 +448,22 @@ def conv_stack_forward(kind, options, sd, x, training=True, drop_masks=None):
             return F.conv1d(v, sd["conv.%d.weight" % i], sd["conv.%d.bias" % i])
 
         m = None if drop_masks is None else drop_masks[i]
+        kp = None if kinks is None else kinks[i]
+        pi = None if pool_idx is None else pool_idx[i]
+        if (kp is not None or pi is not None) and use_ln[i] and use_bn[i]:
+            raise ValueError("forced patterns: one pooling / activation call per layer (laynorm XOR batchnorm)")
         x_in = x
         if use_ln[i]:
-            z = F.max_pool1d(conv(x_in), pool[i])
+            z = _max_pool(conv(x_in), pool[i], pi)
             z = layer_norm(z, sd["ln.%d.gamma" % i], sd["ln.%d.beta" % i])
-            x = _dropout(activation(acts[i], z), drop[i], training, m)
+            x = _dropout(_act_maybe_forced(acts[i], z, kp), drop[i], training, m)
         if use_bn[i]:
-            z = F.max_pool1d(conv(x), pool[i])
+            z = _max_pool(conv(x), pool[i], pi)
             z = batch_norm(z, sd, "bn.%d" % i, training, eps=float(pooled))
-            x = _dropout(activation(acts[i], z), drop[i], training, m)
+            x = _dropout(_act_maybe_forced(acts[i], z, kp), drop[i], training, m)
         if not use_bn[i] and not use_ln[i]:
-            z = F.max_pool1d(conv(x_in), pool[i])
-            x = _dropout(activation(acts[i], z), drop[i], training, m)
+            z = _max_pool(conv(x_in), pool[i], pi)
+            x = _dropout(_act_maybe_forced(acts[i], z, kp), drop[i], training, m)
         cur = pooled
     return x.view(batch, -1)
 
@@ -452,14 +472,14 @@ def conv_stack_forward(kind, options, sd, x, training=True, drop_masks=None):
 # dispatcher + forward_model glue
 # ----------------------------------------------------------------------------
 def arch_forward(arch_class, options, sd, x, training=True, to_do="train", drop_masks=None,
-                 index_like_reference=False):
+                 index_like_reference=False, kinks=None, pool_idx=None):
     if arch_class == "MLP":
-        return mlp_forward(options, sd, x, training, drop_masks)
+        return mlp_forward(options, sd, x, training, drop_masks, kinks)
     if arch_class in _REC:
         return recurrent_forward(arch_class, options, sd, x, training, to_do, drop_masks,
-                                 index_like_reference)
+                                 index_like_reference, kinks=kinks)
     if arch_class in ("CNN", "SincNet"):
-        return conv_stack_forward(arch_class, options, sd, x, training, drop_masks)
+        return conv_stack_forward(arch_class, options, sd, x, training, drop_masks, kinks, pool_idx)
     raise ValueError("oracle does not cover arch_class " + arch_class)
 
 
@@ -479,7 +499,7 @@ def two_head_loss(rec_out, sd_cd, opt_cd, sd_mono, opt_mono, lab_cd, lab_mono, m
 
 
 def recipe_forward(model, options, arch_dict, sds, inp, fea_dict, lab_dict, rec_masks=None, drop_masks=None,
-                   kinks=None, training=True, to_do="train"):
+                   kinks=None, training=True, to_do="train", relu_patterns=None, pool_idx=None):
     """A whole [model] section on one batch, as utils.forward_model evaluates it (utils.py:2296-2420), over this
     oracle's arch functions - the generic form of two_head_loss, for the shipped recipes of the other BASELINE
     configurations (LSTM / GRU / SincNet + MLP / MLP).
@@ -490,6 +510,9 @@ def recipe_forward(model, options, arch_dict, sds, inp, fea_dict, lab_dict, rec_
     rec_masks  recurrent drop masks, consumed layer by layer in call order (torch.bernoulli tap of the reference run)
     drop_masks {"<arch>/drop.<i>": 0/1 mask} of the nn.Dropout modules (unscaled; scaled by 1/(1-p) here)
     kinks      per-layer ReLU patterns of the FIRST recurrent architecture (kink-forced mode)
+    relu_patterns {"<arch>/act.<i>": bool tensor} ReLU patterns of feed-forward layers (MLP / CNN / SincNet), and
+    pool_idx   {"<arch>/conv.<i>": arg-max positions} of the max-pools of conv stacks - another run's discrete
+               decisions, so that both runs differentiate the same piecewise-linear function (test mode)
     -> dict of every named result (out_*, loss_*, err_*)
     """
     import re
@@ -533,7 +556,13 @@ def recipe_forward(model, options, arch_dict, sds, inp, fea_dict, lab_dict, rec_
                     for i, p in enumerate(drops):
                         mk = drop_masks.get("%s/drop.%d" % (name, i))
                         dm.append(None if mk is None else mk.to(x.dtype) / (1.0 - p))
-                outs[out_name] = arch_forward(cls, o, sds[name], x, training, to_do, dm)
+                n_l = len(drops)
+                kp = pi = None
+                if relu_patterns is not None and any(("%s/act.%d" % (name, i)) in relu_patterns for i in range(n_l)):
+                    kp = [relu_patterns.get("%s/act.%d" % (name, i)) for i in range(n_l)]
+                if pool_idx is not None and cls != "MLP" and any(("%s/conv.%d" % (name, i)) in pool_idx for i in range(n_l)):
+                    pi = [pool_idx.get("%s/conv.%d" % (name, i)) for i in range(n_l)]
+                outs[out_name] = arch_forward(cls, o, sds[name], x, training, to_do, dm, kinks=kp, pool_idx=pi)
         elif op == "cost_nll":
             outs[out_name] = F.nll_loss(flat(outs[a]), labels(b))
         elif op == "cost_err":

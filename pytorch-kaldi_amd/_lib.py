@@ -100,6 +100,7 @@ SIGNATURES = {
     "pk_persist_error_count": (ctypes.c_uint, []),
     "pk_persist_error_reset": (None, []),
     "pk_selftest_mfma": (c_int, [P, ctypes.POINTER(c_int)]),
+    "pk_selftest_permlane": (c_int, [P, ctypes.POINTER(c_int)]),
 }
 
 
@@ -173,7 +174,7 @@ class _TimedLib:
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
         sig = SIGNATURES.get(name)
-        if sig is None or not sig[1] or sig[1][0] is not P or name in ("pk_selftest_mfma",):
+        if sig is None or not sig[1] or sig[1][0] is not P or name in ("pk_selftest_mfma", "pk_selftest_permlane"):
             return fn
         prof = self._prof
 

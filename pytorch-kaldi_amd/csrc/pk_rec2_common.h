@@ -290,7 +290,7 @@ struct BoolC {  // (an int: 0 = no edge, 1 = even-H edge in 8-byte halves, 2 = o
 // host-side plumbing shared by both translation units (defined in pk_rec_persist2.hip)
 int pk_rec2_make_plan(int R, int H, Plan2& pl);
 int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidir, int H);
-int pk_rec2_host_setup(R2Args& a, bool backward);                 // error word, trash page, handshake table, tuning knobs
+int pk_rec2_host_setup(R2Args& a, bool backward, int cell);                 // error word, trash page, handshake table, tuning knobs
 int pk_rec2_reset_handshake(hipStream_t st);       // before every launch
 // The clusters of a persistent launch exchange h_t with each other every step: every workgroup of the grid has to be
 // resident at the same time.  Checks the grid against what the device can hold (occupancy query for this kernel, block
@@ -298,6 +298,9 @@ int pk_rec2_reset_handshake(hipStream_t st);       // before every launch
 // ending in bounded-spin time-outs.  (Kernels of OTHER streams or processes can still delay a workgroup's start; that
 // only costs time: every spin is bounded at ~10 ms and reported.)
 int pk_rec2_check_residency(const void* kernel, int threads, size_t lds, int grid, const char* who);
+// third generation (pk_rec_persist3.hip: swapped MFMA operands, no LDS patches): liGRU / RNN unless PK_REC_GEN=2
+int pk_rec3_covers(int cell);
+int pk_rec3_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act, bool backward, bool traced);
 // eight-wave LSTM kernels (pk_rec_persist2_lstm.hip): on unless PK_LSTM_WAVES=4; the launch loop over pl.launches
 int pk_rec2l_enabled();
 int pk_rec2l_launch(hipStream_t st, R2Args& a, const Plan2& pl, int act, bool backward);

@@ -616,7 +616,7 @@ int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidi
 // while the sentinel test was expensive that cost ~2300 clocks and 6 units were best (re-polls 0.4 -> 0.04 per step);
 // with the dword-level test a re-poll is cheap and the DELAY sweep of tools/trace_rec2.py (Li-GRU, BASELINE geometry) is
 // flat between 0 and 2 units (forward 5160-5200, backward 5750-5870 clocks per step) and rises beyond.
-static int default_poll_delay(bool backward) {
+static int default_poll_delay(bool backward, int cell) {
     static int env[2] = {-2, -2};
     int& e = env[backward ? 1 : 0];
     if (e == -2) {
@@ -624,16 +624,21 @@ static int default_poll_delay(bool backward) {
         e = v ? atoi(v) : -1;
     }
     if (e >= 0) return e;
-    // (end of round 2, 16 clusters + self-filling exchange, whole training step on one box: backward 1 -> 18.47 ms,
-    // 0 -> 18.36, 2 -> 18.24; forward 1 vs 2: 18.45 vs 18.47)
+    // Per cell and pass.  Li-GRU (end of round 2, 16 clusters + self-filling exchange, whole training step on one box):
+    // backward 1 -> 18.47 ms, 0 -> 18.36, 2 -> 18.24; forward 1 vs 2: 18.45 vs 18.47.  The eight-wave LSTM backward polls
+    // from TWO waves per SIMD whose helper wave is delayed separately (PK_LSTM_HELPER_DELAY): any idle time in front of
+    // its first poll only delays the hand-over - round 3, timit_lstm step on one box, two rounds each: 0 -> 26.5 / 26.5 ms,
+    // 1 -> 40.8 / 36.6, 2 -> 33.9 / 36.0, 3 -> 35.2 / 39.7 (the round-2 default of 2 for every cell is what made the
+    // driver's LSTM line 33.2 ms against the 26.7 ms measured before that commit).
+    if (backward && cell == PK_CELL_LSTM) return 0;
     return 2;
 }
 
-int pk_rec2_host_setup(R2Args& a, bool backward) {
+int pk_rec2_host_setup(R2Args& a, bool backward, int cell) {
     int rc = ensure_err2();
     if (rc) return rc;
     a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe;
-    a.trash = g2_trash; a.poll_delay = g2_poll_delay >= 0 ? g2_poll_delay : default_poll_delay(backward);
+    a.trash = g2_trash; a.poll_delay = g2_poll_delay >= 0 ? g2_poll_delay : default_poll_delay(backward, cell);
     a.helper_delay = 0;
     a.empty_step = g2_empty_step;
     a.self_fill = 0;
@@ -727,7 +732,7 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.P = P; a.pscale = pscale; a.pshift = pshift; a.U = U; a.mask = mask; a.mask_scalar = mask_scalar;
     a.Y = Y; a.S = S; a.Yb = (unsigned short*)Yb; a.Xb = nullptr; a.Ypitch = (int)y_pitch;
     a.dY = nullptr; a.dP2 = nullptr; a.dGb = nullptr; a.Gpitch = 0;
-    rc = pk_rec2_host_setup(a, false);
+    rc = pk_rec2_host_setup(a, false, cell);
     if (rc) return rc;
     // the bf16 layer output is the mailbox: it must hold the sentinel wherever a poll can arrive before its data.
     // prefilled: 1 = the caller filled it, 2 = fill it on the way if this kernel can (pk_rec_self_fill), 0 = fill here
@@ -735,6 +740,7 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.self_fill = prefilled == 2 ? 1 : 0;
     if (prefilled != 1 && !a.self_fill) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     if (lstm8) return pk_rec2l_launch(st, a, pl, act, false);
+    if (pk_rec3_covers(cell)) return pk_rec3_launch(st, a, pl, cell, act, false, traced(cell, act));
     const int G = pk_cell_gates(cell);
     const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024 + 512) + 16;
     {   // dynamic LDS above the 64 KB default needs the opt-in (exact size: the kernels also hold a little static LDS)
@@ -778,12 +784,13 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.P = nullptr; a.pscale = nullptr; a.pshift = nullptr; a.U = U; a.mask = mask; a.mask_scalar = mask_scalar;
     a.Y = const_cast<float*>(Y); a.S = const_cast<float*>(S); a.Yb = nullptr; a.Xb = nullptr; a.Ypitch = 0;
     a.dY = dY; a.dP2 = dP2; a.dGb = (unsigned short*)dGb; a.Gpitch = (int)g_pitch;
-    rc = pk_rec2_host_setup(a, true);
+    rc = pk_rec2_host_setup(a, true, cell);
     if (rc) return rc;
     const bool lstm8 = cell == PK_CELL_LSTM && pk_rec2l_enabled();
     a.self_fill = prefilled == 2 ? 1 : 0;
     if (prefilled != 1 && !a.self_fill) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
     if (lstm8) return pk_rec2l_launch(st, a, pl, act, true);
+    if (pk_rec3_covers(cell)) return pk_rec3_launch(st, a, pl, cell, act, true, traced(cell, act));
     const size_t atile = (size_t)RMAX * pk_r2_lda_bf16(G * KPAD) * 2;
     const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0);
     const size_t lds = (2 * atile > 96 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(nin + G) * 1024 + (size_t)G * 512) + 16;

@@ -486,7 +486,7 @@ int pk_rec2f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     a.Y = Y; a.S = S; a.Yb = nullptr; a.Xb = nullptr; a.Ypitch = (int)y_pitch;
     a.dY = nullptr; a.dP2 = nullptr; a.dGb = nullptr; a.Gpitch = 0;
     a.Yx = Yx; a.dGx = nullptr;
-    rc = pk_rec2_host_setup(a, false);
+    rc = pk_rec2_host_setup(a, false, cell);
     if (rc) return rc;
     PK_CHECK_HIP(hipMemsetAsync(Yx, 0xFF, (size_t)T * B * y_pitch * 4, st));  // the mailbox: every dword "not written yet"
     const int G = pk_cell_gates(cell);
@@ -524,7 +524,7 @@ int pk_rec2f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     a.Y = const_cast<float*>(Y); a.S = const_cast<float*>(S); a.Yb = nullptr; a.Xb = nullptr; a.Ypitch = 0;
     a.dY = dY; a.dP2 = dP2; a.dGb = nullptr; a.Gpitch = (int)g_pitch;
     a.Yx = nullptr; a.dGx = dGx;
-    rc = pk_rec2_host_setup(a, true);
+    rc = pk_rec2_host_setup(a, true, cell);
     if (rc) return rc;
     PK_CHECK_HIP(hipMemsetAsync(dGx, 0xFF, (size_t)ndir * T * B * g_pitch * 4, st));
     const size_t atile = (size_t)RMAX * pk_r2_lda_f32(G * KPAD) * 4;

@@ -582,7 +582,7 @@ extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, 
     a.P = P; a.pscale = pscale; a.pshift = pshift; a.U = U; a.mask = mask; a.mask_scalar = mask_scalar;
     a.Y = Y; a.S = S; a.Yb = (unsigned short*)Yb; a.Xb = (unsigned short*)Xb; a.Ypitch = (int)y_pitch;
     a.dY = nullptr; a.dP2 = nullptr; a.dGb = nullptr; a.Gpitch = 0;
-    rc = pk_rec2_host_setup(a, false);
+    rc = pk_rec2_host_setup(a, false, cell);
     if (rc) return rc;
     a.self_fill = prefilled == 2 ? 1 : 0;  // (prefilled: see pk_rec_fwd_bf16)
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
@@ -626,7 +626,7 @@ extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, 
     a.P = nullptr; a.pscale = nullptr; a.pshift = nullptr; a.U = U; a.mask = mask; a.mask_scalar = mask_scalar;
     a.Y = const_cast<float*>(Y); a.S = const_cast<float*>(S); a.Yb = nullptr; a.Xb = nullptr; a.Ypitch = 0;
     a.dY = dY; a.dP2 = nullptr; a.dGb = (unsigned short*)dGb; a.Gpitch = (int)g_pitch;
-    rc = pk_rec2_host_setup(a, true);
+    rc = pk_rec2_host_setup(a, true, cell);
     if (rc) return rc;
     a.self_fill = prefilled == 2 ? 1 : 0;
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));

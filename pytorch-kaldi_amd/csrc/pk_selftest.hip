@@ -114,3 +114,32 @@ extern "C" int pk_selftest_mfma(void* stream, int* h_bad_count) {
     *h_bad_count = bad;
     return 0;
 }
+
+// v_permlane16_swap_b32 as the third-generation recurrences use it (pk_rec_persist3.hip::pack_chunk): with both
+// operands = x, the lanes of the even 16-lane rows read (x of lane l, x of lane l + 16).
+namespace {
+__global__ void permlane_swap_kernel(unsigned* out) {
+    const unsigned x = 1000u + threadIdx.x;
+    const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    out[threadIdx.x * 2] = r[0];
+    out[threadIdx.x * 2 + 1] = r[1];
+}
+}  // namespace
+
+extern "C" int pk_selftest_permlane(void* stream, int* h_bad_count) {
+    hipStream_t st = pk_stream(stream);
+    unsigned h[128], *d;
+    PK_CHECK_HIP(hipMalloc((void**)&d, sizeof(h)));
+    hipLaunchKernelGGL(permlane_swap_kernel, dim3(1), dim3(64), 0, st, d);
+    PK_LAUNCH_CHECK();
+    PK_CHECK_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st));
+    PK_CHECK_HIP(hipStreamSynchronize(st));
+    (void)hipFree(d);
+    int bad = 0;
+    for (int l = 0; l < 64; ++l) {
+        if (((l >> 4) & 1) != 0) continue;  // the odd rows hold the same pairs again; only the even rows publish
+        if (h[l * 2] != 1000u + l || h[l * 2 + 1] != 1000u + l + 16) ++bad;
+    }
+    *h_bad_count = bad;
+    return 0;
+}

@@ -135,6 +135,23 @@ def set_forced_dropout(masks):
     _Drops.queue = None if masks is None else list(masks)
 
 
+class _Decisions:
+    relu = None    # queue of bool patterns (input > 0) for feed-forward ReLU calls (NormActDropFn), in call order
+    pool = None    # queue of (pool, window-offset uint8 tensors) for conv1d_pool calls, in call order
+    report = None  # [(kind, differing entries, entries)] as the calls consume their patterns
+
+
+def set_forced_decisions(relu=None, pool=None):
+    """Test mode for feed-forward stacks (the counterpart of set_forced_kinks): `relu` = list of bool tensors, the ReLU
+    pattern (pre-activation > 0) of another run for every ReLU call in forward order; `pool` = list of (pool length,
+    uint8 offsets of the arg-max inside its window) for every conv1d_pool call.  Backward then routes gradients through
+    THOSE decisions (forward values are untouched).  Returns the report list; None / None switches it off."""
+    _Decisions.relu = None if relu is None else list(relu)
+    _Decisions.pool = None if pool is None else list(pool)
+    _Decisions.report = []
+    return _Decisions.report
+
+
 def dropout_mask(like, p):
     """The Bernoulli(1-p) / (1-p) mask of one nn.Dropout call on a tensor shaped `like` (device RNG)."""
     if _Drops.queue is not None:
@@ -740,6 +757,11 @@ class NormActDropFn(torch.autograd.Function):
             y = _new(M, N, like=x2)
             _lib.check(lib.pk_affine_act_fwd(_stream(), _p(a), N, M, N, None, None, 0, _p(mask), _p(y), N),
                        "pk_affine_act_fwd")
+        if _Decisions.relu is not None and act == "relu":
+            # test mode: backward takes the ReLU derivative from the saved OUTPUT (a > 0); give it another run's pattern
+            pat = _Decisions.relu.pop(0).to(a.device).reshape(M, N)
+            _Decisions.report.append(("relu", int(((a > 0) != pat).sum()), M * N))
+            a = torch.where(pat, a.clamp_min(1e-30), torch.zeros_like(a))
         ctx.save_for_backward(x2, gamma, mean, var, a, mask, scale)
         ctx.cfg = (use_bn, training, eps, act)
         ctx.in_shape = x.shape
@@ -1366,6 +1388,13 @@ class ConvPoolFn(torch.autograd.Function):
         work = _new(int(lib.pk_conv_fwd_work_floats(Cin, Cout, K)), like=x)
         _lib.check(lib.pk_conv1d_pool_fwd(_stream(), _p(x), _p(w), _p(bias), B, Cin, L, Cout, K, pool, _p(y),
                                           ctypes.c_void_p(arg.data_ptr()), _p(work)), "pk_conv1d_pool_fwd")
+        if _Decisions.pool is not None:
+            # test mode: backward routes dy to another run's arg-max positions (absolute index = window start + offset)
+            fpool, off = _Decisions.pool.pop(0)
+            assert fpool == pool and tuple(off.shape) == (B, Cout, Lp), (fpool, pool, tuple(off.shape), (B, Cout, Lp))
+            forced = (torch.arange(Lp, device=x.device, dtype=torch.int32) * pool)[None, None, :] + off.to(x.device).to(torch.int32)
+            _Decisions.report.append(("pool", int((forced != arg).sum()), arg.numel()))
+            arg = forced.contiguous()
         ctx.save_for_backward(x, w, arg)
         ctx.pool = pool
         ctx.has_bias = bias is not None

@@ -66,20 +66,42 @@ def dropout_masks(g):
     return out
 
 
+def relu_patterns(g):
+    """[(tag "<arch>/act.<i>", bool tensor)] - the reference run's ReLU patterns of the feed-forward stacks, call order."""
+    out = []
+    for i, (tag, shape) in enumerate(g.meta.get("relus", [])):
+        n = int(np.prod(shape))
+        out.append((tag, torch.from_numpy(np.unpackbits(g.arrays["relu/%d" % i])[:n].reshape(shape).astype(bool))))
+    return out
+
+
+def pool_offsets(g):
+    """[(tag "<arch>/conv.<i>", pool length, uint8 offsets of the arg-max inside its pooling window)], call order."""
+    return [(tag, pool, torch.from_numpy(np.array(g.arrays["pool/%d" % i]).reshape(shape)))
+            for i, (tag, pool, shape) in enumerate(g.meta.get("pools", []))]
+
+
 def oracle_params(nns):
     return {n: {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "running" not in k)
                 for k, v in net.state_dict().items()} for n, net in nns.items()}
 
 
-def oracle_run(O, g, sds, emulate=False):
-    """The oracle on the fixture's batch (CPU): outs dict, gradients left in sds."""
+def oracle_run(O, g, sds, emulate=False, forced=False):
+    """The oracle on the fixture's batch (CPU): outs dict, gradients left in sds.  forced: differentiate on the
+    reference run's discrete decisions (ReLU patterns, pooling arg-max) instead of this run's own."""
     import contextlib
 
     m = g.meta
     dm = {tag: mk for tag, mk in dropout_masks(g)}
+    rp = pi = None
+    if forced:
+        rp = {tag: pat for tag, pat in relu_patterns(g)}
+        pi = {}
+        for tag, pool, off in pool_offsets(g):
+            pi[tag] = (torch.arange(off.shape[-1]) * pool)[None, None, :] + off.long()
     with (O.bf16_operands() if emulate else contextlib.nullcontext()):
         outs = O.recipe_forward(m["model"], m["options"], m["arch_dict"], sds, g.t("inp"), m["fea_dict"], m["lab_dict"],
-                                rec_masks=rec_masks(g), drop_masks=dm)
+                                rec_masks=rec_masks(g), drop_masks=dm, relu_patterns=rp or None, pool_idx=pi or None)
         outs["loss_final"].backward()
     return outs
 
@@ -135,5 +157,6 @@ def check_fp32(g, outs, grads_of, tol=1e-4, tol_grad=1e-4):
     return worst
 
 
-__all__ = ["Golden", "RECIPE_CASES", "build", "check_fp32", "ck", "rows", "rec_masks", "dropout_masks", "oracle_params",
+__all__ = ["Golden", "RECIPE_CASES", "build", "check_fp32", "ck", "rows", "rec_masks", "dropout_masks", "relu_patterns",
+           "pool_offsets", "oracle_params",
            "oracle_run", "grad_items", "grad_total"]

@@ -23,6 +23,15 @@ def test_mfma_fragment_layouts():
     assert bad.value == 0
 
 
+def test_permlane16_swap_lane_mapping():
+    """The lane mapping of v_permlane16_swap_b32 the third-generation recurrences build their publish chunks with."""
+    lib = _lib.load()
+    bad = ctypes.c_int(-1)
+    _lib.check(lib.pk_selftest_permlane(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(bad)),
+               "pk_selftest_permlane")
+    assert bad.value == 0
+
+
 def test_single_hip_runtime():
     """libpk_amd.so must bind to the HIP runtime torch already mapped (one runtime per
     process): exactly one libamdhip64 in /proc/self/maps."""

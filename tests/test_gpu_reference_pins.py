@@ -80,6 +80,7 @@ def _restore_mode():
     F_.set_rec_algo("auto")
     F_.set_forced_kinks(None)
     F_.set_forced_dropout(None)
+    F_.set_forced_decisions(None, None)
 
 
 def _two_step(name, got, model, ref, tight, total=None):
@@ -464,6 +465,13 @@ def test_recipe_scale_golden(case, prec):
             rmasks = rmasks[n:]
             restore.append((net, orig))
     F_amd.set_forced_dropout([mk for _, mk in SU.dropout_masks(g)])
+    # the feed-forward stacks differentiate the reference run's own piecewise-linear function: its ReLU patterns and the
+    # arg-max positions of its max-pools (a conv stack's 4 M pooling windows hold a handful of ties at fp32 resolution,
+    # and ONE re-routed element of a 4 M-element layer moves that layer's parameter gradient by 5e-4 of its norm; the
+    # reference's own fp32 gradients sit 1.4e-2 from an fp64 evaluation for the same reason - both measured)
+    relus, pools = SU.relu_patterns(g), SU.pool_offsets(g)
+    decisions = F_amd.set_forced_decisions([pt for _, pt in relus] if relus else None,
+                                           [(pool, off) for _, pool, off in pools] if pools else None)
     inp = g.t("inp").cuda()
     Tm, Bm = (m["T"], m["B"]) if m["seq"] else (m["B"], 1)
     try:
@@ -473,14 +481,22 @@ def test_recipe_scale_golden(case, prec):
         torch.cuda.synchronize()
     finally:
         F_amd.set_forced_dropout(None)
+        F_amd.set_forced_decisions(None, None)
         for net, orig in restore:
             net.forward = orig
     grads_of = lambda name: [(k, q.grad) for k, q in nns[name].named_parameters()]  # noqa: E731
+    flips = {}
+    for kind, diff, total in decisions:
+        d0, t0 = flips.get(kind, (0, 0))
+        flips[kind] = (d0 + diff, t0 + total)
     if prec == "fp32":
         worst = SU.check_fp32(g, outs, grads_of, tol=1e-4, tol_grad=1e-4)
-        print("\n%s [fp32]: worst gradient row-sample error %.2e (%s)" % (case, worst[0], worst[1]))
+        print("\n%s [fp32]: worst gradient row-sample error %.2e (%s); decisions that differed from the reference's "
+              "(differing, of): %s" % (case, worst[0], worst[1], flips))
+        for kind, (diff, total) in flips.items():  # the engine's own decisions differ only where values tie at fp32 resolution
+            assert diff <= 2e-5 * total + 2, (kind, diff, total)
         return
-    oouts = SU.oracle_run(O, g, init, emulate=True)
+    oouts = SU.oracle_run(O, g, init, emulate=True, forced=True)
     st = m["strides"]
     rep = {}
     for k in m["out_keys"]:
@@ -497,5 +513,6 @@ def test_recipe_scale_golden(case, prec):
         frac = float(ref_rows.double().norm()) / ref_ck[0]
         worst = max(worst, _two_step((name, k), SU.rows(gr, s_), SU.rows(init[name][k].grad, s_), ref_rows, TIGHT_GRAD,
                                      gtot * frac), key=lambda t: t[2])
-    print("\n%s [bf16]: outputs (engine-vs-model, model-vs-ref, engine-vs-ref) %s; worst gradient %s"
-          % (case, {k: tuple("%.1e" % x for x in v) for k, v in rep.items()}, tuple("%.1e" % x for x in worst)))
+    print("\n%s [bf16]: outputs (engine-vs-model, model-vs-ref, engine-vs-ref) %s; worst gradient %s; decisions that bf16 "
+          "rounding changed (differing, of): %s"
+          % (case, {k: tuple("%.1e" % x for x in v) for k, v in rep.items()}, tuple("%.1e" % x for x in worst), flips))

@@ -205,3 +205,10 @@ def test_oracle_recipe_scale_golden(case):
     worst = SU.check_fp32(g, outs, lambda name: [(k, v.grad) for k, v in sds[name].items() if v.requires_grad],
                           tol=TOL, tol_grad=5e-5)
     print("\n%s: oracle vs reference, worst gradient row-sample error %.2e (%s)" % (case, worst[0], worst[1]))
+    if g.meta.get("relus") or g.meta.get("pools"):
+        # the forced-decision mode of the oracle (the reference's ReLU patterns / pooling arg-max injected): the oracle's
+        # own decisions ARE the reference's, so forcing must not change a single gradient beyond summation order
+        sds2 = SU.oracle_params(nns)
+        outs2 = SU.oracle_run(O, g, sds2, forced=True)
+        SU.check_fp32(g, outs2, lambda name: [(k, v.grad) for k, v in sds2[name].items() if v.requires_grad], tol=TOL,
+                      tol_grad=5e-5)

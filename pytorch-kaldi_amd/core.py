@@ -30,6 +30,7 @@ import torch
 from . import _lib
 from . import dp as _dp
 from . import functional as F_
+from . import nn as _nn
 from ._lib import PkError
 from .graphs import GraphedStep
 from .optim import fused_optimizer_init
@@ -220,6 +221,7 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
     config = configparser.ConfigParser()
     config.read(cfg_file)
     seed = int(config["exp"]["seed"])
+    _nn.drain_mask_prefetch()  # (PK_MASK_RNG=reference: no helper thread may be drawing while the generator is re-seeded)
     torch.manual_seed(seed)
     random.seed(seed)
     np.random.seed(seed)
@@ -363,6 +365,7 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
     _lib.raise_if_persist_failed()
     F_.raise_if_bad_labels()
     elapsed_time_chunk = time.time() - start_time
+    _nn.drain_mask_prefetch()  # masks drawn ahead for a batch that will not come: back into the generator
     loss_tot = loss_sum / max(N_batches, 1)
     err_tot = err_sum / max(N_batches, 1)
 

@@ -38,6 +38,7 @@ struct R2Args {
     unsigned long long* trace;  // optional [T][8] phase time stamps of (cluster 0, member 0, wave 0); null = off
     int helper_delay;           // eight-wave LSTM kernels: extra s_sleep units before the second wave of a pair polls
     int self_fill;              // 1 = the kernel writes the "not written yet" pattern itself, PK_R2_FILL_AHEAD steps ahead of its publishes
+    int flush_late;             // third generation: 1 = the step's off-chain HBM traffic is issued behind the MFMA block
     int empty_step;             // diagnostics (traced kernels only): skip the MFMA block and the gate math - what is left
                                 // of a step is the hand-off itself (poll, barrier, flush / prefetch issue, publish)
 };
@@ -298,8 +299,8 @@ int pk_rec2_reset_handshake(hipStream_t st);       // before every launch
 // ending in bounded-spin time-outs.  (Kernels of OTHER streams or processes can still delay a workgroup's start; that
 // only costs time: every spin is bounded at ~10 ms and reported.)
 int pk_rec2_check_residency(const void* kernel, int threads, size_t lds, int grid, const char* who);
-// third generation (pk_rec_persist3.hip: swapped MFMA operands, no LDS patches): liGRU / RNN unless PK_REC_GEN=2
-int pk_rec3_covers(int cell);
+// third generation (pk_rec_persist3.hip: swapped MFMA operands): the backward pass of liGRU / RNN by default (PK_REC_GEN*)
+int pk_rec3_covers(int cell, int backward);
 int pk_rec3_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act, bool backward, bool traced);
 // eight-wave LSTM kernels (pk_rec_persist2_lstm.hip): on unless PK_LSTM_WAVES=4; the launch loop over pl.launches
 int pk_rec2l_enabled();

@@ -642,6 +642,15 @@ int pk_rec2_host_setup(R2Args& a, bool backward, int cell) {
     a.helper_delay = 0;
     a.empty_step = g2_empty_step;
     a.self_fill = 0;
+    {   // PK_REC_FLUSH_LATE=1: the third-generation kernels issue a step's output stores / next-step loads behind its MFMA
+        // block instead of right behind the barrier (A/B switch)
+        static int fl = -1;
+        if (fl < 0) {
+            const char* e = getenv("PK_REC_FLUSH_LATE");
+            fl = (e && e[0] == '1') ? 1 : 0;
+        }
+        a.flush_late = fl;
+    }
     return 0;
 }
 int pk_rec2_check_residency(const void* kernel, int threads, size_t lds, int grid, const char* who) {
@@ -740,7 +749,7 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.self_fill = prefilled == 2 ? 1 : 0;
     if (prefilled != 1 && !a.self_fill) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     if (lstm8) return pk_rec2l_launch(st, a, pl, act, false);
-    if (pk_rec3_covers(cell)) return pk_rec3_launch(st, a, pl, cell, act, false, traced(cell, act));
+    if (pk_rec3_covers(cell, 0)) return pk_rec3_launch(st, a, pl, cell, act, false, traced(cell, act));
     const int G = pk_cell_gates(cell);
     const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024 + 512) + 16;
     {   // dynamic LDS above the 64 KB default needs the opt-in (exact size: the kernels also hold a little static LDS)
@@ -790,7 +799,7 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     a.self_fill = prefilled == 2 ? 1 : 0;
     if (prefilled != 1 && !a.self_fill) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
     if (lstm8) return pk_rec2l_launch(st, a, pl, act, true);
-    if (pk_rec3_covers(cell)) return pk_rec3_launch(st, a, pl, cell, act, true, traced(cell, act));
+    if (pk_rec3_covers(cell, 1)) return pk_rec3_launch(st, a, pl, cell, act, true, traced(cell, act));
     const size_t atile = (size_t)RMAX * pk_r2_lda_bf16(G * KPAD) * 2;
     const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0);
     const size_t lds = (2 * atile > 96 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(nin + G) * 1024 + (size_t)G * 512) + 16;

@@ -206,6 +206,90 @@ _REC_SPEC = {
 }
 
 
+class _MaskPrefetcher:
+    """PK_MASK_RNG=reference without the host on the critical path.  The reference draws its drop masks with
+    torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p)) on the global CPU generator (e.g. neural_networks.py:1102-1107):
+    a scalar loop, 5.6 ms per 256 x 550 mask.  The masks do not depend on data - only on the ORDER in which the
+    generator is consumed - so a helper thread draws the NEXT forward call's masks (same shapes as this call's, layer
+    by layer, the very same calls) while the GPU works on this one.  The generator state from before the ahead-of-time
+    draws is kept: if the next call turns out to want other shapes (last batch of a chunk), or somebody else drew from
+    the generator in the meantime (its state differs from the one the helper left), that state is restored and the
+    masks are drawn on the spot - the stream stays exactly the reference's.  Nothing else in the engine's step touches
+    the CPU generator (batch padding uses python's random, nn.Dropout masks the device generator)."""
+
+    live = []  # every prefetcher that may hold ahead-of-time draws (drain_mask_prefetch)
+
+    def __init__(self):
+        _MaskPrefetcher.live.append(self)
+        self._thread = None
+        self._sig = None      # [(rows, H, p)] of the call being prefetched
+        self._masks = None
+        self._state0 = None   # generator state before the ahead-of-time draws
+        self._state1 = None   # ... and after them
+        self._cur = []        # signature of the call in progress
+        self._taken = 0
+
+    @staticmethod
+    def _draw(rows, H, p):
+        return torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p))  # the reference's own call
+
+    def _run(self, sig):
+        self._state0 = torch.get_rng_state()
+        self._masks = [self._draw(*s_) for s_ in sig]
+        self._state1 = torch.get_rng_state()
+
+    def _join(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+
+    def get(self, i, n_lay, rows, H, p):
+        """Mask of layer i (0 .. n_lay - 1, asked for in layer order) of the current forward call."""
+        import threading
+
+        if i == 0:
+            self._cur, self._taken = [], 0
+            self._join()
+            if self._masks is not None and not torch.equal(torch.get_rng_state(), self._state1):
+                self._masks = None  # the generator moved on without us (manual_seed, somebody else's draws): theirs now
+        want = (rows, H, p)
+        self._cur.append(want)
+        if self._masks is not None and self._taken == i and i < len(self._sig) and self._sig[i] == want:
+            m = self._masks[i]
+            self._taken = i + 1
+        else:
+            if self._masks is not None:
+                # other shapes than the ones drawn ahead (last batch of a chunk): give the generator back the draws
+                # nobody will use - rewind, and re-draw the i masks of this call that were used
+                torch.set_rng_state(self._state0)
+                for s_ in self._cur[:-1]:
+                    self._draw(*s_)
+                self._masks = None
+            m = self._draw(*want)
+        if i == n_lay - 1:  # this call is served: draw the next call's masks while the GPU works on this one
+            self._masks = None
+            self._sig = list(self._cur)
+            self._thread = threading.Thread(target=self._run, args=(self._sig,), daemon=True)
+            self._thread.start()
+        return m
+
+    def drain(self):
+        """Un-draw whatever was drawn ahead (before anything else reads the generator: checkpointing its state, a
+        comparison with a reference run)."""
+        self._join()
+        if self._masks is not None and torch.equal(torch.get_rng_state(), self._state1):
+            torch.set_rng_state(self._state0)
+        self._masks = None
+
+
+def drain_mask_prefetch():
+    """Un-draw every mask drawn ahead of time (PK_MASK_RNG=reference) and forget the prefetchers: call before
+    torch.manual_seed / before reading the CPU generator's state (core.run_nn_dp does, at both ends of a chunk)."""
+    for pf in _MaskPrefetcher.live:
+        pf.drain()
+    _MaskPrefetcher.live = []
+
+
 class _Recurrent(nn.Module):
     """Shared body of LSTM / GRU / liGRU / minimalGRU / RNN (neural_networks.py:300-655, 997-1461)."""
 
@@ -282,7 +366,9 @@ class _Recurrent(nn.Module):
         rows = 2 * batch if self.bidir else batch
         if F_.settings.mask_rng == "device":
             return torch.empty(rows, self._lay[i], device=device).bernoulli_(1 - p), 1.0
-        m = torch.bernoulli(torch.Tensor(rows, self._lay[i]).fill_(1 - p))  # the reference's own call
+        if getattr(self, "_prefetch", None) is None or self._prefetch not in _MaskPrefetcher.live:
+            self._prefetch = _MaskPrefetcher()
+        m = self._prefetch.get(i, self._n_lay, rows, self._lay[i], p)  # the reference's own call, a forward call ahead
         return self._to_device_async(i, m, device), 1.0
 
     def _to_device_async(self, i, m, device):

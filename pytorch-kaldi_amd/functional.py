@@ -468,6 +468,22 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class _DxShare:
+    """Several perf-mode output layers on ONE input (the senone and the monophone head both read the last recurrent
+    layer's output): each head's backward produces a full dX (64 000 x 1100 fp32 = 282 MB at the benchmarked shape) and
+    autograd adds them with an element-wise kernel (0.2 ms, 846 MB of traffic).  Instead the first head to run backward
+    allocates dX and every later head's dX GEMM accumulates into it (beta = 1) and returns no gradient of its own.
+    Keyed by the input's identity at forward time; the table is cleared whenever a new forward pass builds heads, i.e.
+    after the backward pass that used it.  PK_HEAD_DX_SHARE=0 switches it off."""
+    on = os.environ.get("PK_HEAD_DX_SHARE", "1") != "0"
+    epoch = 0
+    table = {}  # key -> (epoch, dx tensor)
+
+
+def _dx_share_key(x):
+    return (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()))
+
+
 def _linear_bwd_bf16(ctx, dyb, xb, wb, like):
     """dX and dW of a perf-mode Linear from the bf16 copy of the output gradient (ctx: dims, in_shape, wparam, and
     xseg = (nseg, seglen, segpad) when xb is a re-pitched twin of the input: wb is then the plain-pitch weight copy)."""
@@ -476,9 +492,20 @@ def _linear_bwd_bf16(ctx, dyb, xb, wb, like):
     Kx = K if xseg is None else xseg[0] * xseg[2]  # columns of xb that carry data (pad columns are zero)
     dx = dw = None
     if ctx.needs_input_grad[0]:  # dx[m,k] = sum_n dy[m,n] W[n,k]: A k-contiguous, B = W is k-major
-        dx = _new(M, K, like=like)
-        gemm_bf16(M, K, N, dyb, dyb.shape[1], 1, wb, wb.shape[1], 0, dx, K)
-        dx = dx.view(ctx.in_shape)
+        key = getattr(ctx, "dx_share", None)
+        shared = _DxShare.table.get(key) if key is not None else None
+        if shared is not None and shared[0] == _DxShare.epoch and id(ctx) not in shared[2]:
+            # another head on the same input already produced dX in this backward pass: accumulate into it
+            # (a head that finds ITSELF among the contributors is in a second backward pass over a retained graph)
+            gemm_bf16(M, K, N, dyb, dyb.shape[1], 1, wb, wb.shape[1], 0, shared[1], K, beta=1.0)
+            shared[2].add(id(ctx))
+            dx = None
+        else:
+            dx = _new(M, K, like=like)
+            gemm_bf16(M, K, N, dyb, dyb.shape[1], 1, wb, wb.shape[1], 0, dx, K)
+            if key is not None:
+                _DxShare.table[key] = (_DxShare.epoch, dx, {id(ctx)})
+            dx = dx.view(ctx.in_shape)
     if ctx.needs_input_grad[1]:  # dw[n,k] = sum_m dy[m,n] x[m,k]: both operands k-major
         wp = ctx.wparam
         side = M >= 4096 and wp is not None and wp.is_contiguous() and side_targets_ok([wp])
@@ -591,6 +618,8 @@ def linear_log_softmax(x, weight, bias=None):
             xb, xseg = tw
             wb = cvt_bf16(w, *xseg)
             assert wb.shape[1] == xb.shape[1]
+    _DxShare.epoch += 1   # (a new forward pass: whatever the previous backward pass shared is history)
+    _DxShare.table.clear()
     y = LinearLogSoftmaxFn.apply(x, weight if weight.is_contiguous() else w, bias, xb, wb, wb_plain, xseg)
     y._pk_head = (x, weight, bias, xb, wb_plain, xseg, y._version)
     return y
@@ -615,6 +644,7 @@ class HeadNllFn(torch.autograd.Function):
         _lib.check(lib.pk_nll_err_fwd(_stream(), _p(y), _p(lab), int(ignore_index), M, N, _p(part), _p(out4)),
                    "pk_nll_err_fwd")
         ctx.save_for_backward(xb, wb, y, lab, out4)
+        ctx.dx_share = _dx_share_key(x) if (_DxShare.on and x.is_contiguous()) else None
         ctx.dims = (M, N, x.shape[-1])
         ctx.has_bias = bias is not None
         ctx.in_shape = x.shape

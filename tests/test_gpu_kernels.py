@@ -651,3 +651,35 @@ def test_projection_statistics_at_250_row_blocks(K):
     Cd = C.double()
     assert rel_err(mean, Cd.mean(0)) < 1e-5
     assert rel_err(var, Cd.var(0, unbiased=False)) < 1e-5
+
+
+def test_output_layers_on_one_input_share_their_input_gradient():
+    """Two perf-mode heads behind one activation (senone + monophone): the second head's dX GEMM accumulates into the
+    first one's buffer (functional._DxShare) instead of autograd adding two 282 MB tensors.  Same gradients as the
+    unshared path, also over a second backward pass through a retained graph."""
+    g = torch.Generator().manual_seed(5)
+    rows, K = 4200, 144
+    x0 = torch.randn(rows, K, generator=g)
+    w1, w2 = torch.randn(37, K, generator=g) / 12, torch.randn(11, K, generator=g) / 12
+    l1, l2 = torch.randint(0, 37, (rows,), generator=g).cuda(), torch.randint(0, 11, (rows,), generator=g).cuda()
+    F_.set_precision("bf16")
+    res = {}
+    try:
+        for share in (True, False):
+            F_._DxShare.on = share
+            x = x0.clone().cuda().requires_grad_(True)
+            h = x * 1.0  # a non-leaf input, like a recurrent layer's output
+            a, b = w1.clone().cuda().requires_grad_(True), w2.clone().cuda().requires_grad_(True)
+            y1, y2 = F_.linear_log_softmax(h, a, None), F_.linear_log_softmax(h, b, None)
+            loss = F_.head_nll(y1, l1)[0] + 0.5 * F_.head_nll(y2, l2)[0]
+            loss.backward(retain_graph=True)
+            g1 = x.grad.clone()
+            loss.backward()  # second pass over the retained graph: gradients double
+            torch.cuda.synchronize()
+            res[share] = (g1, x.grad.clone(), a.grad.clone(), b.grad.clone())
+    finally:
+        F_._DxShare.on = True
+        F_.set_precision("fp32")
+    for got, ref in zip(res[True], res[False]):
+        assert rel_err(got, ref) < 1e-6
+    assert rel_err(res[True][1], 2 * res[True][0]) < 1e-6

@@ -11,6 +11,7 @@ import os
 import sys
 
 d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r02"  # file-name prefix of the round
 
 
 def table(name):
@@ -20,24 +21,29 @@ def table(name):
     return out
 
 
-fetch, write, sq = table("r02_pmc_fetch_size.csv"), table("r02_pmc_write_size.csv"), table("r02_pmc_sq.csv")
-ENTRY = {"pk_rec_bwd_bf16": "rec2_bwd_kernel<0, 1", "pk_rec_fwd_bf16": "rec2_fwd_kernel<0, 1"}
+fetch, write, sq = table(TAG + "_pmc_fetch_size.csv"), table(TAG + "_pmc_write_size.csv"), table(TAG + "_pmc_sq.csv")
+# (round 3: the backward pass runs the third-generation kernel, pk_rec_persist3.hip)
+ENTRY = {"pk_rec_bwd_bf16": ("rec3_bwd_kernel<0, 1", "rec2_bwd_kernel<0, 1"), "pk_rec_fwd_bf16": ("rec2_fwd_kernel<0, 1", "rec3_fwd_kernel<0, 1")}
 traffic = {"_note": "HBM bytes per launch from rocprofv3 --pmc (separate passes for FETCH_SIZE and WRITE_SIZE, bench.py --steps 2 "
-           "--warmup 1; profiles/r02_pmc_fetch_size.csv, profiles/r02_pmc_write_size.csv, values in KB). FETCH_SIZE is doubled "
+           "--warmup 1; profiles/<round>_pmc_fetch_size.csv, profiles/<round>_pmc_write_size.csv, values in KB). FETCH_SIZE is doubled "
            "as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads on gfx950; WRITE_SIZE is used as reported. "
            "Written by tools/pmc_summaries.py."}
-for entry, prefix in ENTRY.items():
-    kf = [k for k in fetch if k.startswith(prefix)]
-    kw = [k for k in write if k.startswith(prefix)]
+for entry, prefixes in ENTRY.items():
+    kf = kw = prefix = None
+    for prefix in prefixes:
+        kf = [k for k in fetch if k.startswith(prefix)]
+        kw = [k for k in write if k.startswith(prefix)]
+        if kf and kw:
+            break
     if not kf or not kw:
         continue
     f, w = fetch[kf[0]]["FETCH_SIZE"][0], write[kw[0]]["WRITE_SIZE"][0]
     traffic[entry] = {"kernel": prefix, "fetch_kb_reported": round(f, 3), "write_kb_reported": round(w, 3),
                       "traffic_bytes": int(round((2.0 * f + w) * 1024.0))}
-json.dump(traffic, open(os.path.join(d, "r02_pmc_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(d, TAG + "_pmc_traffic.json"), "w"), indent=1)
 busy = {"_note": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
         "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -- python bench.py --steps 2 --warmup 1 "
-        "(profiles/r02_pmc_sq.csv). Shares are of SQ_WAVE_CYCLES (quad-cycles): wait_any = parked in s_waitcnt / s_barrier, "
+        "(profiles/<round>_pmc_sq.csv). Shares are of SQ_WAVE_CYCLES (quad-cycles): wait_any = parked in s_waitcnt / s_barrier, "
         "wait_inst = issue stalls, active = issuing. mfma_busy_frac_per_simd = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / "
         "(GRBM_GUI_ACTIVE / 8 XCDs): the fraction of the launch during which a SIMD's matrix pipe was busy = MFMA "
         "utilisation. Written by tools/pmc_summaries.py.", "kernels": {}}
@@ -53,7 +59,7 @@ for k, c in rows[:14]:
         "active_inst_share": round(c.get("SQ_ACTIVE_INST_ANY", (0,))[0] / wc, 3),
         "mfma_busy_frac_per_simd": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", (0,))[0] / 1024.0 / (c["GRBM_GUI_ACTIVE"][0] / 8.0), 4),
         "lds_bank_conflict_cycles": c.get("SQ_LDS_BANK_CONFLICT", (0,))[0]}
-json.dump(busy, open(os.path.join(d, "r02_pmc_mfma_busy.json"), "w"), indent=1)
+json.dump(busy, open(os.path.join(d, TAG + "_pmc_mfma_busy.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1)[:900])
 for k, v in list(busy["kernels"].items())[:8]:
     print("%-60s %s" % (k[:60], v))

@@ -467,10 +467,7 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
     float* wp_a = wp + (lane >> 2) * PK3_PROW + (lane & 3) * 4;
 
     // saved tensors of a step, one 16-byte access each: [0..NS) gates, NS = h_{t-1}, NS+1 = dY
-    // Two register sets that swap roles every step (the time loop is unrolled by two): the set a step computes on was
-    // loaded, in the access layout, during the step before.  A copy "this = next" at the end of a step would have to
-    // wait for those loads - and vmcnt counts in issue order, so also for the fill stores in front of them.
-    f32x4 iv[NIN], inext[NIN];
+    f32x4 iv[NIN], inext[NIN];  // this step (gate layout) / the next one (access layout, loaded a step ahead)
     auto load_step_e = [&](f32x4 (&dst)[NIN], int t, auto E) {
         constexpr int EE = decltype(E)::value;
         const unsigned ts = (unsigned)(adir ? (T - 1 - t) : t);
@@ -492,10 +489,10 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
 #pragma unroll
         for (int g = 0; g < G; ++g) st4<decltype(E)::value>(a.dP2, vG0 + ts * vGs + g * H, anv, trash, gout[g]);
     };
-#define PK3_LS0(E) load_step_e(iv, T - 1, E)
+#define PK3_LS0(E) load_step_e(inext, T - 1, E)
     PK_EDGE_DISPATCH(PK3_LS0);
 #pragma unroll
-    for (int k = 0; k < NIN; ++k) inext[k] = iv[k];
+    for (int k = 0; k < NIN; ++k) iv[k] = inext[k];
 #pragma unroll
     for (int g = 0; g < G; ++g) gout[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -522,7 +519,8 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
     auto run = [&](auto FASTC, auto SEC) {
     constexpr bool fast = decltype(FASTC)::value != 0;
     constexpr int SE = decltype(SEC)::value;
-    auto step = [&](const int t, const int it, f32x4 (&ivc)[NIN], f32x4 (&ivn)[NIN]) {
+    int it = 0;
+    for (int t = T - 1; t >= 0; --t, ++it) {
         const int step_idx = it;
         PK_TRACE(0);
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -540,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
         PK_TRACE(1);
         if (COAL) {  // this step's saved tensors (loaded a step ago, access layout) -> my patches
 #pragma unroll
-            for (int k = 0; k < NIN; ++k) *reinterpret_cast<f32x4*>(wp_a + k * PK3_PATCH_F) = ivc[k];
+            for (int k = 0; k < NIN; ++k) *reinterpret_cast<f32x4*>(wp_a + k * PK3_PATCH_F) = inext[k];
         }
         if (t < T - 1) PK_BARRIER_LDS();
         else if (COAL) PK_LDS_ORDER();
@@ -555,16 +553,15 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
 #pragma unroll
             for (int f = 0; f < PKD; ++f) df[f] = *reinterpret_cast<const bf16x8*>(Ar + ((f / KSTEPS) * KPAD + (f % KSTEPS) * 32) * 2);
         }
-        f32x4 gvl[COAL ? NIN : 1];  // COAL: this step's tensors in the gate layout, back from my patches
         if (COAL) {
 #pragma unroll
-            for (int k = 0; k < NIN; ++k) gvl[COAL ? k : 0] = *reinterpret_cast<const f32x4*>(wp_g + k * PK3_PATCH_F);
+            for (int k = 0; k < NIN; ++k) iv[k] = *reinterpret_cast<const f32x4*>(wp_g + k * PK3_PATCH_F);
         }
         // off the dependency chain: fp32 gate gradients of the previous step (if wanted), the saved tensors of the next
         // one, the fill pattern ahead - in front of the MFMA block, or (flush_late) behind it
         auto side_traffic = [&]() {
             if (t > 0) {  // (loads first: see the forward kernel)
-#define PK3_LS1(E) load_step_e(ivn, t - 1, E)
+#define PK3_LS1(E) load_step_e(inext, t - 1, E)
                 PK_EDGE_DISPATCH_S(PK3_LS1);
             }
             if (t < T - 1 && a.dP2 != nullptr) {
@@ -604,8 +601,8 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
         for (int r = 0; r < 4; ++r) {
             float s[NS];
 #pragma unroll
-            for (int k = 0; k < NS; ++k) s[k] = COAL ? gvl[COAL ? k : 0][r] : ivc[k][r];
-            const float hp = COAL ? gvl[COAL ? NS : 0][r] : ivc[NS][r], dy = COAL ? gvl[COAL ? NS + 1 : 0][r] : ivc[NS + 1][r];
+            for (int k = 0; k < NS; ++k) s[k] = iv[k][r];
+            const float hp = iv[NS][r], dy = iv[NS + 1][r];
             const float dh = dy + dh_dir[r] + acc0[r] + acc1[r];
             float dg[G], dhd, dcp, dc0 = 0.f;
             if (empty) {
@@ -640,15 +637,11 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
         } else {
 #pragma unroll
             for (int g = 0; g < G; ++g) gout[g] = f32x4{dgv[g][0], dgv[g][1], dgv[g][2], dgv[g][3]};
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) iv[k] = inext[k];
         }
         PK_TRACE(5);
-    };
-    int t = T - 1, it = 0;
-    for (; t >= 1; t -= 2, it += 2) {
-        step(t, it, iv, inext);
-        step(t - 1, it + 1, inext, iv);
     }
-    if (t == 0) step(0, it, iv, inext);
     };
     PK_RUN_SPECIALISED(run, fast_rt);
     if (COAL) PK_LDS_ORDER();

@@ -209,23 +209,24 @@ _REC_SPEC = {
 class _MaskPrefetcher:
     """PK_MASK_RNG=reference without the host on the critical path.  The reference draws its drop masks with
     torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p)) on the global CPU generator (e.g. neural_networks.py:1102-1107):
-    a scalar loop, 5.6 ms per 256 x 550 mask.  The masks do not depend on data - only on the ORDER in which the
-    generator is consumed - so a helper thread draws the NEXT forward call's masks (same shapes as this call's, layer
-    by layer, the very same calls) while the GPU works on this one.  The generator state from before the ahead-of-time
-    draws is kept: if the next call turns out to want other shapes (last batch of a chunk), or somebody else drew from
-    the generator in the meantime (its state differs from the one the helper left), that state is restored and the
-    masks are drawn on the spot - the stream stays exactly the reference's.  Nothing else in the engine's step touches
-    the CPU generator (batch padding uses python's random, nn.Dropout masks the device generator)."""
+    a scalar loop that, called from a thread with an intra-op pool, also fights over the generator's lock (42 ms per
+    256 x 550 mask on 8 threads, ~5 ms on one).  The masks do not depend on data - only on the ORDER in which the
+    generator is consumed - so ONE long-lived, single-threaded helper draws the NEXT forward call's masks (same shapes
+    as this call's, layer by layer, the very same calls) while the GPU works on this one; it starts as soon as this
+    call has taken delivery of its own set.  The generator state from before every ahead-of-time set is kept: if the
+    next call turns out to want other shapes (last batch of a chunk), or somebody else drew from / re-seeded the
+    generator in the meantime (its state differs from the one the helper left), that state is restored and the masks
+    are drawn on the spot - the stream stays exactly the reference's.  Nothing else in the engine's step touches the
+    CPU generator (batch padding uses python's random, nn.Dropout masks the device generator)."""
 
-    live = []  # every prefetcher that may hold ahead-of-time draws (drain_mask_prefetch)
+    live = []     # every prefetcher that may hold ahead-of-time draws (drain_mask_prefetch)
+    _jobs = None  # the helper's queue
 
     def __init__(self):
         _MaskPrefetcher.live.append(self)
-        self._thread = None
-        self._sig = None      # [(rows, H, p)] of the call being prefetched
-        self._masks = None
-        self._state0 = None   # generator state before the ahead-of-time draws
-        self._state1 = None   # ... and after them
+        self._done = None     # event of the set being drawn
+        self._ahead = None    # dict(sig, masks, state0, state1): the set drawn ahead (complete once _done is set)
+        self._ready = None    # the set this forward call is being served from
         self._cur = []        # signature of the call in progress
         self._taken = 0
 
@@ -233,19 +234,9 @@ class _MaskPrefetcher:
     def _draw(rows, H, p):
         return torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p))  # the reference's own call
 
-    def _run(self, sig):
-        self._state0 = torch.get_rng_state()
-        self._masks = [self._draw(*s_) for s_ in sig]
-        self._state1 = torch.get_rng_state()
-
-    # ONE long-lived helper thread for the whole process (a fresh thread per forward call would make OpenMP build a new
-    # worker team for it every time - measured: 210 ms per step instead of the 109 ms of drawing in line); the draws are
-    # a sequential stream, so the helper runs them single-threaded
-    _jobs = None
-
     @classmethod
     def _worker(cls):
-        torch.set_num_threads(1)
+        torch.set_num_threads(1)  # (a sequential stream; a fresh thread per call would also make OpenMP build a team each time)
         while True:
             fn, done = cls._jobs.get()
             try:
@@ -260,48 +251,60 @@ class _MaskPrefetcher:
         if _MaskPrefetcher._jobs is None:
             _MaskPrefetcher._jobs = queue.Queue()
             threading.Thread(target=_MaskPrefetcher._worker, daemon=True).start()
-        self._thread = threading.Event()
-        _MaskPrefetcher._jobs.put((lambda: self._run(sig), self._thread))
+        box = {"sig": list(sig)}
+
+        def run():
+            box["state0"] = torch.get_rng_state()
+            box["masks"] = [self._draw(*s_) for s_ in box["sig"]]
+            box["state1"] = torch.get_rng_state()
+
+        self._ahead, self._done = box, threading.Event()
+        _MaskPrefetcher._jobs.put((run, self._done))
 
     def _join(self):
-        if self._thread is not None:
-            self._thread.wait()
-            self._thread = None
+        if self._done is not None:
+            self._done.wait()
+            self._done = None
+
+    def _rewind(self, to_state, redraw):
+        """Give the generator back every draw made ahead that nobody will use: back to `to_state`, then the masks of
+        the current call that WERE used are drawn again (same values) so that the stream continues behind them."""
+        self._join()
+        torch.set_rng_state(to_state)
+        for s_ in redraw:
+            self._draw(*s_)
+        self._ahead = self._ready = None
 
     def get(self, i, n_lay, rows, H, p):
         """Mask of layer i (0 .. n_lay - 1, asked for in layer order) of the current forward call."""
         if i == 0:
-            self._cur, self._taken = [], 0
+            self._cur, self._taken, self._ready = [], 0, None
             self._join()
-            if self._masks is not None and not torch.equal(torch.get_rng_state(), self._state1):
-                self._masks = None  # the generator moved on without us (manual_seed, somebody else's draws): theirs now
+            if self._ahead is not None:
+                if torch.equal(torch.get_rng_state(), self._ahead["state1"]):
+                    self._ready, self._ahead = self._ahead, None
+                    self._start(self._ready["sig"])  # the call after this one, while this one runs
+                else:
+                    self._ahead = None  # the generator moved on without us (manual_seed, somebody else's draws): theirs now
         want = (rows, H, p)
         self._cur.append(want)
-        if self._masks is not None and self._taken == i and i < len(self._sig) and self._sig[i] == want:
-            m = self._masks[i]
+        rd = self._ready
+        if rd is not None and self._taken == i and i < len(rd["sig"]) and rd["sig"][i] == want:
             self._taken = i + 1
-        else:
-            if self._masks is not None:
-                # other shapes than the ones drawn ahead (last batch of a chunk): give the generator back the draws
-                # nobody will use - rewind, and re-draw the i masks of this call that were used
-                torch.set_rng_state(self._state0)
-                for s_ in self._cur[:-1]:
-                    self._draw(*s_)
-                self._masks = None
-            m = self._draw(*want)
-        if i == n_lay - 1:  # this call is served: draw the next call's masks while the GPU works on this one
-            self._masks = None
-            self._sig = list(self._cur)
-            self._start(self._sig)
+            return rd["masks"][i]
+        if rd is not None:  # other shapes than the ones drawn ahead: un-draw this set's unused masks and the next set
+            self._rewind(rd["state0"], self._cur[:-1])
+        m = self._draw(*want)
+        if i == n_lay - 1 and self._done is None and self._ahead is None:
+            self._start(self._cur)  # first call, or the call after a mismatch: start drawing ahead again
         return m
 
     def drain(self):
-        """Un-draw whatever was drawn ahead (before anything else reads the generator: checkpointing its state, a
-        comparison with a reference run)."""
+        """Un-draw whatever was drawn ahead (before anything else reads or re-seeds the generator)."""
         self._join()
-        if self._masks is not None and torch.equal(torch.get_rng_state(), self._state1):
-            torch.set_rng_state(self._state0)
-        self._masks = None
+        if self._ahead is not None and torch.equal(torch.get_rng_state(), self._ahead["state1"]):
+            torch.set_rng_state(self._ahead["state0"])
+        self._ahead = self._ready = None
 
 
 def drain_mask_prefetch():

@@ -547,6 +547,262 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
     }
 }
 
+// ============================================================================
+// backward, third generation (round 3): the same two-phase step with the MFMA operands swapped (pk_rec_persist3.hip has
+// the reasoning).  A lane holds four consecutive units of one row: the saved tensors (z(, r), a, h_{t-1}, dY) are loaded
+// with one 16-byte access per lane straight into the layout the gate math works in, the bf16 chunks of da and dz(, dr)
+// are assembled with v_permlane16_swap_b32 - no wave-private LDS patches, no LDS drain in front of either publish.
+// ============================================================================
+__device__ __forceinline__ u32x4 pack_chunk_g(unsigned lo, unsigned hi) {
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return u32x4{a[0], b[0], a[1], b[1]};
+}
+__device__ __forceinline__ unsigned pack2_g(float x, float y) { return (unsigned)to_bf_pub(x) | ((unsigned)to_bf_pub(y) << 16); }
+
+template <int CELL, int ACT>
+__global__ __launch_bounds__(256, 1) void rec3g_bwd_kernel(R2Args a) {
+    const int act = ACT >= 0 ? ACT : a.act;
+    constexpr int G = pk_cell_gates(CELL), G1 = G - 1, NS = pk_cell_saved(CELL);
+    constexpr bool GRU = (CELL == PK_CELL_GRU);
+    constexpr int LDB = pk_r2_lda_bf16(G1 * KPAD);  // tile of [dz(,dr)]_{t+1}
+    constexpr int LDA = pk_r2_lda_bf16(KPAD);       // tile of da_t
+    constexpr int BTILE = RMAX * LDB * 2, ATILE = RMAX * LDA * 2;
+    constexpr int NCHB = (RMAX * G1 * (KPAD / 8) + 255) / 256;
+    constexpr int NCHA = (RMAX * (KPAD / 8) + 255) / 256;
+    constexpr int NIN = G + 2;                   // saved z(,r),a | h_{t-1} | dY
+    constexpr int LDS_TRASH = BTILE + ATILE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x % a.C, p = blockIdx.x / a.C;
+    const int H = a.H, Hp = a.Hp, B = a.B, T = a.T;
+    const unsigned TB = (unsigned)T * B;
+    const int n_base = a.row0 + c * a.rpc;
+    int nrows = a.R - n_base;
+    nrows = nrows < a.rpc ? nrows : a.rpc;
+    if (nrows <= 0) return;
+    const int ubase = p * 64 + wave * 16;
+    const int kq = lane >> 4;
+    const int frag_unit = ubase + (lane & 15);
+    const bool frag_ok = frag_unit < H;
+
+    // A[m = unit][kidx = (g, j)] = U_g[j][unit]; gate G-1 = U_h (the q = da.U_h product of phase 2)
+    bf16x8 Uf[G][KSTEPS];
+    {
+        const unsigned szU = (unsigned)((size_t)G * H * H * 4);
+        const __amdgpu_buffer_rsrc_t rsU = make_rsrc(a.U, szU);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                unsigned raw[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = kk * 32 + kq * 8 + e;
+                    raw[e] = __builtin_amdgcn_raw_buffer_load_b32(rsU, (frag_ok && j < H) ? (unsigned)(((g * H + j) * H + frag_unit) * 4) : szU, 0, 0);
+                }
+                bf16x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (short)pk_f2bf(__uint_as_float(raw[e]));
+                Uf[g][kk] = f;
+            }
+    }
+    for (int i = tid; i < (LDS_TRASH + 16) / 4; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+
+    const int CPR = Hp >> 3;
+    const unsigned TS = (unsigned)B * a.Gpitch * 2u;
+    const unsigned ndir = (unsigned)(a.R / B);
+    const unsigned szGb = ndir * (unsigned)T * TS;
+    // phase 1 (iteration it >= 1, t = T-1-it) reads gates 0..G-2 of step t+1: storage time (dir ? it-1 : T-it)
+    unsigned cbB[NCHB], csB[NCHB];
+    int clB[NCHB];
+#pragma unroll
+    for (int i = 0; i < NCHB; ++i) {
+        const int ci = tid + 256 * i;
+        const bool ok = ci < nrows * G1 * CPR;
+        const int row = ok ? ci / (G1 * CPR) : 0;
+        const int rem = ok ? ci - row * (G1 * CPR) : 0;
+        const int g = rem / CPR, col = rem - g * CPR;
+        const int n = n_base + row;
+        const int dir = n >= B ? 1 : 0, b = n - dir * B;
+        cbB[i] = ok ? (unsigned)dir * (unsigned)T * TS + ((unsigned)b * a.Gpitch + g * Hp + col * 8) * 2u +
+                          (unsigned)(dir ? 0 : (T - 1)) * TS
+                    : szGb;
+        csB[i] = ok ? (dir ? TS : 0u - TS) : 0u;
+        clB[i] = ok ? row * (LDB * 2) + (g * KPAD + col * 8) * 2 : LDS_TRASH;
+    }
+    // phase 2 (iteration it, t = T-1-it) reads gate G-1 of step t: storage time (dir ? it : T-1-it)
+    unsigned cbA[NCHA], csA[NCHA];
+    int clA[NCHA];
+#pragma unroll
+    for (int i = 0; i < NCHA; ++i) {
+        const int ci = tid + 256 * i;
+        const bool ok = ci < nrows * CPR;
+        const int row = ok ? ci / CPR : 0, col = ok ? ci - row * CPR : 0;
+        const int n = n_base + row;
+        const int dir = n >= B ? 1 : 0, b = n - dir * B;
+        cbA[i] = ok ? (unsigned)dir * (unsigned)T * TS + ((unsigned)b * a.Gpitch + G1 * Hp + col * 8) * 2u +
+                          (unsigned)(dir ? 0 : (T - 1)) * TS
+                    : szGb;
+        csA[i] = ok ? (dir ? TS : 0u - TS) : 0u;
+        clA[i] = ok ? BTILE + row * (LDA * 2) + col * 16 : LDS_TRASH;
+    }
+    // ---- my (row, 4 units): row = lane & 15, units u0 .. u0 + 3
+    const int row = lane & 15, u0 = ubase + kq * 4;
+    const bool row_ok = row < nrows;
+    const int n = n_base + (row_ok ? row : 0);
+    const int dir = n >= B ? 1 : 0, bb = n - dir * B;
+    int nv = H - u0;
+    nv = nv > 4 ? 4 : (nv < 0 ? 0 : nv);
+    const int edge = __any(nv > 0 && nv < 4) != 0 ? ((H & 1) ? 2 : 1) : 0;
+    nv = row_ok ? nv : 0;
+    float msk[4], dh_dir[4];
+    bool ok4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ok4[r] = r < nv;
+        msk[r] = (a.mask != nullptr && ok4[r]) ? a.mask[(long)n * H + u0 + r] : a.mask_scalar;
+        dh_dir[r] = 0.f;
+    }
+    const unsigned vY0 = ((unsigned)bb * a.YH + dir * H + u0), vYs = (unsigned)B * a.YH;
+    const unsigned vS0 = (((unsigned)dir * TB + bb) * (NS * H) + u0), vSs = (unsigned)B * NS * H;
+    const int pu0 = ubase + (kq >> 1) * 8;
+    const bool pk_ok = (kq & 1) == 0 && row_ok && pu0 < Hp;
+    const unsigned pbase = pk_ok ? (unsigned)dir * (unsigned)T * TS + ((unsigned)bb * a.Gpitch + pu0) * 2u : szGb;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dGb, szGb);
+
+    f32x4 iv[NIN], inext[NIN];  // this step / the next one (loaded a step ahead)
+    auto load_step_e = [&](f32x4 (&dst)[NIN], int t, auto E) {
+        constexpr int EE = decltype(E)::value;
+        const unsigned ts = (unsigned)(dir ? (T - 1 - t) : t);
+        const unsigned tp = t > 0 ? (dir ? ts + 1 : ts - 1) : ts;
+#pragma unroll
+        for (int k = 0; k < G; ++k) dst[k] = ld4<EE>(a.S, vS0 + ts * vSs + k * H, nv);
+        dst[G] = ld4<EE>(a.Y, vY0 + tp * vYs, t > 0 ? nv : 0);
+        dst[G + 1] = ld4<EE>(a.dY, vY0 + ts * vYs, nv);
+        if (t == 0) dst[G] = f32x4{0.f, 0.f, 0.f, 0.f};  // h_{-1} = 0
+    };
+#define PKG3_LS0(E) load_step_e(iv, T - 1, E)
+    PK_EDGE_DISPATCH(PKG3_LS0);
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) inext[k] = iv[k];
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    auto fill_slab = [&](int tt, auto FASTC) {  // my G chunks of the slab that step tt will publish
+        const unsigned off = pbase + (pk_ok ? (unsigned)(dir ? (T - 1 - tt) : tt) * TS : 0u);
+#pragma unroll
+        for (int g = 0; g < G; ++g) pub_store<decltype(FASTC)::value != 0>(rs, off + (pk_ok ? (unsigned)(g * Hp) * 2u : 0u), sentinel);
+    };
+    if (a.self_fill) {
+        for (int k = 0; k < PK_R2_FILL_AHEAD && k < T; ++k) fill_slab(T - 1 - k, BoolC<0>());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    bool dead = false;
+    const bool fast = cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): nothing in flight when the time loop is entered (pk_rec_persist3.hip)
+    int it = 0;
+    for (int t = T - 1; t >= 0; --t, ++it) {
+        int retries = 0;
+        // ---------------- phase 1: carry GEMM over [dz(,dr)]_{t+1}, then da_t
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < T - 1) {
+            unsigned goff[NCHB];
+#pragma unroll
+            for (int i = 0; i < NCHB; ++i) goff[i] = cbB[i] + (unsigned)(it - 1) * csB[i];
+            for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);  // see pk_rec2_host_setup
+            dead = fast ? poll_to_lds<NCHB, true>(rs, goff, clB, smem, a.err, a.spin_limit, lane, dead, retries)
+                        : poll_to_lds<NCHB, false>(rs, goff, clB, smem, a.err, a.spin_limit, lane, dead, retries);
+            PK_BARRIER_LDS();
+        }
+        // off the dependency chain: the saved tensors of the next step (loads first), the fill pattern ahead
+        if (t > 0) {
+#define PKG3_LS1(E) load_step_e(inext, t - 1, E)
+            PK_EDGE_DISPATCH(PKG3_LS1);
+        }
+        if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) {
+            if (fast) fill_slab(t - PK_R2_FILL_AHEAD, BoolC<1>());
+            else fill_slab(t - PK_R2_FILL_AHEAD, BoolC<0>());
+        }
+        if (t < T - 1) {
+            const unsigned char* Ar = smem + (lane & 15) * (LDB * 2) + kq * 16;
+#pragma unroll
+            for (int g = 0; g < G1; ++g)
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const bf16x8 df = *reinterpret_cast<const bf16x8*>(Ar + (g * KPAD + kk * 32) * 2);
+                    if ((kk & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Uf[g][kk], df, acc0, 0, 0, 0);
+                    else acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Uf[g][kk], df, acc1, 0, 0, 0);
+                }
+        }
+        float da[4], dzp[4], dhd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float z = iv[0][r], at = iv[G1][r], hp = iv[G][r];
+            const float dh = iv[G + 1][r] + dh_dir[r] + acc0[r] + acc1[r];
+            const float cand = pk_act(act, at) * msk[r];
+            dzp[r] = ok4[r] ? dh * (hp - cand) * z * (1.f - z) : 0.f;
+            dhd[r] = ok4[r] ? dh * z : 0.f;
+            da[r] = ok4[r] ? dh * (1.f - z) * msk[r] * pk_act_grad_from_in(act, at) : 0.f;
+        }
+        const unsigned poff = pbase + (pk_ok ? (unsigned)(dir ? (T - 1 - t) : t) * TS : 0u);
+        {
+            const u32x4 o = pack_chunk_g(pack2_g(da[0], da[1]), pack2_g(da[2], da[3]));
+            const unsigned og = poff + (pk_ok ? (unsigned)(G1 * Hp) * 2u : 0u);
+            if (fast) pub_store<true>(rs, og, o);
+            else pub_store<false>(rs, og, o);
+        }
+        // ---------------- phase 2: q = da_t . U_h, then dz(,dr) and the direct carry
+        f32x4 qa = f32x4{0.f, 0.f, 0.f, 0.f}, qb = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {  // (at t = 0 q only multiplies h_{-1} = 0 and feeds a carry nobody reads)
+            unsigned goff[NCHA];
+#pragma unroll
+            for (int i = 0; i < NCHA; ++i) goff[i] = cbA[i] + (unsigned)it * csA[i];
+            for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);  // see pk_rec2_host_setup
+            dead = fast ? poll_to_lds<NCHA, true>(rs, goff, clA, smem, a.err, a.spin_limit, lane, dead, retries)
+                        : poll_to_lds<NCHA, false>(rs, goff, clA, smem, a.err, a.spin_limit, lane, dead, retries);
+            PK_BARRIER_LDS();
+            const unsigned char* Ar = smem + BTILE + (lane & 15) * (LDA * 2) + kq * 16;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const bf16x8 df = *reinterpret_cast<const bf16x8*>(Ar + kk * 64);
+                if ((kk & 1) == 0) qa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Uf[G1][kk], df, qa, 0, 0, 0);
+                else qb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Uf[G1][kk], df, qb, 0, 0, 0);
+            }
+        }
+        float dzv[4], drv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float q = ok4[r] ? qa[r] + qb[r] : 0.f;
+            const float z = iv[0][r], hp = iv[G][r];
+            drv[r] = 0.f;
+            if (GRU) {
+                const float rg = iv[1][r];
+                dzv[r] = dzp[r];
+                drv[r] = q * hp * rg * (1.f - rg);
+                dh_dir[r] = dhd[r] + q * rg;
+            } else {
+                dzv[r] = dzp[r] + q * hp * z * (1.f - z);
+                dh_dir[r] = dhd[r] + q * z;
+            }
+        }
+        {
+            const u32x4 o = pack_chunk_g(pack2_g(dzv[0], dzv[1]), pack2_g(dzv[2], dzv[3]));
+            if (fast) pub_store<true>(rs, poff, o);
+            else pub_store<false>(rs, poff, o);
+        }
+        if (GRU) {
+            const u32x4 o = pack_chunk_g(pack2_g(drv[0], drv[1]), pack2_g(drv[2], drv[3]));
+            const unsigned og = poff + (pk_ok ? (unsigned)Hp * 2u : 0u);
+            if (fast) pub_store<true>(rs, og, o);
+            else pub_store<false>(rs, og, o);
+        }
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) iv[k] = inext[k];
+    }
+}
+
 size_t granted_lds[2][2][3] = {{{0, 0, 0}, {0, 0, 0}}, {{0, 0, 0}, {0, 0, 0}}};
 typedef void (*Rec2gKernel)(R2Args);
 inline int act_slot(int act) { return act == PK_ACT_RELU ? 0 : act == PK_ACT_TANH ? 1 : 2; }
@@ -560,6 +816,22 @@ Rec2gKernel pick_bwd(int act) {
     return act == PK_ACT_RELU ? rec2g_bwd_kernel<CELL, PK_ACT_RELU> : act == PK_ACT_TANH ? rec2g_bwd_kernel<CELL, PK_ACT_TANH>
                                                                                         : rec2g_bwd_kernel<CELL, -1>;
 }
+
+template <int CELL>
+Rec2gKernel pick_bwd3(int act) {
+    return act == PK_ACT_RELU ? rec3g_bwd_kernel<CELL, PK_ACT_RELU> : act == PK_ACT_TANH ? rec3g_bwd_kernel<CELL, PK_ACT_TANH>
+                                                                                        : rec3g_bwd_kernel<CELL, -1>;
+}
+// PK_GRU_BWD_GEN=2 keeps the second-generation backward kernel (A/B measurements)
+inline bool bwd_gen3() {
+    static int g = -1;
+    if (g < 0) {
+        const char* e = getenv("PK_GRU_BWD_GEN");
+        g = (e && e[0] == '2') ? 2 : 3;
+    }
+    return g == 3;
+}
+size_t granted_lds3[2][3] = {{0, 0, 0}, {0, 0, 0}};
 
 }  // namespace
 
@@ -630,13 +902,16 @@ extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, 
     if (rc) return rc;
     a.self_fill = prefilled == 2 ? 1 : 0;
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
-    const size_t lds = (size_t)RMAX * pk_r2_lda_bf16(G1 * KPAD) * 2 + (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 +
-                       4 * ((size_t)(G + 2) * 1024 + (size_t)G * 512) + 16;
+    const bool g3 = bwd_gen3();
+    const size_t tiles = (size_t)RMAX * pk_r2_lda_bf16(G1 * KPAD) * 2 + (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2;
+    const size_t lds = g3 ? tiles + 32 : tiles + 4 * ((size_t)(G + 2) * 1024 + (size_t)G * 512) + 16;
     const int slot = cell == PK_CELL_GRU ? 0 : 1;
-    const Rec2gKernel fn = cell == PK_CELL_GRU ? pick_bwd<PK_CELL_GRU>(act) : pick_bwd<PK_CELL_MINGRU>(act);
-    if (granted_lds[1][slot][act_slot(act)] < lds) {
+    const Rec2gKernel fn = g3 ? (cell == PK_CELL_GRU ? pick_bwd3<PK_CELL_GRU>(act) : pick_bwd3<PK_CELL_MINGRU>(act))
+                              : (cell == PK_CELL_GRU ? pick_bwd<PK_CELL_GRU>(act) : pick_bwd<PK_CELL_MINGRU>(act));
+    size_t& granted = g3 ? granted_lds3[slot][act_slot(act)] : granted_lds[1][slot][act_slot(act)];
+    if (granted < lds) {
         PK_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        granted_lds[1][slot][act_slot(act)] = lds;
+        granted = lds;
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;

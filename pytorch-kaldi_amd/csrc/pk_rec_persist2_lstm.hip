@@ -642,12 +642,293 @@ __global__ __launch_bounds__(512, 1) void rec2l_bwd_kernel(R2Args a) {
     flush_outputs(0);
 }
 
+// ============================================================================
+// backward, third generation (round 3): MFMA operands swapped - see pk_rec_persist3.hip.  A lane holds FOUR CONSECUTIVE
+// UNITS of ONE row (row = lane & 15, units 4 * (lane >> 4) .. + 3), which is the layout of every tensor the step reads
+// (S, Y, dY rows) and of half a publish chunk: the eight saved tensors come in with one 16-byte load per lane and are
+// handed inside the pair through lane-indexed LDS slots (same lane mapping in both waves: no transposition), the bf16
+// gate gradients leave through two v_permlane16_swap_b32 per chunk.  What is gone per step: 8 transposing patch
+// writes + 32 four-byte patch reads (inputs), 16 two-byte patch writes + an LDS drain + 2 patch reads (publish).
+// Same pair structure as rec2l_bwd_kernel: wave h of a pair multiplies gates (2h, 2h+1) of K, the second wave hands its
+// partial sum over at barrier B, the first does the gate math and publishes.
+// ============================================================================
+__device__ __forceinline__ u32x4 pack_chunk_l(unsigned lo, unsigned hi) {
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return u32x4{a[0], b[0], a[1], b[1]};
+}
+__device__ __forceinline__ unsigned pack2_l(float x, float y) { return (unsigned)to_bf_pub(x) | ((unsigned)to_bf_pub(y) << 16); }
+
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void rec3l_bwd_kernel(R2Args a) {
+    const int act = ACT >= 0 ? ACT : a.act;
+    constexpr int LDA = pk_r2_lda_bf16(LG * KPAD);
+    constexpr int ATILE = RMAX * LDA * 2;                        // one tile (74 KB): barrier B of a step frees it
+    constexpr int NCH = (RMAX * LG * (KPAD / 8) + 511) / 512;    // 9
+    constexpr int NIN = LNS + 3;                                 // f, i, o, g, c | h_{t-1}, dY, c_{t-1}
+    constexpr int NLD = NIN / 2;                                 // slots each wave of a pair loads (4)
+    constexpr int XIN = ATILE;                                   // [4 pairs][NIN slots][64 lanes] x 16 bytes: the pair's inputs
+    constexpr int XCH = XIN + 4 * NIN * 1024;                    // [4 pairs][64 lanes] x 16 bytes: partial dh
+    constexpr int LTAB = XCH + 4 * 1024;                         // [NCH][512] LDS byte offsets of the polled chunks
+    constexpr int LDS_TRASH = LTAB + NCH * 512 * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, uw = wave & 3;
+    const int half = __builtin_amdgcn_readfirstlane(wave >> 2);  // 0: gates f, i of K + the gate math; 1: gates o, g of K
+    const int g0 = half * GW;
+    const int c = blockIdx.x % a.C, p = blockIdx.x / a.C;
+    const int H = a.H, Hp = a.Hp, B = a.B, T = a.T, GH = LG * H;
+    const unsigned TB = (unsigned)T * B;
+    const int n_base = a.row0 + c * a.rpc;
+    int nrows = a.R - n_base;
+    nrows = nrows < a.rpc ? nrows : a.rpc;
+    if (nrows <= 0) return;
+    const int ubase = p * 64 + uw * 16;
+    const int kq = lane >> 4;
+    const int frag_unit = ubase + (lane & 15);
+    const bool frag_ok = frag_unit < H;
+
+    // A[m = unit][kidx = (g, j)] = U_g[j][unit], my two gates
+    bf16x8 Uf[GW][KSTEPS];
+    {
+        const unsigned szU = (unsigned)((size_t)LG * H * H * 4);
+        const __amdgpu_buffer_rsrc_t rsU = make_rsrc(a.U, szU);
+#pragma unroll
+        for (int gg = 0; gg < GW; ++gg)
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                unsigned raw[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int j = kk * 32 + kq * 8 + e;
+                    raw[e] = __builtin_amdgcn_raw_buffer_load_b32(
+                        rsU, (frag_ok && j < H) ? (unsigned)((((g0 + gg) * H + j) * H + frag_unit) * 4) : szU, 0, 0);
+                }
+                bf16x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (short)pk_f2bf(__uint_as_float(raw[e]));
+                Uf[gg][kk] = f;
+                if (kk % 3 == 2) {  // fenced in groups of 24 loads (see the forward kernel)
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+    }
+    for (int i = tid; i < (LDS_TRASH + 16) / 4; i += 512) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+
+    // ---- poll descriptors (as rec2l_bwd_kernel): running offsets, LDS destinations in an LDS table
+    const int CPR = Hp >> 3;
+    const unsigned TS = (unsigned)B * a.Gpitch * 2u;
+    const unsigned ndir = (unsigned)(a.R / B);
+    const unsigned szGb = ndir * (unsigned)T * TS;
+    unsigned goff[NCH], dirbits = 0u;
+    int clds[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ci = tid + 512 * i;
+        const bool ok = ci < nrows * LG * CPR;
+        const int row = ok ? ci / (LG * CPR) : 0;
+        const int rem = ok ? ci - row * (LG * CPR) : 0;
+        const int g = rem / CPR, col = rem - g * CPR;
+        const int n = n_base + row;
+        const int dir = n >= B ? 1 : 0, b = n - dir * B;
+        goff[i] = (unsigned)dir * (unsigned)T * TS + ((unsigned)b * a.Gpitch + g * Hp + col * 8) * 2u +
+                  (unsigned)(dir ? 0 : (T - 1)) * TS;
+        dirbits |= (unsigned)dir << i;
+        clds[i] = ok ? row * (LDA * 2) + (g * KPAD + col * 8) * 2 : LDS_TRASH;
+    }
+    // ---- my (row, 4 units): row = lane & 15, units u0 .. u0 + 3
+    const int row = lane & 15, u0 = ubase + kq * 4;
+    const bool row_ok = row < nrows;
+    const int n = n_base + (row_ok ? row : 0);
+    const int dir = n >= B ? 1 : 0, bb = n - dir * B;
+    int nv = H - u0;
+    nv = nv > 4 ? 4 : (nv < 0 ? 0 : nv);
+    const int edge = __any(nv > 0 && nv < 4) != 0 ? ((H & 1) ? 2 : 1) : 0;
+    nv = row_ok ? nv : 0;
+    float msk[4], dc_car[4];
+    bool ok4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ok4[r] = r < nv;
+        msk[r] = (a.mask != nullptr && ok4[r]) ? a.mask[(long)n * H + u0 + r] : a.mask_scalar;
+        dc_car[r] = 0.f;
+    }
+    const unsigned vY0 = ((unsigned)bb * a.YH + dir * H + u0), vYs = (unsigned)B * a.YH;
+    const unsigned vS0 = (((unsigned)dir * TB + bb) * (LNS * H) + u0), vSs = (unsigned)B * LNS * H;
+    const unsigned vG0 = (((unsigned)dir * TB + bb) * GH + u0), vGs = (unsigned)B * GH;
+    // ---- publish (first wave): the lanes of the even 16-lane rows store one chunk per gate (my row, 8 units from pu0)
+    const int pu0 = ubase + (kq >> 1) * 8;
+    const bool pk_ok = (kq & 1) == 0 && row_ok && pu0 < Hp;
+    const unsigned pbase = pk_ok ? (unsigned)dir * (unsigned)T * TS + ((unsigned)bb * a.Gpitch + pu0) * 2u : szGb;
+    unsigned char* xin = smem + XIN + uw * (NIN * 1024) + lane * 16;  // + slot * 1024
+    unsigned char* xch = smem + XCH + uw * 1024 + lane * 16;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dGb, szGb);
+    float* trash = a.trash + (tid & 63) * 4;
+
+    // saved tensors of one step, one 16-byte load each.  First wave: f, i, o, g; second wave: c, h_{t-1}, dY, c_{t-1}.
+    // Running element offsets (oS into S, oY into Y / dY), one time slab per load, up for the backward direction's rows
+    // and down for the forward one's.
+    const unsigned dS = dir ? vSs : 0u - vSs, dYs = dir ? vYs : 0u - vYs;
+    unsigned oS = vS0 + (unsigned)(dir ? 0 : T - 1) * vSs, oY = vY0 + (unsigned)(dir ? 0 : T - 1) * vYs;
+    f32x4 iv[NLD];
+    auto load_step_e = [&](int t, auto E, auto HALFC) {
+        constexpr int EE = decltype(E)::value;
+        if constexpr (decltype(HALFC)::value == 0) {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) iv[k] = ld4<EE>(a.S, oS + k * H, nv);
+        } else {
+            const int nvp = t > 0 ? nv : 0;  // step t-1 sits one slab further along (nothing there when t == 0)
+            iv[0] = ld4<EE>(a.S, oS + 4 * H, nv);
+            iv[1] = ld4<EE>(a.Y, oY + dYs, nvp);
+            iv[2] = ld4<EE>(a.dY, oY, nv);
+            iv[3] = ld4<EE>(a.S, oS + dS + 4 * H, nvp);
+            if (t == 0) {  // h_{-1} = c_{-1} = 0
+                iv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                iv[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        oS += dS;
+        oY += dYs;
+    };
+    if (half == 0) {
+#define PK_L3S0(E) load_step_e(T - 1, E, BoolC<0>())
+        PK_EDGE_DISPATCH(PK_L3S0);
+    } else {
+#define PK_L3S1(E) load_step_e(T - 1, E, BoolC<1>())
+        PK_EDGE_DISPATCH(PK_L3S1);
+    }
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    auto fill_slab = [&](int tt, auto FASTC) {  // my LG chunks of the slab that step tt will publish
+        const unsigned off = pbase + (pk_ok ? (unsigned)(dir ? (T - 1 - tt) : tt) * TS : 0u);
+#pragma unroll
+        for (int g = 0; g < LG; ++g) pub_store<decltype(FASTC)::value != 0>(rs, off + (pk_ok ? (unsigned)(g * Hp) * 2u : 0u), sentinel);
+    };
+    if (a.self_fill && half == 0) {
+        for (int k = 0; k < PK_R2_FILL_AHEAD && k < T; ++k) fill_slab(T - 1 - k, BoolC<0>());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    int* ltab = reinterpret_cast<int*>(smem + LTAB) + tid;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) ltab[i * 512] = clds[i];
+
+    bool dead = false;
+    const bool fast_rt = __builtin_amdgcn_readfirstlane((int)(cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0)) != 0;
+    auto run = [&](auto HALFC) {
+    constexpr int HALF = decltype(HALFC)::value;
+    const bool fast = fast_rt;
+    int it = 0;
+    for (int t = T - 1; t >= 0; --t, ++it) {
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned char* At = smem;
+        // this step's saved tensors (loaded a step ago) go to the pair's slots BEFORE the poll: their registers are free
+        // while the poll holds its chunks (the slots were last read before barrier B of the previous step)
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) *reinterpret_cast<f32x4*>(xin + (HALF * NLD + k) * 1024) = iv[k];
+        if (t < T - 1) {
+            const int nap = a.poll_delay + (HALF ? a.helper_delay : 0);
+            for (int d = 0; d < nap; ++d) __builtin_amdgcn_s_sleep(1);
+            int retries = 0;
+            dead = fast ? poll_to_lds_tab<NCH, true>(rs, goff, ltab, At, a.err, a.spin_limit, lane, dead, retries)
+                        : poll_to_lds_tab<NCH, false>(rs, goff, ltab, At, a.err, a.spin_limit, lane, dead, retries);
+        }
+        PK_BARRIER_LDS();  // A: the polled dgates_{t+1} tile and the pair's input slots are complete
+        if constexpr (HALF == 0) {
+            if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) {
+                if (fast) fill_slab(t - PK_R2_FILL_AHEAD, BoolC<1>());
+                else fill_slab(t - PK_R2_FILL_AHEAD, BoolC<0>());
+            }
+        }
+        if (t < T - 1) {
+            const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
+#pragma unroll
+            for (int gg = 0; gg < GW; ++gg)
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk) {
+                    const bf16x8 df = *reinterpret_cast<const bf16x8*>(Ar + ((HALF * GW + gg) * KPAD + kk * 32) * 2);
+                    if ((kk & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Uf[gg][kk], df, acc0, 0, 0, 0);
+                    else acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Uf[gg][kk], df, acc1, 0, 0, 0);
+                }
+        }
+        // saved tensors of the next step: issued BEHIND the MFMA block (their registers are free during it; they have the
+        // gate math, the publish and the cluster hand-over to land)
+        if (t > 0) {
+#define PK_L3SN(E) load_step_e(t - 1, E, HALFC)
+            PK_EDGE_DISPATCH(PK_L3SN);
+        }
+        if constexpr (HALF == 1) *reinterpret_cast<f32x4*>(xch) = acc0 + acc1;
+        // the first wave reads the pair's inputs before the barrier: they were complete at barrier A
+        f32x4 sin[NIN];
+        if constexpr (HALF == 0) {
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) sin[k] = *reinterpret_cast<const f32x4*>(xin + k * 1024);
+        }
+        PK_BARRIER_LDS();  // B: the partial sums are handed over, and everybody is done reading the A tile
+        if constexpr (HALF == 0) {
+            const f32x4 part = *reinterpret_cast<const f32x4*>(xch);
+            float dgv[LG][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s[LNS];
+#pragma unroll
+                for (int k = 0; k < LNS; ++k) s[k] = sin[k][r];
+                const float hp = sin[LNS][r], dy = sin[LNS + 1][r], cp = sin[LNS + 2][r];
+                const float dh = dy + acc0[r] + acc1[r] + part[r];
+                float dg[LG], dhd, dcp;
+                pk_cell_bwd<PK_CELL_LSTM>(act, s, hp, cp, msk[r], dh, dc_car[r], dg, dhd, dcp);
+                dc_car[r] = ok4[r] ? dcp : 0.f;
+#pragma unroll
+                for (int g = 0; g < LG; ++g) dgv[g][r] = ok4[r] ? dg[g] : 0.f;
+            }
+            {
+                const unsigned off = pbase + (pk_ok ? (unsigned)(dir ? (T - 1 - t) : t) * TS : 0u);
+#pragma unroll
+                for (int g = 0; g < LG; ++g) {
+                    const u32x4 o = pack_chunk_l(pack2_l(dgv[g][0], dgv[g][1]), pack2_l(dgv[g][2], dgv[g][3]));
+                    const unsigned og = off + (pk_ok ? (unsigned)(g * Hp) * 2u : 0u);
+                    if (fast) pub_store<true>(rs, og, o);
+                    else pub_store<false>(rs, og, o);
+                }
+            }
+            if (a.dP2 != nullptr) {  // fp32 gate gradients (only when the caller wants them): straight from registers
+                const unsigned ts = (unsigned)(dir ? (T - 1 - t) : t);
+#define PK_L3FO(E)                                                                                                         \
+    _Pragma("unroll") for (int g = 0; g < LG; ++g)                                                                         \
+        st4<decltype(E)::value>(a.dP2, vG0 + ts * vGs + g * H, nv, trash, f32x4{dgv[g][0], dgv[g][1], dgv[g][2], dgv[g][3]})
+                PK_EDGE_DISPATCH(PK_L3FO);
+            }
+        }
+        // next step's poll offsets, behind the publish (the empty asm keeps the nine selects in the loop)
+        if (t < T - 1) {
+            asm volatile("" : "+v"(dirbits));
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) goff[i] += ((dirbits >> i) & 1u) ? TS : 0u - TS;
+        }
+    }
+    };
+    if (half == 0) run(BoolC<0>());
+    else run(BoolC<1>());
+}
+
 typedef void (*Rec2Kernel)(R2Args);
 Rec2Kernel pick_fwd(int act) {
     return act == PK_ACT_RELU ? rec2l_fwd_kernel<PK_ACT_RELU> : act == PK_ACT_TANH ? rec2l_fwd_kernel<PK_ACT_TANH> : rec2l_fwd_kernel<-1>;
 }
 Rec2Kernel pick_bwd(int act) {
     return act == PK_ACT_RELU ? rec2l_bwd_kernel<PK_ACT_RELU> : act == PK_ACT_TANH ? rec2l_bwd_kernel<PK_ACT_TANH> : rec2l_bwd_kernel<-1>;
+}
+Rec2Kernel pick_bwd3(int act) {
+    return act == PK_ACT_RELU ? rec3l_bwd_kernel<PK_ACT_RELU> : act == PK_ACT_TANH ? rec3l_bwd_kernel<PK_ACT_TANH> : rec3l_bwd_kernel<-1>;
+}
+// PK_LSTM_BWD_GEN=2 keeps the second-generation backward kernel (A/B measurements)
+inline bool bwd_gen3() {
+    static int g = -1;
+    if (g < 0) {
+        const char* e = getenv("PK_LSTM_BWD_GEN");
+        g = (e && e[0] == '2') ? 2 : 3;
+    }
+    return g == 3;
 }
 inline int act_slot(int act) { return act == PK_ACT_RELU ? 0 : act == PK_ACT_TANH ? 1 : 2; }
 
@@ -687,10 +968,14 @@ int pk_rec2l_launch(hipStream_t st, R2Args& a, const Plan2& pl, int act, bool ba
         lds = (size_t)RMAX * pk_r2_lda_bf16(LG * KPAD) * 2 + 4 * ((size_t)(LNS + 3 + LG) * 1024 + LG * 512) + 4 * 1024 +
               (size_t)((RMAX * LG * (KPAD / 8) + 511) / 512) * 512 * 4 + 16;
     }
-    Rec2Kernel k = backward ? pick_bwd(act) : pick_fwd(act);
+    const bool g3 = backward && bwd_gen3();
+    if (g3)  // A tile | the pairs' input slots | partial sums | LDS table | trash
+        lds = (size_t)RMAX * pk_r2_lda_bf16(LG * KPAD) * 2 + 4 * (size_t)(LNS + 3) * 1024 + 4 * 1024 +
+              (size_t)((RMAX * LG * (KPAD / 8) + 511) / 512) * 512 * 4 + 32;
+    Rec2Kernel k = backward ? (g3 ? pick_bwd3(act) : pick_bwd(act)) : pick_fwd(act);
     {
-        static size_t granted[2][3] = {{0, 0, 0}, {0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
-        size_t& g = granted[backward ? 1 : 0][act_slot(act)];
+        static size_t granted[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
+        size_t& g = granted[backward ? (g3 ? 2 : 1) : 0][act_slot(act)];
         if (g < lds) {
             PK_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             g = lds;

@@ -8,7 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BASE = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-LINES = ["profiles/r02_bench_bf16.json", "profiles/r01_bench_bf16.json", "profiles/r01_bench_fp32_with_cpu_baseline.json",
+LINES = ["profiles/r03_bench_bf16.json", "profiles/r02_bench_bf16.json", "profiles/r01_bench_bf16.json", "profiles/r01_bench_fp32_with_cpu_baseline.json",
          "profiles/r01_timit_lstm_8wave_bench.json", "profiles/r01_timit_lstm_4wave_bench.json"]
 
 
@@ -45,6 +45,7 @@ def test_headline_line_names_the_baseline_workload():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["unit"] == "frames/s" and c["cores"] >= 1
+    assert c["B"] == 128                                 # the sample is taken at the metric's batch
     assert d["roofline"]["traffic"] is not None          # PMC-measured HBM bytes of the dominant launch
 
 
@@ -62,7 +63,7 @@ def test_round2_line_carries_the_parity_mode_and_every_baseline_configuration():
         assert o["ms_per_step"] > 0 and o["value"] > 0 and "workload" in o["config"] and "kernel" in o["roofline"]
     r = d["roofline"]
     assert r["dependent_steps_per_launch"] == 500 and 0 < r["latency_frac"] < 1 and 0 < r["structure_frac"] <= 1
-    assert "r02_pmc_traffic" in r["traffic_source"]
+    assert "pmc_traffic" in r["traffic_source"]
 
 
 def test_bench_starts_its_own_ranks():
@@ -80,3 +81,24 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["sum_of_ranks_plus_1"] == 3.0
+
+
+def test_round3_line_carries_the_chunk_loop_and_the_reference_caller():
+    """Round 3: the nearer roof by arithmetic intensity + a latency record, the same workload through run_nn_dp and as the
+    reference's own caller drives it, parity-mode records of the LSTM / GRU configurations, the CPU port at the metric's
+    full shape."""
+    d = _line("profiles/r03_bench_bf16.json")
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["arithmetic_intensity"] < r["ridge"] and r["latency"]["bound"] == "latency"
+    assert abs(r["hbm"]["frac"] - r["frac"]) < 1e-9 and 0 < r["mfma"]["frac"] < r["hbm"]["frac"]
+    t = d["through_run_nn"]
+    assert "error" not in t and abs(t["value"] - 128 * 500 / (t["ms_per_step"] * 1e-3)) < 0.01 * t["value"]
+    assert t["ms_per_step"] < 1.05 * d["ms_per_step"]   # the chunk loop costs a few per cent at most
+    rc = d["reference_caller"]
+    assert "error" not in rc and rc["config"]["optimizer"] == "torch" and rc["config"]["host_sync"] == "every step"
+    got = {o["recipe"]: o for o in d["other_configs"]}
+    for name in ("timit_lstm", "libri_gru"):
+        assert len(got[name]["regions_ms_per_step"]) == 3 and got[name]["steps"] >= 50
+        assert got[name]["parity_mode"]["dtype"] == "fp32"
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_full_shape.json")))
+    assert (full["T"], full["B"]) == (500, 128) and full["kind"] == "port" and full["value"] > 0

@@ -316,6 +316,18 @@ void pk_persist_error_reset(void);
 
 /* ---- self tests (tests/ only): MFMA fragment-layout check on the device.
  * Writes 0 to *h_bad_count if every layout assumption holds. */
+/* One perf-mode MLP layer of a SMALL batch in one launch (neural_networks.py:139-148, the drop(act(bn(wx(x)))) order with
+ * BatchNorm1d in training mode): z = x W^T + b on bf16 operands, batch statistics of z's columns, a = act(bn(z)),
+ * y = a * mask, yb = bf16(y); running statistics updated (momentum, unbiased variance).  The whole batch (M <= 128 rows)
+ * sits in one row tile, so the statistics are a reduction inside the workgroup that owns the columns.
+ * xb [M][ldx], wb [N][ldw] bf16, k-contiguous; z, a, y fp32 [M][N] (y NULL when mask is NULL: the output is a);
+ * yb bf16 [M][ldyb]; mean, var [N] = biased batch statistics (what pk_bn_bwd_* take).  pk_linear_bn_act_bf16_covers:
+ * does the shape take this path (2 <= M <= 128, N a multiple of 8)? */
+int pk_linear_bn_act_bf16_covers(int64_t M, int64_t N, int64_t K);
+int pk_linear_bn_act_bf16(void* stream, int M, int N, int K, const uint16_t* xb, int64_t ldx, const uint16_t* wb, int64_t ldw,
+                          const float* bias, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, int act, const float* mask, float* z, float* a,
+                          float* y, uint16_t* yb, int64_t ldyb, float* mean, float* var);
 int pk_selftest_mfma(void* stream, int* h_bad_count);
 /* v_permlane16_swap_b32 lane mapping the third-generation persistent recurrences rely on when they assemble a 16-byte
  * publish chunk from two lanes (pk_rec_persist3.hip) */

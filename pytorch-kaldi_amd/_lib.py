@@ -99,6 +99,9 @@ SIGNATURES = {
     "pk_adam_step": (c_int, [P, P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int]),
     "pk_persist_error_count": (ctypes.c_uint, []),
     "pk_persist_error_reset": (None, []),
+    "pk_linear_bn_act_bf16_covers": (c_int, [c_int64, c_int64, c_int64]),
+    "pk_linear_bn_act_bf16": (c_int, [P, c_int, c_int, c_int, P, c_int64, P, c_int64, P, P, P, c_float, c_float, P, P, c_int, P,
+                                      P, P, P, P, c_int64, P, P]),
     "pk_selftest_mfma": (c_int, [P, ctypes.POINTER(c_int)]),
     "pk_selftest_permlane": (c_int, [P, ctypes.POINTER(c_int)]),
 }

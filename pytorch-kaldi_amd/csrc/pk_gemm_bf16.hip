@@ -276,6 +276,206 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 4) void gemm_bf16x_kernel(BA
 }
 
 // ============================================================================
+// One MLP layer of a small batch in ONE launch (round 3): z = x W^T + b on bf16 operands, BatchNorm1d in training mode
+// over the batch, activation, drop mask, and the bf16 copy the next layer's GEMM reads.
+// Reference: neural_networks.py:139-148 (`drop(act(bn(wx(x))))`, the order every shipped MLP recipe takes).
+//
+// With M <= 128 rows the whole batch sits in ONE row tile, so a workgroup that owns 128 output columns holds every row
+// of those columns in its accumulators: the batch statistics are a reduction inside the workgroup (two passes over the
+// registers: mean, then centred second moment - nothing cancels) and the normalised, activated, masked layer output
+// leaves together with z, the statistics and the running-statistics update.  Replaces seven launches of the unfused
+// pipeline (GEMM, 2 x statistics, finalize, affine + activation, mask, bf16 conversion of the next layer's input).
+// ============================================================================
+struct BnActArgs {
+    const float *gamma, *beta, *mask;
+    float eps, momentum, unbias;
+    float *rmean, *rvar, *mean, *var;
+    float *zout, *aout, *yout;  // fp32 [M][N]: pre-BN output, activation output (pre-mask), layer output (null: no mask)
+    unsigned short* yb;         // bf16 [M][ldyb] layer output
+    long ldyb;
+    int act;
+};
+
+template <int STAGES>
+__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 4) void gemm_bf16x_bnact_kernel(BArgs p, BnActArgs q) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [STAGES][A 16 KB | B 16 KB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tn = blockIdx.x;
+    if (tn >= p.tiles_n) return;
+    const int m0 = 0, n0 = tn * TN;
+    const int nk = (p.K + TK - 1) / TK;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int kt, unsigned char* buf) {
+        const int k0 = kt * TK;
+        stage<true>(p.A, p.lda, m0, p.M, k0, p.K, p.zeros, buf, tid, wave);
+        stage<true>(p.B, p.ldb, n0, p.N, k0, p.K, p.zeros, buf + 16384, tid, wave);
+    };
+    if (STAGES == 2) {
+        if (nk > 0) fetch(0, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        unsigned char* cur = smem + (STAGES == 2 ? (kt & 1) * 32768 : 0);
+        if (STAGES == 2) {
+            if (kt + 1 < nk) fetch(kt + 1, smem + ((kt + 1) & 1) * 32768);
+        } else {
+            fetch(kt, cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag<true>(cur, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = frag<true>(cur + 16384, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // ---- epilogue.  acc[i][j][r]: row = wm*64 + i*16 + (lane & 15), column = n0 + wn*64 + j*16 + (lane >> 4)*4 + r
+    float* red = reinterpret_cast<float*>(smem);  // [pass 2][wn 2][wm 2][64 columns] (all waves are past the main loop)
+    const int kq = lane >> 4, lr = lane & 15;
+    const int cbase = n0 + wn * 64 + kq * 4;
+    bool rok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rok[i] = wm * 64 + i * 16 + lr < p.M;
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = cbase + j * 16 + r;
+            bv[j][r] = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j][r];
+    // sum over the wave's 64 rows of every one of my 16 columns: over i in registers, over the 16 lanes of a lane row
+    // by xor-shuffles (masks 1, 2, 4, 8 stay inside a group of 16 lanes), over the two row halves through LDS
+    auto column_total = [&](float (&s)[4][4], int pass) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = s[j][r];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                s[j][r] = v;
+            }
+        float* mine = red + ((pass * 2 + wn) * 2 + wm) * 64;
+        if (lr == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[j * 16 + kq * 4 + r] = s[j][r];
+        }
+        __syncthreads();
+        const float* other = red + ((pass * 2 + wn) * 2 + (wm ^ 1)) * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // (row half 0 first on both sides: the two waves of a column range end with bit-identical totals)
+                const float mv = s[j][r], ov = other[j * 16 + kq * 4 + r];
+                s[j][r] = wm == 0 ? mv + ov : ov + mv;
+            }
+    };
+    float mean[4][4], var[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t += rok[i] ? acc[i][j][r] : 0.f;
+            mean[j][r] = t;
+        }
+    column_total(mean, 0);
+    const float invM = 1.0f / (float)p.M;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            mean[j][r] *= invM;
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = acc[i][j][r] - mean[j][r];
+                t += rok[i] ? d * d : 0.f;
+            }
+            var[j][r] = t;
+        }
+    column_total(var, 1);
+    float sc[4][4], sh[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = cbase + j * 16 + r;
+            const bool cok = col < p.N;
+            var[j][r] *= invM;
+            const float inv = 1.0f / sqrtf(var[j][r] + q.eps);
+            const float g = (q.gamma != nullptr && cok) ? q.gamma[col] : 1.f, b = (q.beta != nullptr && cok) ? q.beta[col] : 0.f;
+            sc[j][r] = g * inv;
+            sh[j][r] = b - mean[j][r] * sc[j][r];
+            if (wm == 0 && lr == 0 && cok) {  // one lane per column: the statistics backward needs, the running statistics
+                q.mean[col] = mean[j][r];
+                q.var[col] = var[j][r];
+                if (q.rmean != nullptr) {
+                    q.rmean[col] = (1.f - q.momentum) * q.rmean[col] + q.momentum * mean[j][r];
+                    q.rvar[col] = (1.f - q.momentum) * q.rvar[col] + q.momentum * (var[j][r] * q.unbias);
+                }
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + lr;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = cbase + j * 16;
+            if (col >= p.N) continue;  // (N is a multiple of 4 on this path: a lane's four columns are in or out together)
+            const f32x4 z = acc[i][j];
+            f32x4 av, yv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) av[r] = pk_act(q.act, z[r] * sc[j][r] + sh[j][r]);
+            const long o = (long)row * p.ldc + col;
+            *reinterpret_cast<f32x4*>(q.zout + o) = z;
+            *reinterpret_cast<f32x4*>(q.aout + o) = av;
+            yv = av;
+            if (q.mask != nullptr) {
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(q.mask + o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[r] = av[r] * mk[r];
+                *reinterpret_cast<f32x4*>(q.yout + o) = yv;
+            }
+            uint2 pk;
+            pk.x = pk_pack_bf2(yv[0], yv[1]);
+            pk.y = pk_pack_bf2(yv[2], yv[3]);
+            *reinterpret_cast<uint2*>(q.yb + (long)row * q.ldyb + col) = pk;
+        }
+    }
+}
+
+// ============================================================================
 // 256 x 256 x 64 block tile, 8 waves, eight phases per pair of k-tiles.
 //
 // The 128 x 128 kernels above top out at 640-680 TFLOP/s: every k-tile is [stage, wait for ALL loads, barrier, 32
@@ -868,3 +1068,49 @@ extern "C" int pk_gemm_bf16_stats(void* stream, int M, int N, int K, float alpha
                           fused ? stats : nullptr);
 }
 
+// One perf-mode MLP layer of a batch of up to 128 rows in one launch: see gemm_bf16x_bnact_kernel.
+// xb [M][ldx] / wb [N][ldw] bf16 (k-contiguous), z / a / y fp32 [M][N] (y null = no mask: the layer output is a),
+// yb bf16 [M][ldyb] (ldyb >= N, both multiples of 8), mean / var [N] (biased batch statistics, saved for backward).
+// pk_linear_bn_act_bf16_covers says whether a shape takes this path.
+extern "C" int pk_linear_bn_act_bf16_covers(int64_t M, int64_t N, int64_t K) {
+    return M >= 2 && M <= TM && N >= 8 && (N % 8) == 0 && K >= 1;
+}
+extern "C" int pk_linear_bn_act_bf16(void* stream, int M, int N, int K, const uint16_t* xb, int64_t ldx, const uint16_t* wb,
+                                     int64_t ldw, const float* bias, const float* gamma, const float* beta, float eps,
+                                     float momentum, float* running_mean, float* running_var, int act, const float* mask,
+                                     float* z, float* a, float* y, uint16_t* yb, int64_t ldyb, float* mean, float* var) {
+    PK_REQUIRE(pk_linear_bn_act_bf16_covers(M, N, K), "pk_linear_bn_act_bf16: needs 2 <= M <= 128 rows and N a multiple of 8 (got %d x %d)", M, N);
+    PK_REQUIRE((ldx % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)xb & 15) == 0 && ((uintptr_t)wb & 15) == 0 && ldx >= ((K + 7) & ~7) &&
+                   ldw >= ((K + 7) & ~7),
+               "pk_linear_bn_act_bf16: operands need 16-byte aligned bases and pitches that are multiples of 8 elements");
+    PK_REQUIRE(z && a && yb && mean && var && (mask == nullptr || y != nullptr) && ldyb >= N && (ldyb % 4) == 0,
+               "pk_linear_bn_act_bf16: null output or bad pitch");
+    PK_REQUIRE((((uintptr_t)z | (uintptr_t)a | (uintptr_t)y | (uintptr_t)mask) & 15) == 0 && ((uintptr_t)yb & 7) == 0,
+               "pk_linear_bn_act_bf16: fp32 matrices need 16-byte aligned bases");
+    hipStream_t st = pk_stream(stream);
+    BArgs p;
+    p.M = M; p.N = N; p.K = K;
+    p.alpha = 1.f; p.beta = 0.f;
+    p.A = xb; p.lda = ldx; p.B = wb; p.ldb = ldw;
+    p.C = z; p.ldc = N; p.bias = bias;
+    p.stats = nullptr; p.ws = nullptr;
+    p.tiles_m = 1; p.tiles_n = (N + TN - 1) / TN;
+    p.k_per_split = ((K + TK - 1) / TK) * TK;
+    p.items = p.tiles_n; p.per_xcd = (p.items + 7) / 8;
+    static void* zp = nullptr;
+    if (zp == nullptr) PK_CHECK_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)));
+    p.zeros = (const unsigned short*)zp;
+    BnActArgs q;
+    q.gamma = gamma; q.beta = beta; q.mask = mask;
+    q.eps = eps; q.momentum = momentum; q.unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
+    q.rmean = running_mean; q.rvar = running_var; q.mean = mean; q.var = var;
+    q.zout = z; q.aout = a; q.yout = y; q.yb = (unsigned short*)yb; q.ldyb = ldyb; q.act = act;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_bnact_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16x_bnact_kernel<2>), dim3((unsigned)p.tiles_n), dim3(256), 65536, st, p, q);
+    PK_LAUNCH_CHECK();
+    return 0;
+}

@@ -825,6 +825,86 @@ class NormActDropFn(torch.autograd.Function):
         return dx.view(ctx.in_shape), dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+class LinearBnActFn(torch.autograd.Function):
+    """drop(act(bn(x W^T + b))) of ONE perf-mode MLP layer on a batch of up to 128 rows as one launch
+    (pk_linear_bn_act_bf16: the whole batch sits in one row tile of the GEMM, so the BatchNorm statistics are a reduction
+    inside the workgroup that owns the columns).  Forward replaces LinearFn + NormActDropFn + the next layer's bf16
+    conversion (seven launches); backward runs the same kernels those two nodes run (activation / BatchNorm backward on
+    the saved z, a, statistics; dX / dW / db from the bf16 copies).  y carries its bf16 twin for the next layer."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, act, mask, xb):
+        _need_gpu(x, weight, bias, gamma, beta, mask)
+        lib = _lib.load()
+        x2 = _rows2d(x)
+        M, K = x2.shape
+        N = weight.shape[0]
+        wb = cvt_bf16(weight.contiguous())
+        if xb is None:
+            xb = cvt_bf16(x2)
+        z, a = _new(M, N, like=x2), _new(M, N, like=x2)
+        y = _new(M, N, like=x2) if mask is not None else a
+        yb = torch.empty(M, N, device=x2.device, dtype=torch.bfloat16)
+        mean, var = _new(N, like=x2), _new(N, like=x2)
+        _lib.check(lib.pk_linear_bn_act_bf16(_stream(), M, N, K, _p(xb), xb.shape[1], _p(wb), wb.shape[1], _p(bias), _p(gamma),
+                                             _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var),
+                                             ACT[act], _p(mask), _p(z), _p(a), _p(y) if mask is not None else None, _p(yb), N,
+                                             _p(mean), _p(var)), "pk_linear_bn_act_bf16")
+        if _Decisions.relu is not None and act == "relu":  # test mode (see NormActDropFn)
+            pat = _Decisions.relu.pop(0).to(a.device).reshape(M, N)
+            _Decisions.report.append(("relu", int(((a > 0) != pat).sum()), M * N))
+            a = torch.where(pat, a.clamp_min(1e-30), torch.zeros_like(a))
+        ctx.save_for_backward(xb, wb, z, gamma, mean, var, a, mask)
+        ctx.cfg = (float(eps), act)
+        ctx.dims = (M, N, K)
+        ctx.has_bias = bias is not None
+        ctx.in_shape = x.shape
+        ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None
+        ctx.mark_non_differentiable(yb)
+        return y, yb
+
+    @staticmethod
+    def backward(ctx, dy, _dyb):
+        lib = _lib.load()
+        xb, wb, z, gamma, mean, var, a, mask = ctx.saved_tensors
+        eps, act = ctx.cfg
+        M, N, K = ctx.dims
+        dy2 = _rows2d(dy.contiguous())
+        g = _new(M, N, like=z)
+        _lib.check(lib.pk_act_bwd(_stream(), _p(dy2), _p(a), _p(mask), ACT[act], M * N, _p(g)), "pk_act_bwd")
+        part = _new(int(lib.pk_bn_partial_floats(M, N)), like=z)
+        sum_g, sum_gx = _new(N, like=z), _new(N, like=z)
+        _lib.check(lib.pk_bn_bwd_reduce(_stream(), _p(g), None, N, _p(z), N, M, N, _p(mean), _p(var), eps, _p(part), _p(sum_g),
+                                        _p(sum_gx)), "pk_bn_bwd_reduce")
+        dz = _new(M, N, like=z)
+        _lib.check(lib.pk_bn_bwd_apply(_stream(), _p(g), None, N, _p(z), N, M, N, _p(mean), _p(var), eps, _p(gamma), _p(sum_g),
+                                       _p(sum_gx), float(M), _p(dz), N), "pk_bn_bwd_apply")
+        dx, dw = _linear_bwd_bf16(ctx, cvt_bf16(dz), xb, wb, dz)
+        db = colsum(dz) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, sum_gx, sum_g, None, None, None, None, None, None, None
+
+
+def linear_bn_act_ok(x, weight, training, use_bn, act):
+    """The one-launch MLP layer covers perf mode, training-mode BatchNorm, 2-D batches of up to 128 rows."""
+    return (bf16_mode() and training and use_bn and x.dim() == 2 and act in ACT and x.is_cuda
+            and os.environ.get("PK_MLP_FUSED", "1") != "0"
+            and _lib.load().pk_linear_bn_act_bf16_covers(x.shape[0], weight.shape[0], x.shape[1]) == 1)
+
+
+def linear_bn_act(x, weight, bias, bn, act, mask):
+    """-> y = mask * act(bn(x W^T + b)); y._pk_yb = its bf16 copy (what the next layer's GEMM reads)."""
+    twin = getattr(x, "_pk_yb", None)
+    xb = twin[0] if (twin is not None and twin[1] == x._version and twin[0].shape[0] == x.shape[0]) else None
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    y, yb = LinearBnActFn.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                                act, mask, xb)
+    y._pk_yb = (yb, y._version)
+    if yb.shape[1] % 64 == 0:  # also in the form the output layers look for (input_twin): one segment, no re-pitching
+        y._pk_twin = (yb, (1, yb.shape[1], yb.shape[1]), y._version)
+    return y
+
+
 def norm_act_drop(x, bn, use_bn, training, act, mask=None, eps=None):
     """bn: an nn.BatchNorm1d used as a parameter container (or None)."""
     if use_bn:

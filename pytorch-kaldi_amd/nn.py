@@ -184,6 +184,15 @@ class MLP(nn.Module):
                     and F_.linear_log_softmax_ok(x, self.wx[i].weight)):
                 x = F_.linear_log_softmax(x, self.wx[i].weight, self.wx[i].bias)  # perf-mode output layer: one node
                 continue
+            if (not self.dnn_use_laynorm[i] and self.dnn_act[i] != "softmax"
+                    and F_.linear_bn_act_ok(x, self.wx[i].weight, self.training, bool(self.dnn_use_batchnorm[i]), self.dnn_act[i])):
+                # perf mode, small batch: the whole layer - GEMM, batch statistics, BatchNorm, activation, drop mask, the
+                # bf16 copy the next layer reads - is one launch (functional.LinearBnActFn)
+                mask = None
+                if self.training and self.dnn_drop[i] > 0.0:
+                    mask = F_.dropout_mask(torch.empty(x.shape[0], self.dnn_lay[i], device=x.device), self.dnn_drop[i])
+                x = F_.linear_bn_act(x, self.wx[i].weight, self.wx[i].bias, self.bn[i], self.dnn_act[i], mask)
+                continue
             z = F_.linear(x, self.wx[i].weight, self.wx[i].bias)
             if self.dnn_use_laynorm[i]:
                 z = self.ln[i](z)

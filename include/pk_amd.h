@@ -208,14 +208,20 @@ int pk_nll_logsoftmax_bwd_bf16(void* stream, const float* y, const int64_t* lab,
  *                      stored at its ORIGINAL time index.
  *   S      [T, R, NS*H] saved per-step tensors for backward (cell-dependent:
  *                      liGRU z,a; RNN a; LSTM f,i,o,g,c; GRU z,r,a; minGRU z,a)
- *   ln_gamma/ln_beta [H] or NULL: per-step LayerNorm of h_t (stepwise only).
- *   LNS    [T, R, 2+H]   saved LN stats + pre-LN h when LayerNorm is on.
- * work: scratch, >= pk_rec_work_floats() floats.
- * algo: PK_REC_STEPWISE handles everything; PK_REC_PERSISTENT handles
- * liGRU/RNN/LSTM without per-step LayerNorm and returns an error otherwise. */
+ *   ln_gamma/ln_beta [H] or NULL: per-step LayerNorm of h_t (neural_networks.py:23-33 applied at :466-467,
+ *                      :638-639, :1138-1139, :1299-1300, :1444-1445), eps 1e-6.
+ *   LNS    >= pk_rec_ln_saved_floats() floats when LayerNorm is on: LN statistics + pre-LN h, saved for backward
+ *                      (opaque: the step-wise and the persistent algorithm lay it out differently).
+ * work: scratch, >= pk_rec_work_floats() floats; PK_REC_PERSISTENT with LayerNorm: >= pk_rec_work_floats() +
+ *                      pk_rec_ln_work_floats() floats (the row-statistics exchange sits behind the base scratch).
+ * algo: PK_REC_STEPWISE handles everything; PK_REC_PERSISTENT handles liGRU/RNN/LSTM (per-step LayerNorm inside
+ * the time loop: liGRU / RNN here in fp32, liGRU / RNN / LSTM in bf16 through pk_rec_fwd_bf16_ln) and returns an error
+ * otherwise. */
 int pk_rec_num_saved(int cell);
 int pk_rec_num_gates(int cell);
 int64_t pk_rec_work_floats(int cell, int T, int B, int bidir, int H);
+int64_t pk_rec_ln_saved_floats(int T, int B, int bidir, int H);
+int64_t pk_rec_ln_work_floats(int T, int B, int bidir, int H);
 int pk_rec_fwd(void* stream, int algo, int prec, int cell, int act, int T, int B, int bidir, int H,
                const float* P, const float* pscale, const float* pshift, const float* U, const float* mask,
                float mask_scalar, const float* ln_gamma, const float* ln_beta, float* Y, float* S, float* LNS,
@@ -253,6 +259,20 @@ int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, in
 int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
                     float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, uint16_t* dGb,
                     int64_t g_pitch, int prefilled);
+/* ... with per-step LayerNorm of h_t inside the persistent time loop (liGRU / RNN / LSTM; the reference's
+ * `if self.*_use_laynorm[i]: ht = self.ln[i](ht)`, neural_networks.py:466-467, :1138-1139, :1444-1445): every step
+ * exchanges the rows' partial sums between the workgroups of a cluster a second time (fp32, 32 bytes per wave and row
+ * quad) before h_t is normalised, stored, published and fed back.  LNS >= pk_rec_ln_saved_floats() floats (forward
+ * writes, backward reads), lnwork >= pk_rec_ln_work_floats() floats of scratch per call, dln_gamma / dln_beta [H]
+ * (overwritten).  Y / Yb hold the normalised h_t. */
+int pk_rec_fwd_bf16_ln(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
+                       const float* pscale, const float* pshift, const float* U, const float* mask, float mask_scalar,
+                       const float* ln_gamma, const float* ln_beta, float ln_eps, float* Y, float* S, float* LNS,
+                       uint16_t* Yb, int64_t y_pitch, int prefilled, float* lnwork);
+int pk_rec_bwd_bf16_ln(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
+                       float mask_scalar, const float* ln_gamma, float ln_eps, const float* Y, const float* S,
+                       const float* LNS, const float* dY, float* dP2, uint16_t* dGb, int64_t g_pitch, int prefilled,
+                       float* lnwork, float* dln_gamma, float* dln_beta);
 /* diagnostics: when non-NULL, cluster 0 / member 0 / wave 0 of every following launch writes
  * T x 8 shader-clock stamps (phase boundaries of each step) to this device buffer. */
 void pk_persist2_set_trace(void* dev_buf);
@@ -332,6 +352,9 @@ int pk_selftest_mfma(void* stream, int* h_bad_count);
 /* v_permlane16_swap_b32 lane mapping the third-generation persistent recurrences rely on when they assemble a 16-byte
  * publish chunk from two lanes (pk_rec_persist3.hip) */
 int pk_selftest_permlane(void* stream, int* h_bad_count);
+/* the DPP row sum (quad_perm x2, row_half_mirror, row_mirror) of the per-step LayerNorm exchange in the persistent
+ * recurrences: every lane of a 16-lane row must end with the row's total */
+int pk_selftest_dpp_row_sum(void* stream, int* h_bad_count);
 
 /* ---- chunk loader pieces (next row): binary Kaldi matrix tables and the whole-chunk transforms
  * of data_io.load_chunk.  Host memory; plain files (the reference reads through Kaldi pipes, which stay outside).

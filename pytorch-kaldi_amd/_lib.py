@@ -62,6 +62,8 @@ SIGNATURES = {
     "pk_rec_num_saved": (c_int, [c_int]),
     "pk_rec_num_gates": (c_int, [c_int]),
     "pk_rec_work_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
+    "pk_rec_ln_saved_floats": (c_int64, [c_int, c_int, c_int, c_int]),
+    "pk_rec_ln_work_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "pk_rec_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, P,
                            P, P, P]),
     "pk_rec_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, P,
@@ -71,6 +73,10 @@ SIGNATURES = {
     "pk_gemm_bf16_auto_splitk_cus": (c_int, [c_int, c_int, c_int, c_int]),
     "pk_rec_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, P, c_int64, c_int]),
     "pk_rec_bwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int64, c_int]),
+    "pk_rec_fwd_bf16_ln": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, c_float, P, P, P,
+                                   P, c_int64, c_int, P]),
+    "pk_rec_bwd_bf16_ln": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, c_float, P, P, P, P, P, P,
+                                   c_int64, c_int, P, P, P]),
     "pk_rec2p_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, P, P, c_int64, c_int]),
     "pk_rec2p_bwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, c_int64, c_int]),
     "pk_persist2_set_trace": (None, [P]),
@@ -104,6 +110,7 @@ SIGNATURES = {
                                       P, P, P, P, c_int64, P, P]),
     "pk_selftest_mfma": (c_int, [P, ctypes.POINTER(c_int)]),
     "pk_selftest_permlane": (c_int, [P, ctypes.POINTER(c_int)]),
+    "pk_selftest_dpp_row_sum": (c_int, [P, ctypes.POINTER(c_int)]),
 }
 
 
@@ -177,7 +184,7 @@ class _TimedLib:
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
         sig = SIGNATURES.get(name)
-        if sig is None or not sig[1] or sig[1][0] is not P or name in ("pk_selftest_mfma", "pk_selftest_permlane"):
+        if sig is None or not sig[1] or sig[1][0] is not P or name.startswith("pk_selftest_"):
             return fn
         prof = self._prof
 

@@ -150,3 +150,13 @@ __device__ __forceinline__ void pk_cell_bwd_pb(const float* s, float hp, float q
         dh_direct += q * z;
     }
 }
+
+// per-step LayerNorm of h_t in the persistent recurrences: what the entry points hand to the launchers (null pointer to
+// the struct = a layer without it)
+struct PkLnHost {
+    const float *gamma, *beta;  // [H]
+    float eps;
+    float* LNS;     // saved for backward: >= pk_rec_ln_saved_floats floats
+    float* lnwork;  // scratch: >= pk_rec_ln_work_floats floats
+    float *dgamma, *dbeta;  // backward only
+};

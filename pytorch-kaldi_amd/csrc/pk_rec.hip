@@ -13,10 +13,10 @@
 // persistent algorithm (pk_rec_persist.hip)
 int pk_rec_fwd_persistent(hipStream_t st, int prec, int cell, int act, int T, int B, int bidir, int H, const float* P,
                           const float* pscale, const float* pshift, const float* U, const float* mask,
-                          float mask_scalar, float* Y, float* S, float* work);
+                          float mask_scalar, float* Y, float* S, float* work, const PkLnHost* ln);
 int pk_rec_bwd_persistent(hipStream_t st, int prec, int cell, int act, int T, int B, int bidir, int H, const float* U,
                           const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
-                          float* dP2, float* work);
+                          float* dP2, float* work, const PkLnHost* ln);
 
 namespace {
 
@@ -543,16 +543,18 @@ extern "C" int pk_rec_fwd(void* stream, int algo, int prec, int cell, int act, i
     PK_TRY(check_common("pk_rec_fwd", algo, prec, cell, act, T, B, bidir, H));
     PK_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr) && (ln_gamma == nullptr) == (LNS == nullptr),
                "pk_rec_fwd: ln_gamma, ln_beta and LNS go together");
-    PK_REQUIRE(ln_gamma == nullptr || algo == PK_REC_STEPWISE,
-               "pk_rec_fwd: per-step LayerNorm runs in the step-wise algorithm only");
     PK_REQUIRE(ln_gamma == nullptr || H > 1, "pk_rec_fwd: LayerNorm needs H > 1");
     hipStream_t st = pk_stream(stream);
     StepGeom g;
     g.T = T; g.B = B; g.R = B * (1 + bidir); g.H = H;
     g.G = pk_cell_gates(cell); g.NS = pk_cell_saved(cell); g.YH = (1 + bidir) * H;
-    if (algo == PK_REC_PERSISTENT)
+    if (algo == PK_REC_PERSISTENT) {
+        // per-step LayerNorm: LNS holds pk_rec_ln_saved_floats floats and the scratch of pk_rec_ln_work_floats floats sits
+        // behind the pk_rec_work_floats floats of `work`
+        PkLnHost ln = {ln_gamma, ln_beta, 1e-6f, LNS, work ? work + pk_rec_work_floats(cell, T, B, bidir, H) : nullptr, nullptr, nullptr};
         return pk_rec_fwd_persistent(st, prec, cell, act, T, B, bidir, H, P, pscale, pshift, U, mask, mask_scalar, Y, S,
-                                     work);
+                                     work, ln_gamma ? &ln : nullptr);
+    }
     switch (cell) {
         case PK_CELL_LIGRU: return fwd_stepwise<PK_CELL_LIGRU>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, ln_gamma, ln_beta, Y, S, LNS, work);
         case PK_CELL_RNN: return fwd_stepwise<PK_CELL_RNN>(st, prec, act, g, P, pscale, pshift, U, mask, mask_scalar, ln_gamma, ln_beta, Y, S, LNS, work);
@@ -570,15 +572,16 @@ extern "C" int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, i
     PK_REQUIRE((ln_gamma == nullptr) == (LNS == nullptr) && (ln_gamma == nullptr) == (dln_gamma == nullptr) &&
                    (ln_gamma == nullptr) == (dln_beta == nullptr),
                "pk_rec_bwd: ln_gamma, LNS, dln_gamma and dln_beta go together");
-    PK_REQUIRE(ln_gamma == nullptr || algo == PK_REC_STEPWISE,
-               "pk_rec_bwd: per-step LayerNorm runs in the step-wise algorithm only");
     hipStream_t st = pk_stream(stream);
     StepGeom g;
     g.T = T; g.B = B; g.R = B * (1 + bidir); g.H = H;
     g.G = pk_cell_gates(cell); g.NS = pk_cell_saved(cell); g.YH = (1 + bidir) * H;
     int rc;
     if (algo == PK_REC_PERSISTENT) {
-        rc = pk_rec_bwd_persistent(st, prec, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dP2, work);
+        PkLnHost ln = {ln_gamma, nullptr, 1e-6f, const_cast<float*>(LNS), work ? work + pk_rec_work_floats(cell, T, B, bidir, H) : nullptr,
+                       dln_gamma, dln_beta};
+        rc = pk_rec_bwd_persistent(st, prec, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dP2, work,
+                                   ln_gamma ? &ln : nullptr);
     } else {
         switch (cell) {
             case PK_CELL_LIGRU: rc = bwd_stepwise<PK_CELL_LIGRU>(st, prec, act, g, U, mask, mask_scalar, ln_gamma, Y, S, LNS, dY, dP2, dln_gamma, dln_beta, work); break;

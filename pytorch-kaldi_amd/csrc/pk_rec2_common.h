@@ -41,6 +41,15 @@ struct R2Args {
     int flush_late;             // third generation: 1 = the step's off-chain HBM traffic is issued behind the MFMA block
     int empty_step;             // diagnostics (traced kernels only): skip the MFMA block and the gate math - what is left
                                 // of a step is the hand-off itself (poll, barrier, flush / prefetch issue, publish)
+    // ---- per-step LayerNorm of h_t inside the time loop (LN kernels only; ln_gamma == null otherwise)
+    const float *ln_gamma, *ln_beta;  // [H]
+    float ln_eps;
+    float* lnh;      // pre-LN h_t, same layout as Y ([T][B][YH], storage time)
+    float* lnstat;   // [T][R][2]: mean, 1 / (std + eps) of (step t, row n)
+    float* lnx;      // row-statistics exchange [T][ln_ncg][4 row quads][4 * Pn slots][8 floats], 0xFF-filled before the launch
+    float* lnpart;   // backward: [2][ln_ncg][KPAD] per-cluster partial sums of d gamma, d beta
+    int ln_cg0;      // global index of this launch's first cluster
+    int ln_ncg;      // clusters over all launches
 };
 
 struct Plan2 {
@@ -157,6 +166,101 @@ __device__ __forceinline__ bool poll_to_lds(__amdgpu_buffer_rsrc_t rs, const uns
 #pragma unroll
     for (int i = 0; i < NCH; ++i) *reinterpret_cast<u32x4*>(tile + loff[i]) = v[i];
     return dead;
+}
+
+// ---- per-step LayerNorm (neural_networks.py:23-33 applied to h_t at :466-467, :1138-1139, :1444-1445): the row
+// statistics need every unit of the row, i.e. one more exchange between the members of a cluster inside the step.
+// Sum over the 16 lanes of a DPP row (= the 16 units a wave holds for one row quad), every lane ends with the total.
+// Each stage adds the value of ONE partner group, so the result is bit-identical on all 16 lanes.
+__device__ __forceinline__ float dpp_row_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+__device__ __forceinline__ unsigned ln_bits(float f) {
+    const unsigned u = __float_as_uint(f);
+    return u == 0xFFFFFFFFu ? 0x7FC00000u : u;  // the one NaN encoding that reads as "not written yet"
+}
+// Two sums per row over ALL units of the cluster.  In: a[r], b[r] = this lane's terms for rows kq*4 + r (zero for
+// units / rows outside the layer).  Every WAVE publishes its 16-unit partial sums (lane 0 of each DPP row: one 32-byte
+// entry per row quad, slot = member * 4 + wave) and then polls all 4 * Pn entries of its row quads - lane u of a DPP row
+// takes slots u, u + 16, u + 32 - with the data as the flag, like the h_t exchange itself.  No workgroup barrier, no
+// LDS.  Fixed summation order: every lane, wave and member of the cluster ends with bit-identical totals.
+//   pub_off: byte offset of my entry in this step's slab (lanes that do not publish: out of range, dropped)
+//   poll_off[s]: byte offsets of the entries I poll (slots beyond 4 * Pn: out of range, answered with zeros)
+template <bool FAST>
+__device__ __forceinline__ bool ln_row_allreduce(__amdgpu_buffer_rsrc_t rsx, unsigned pub_off, const unsigned (&poll_off)[3],
+                                                 float (&a)[4], float (&b)[4], unsigned* err, int spin_limit, int lane, bool dead) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        a[r] = dpp_row_sum(a[r]);
+        b[r] = dpp_row_sum(b[r]);
+    }
+    pub_store<FAST>(rsx, pub_off, u32x4{ln_bits(a[0]), ln_bits(b[0]), ln_bits(a[1]), ln_bits(b[1])});
+    pub_store<FAST>(rsx, pub_off + 16u, u32x4{ln_bits(a[2]), ln_bits(b[2]), ln_bits(a[3]), ln_bits(b[3])});
+    u32x4 v[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) v[i] = poll_load<FAST>(rsx, poll_off[i >> 1] + (unsigned)(i & 1) * 16u);
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bad = bad | has_sent16(v[i]);
+    if (__any(bad) && !dead) {
+        int spins = 0;
+        while (true) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (has_sent16(v[i])) v[i] = poll_load<FAST>(rsx, poll_off[i >> 1] + (unsigned)(i & 1) * 16u);
+            bad = false;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) bad = bad | has_sent16(v[i]);
+            if (!__any(bad)) break;
+            if (spin_check2(spins, spin_limit, err, lane)) {
+                dead = true;
+                break;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ch = r >> 1, e = (r & 1) * 2;
+        float sa = __uint_as_float(v[ch][e]), sb = __uint_as_float(v[ch][e + 1]);
+        sa += __uint_as_float(v[2 + ch][e]);
+        sb += __uint_as_float(v[2 + ch][e + 1]);
+        sa += __uint_as_float(v[4 + ch][e]);
+        sb += __uint_as_float(v[4 + ch][e + 1]);
+        a[r] = dpp_row_sum(sa);
+        b[r] = dpp_row_sum(sb);
+    }
+    return dead;
+}
+// byte offsets into the row-statistics exchange for one lane at step 0; a slot this lane does not use is out of range
+// (== size: stores are dropped, loads answer zeros - never the sentinel) at every step
+struct LnSlots {
+    unsigned pub, poll[3], slab, size;
+    bool pub_ok, poll_ok[3];
+    __device__ __forceinline__ unsigned pub_at(int step) const { return pub_ok ? pub + (unsigned)step * slab : size; }
+    __device__ __forceinline__ void poll_at(int step, unsigned (&o)[3]) const {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o[i] = poll_ok[i] ? poll[i] + (unsigned)step * slab : size;
+    }
+};
+__device__ __forceinline__ LnSlots ln_slots(const R2Args& a, int c, int p, int wave, int lane, int T) {
+    LnSlots s;
+    const unsigned nslot = 4u * (unsigned)a.Pn, kq = (unsigned)lane >> 4, u = (unsigned)lane & 15u;
+    s.slab = (unsigned)a.ln_ncg * 4u * nslot * 32u;
+    s.size = (unsigned)T * s.slab;
+    const unsigned base = (((unsigned)(a.ln_cg0 + c) * 4u + kq) * nslot) * 32u;
+    s.pub_ok = u == 0u;
+    s.pub = base + ((unsigned)p * 4u + (unsigned)wave) * 32u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const unsigned slot = u + 16u * (unsigned)i;
+        s.poll_ok[i] = slot < nslot;
+        s.poll[i] = base + slot * 32u;
+    }
+    return s;
 }
 
 // One-time placement handshake: every member publishes the XCD it runs on (write-through) and
@@ -290,6 +394,9 @@ struct BoolC {  // (an int: 0 = no edge, 1 = even-H edge in 8-byte halves, 2 = o
 
 // host-side plumbing shared by both translation units (defined in pk_rec_persist2.hip)
 int pk_rec2_make_plan(int R, int H, Plan2& pl);
+// per-step LayerNorm (PkLnHost: pk_cell.h)
+int pk_rec2_ln_setup(hipStream_t st, R2Args& a, const Plan2& pl, const PkLnHost* ln, bool backward);  // fills a.ln_*, fills the exchange
+int pk_rec2_ln_finish(hipStream_t st, const R2Args& a, const PkLnHost* ln);  // backward: per-cluster partial sums -> d gamma, d beta
 int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidir, int H);
 int pk_rec2_host_setup(R2Args& a, bool backward, int cell);                 // error word, trash page, handshake table, tuning knobs
 int pk_rec2_reset_handshake(hipStream_t st);       // before every launch

@@ -625,9 +625,10 @@ extern "C" void pk_persist_error_reset(void) {
 int pk_rec2f_covers(int cell, int H);
 int64_t pk_rec_work_base_floats(int cell, int B, int bidir, int H);
 int pk_rec2f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int H, const float* P, const float* pscale,
-                 const float* pshift, const float* U, const float* mask, float mask_scalar, float* Y, float* S, float* Yx);
+                 const float* pshift, const float* U, const float* mask, float mask_scalar, float* Y, float* S, float* Yx,
+                 const PkLnHost* ln);
 int pk_rec2f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
-                 float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, float* dGx);
+                 float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, float* dGx, const PkLnHost* ln);
 static bool use_gen2_f32(int prec, int cell, int H) {
     static int off = -1;
     if (off < 0) {
@@ -639,12 +640,14 @@ static bool use_gen2_f32(int prec, int cell, int H) {
 
 int pk_rec_fwd_persistent(hipStream_t st, int prec, int cell, int act, int T, int B, int bidir, int H, const float* P,
                           const float* pscale, const float* pshift, const float* U, const float* mask,
-                          float mask_scalar, float* Y, float* S, float* work) {
+                          float mask_scalar, float* Y, float* S, float* work, const PkLnHost* ln) {
     if (use_gen2_f32(prec, cell, H)) {
         PK_REQUIRE(work != nullptr, "pk_rec_fwd: work buffer missing");
         return pk_rec2f_fwd(st, cell, act, T, B, bidir, H, P, pscale, pshift, U, mask, mask_scalar, Y, S,
-                            work + pk_rec_work_base_floats(cell, B, bidir, H));
+                            work + pk_rec_work_base_floats(cell, B, bidir, H), ln);
     }
+    PK_REQUIRE(ln == nullptr, "pk_rec_fwd: per-step LayerNorm in the persistent algorithm is covered for liGRU / RNN in fp32 "
+               "(second-generation kernels) and for liGRU / RNN / LSTM in bf16 (pk_rec_fwd_bf16_ln); cell %d prec %d is not", cell, prec);
     int rc = check_persist("pk_rec_fwd", cell, H);
     if (rc) return rc;
     rc = ensure_err();
@@ -667,12 +670,13 @@ int pk_rec_fwd_persistent(hipStream_t st, int prec, int cell, int act, int T, in
 
 int pk_rec_bwd_persistent(hipStream_t st, int prec, int cell, int act, int T, int B, int bidir, int H, const float* U,
                           const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
-                          float* dP2, float* work) {
+                          float* dP2, float* work, const PkLnHost* ln) {
     if (use_gen2_f32(prec, cell, H)) {
         PK_REQUIRE(work != nullptr, "pk_rec_bwd: work buffer missing");
         return pk_rec2f_bwd(st, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dP2,
-                            work + pk_rec_work_base_floats(cell, B, bidir, H));
+                            work + pk_rec_work_base_floats(cell, B, bidir, H), ln);
     }
+    PK_REQUIRE(ln == nullptr, "pk_rec_bwd: per-step LayerNorm in the persistent algorithm does not cover cell %d prec %d", cell, prec);
     int rc = check_persist("pk_rec_bwd", cell, H);
     if (rc) return rc;
     rc = ensure_err();

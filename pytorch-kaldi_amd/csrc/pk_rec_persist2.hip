@@ -36,14 +36,19 @@ namespace {
 // ACT >= 0: the activation is a compile-time constant (relu, tanh: what the shipped recipes use) and the switch in
 // pk_act folds away; ACT < 0: run-time a.act.  With the run-time switch the gate math of one step executes ~40 scalar
 // branches (one switch per row and use), which shows up as several hundred clocks on the dependency chain.
-template <int CELL, int ACT, bool TR>
+// LN: per-step LayerNorm of h_t (a.ln_gamma / ln_beta; neural_networks.py:23-33 at :466-467, :1138-1139, :1444-1445): the
+// row statistics take one more exchange inside the step (ln_row_allreduce, pk_rec2_common.h: fp32 partial sums, no
+// barrier); the normalised h_t is what is stored, published and fed back, the pre-LN value and (mean, 1 / (std + eps))
+// are saved for the backward pass.
+template <int CELL, int ACT, bool TR, bool LN = false>
 __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
     constexpr int LDA = pk_r2_lda_bf16(KPAD);      // bf16 elements per A-tile row (1312 B: conflict-free b128 reads)
     constexpr int ATILE = RMAX * LDA * 2;         // bytes
     constexpr int NCH = (RMAX * (KPAD / 8) + 255) / 256;  // 16-byte chunks polled per lane (5)
-    constexpr int WAVE_LDS = (G + 1 + NS) * 1024 + 512;   // P stage | Y | S slots | bf16 publish patch
+    constexpr int NF = G + 1 + NS + (LN ? 1 : 0);         // fp32 patches of a wave
+    constexpr int WAVE_LDS = NF * 1024 + 512;             // P stage | Y | S slots (| pre-LN h) | bf16 publish patch
     constexpr int LDS_TRASH = 2 * ATILE + 4 * WAVE_LDS;   // 16-byte dump slot for chunks a lane does not own
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][ATILE] | 4 x WAVE_LDS | trash
 
@@ -149,9 +154,22 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     float* patchP = reinterpret_cast<float*>(wl);                     // [G][256]
     float* patchY = reinterpret_cast<float*>(wl + G * 1024);          // [256]
     float* patchS = reinterpret_cast<float*>(wl + (G + 1) * 1024);    // [NS][256]
-    unsigned short* patchB = reinterpret_cast<unsigned short*>(wl + (G + 1 + NS) * 1024);  // [16][16] bf16
+    float* patchL = reinterpret_cast<float*>(wl + (G + 1 + NS) * 1024);  // (LN only) [256]
+    unsigned short* patchB = reinterpret_cast<unsigned short*>(wl + NF * 1024);  // [16][16] bf16
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.Yb, szYb);
     float* trash = a.trash + (tid & 63) * 4;
+    // ---- per-step LayerNorm state
+    const LnSlots ls = LN ? ln_slots(a, c, p, wave, lane, T) : LnSlots();
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(LN ? (const void*)a.lnx : (const void*)a.Yb, LN ? ls.size : 0u);
+    const float gam = (LN && unit_ok) ? a.ln_gamma[unit] : 0.f, bet = (LN && unit_ok) ? a.ln_beta[unit] : 0.f;
+    const float invH = 1.0f / (float)H, inv_nm1 = 1.0f / (float)(H - 1);
+    float piv[4] = {0.f, 0.f, 0.f, 0.f};  // pivot of the one-pass variance: the row's mean of the previous step
+    // the statistics of row kq*4 + u are written by lane u (< 4) of each DPP row of (member 0, wave 0)
+    pk_f32x2 st_val = {0.f, 0.f};
+    const int st_row = kq * 4 + (lane & 3);
+    const bool st_ok = LN && p == 0 && wave == 0 && (lane & 15) < 4 && st_row < nrows;
+    float* const st_base = st_ok ? a.lnstat + (long)(n_base + st_row) * 2 : trash;
+    const long st_step = st_ok ? (long)a.R * 2 : 0;
 
     // projections of step tt (vector layout; staged to the gate-math layout at the top of that step)
     f32x4 pv[G];
@@ -167,6 +185,10 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
         st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchY, lane));
 #pragma unroll
         for (int k = 0; k < NS; ++k) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, patch_get_vec(patchS + k * 256, lane));
+        if (LN) {
+            st4<EE>(a.lnh, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchL, lane));
+            *reinterpret_cast<pk_f32x2*>(st_base + (long)tt * st_step) = st_val;
+        }
     };
 #define PK_LP0(E) load_proj(0, E)
     PK_EDGE_DISPATCH(PK_LP0);
@@ -182,8 +204,8 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     // (made explicitly wave-uniform: the specialised loops below must be entered through scalar branches)
     const bool fast_rt = __builtin_amdgcn_readfirstlane((int)(cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0)) != 0;
     // the time loop, instantiated per (XCD-local fast path?, static edge case?) so that neither choice is a branch in it
-    auto run = [&](auto FASTC, auto SEC) {
-    constexpr bool fast = decltype(FASTC)::value != 0;
+    auto run = [&](auto FASTC, auto SEC) {  // FASTC < 0: run-time choice (the LayerNorm variants: one copy of the loop)
+    const bool fast = decltype(FASTC)::value < 0 ? fast_rt : decltype(FASTC)::value != 0;
     constexpr int SE = decltype(SEC)::value;
     for (int t = 0; t < T; ++t) {
         const int step_idx = t;
@@ -262,7 +284,39 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
             hv[r] = h;
 #pragma unroll
             for (int k = 0; k < NS; ++k) sv[k][r] = s[k];
-            patchB[(kq * 4 + r) * 16 + (lane & 15)] = to_bf_pub(h);
+            if (!LN) patchB[(kq * 4 + r) * 16 + (lane & 15)] = to_bf_pub(h);
+        }
+        if (LN) {
+            float la[4], lb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = hv[r] - piv[r];
+                la[r] = rvf[r] != 0.f ? d : 0.f;
+                lb[r] = rvf[r] != 0.f ? d * d : 0.f;
+            }
+            unsigned po[3];
+            ls.poll_at(t, po);
+            dead = fast ? ln_row_allreduce<true>(rsx, ls.pub_at(t), po, la, lb, a.err, a.spin_limit, lane, dead)
+                        : ln_row_allreduce<false>(rsx, ls.pub_at(t), po, la, lb, a.err, a.spin_limit, lane, dead);
+            patch_put_cd(patchL, kq, lane, hv);  // the pre-LN value, saved for backward
+            float mu4[4], ri4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float md = la[r] * invH;
+                const float mu = piv[r] + md;
+                const float var = fmaxf((lb[r] - la[r] * md) * inv_nm1, 0.f);
+                const float ri = 1.0f / (sqrtf(var) + a.ln_eps);
+                const float hn = rvf[r] != 0.f ? gam * ((hv[r] - mu) * ri) + bet : 0.f;
+                hv[r] = hn;
+                hprev[r] = hn;
+                piv[r] = mu;
+                mu4[r] = mu;
+                ri4[r] = ri;
+                patchB[(kq * 4 + r) * 16 + (lane & 15)] = to_bf_pub(hn);
+            }
+            const int u3 = lane & 3;
+            st_val[0] = u3 == 0 ? mu4[0] : u3 == 1 ? mu4[1] : u3 == 2 ? mu4[2] : mu4[3];
+            st_val[1] = u3 == 0 ? ri4[0] : u3 == 1 ? ri4[1] : u3 == 2 ? ri4[2] : ri4[3];
         }
         PK_TRACE(4);
         // ---- publish h_t first: it is what the other workgroups of the cluster wait for
@@ -282,7 +336,11 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
         PK_TRACE(5);
     }
     };
-    PK_RUN_SPECIALISED(run, fast_rt);
+    if constexpr (LN) {
+        run(BoolC<-1>(), BoolC<-1>());
+    } else {
+        PK_RUN_SPECIALISED(run, fast_rt);
+    }
 #define PK_FOL(E) flush_outputs(T - 1, E)
     PK_EDGE_DISPATCH(PK_FOL);
 }
@@ -290,7 +348,9 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
 // ============================================================================
 // backward: dL/dh_{t-1} = direct + [dgates_t] . [U_0; U_1; ...]
 // ============================================================================
-template <int CELL, int ACT, bool TR>
+// LN: the gradient arriving at h_t goes through the LayerNorm backward first (two more row sums -> ln_row_allreduce);
+// d gamma / d beta are accumulated per lane over the steps and leave as per-cluster partial sums (a.lnpart).
+template <int CELL, int ACT, bool TR, bool LN = false>
 __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
@@ -299,7 +359,8 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
     constexpr int ATILE = RMAX * LDA * 2;
     constexpr int NBUF = (2 * ATILE > 96 * 1024) ? 1 : 2;  // LSTM: one A tile (74 KB) + an extra barrier per step
     constexpr int NCH = (RMAX * G * (KPAD / 8) + 255) / 256;
-    constexpr int NIN = NS + 2 + (LSTM ? 1 : 0);            // saved gates, h_{t-1}, dY (, c_{t-1})
+    constexpr int NIN = NS + 2 + (LSTM ? 1 : 0) + (LN ? 1 : 0);  // saved gates, h_{t-1}, dY (, c_{t-1}) (, pre-LN h_t)
+    constexpr int ILN = NS + 2 + (LSTM ? 1 : 0);            // slot of the pre-LN h_t
     constexpr int WAVE_LDS = (NIN + G) * 1024 + G * 512;    // input patches | dgate fp32 patches | dgate bf16 patches
     constexpr int LDS_TRASH = NBUF * ATILE + 4 * WAVE_LDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -397,6 +458,8 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
     unsigned short* patchB = reinterpret_cast<unsigned short*>(wl + (NIN + G) * 1024);  // [G][16][16] bf16
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dGb, szGb);
     float* trash = a.trash + (tid & 63) * 4;
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(LN ? (const void*)a.lnx : (const void*)a.dGb,
+                                                 LN ? (unsigned)T * ((unsigned)a.ln_ncg * 4u * 4u * (unsigned)a.Pn * 32u) : 0u);
 
     // saved tensors of one step in the vector layout: [0..NS) gates, NS = h_{t-1}, NS+1 = dY, NS+2 = c_{t-1}
     f32x4 iv[NIN];
@@ -409,12 +472,31 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
         for (int k = 0; k < NS; ++k) iv[k] = ld4<EE>(a.S, vS0 + ts * vSs + k * H, vnv);
         iv[NS] = ld4<EE>(a.Y, vY0 + tp * vYs, nvp);
         iv[NS + 1] = ld4<EE>(a.dY, vY0 + ts * vYs, vnv);
-        if (LSTM) iv[NIN - 1] = ld4<EE>(a.S, vS0 + tp * vSs + 4 * H, nvp);
+        if (LSTM) iv[NS + 2] = ld4<EE>(a.S, vS0 + tp * vSs + 4 * H, nvp);
+        if (LN) iv[ILN] = ld4<EE>(a.lnh, vY0 + ts * vYs, vnv);
         if (t == 0) {  // h_{-1} = c_{-1} = 0
             iv[NS] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (LSTM) iv[NIN - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (LSTM) iv[NS + 2] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
+    // ---- per-step LayerNorm state: (mean, 1/(std+eps)) of my four rows, loaded one step ahead like the saved gates
+    const LnSlots ls = LN ? ln_slots(a, c, p, wave, lane, T) : LnSlots();
+    const float gam = (LN && unit_ok) ? a.ln_gamma[unit] : 0.f;
+    const float invH = 1.0f / (float)H, inv_nm1 = 1.0f / (float)(H - 1);
+    float accg = 0.f, accb = 0.f;
+    pk_f32x2 stn[4];
+    long st_off[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = kq * 4 + r;
+        st_off[r] = (LN && row < nrows) ? (long)(n_base + row) * 2 : 0;
+        stn[r] = pk_f32x2{0.f, 1.f};
+    }
+    auto load_stats = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stn[r] = *reinterpret_cast<const pk_f32x2*>(a.lnstat + (long)t * a.R * 2 + st_off[r]);
+    };
+    if (LN) load_stats(T - 1);
     auto load_step = [&](int t, auto SEC) {  // SEC: BoolC<0> = static no-edge case, BoolC<-1> = run-time dispatch
         constexpr int SE = decltype(SEC)::value;
 #define PK_LS(E) load_step_e(t, E)
@@ -468,6 +550,12 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
             if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
         }
         PK_TRACE(1);
+        float mu4[4], ri4[4];  // this step's row statistics (the loads are a whole step old)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            mu4[r] = stn[r][0];
+            ri4[r] = stn[r][1];
+        }
 #pragma unroll
         for (int k = 0; k < NIN; ++k) patch_put_vec(patchI + k * 256, lane, iv[k]);
         if (t < T - 1) PK_BARRIER_LDS();
@@ -477,6 +565,7 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
         // the saved tensors of the next one
         if (t < T - 1) flush_outputs(t + 1, SEC);
         if (t > 0) load_step(t - 1, SEC);
+        if (LN && t > 0) load_stats(t - 1);
         if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) {
             if (fast) fill_slab(t - PK_R2_FILL_AHEAD, BoolC<1>());
             else fill_slab(t - PK_R2_FILL_AHEAD, BoolC<0>());
@@ -499,14 +588,41 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
 #pragma unroll
         for (int k = 0; k < NIN; ++k) patch_get_cd(patchI + k * 256, kq, lane, sin[k]);
         float dgv[G][4];
+        float dh4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh4[r] = sin[NS + 1][r] + dh_dir[r] + acc0[r] + acc1[r];
+        if (LN) {
+            // dL/d(pre-LN h) = rinv * (g - mean(g)) - d * rinv^2 * sum(g d) / ((H - 1) std),  g = dh * gamma, d = x - mean
+            float la[4], lb[4], dd[4], gg[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = rvf[r] != 0.f;
+                dd[r] = sin[ILN][r] - mu4[r];
+                gg[r] = dh4[r] * gam;
+                la[r] = ok ? gg[r] : 0.f;
+                lb[r] = ok ? gg[r] * dd[r] : 0.f;
+                accg += ok ? dh4[r] * (dd[r] * ri4[r]) : 0.f;
+                accb += ok ? dh4[r] : 0.f;
+            }
+            unsigned po[3];
+            ls.poll_at(it, po);
+            dead = fast ? ln_row_allreduce<true>(rsx, ls.pub_at(it), po, la, lb, a.err, a.spin_limit, lane, dead)
+                        : ln_row_allreduce<false>(rsx, ls.pub_at(it), po, la, lb, a.err, a.spin_limit, lane, dead);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sd = 1.0f / ri4[r] - a.ln_eps;
+                const float k2 = ri4[r] * ri4[r] * lb[r] * inv_nm1 / sd;
+                dh4[r] = ri4[r] * (gg[r] - la[r] * invH) - k2 * dd[r];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float s[NS];
 #pragma unroll
             for (int k = 0; k < NS; ++k) s[k] = sin[k][r];
-            const float hp = sin[NS][r], dy = sin[NS + 1][r];
-            const float cp = LSTM ? sin[NIN - 1][r] : 0.f;
-            const float dh = dy + dh_dir[r] + acc0[r] + acc1[r];
+            const float hp = sin[NS][r];
+            const float cp = LSTM ? sin[NS + 2][r] : 0.f;
+            const float dh = dh4[r];
             float dg[G], dhd, dcp;
             if (empty) {
                 dhd = 0.f;
@@ -550,6 +666,16 @@ __global__ __launch_bounds__(256, 1) void rec2_bwd_kernel(R2Args a) {
     // 2-4 % SLOWER on the same box, while the forward kernel gains 4 % from it)
     run(BoolC<-1>(), BoolC<-1>());
     flush_outputs(0, BoolC<-1>());
+    if (LN) {  // my unit's share of d gamma / d beta over this cluster's rows and all steps: one owner per (cluster, unit)
+        accg += __shfl_xor(accg, 16, 64);
+        accg += __shfl_xor(accg, 32, 64);
+        accb += __shfl_xor(accb, 16, 64);
+        accb += __shfl_xor(accb, 32, 64);
+        if (lane < 16) {
+            a.lnpart[(long)(a.ln_cg0 + c) * KPAD + unit] = accg;
+            a.lnpart[(long)(a.ln_ncg + a.ln_cg0 + c) * KPAD + unit] = accb;
+        }
+    }
 }
 
 unsigned long long* g2_trace = nullptr;  // set by pk_persist2_set_trace (diagnostics only)
@@ -602,6 +728,50 @@ int pk_rec2_make_plan(int R, int H, Plan2& pl) {
     pl.C = C;
     pl.rpc = rpc;
     return 0;
+}
+
+// ---- per-step LayerNorm: layout of the saved tensor and of the scratch (one definition for kernels, host and callers)
+static inline int64_t ln_stat_offset(int64_t T, int64_t R, int64_t H) { return (T * R * H + 3) / 4 * 4; }
+extern "C" int64_t pk_rec_ln_saved_floats(int T, int B, int bidir, int H) {
+    const int64_t R = (int64_t)B * (1 + bidir);
+    const int64_t pers = ln_stat_offset(T, R, H) + (int64_t)T * R * 2 + 64;  // pre-LN h in Y's layout | (mean, rinv) per (step, row)
+    const int64_t step = (int64_t)T * R * (H + 2);                           // step-wise algorithm: [mean, rinv, pre-LN h] rows
+    return pers > step ? pers : step;
+}
+static int64_t ln_exchange_floats(int T, const Plan2& pl) { return (int64_t)T * pl.launches * pl.C * 4 * (4 * pl.Pn) * 8; }
+extern "C" int64_t pk_rec_ln_work_floats(int T, int B, int bidir, int H) {
+    Plan2 pl;
+    if (T <= 0 || B <= 0 || H <= 0 || H > KPAD || pk_rec2_make_plan(B * (1 + bidir), H, pl) != 0) return 0;
+    const int64_t ncg = (int64_t)pl.launches * pl.C;
+    return ln_exchange_floats(T, pl) + 2 * ncg * KPAD + pk_bn_partial_floats(ncg, KPAD) + 256;
+}
+int pk_rec2_ln_setup(hipStream_t st, R2Args& a, const Plan2& pl, const PkLnHost* ln, bool backward) {
+    a.ln_gamma = a.ln_beta = nullptr;
+    a.lnh = a.lnstat = a.lnx = a.lnpart = nullptr;
+    a.ln_eps = 0.f; a.ln_cg0 = 0; a.ln_ncg = 0;
+    if (ln == nullptr) return 0;
+    PK_REQUIRE(ln->gamma && ln->LNS && ln->lnwork && (backward ? (ln->dgamma && ln->dbeta) : ln->beta != nullptr),
+               "persistent recurrence with per-step LayerNorm: gamma / beta / LNS / scratch pointers missing");
+    PK_REQUIRE(a.H > 1, "per-step LayerNorm needs H > 1");
+    const int64_t xf = ln_exchange_floats(a.T, pl);
+    PK_REQUIRE((double)xf * 4.0 < 4.0e9, "per-step LayerNorm: the row-statistics exchange exceeds the 4 GB buffer-descriptor range");
+    PK_REQUIRE((((uintptr_t)ln->LNS | (uintptr_t)ln->lnwork) & 15) == 0, "per-step LayerNorm: LNS / scratch must be 16-byte aligned");
+    a.ln_gamma = ln->gamma; a.ln_beta = ln->beta; a.ln_eps = ln->eps;
+    a.lnh = ln->LNS;
+    a.lnstat = ln->LNS + ln_stat_offset(a.T, a.R, a.H);
+    a.lnx = ln->lnwork;
+    a.lnpart = ln->lnwork + xf;
+    a.ln_ncg = pl.launches * pl.C;
+    PK_CHECK_HIP(hipMemsetAsync(a.lnx, 0xFF, (size_t)xf * 4, st));  // every dword "not written yet"
+    if (backward) PK_CHECK_HIP(hipMemsetAsync(a.lnpart, 0, (size_t)2 * a.ln_ncg * KPAD * 4, st));  // clusters without rows add nothing
+    return 0;
+}
+int pk_rec2_ln_finish(hipStream_t st, const R2Args& a, const PkLnHost* ln) {
+    if (ln == nullptr) return 0;
+    float* part = a.lnpart + (size_t)2 * a.ln_ncg * KPAD;
+    int rc = pk_colsum((void*)st, a.lnpart, nullptr, KPAD, a.ln_ncg, a.H, part, ln->dgamma);
+    if (rc) return rc;
+    return pk_colsum((void*)st, a.lnpart + (size_t)a.ln_ncg * KPAD, nullptr, KPAD, a.ln_ncg, a.H, part, ln->dbeta);
 }
 
 int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidir, int H) {
@@ -713,6 +883,15 @@ Rec2Kernel pick_bwd(int act) {
          : act == PK_ACT_TANH ? rec2_bwd_kernel<CELL, PK_ACT_TANH, false> : rec2_bwd_kernel<CELL, -1, false>;
 }
 inline bool traced(int cell, int act) { return g2_trace != nullptr && cell == PK_CELL_LIGRU && act == PK_ACT_RELU; }
+// (the LayerNorm variants exist with the run-time activation only: no shipped recipe normalises h_t)
+inline Rec2Kernel pick_fwd_ln(int cell) {
+    return cell == PK_CELL_LIGRU ? rec2_fwd_kernel<PK_CELL_LIGRU, -1, false, true>
+         : cell == PK_CELL_RNN ? rec2_fwd_kernel<PK_CELL_RNN, -1, false, true> : rec2_fwd_kernel<PK_CELL_LSTM, -1, false, true>;
+}
+inline Rec2Kernel pick_bwd_ln(int cell) {
+    return cell == PK_CELL_LIGRU ? rec2_bwd_kernel<PK_CELL_LIGRU, -1, false, true>
+         : cell == PK_CELL_RNN ? rec2_bwd_kernel<PK_CELL_RNN, -1, false, true> : rec2_bwd_kernel<PK_CELL_LSTM, -1, false, true>;
+}
 inline Rec2Kernel pick_fwd(int cell, int act) {
     if (traced(cell, act)) return rec2_fwd_kernel<PK_CELL_LIGRU, PK_ACT_RELU, true>;
     return cell == PK_CELL_LIGRU ? pick_fwd<PK_CELL_LIGRU>(act) : cell == PK_CELL_RNN ? pick_fwd<PK_CELL_RNN>(act) : pick_fwd<PK_CELL_LSTM>(act);
@@ -722,9 +901,10 @@ inline Rec2Kernel pick_bwd(int cell, int act) {
     return cell == PK_CELL_LIGRU ? pick_bwd<PK_CELL_LIGRU>(act) : cell == PK_CELL_RNN ? pick_bwd<PK_CELL_RNN>(act) : pick_bwd<PK_CELL_LSTM>(act);
 }
 
-extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
-                               const float* pscale, const float* pshift, const float* U, const float* mask,
-                               float mask_scalar, float* Y, float* S, uint16_t* Yb, int64_t y_pitch, int prefilled) {
+static int rec_fwd_bf16_impl(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
+                             const float* pscale, const float* pshift, const float* U, const float* mask,
+                             float mask_scalar, float* Y, float* S, uint16_t* Yb, int64_t y_pitch, int prefilled,
+                             const PkLnHost* ln) {
     int rc = pk_rec2_check("pk_rec_fwd_bf16", 1, cell, T, B, bidir, H);
     if (rc) return rc;
     hipStream_t st = pk_stream(stream);
@@ -748,35 +928,57 @@ extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, in
     const bool lstm8 = cell == PK_CELL_LSTM && pk_rec2l_enabled();
     a.self_fill = prefilled == 2 ? 1 : 0;
     if (prefilled != 1 && !a.self_fill) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
-    if (lstm8) return pk_rec2l_launch(st, a, pl, act, false);
-    if (pk_rec3_covers(cell, 0)) return pk_rec3_launch(st, a, pl, cell, act, false, traced(cell, act));
+    rc = pk_rec2_ln_setup(st, a, pl, ln, false);
+    if (rc) return rc;
+    // (per-step LayerNorm lives in the four-wave second-generation kernels of this file, for every cell)
+    if (lstm8 && !ln) return pk_rec2l_launch(st, a, pl, act, false);
+    if (!ln && pk_rec3_covers(cell, 0)) return pk_rec3_launch(st, a, pl, cell, act, false, traced(cell, act));
     const int G = pk_cell_gates(cell);
-    const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024 + 512) + 16;
+    const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell) + (ln ? 1 : 0)) * 1024 + 512) + 16;
+    const Rec2Kernel k = ln ? pick_fwd_ln(cell) : pick_fwd(cell, act);
     {   // dynamic LDS above the 64 KB default needs the opt-in (exact size: the kernels also hold a little static LDS)
-        static size_t granted[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
+        static size_t granted[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
         const int slot = cell == PK_CELL_LIGRU ? 0 : cell == PK_CELL_RNN ? 1 : 2;
-        const int as = traced(cell, act) ? 3 : act_slot(act);
+        const int as = ln ? 4 : traced(cell, act) ? 3 : act_slot(act);
         if (granted[slot][as] < lds) {
-            PK_CHECK_HIP(hipFuncSetAttribute((const void*)pick_fwd(cell, act), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             granted[slot][as] = lds;
         }
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
+        a.ln_cg0 = l * pl.C;
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
-        rc = pk_rec2_check_residency((const void*)pick_fwd(cell, act), 256, lds, pl.C * pl.Pn, "pk_rec_fwd_bf16");
+        rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_fwd_bf16");
         if (rc) return rc;
-        hipLaunchKernelGGL(pick_fwd(cell, act), grid, block, lds, st, a);
+        hipLaunchKernelGGL(k, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }
     return 0;
 }
+extern "C" int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
+                               const float* pscale, const float* pshift, const float* U, const float* mask,
+                               float mask_scalar, float* Y, float* S, uint16_t* Yb, int64_t y_pitch, int prefilled) {
+    return rec_fwd_bf16_impl(stream, cell, act, T, B, bidir, H, P, pscale, pshift, U, mask, mask_scalar, Y, S, Yb, y_pitch,
+                             prefilled, nullptr);
+}
+// ... with per-step LayerNorm of h_t (neural_networks.py:466-467, :1138-1139, :1444-1445; liGRU / RNN / LSTM):
+// LNS >= pk_rec_ln_saved_floats floats (saved for backward), lnwork >= pk_rec_ln_work_floats floats of scratch.
+extern "C" int pk_rec_fwd_bf16_ln(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
+                                  const float* pscale, const float* pshift, const float* U, const float* mask,
+                                  float mask_scalar, const float* ln_gamma, const float* ln_beta, float ln_eps, float* Y,
+                                  float* S, float* LNS, uint16_t* Yb, int64_t y_pitch, int prefilled, float* lnwork) {
+    PK_REQUIRE(ln_gamma && ln_beta && LNS && lnwork, "pk_rec_fwd_bf16_ln: null LayerNorm argument");
+    const PkLnHost ln = {ln_gamma, ln_beta, ln_eps, LNS, lnwork, nullptr, nullptr};
+    return rec_fwd_bf16_impl(stream, cell, act, T, B, bidir, H, P, pscale, pshift, U, mask, mask_scalar, Y, S, Yb, y_pitch,
+                             prefilled, &ln);
+}
 
-extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
-                               const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
-                               float* dP2, uint16_t* dGb, int64_t g_pitch, int prefilled) {
+static int rec_bwd_bf16_impl(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
+                             const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
+                             float* dP2, uint16_t* dGb, int64_t g_pitch, int prefilled, const PkLnHost* ln) {
     int rc = pk_rec2_check("pk_rec_bwd_bf16", 1, cell, T, B, bidir, H);
     if (rc) return rc;
     hipStream_t st = pk_stream(stream);
@@ -798,29 +1000,48 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
     const bool lstm8 = cell == PK_CELL_LSTM && pk_rec2l_enabled();
     a.self_fill = prefilled == 2 ? 1 : 0;
     if (prefilled != 1 && !a.self_fill) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
-    if (lstm8) return pk_rec2l_launch(st, a, pl, act, true);
-    if (pk_rec3_covers(cell, 1)) return pk_rec3_launch(st, a, pl, cell, act, true, traced(cell, act));
+    rc = pk_rec2_ln_setup(st, a, pl, ln, true);
+    if (rc) return rc;
+    if (lstm8 && !ln) return pk_rec2l_launch(st, a, pl, act, true);
+    if (!ln && pk_rec3_covers(cell, 1)) return pk_rec3_launch(st, a, pl, cell, act, true, traced(cell, act));
     const size_t atile = (size_t)RMAX * pk_r2_lda_bf16(G * KPAD) * 2;
-    const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0);
+    const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0) + (ln ? 1 : 0);
     const size_t lds = (2 * atile > 96 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(nin + G) * 1024 + (size_t)G * 512) + 16;
+    const Rec2Kernel k = ln ? pick_bwd_ln(cell) : pick_bwd(cell, act);
     {
-        static size_t granted[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
+        static size_t granted[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
         const int slot = cell == PK_CELL_LIGRU ? 0 : cell == PK_CELL_RNN ? 1 : 2;
-        const int as = traced(cell, act) ? 3 : act_slot(act);
+        const int as = ln ? 4 : traced(cell, act) ? 3 : act_slot(act);
         if (granted[slot][as] < lds) {
-            PK_CHECK_HIP(hipFuncSetAttribute((const void*)pick_bwd(cell, act), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PK_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             granted[slot][as] = lds;
         }
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
+        a.ln_cg0 = l * pl.C;
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
-        rc = pk_rec2_check_residency((const void*)pick_bwd(cell, act), 256, lds, pl.C * pl.Pn, "pk_rec_bwd_bf16");
+        rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_bwd_bf16");
         if (rc) return rc;
-        hipLaunchKernelGGL(pick_bwd(cell, act), grid, block, lds, st, a);
+        hipLaunchKernelGGL(k, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }
-    return 0;
+    return pk_rec2_ln_finish(st, a, ln);
+}
+extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
+                               const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
+                               float* dP2, uint16_t* dGb, int64_t g_pitch, int prefilled) {
+    return rec_bwd_bf16_impl(stream, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dP2, dGb, g_pitch, prefilled,
+                             nullptr);
+}
+extern "C" int pk_rec_bwd_bf16_ln(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
+                                  const float* mask, float mask_scalar, const float* ln_gamma, float ln_eps, const float* Y,
+                                  const float* S, const float* LNS, const float* dY, float* dP2, uint16_t* dGb,
+                                  int64_t g_pitch, int prefilled, float* lnwork, float* dln_gamma, float* dln_beta) {
+    PK_REQUIRE(ln_gamma && LNS && lnwork && dln_gamma && dln_beta, "pk_rec_bwd_bf16_ln: null LayerNorm argument");
+    const PkLnHost ln = {ln_gamma, nullptr, ln_eps, const_cast<float*>(LNS), lnwork, dln_gamma, dln_beta};
+    return rec_bwd_bf16_impl(stream, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dP2, dGb, g_pitch, prefilled,
+                             &ln);
 }

@@ -40,14 +40,17 @@ __device__ __forceinline__ u32x4 no_sentinel(f32x4 v) {
 // ============================================================================
 // forward
 // ============================================================================
-template <int CELL, int ACT>
+// LN: per-step LayerNorm of h_t (a.ln_gamma / ln_beta): the row statistics take one more exchange inside the step
+// (ln_row_allreduce, pk_rec2_common.h); the normalised h_t is what is stored, published and fed back, the pre-LN value
+// and (mean, 1 / (std + eps)) are saved for the backward pass.
+template <int CELL, int ACT, bool LN>
 __global__ __launch_bounds__(256, 1) void rec2f_fwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
     constexpr int LDA = pk_r2_lda_f32(KPAD);       // floats per A-tile row (conflict-free b128 reads, pk_rec2_common.h)
     constexpr int ATILE = RMAX * LDA * 4;          // bytes
     constexpr int NCH = (RMAX * (KPAD / 4) + 255) / 256;  // 16-byte chunks polled per lane (9)
-    constexpr int WAVE_LDS = (G + 1 + NS) * 1024;  // P stage | Y | S slots
+    constexpr int WAVE_LDS = (G + 1 + NS + (LN ? 1 : 0)) * 1024;  // P stage | Y | S slots (| pre-LN h)
     constexpr int LDS_TRASH = 2 * ATILE + 4 * WAVE_LDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][ATILE] | 4 x WAVE_LDS | trash
 
@@ -132,8 +135,21 @@ __global__ __launch_bounds__(256, 1) void rec2f_fwd_kernel(R2Args a) {
     float* patchP = reinterpret_cast<float*>(wl);
     float* patchY = reinterpret_cast<float*>(wl + G * 1024);
     float* patchS = reinterpret_cast<float*>(wl + (G + 1) * 1024);
+    float* patchL = reinterpret_cast<float*>(wl + (G + 1 + NS) * 1024);  // (LN only)
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.Yx, szYx);
     float* trash = a.trash + (tid & 63) * 4;
+    // ---- per-step LayerNorm state
+    const LnSlots ls = LN ? ln_slots(a, c, p, wave, lane, T) : LnSlots();
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(LN ? a.lnx : a.Yx, LN ? ls.size : 0u);
+    const float gam = (LN && unit_ok) ? a.ln_gamma[unit] : 0.f, bet = (LN && unit_ok) ? a.ln_beta[unit] : 0.f;
+    const float invH = 1.0f / (float)H, inv_nm1 = 1.0f / (float)(H - 1);
+    float piv[4] = {0.f, 0.f, 0.f, 0.f};  // pivot of the one-pass variance: the row's mean of the previous step
+    // the statistics of row kq*4 + u are written by lane u (< 4) of each DPP row of (member 0, wave 0)
+    pk_f32x2 st_val = {0.f, 0.f};
+    const int st_row = kq * 4 + (lane & 3);
+    const bool st_ok = LN && p == 0 && wave == 0 && (lane & 15) < 4 && st_row < nrows;
+    float* const st_base = st_ok ? a.lnstat + (long)(n_base + st_row) * 2 : trash;
+    const long st_step = st_ok ? (long)a.R * 2 : 0;
 
     f32x4 pv[G];
     auto load_proj = [&](int tt, auto E) {
@@ -147,6 +163,10 @@ __global__ __launch_bounds__(256, 1) void rec2f_fwd_kernel(R2Args a) {
         st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchY, lane));
 #pragma unroll
         for (int k = 0; k < NS; ++k) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, patch_get_vec(patchS + k * 256, lane));
+        if (LN) {
+            st4<EE>(a.lnh, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchL, lane));
+            *reinterpret_cast<pk_f32x2*>(st_base + (long)tt * st_step) = st_val;
+        }
     };
 #define PK_LP0(E) load_proj(0, E)
     PK_EDGE_DISPATCH(PK_LP0);
@@ -212,6 +232,38 @@ __global__ __launch_bounds__(256, 1) void rec2f_fwd_kernel(R2Args a) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) sv[k][r] = s[k];
         }
+        if (LN) {
+            // h_t = gamma * (x - mean) / (std + eps) + beta over the row's H units, unbiased std (neural_networks.py:23-33)
+            float la[4], lb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = hv[r] - piv[r];
+                la[r] = rvf[r] != 0.f ? d : 0.f;
+                lb[r] = rvf[r] != 0.f ? d * d : 0.f;
+            }
+            unsigned po[3];
+            ls.poll_at(t, po);
+            dead = fast ? ln_row_allreduce<true>(rsx, ls.pub_at(t), po, la, lb, a.err, a.spin_limit, lane, dead)
+                        : ln_row_allreduce<false>(rsx, ls.pub_at(t), po, la, lb, a.err, a.spin_limit, lane, dead);
+            patch_put_cd(patchL, kq, lane, hv);  // the pre-LN value, saved for backward
+            float mu4[4], ri4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float md = la[r] * invH;
+                const float mu = piv[r] + md;
+                const float var = fmaxf((lb[r] - la[r] * md) * inv_nm1, 0.f);
+                const float ri = 1.0f / (sqrtf(var) + a.ln_eps);
+                const float hn = rvf[r] != 0.f ? gam * ((hv[r] - mu) * ri) + bet : 0.f;
+                hv[r] = hn;
+                hprev[r] = hn;
+                piv[r] = mu;
+                mu4[r] = mu;
+                ri4[r] = ri;
+            }
+            const int u3 = lane & 3;
+            st_val[0] = u3 == 0 ? mu4[0] : u3 == 1 ? mu4[1] : u3 == 2 ? mu4[2] : mu4[3];
+            st_val[1] = u3 == 0 ? ri4[0] : u3 == 1 ? ri4[1] : u3 == 2 ? ri4[2] : ri4[3];
+        }
         // ---- h_t through the wave's Y patch into the vector layout, then publish: one 16-byte store per lane
         patch_put_cd(patchY, kq, lane, hv);
         PK_LDS_ORDER();
@@ -233,7 +285,9 @@ __global__ __launch_bounds__(256, 1) void rec2f_fwd_kernel(R2Args a) {
 // ============================================================================
 // backward: dL/dh_{t-1} = direct + [dgates_t] . [U_0; U_1; ...]
 // ============================================================================
-template <int CELL, int ACT>
+// LN: the gradient arriving at h_t goes through the LayerNorm backward first (two more row sums -> ln_row_allreduce);
+// d gamma / d beta are accumulated per lane over the steps and leave as per-cluster partial sums (a.lnpart).
+template <int CELL, int ACT, bool LN>
 __global__ __launch_bounds__(256, 1) void rec2f_bwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
@@ -241,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void rec2f_bwd_kernel(R2Args a) {
     constexpr int ATILE = RMAX * LDA * 4;
     constexpr int NBUF = (2 * ATILE > 100 * 1024) ? 1 : 2;  // two gates: one 74 KB tile + an extra barrier per step
     constexpr int NCH = (RMAX * G * (KPAD / 4) + 255) / 256;  // 9 per gate
-    constexpr int NIN = NS + 2;                    // saved gates, h_{t-1}, dY
+    constexpr int NIN = NS + 2 + (LN ? 1 : 0);     // saved gates, h_{t-1}, dY (, pre-LN h_t)
     constexpr int WAVE_LDS = (NIN + G) * 1024;     // input patches | fp32 gate-gradient patches
     constexpr int LDS_TRASH = NBUF * ATILE + 4 * WAVE_LDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -338,8 +392,28 @@ __global__ __launch_bounds__(256, 1) void rec2f_bwd_kernel(R2Args a) {
         for (int k = 0; k < NS; ++k) iv[k] = ld4<EE>(a.S, vS0 + ts * vSs + k * H, vnv);
         iv[NS] = ld4<EE>(a.Y, vY0 + tp * vYs, nvp);
         iv[NS + 1] = ld4<EE>(a.dY, vY0 + ts * vYs, vnv);
+        if (LN) iv[NS + 2] = ld4<EE>(a.lnh, vY0 + ts * vYs, vnv);
         if (t == 0) iv[NS] = f32x4{0.f, 0.f, 0.f, 0.f};  // h_{-1} = 0
     };
+    // ---- per-step LayerNorm state: (mean, 1/(std+eps)) of my four rows, loaded one step ahead like the saved gates
+    const LnSlots ls = LN ? ln_slots(a, c, p, wave, lane, T) : LnSlots();
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(LN ? a.lnx : a.dGx, LN ? ls.size : 0u);
+    const float gam = (LN && unit_ok) ? a.ln_gamma[unit] : 0.f;
+    const float invH = 1.0f / (float)H, inv_nm1 = 1.0f / (float)(H - 1);
+    float accg = 0.f, accb = 0.f;
+    pk_f32x2 stn[4];
+    long st_off[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = kq * 4 + r;
+        st_off[r] = (LN && row < nrows) ? (long)(n_base + row) * 2 : 0;
+        stn[r] = pk_f32x2{0.f, 1.f};
+    }
+    auto load_stats = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stn[r] = *reinterpret_cast<const pk_f32x2*>(a.lnstat + (long)t * a.R * 2 + st_off[r]);
+    };
+    if (LN) load_stats(T - 1);
     auto flush_outputs_e = [&](int tt, auto E) {
         const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
 #pragma unroll
@@ -365,6 +439,12 @@ __global__ __launch_bounds__(256, 1) void rec2f_bwd_kernel(R2Args a) {
             dead = fast ? poll_to_lds<NCH, true>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries)
                         : poll_to_lds<NCH, false>(rs, goff, clds, At, a.err, a.spin_limit, lane, dead, retries);
         }
+        float mu4[4], ri4[4];  // this step's row statistics (the loads are a whole step old)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            mu4[r] = stn[r][0];
+            ri4[r] = stn[r][1];
+        }
 #pragma unroll
         for (int k = 0; k < NIN; ++k) patch_put_vec(patchI + k * 256, lane, iv[k]);
         if (t < T - 1) PK_BARRIER_LDS();
@@ -377,6 +457,7 @@ __global__ __launch_bounds__(256, 1) void rec2f_bwd_kernel(R2Args a) {
         if (t > 0) {
 #define PK_LS1(E) load_step_e(t - 1, E)
             PK_EDGE_DISPATCH(PK_LS1);
+            if (LN) load_stats(t - 1);
         }
         if (t < T - 1) {
             const float* Ar = reinterpret_cast<const float*>(At) + (lane & 15) * LDA + kq * 4;
@@ -397,13 +478,40 @@ __global__ __launch_bounds__(256, 1) void rec2f_bwd_kernel(R2Args a) {
 #pragma unroll
         for (int k = 0; k < NIN; ++k) patch_get_cd(patchI + k * 256, kq, lane, sin[k]);
         float dgv[G][4];
+        float dh4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh4[r] = sin[NS + 1][r] + dh_dir[r] + acc0[r] + acc1[r];
+        if (LN) {
+            // dL/d(pre-LN h) = rinv * (g - mean(g)) - d * rinv^2 * sum(g d) / ((H - 1) std),  g = dh * gamma, d = x - mean
+            float la[4], lb[4], dd[4], gg[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = rvf[r] != 0.f;
+                dd[r] = sin[NS + 2][r] - mu4[r];
+                gg[r] = dh4[r] * gam;
+                la[r] = ok ? gg[r] : 0.f;
+                lb[r] = ok ? gg[r] * dd[r] : 0.f;
+                accg += ok ? dh4[r] * (dd[r] * ri4[r]) : 0.f;
+                accb += ok ? dh4[r] : 0.f;
+            }
+            unsigned po[3];
+            ls.poll_at(it, po);
+            dead = fast ? ln_row_allreduce<true>(rsx, ls.pub_at(it), po, la, lb, a.err, a.spin_limit, lane, dead)
+                        : ln_row_allreduce<false>(rsx, ls.pub_at(it), po, la, lb, a.err, a.spin_limit, lane, dead);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sd = 1.0f / ri4[r] - a.ln_eps;
+                const float k2 = ri4[r] * ri4[r] * lb[r] * inv_nm1 / sd;
+                dh4[r] = ri4[r] * (gg[r] - la[r] * invH) - k2 * dd[r];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float s[NS];
 #pragma unroll
             for (int k = 0; k < NS; ++k) s[k] = sin[k][r];
-            const float hp = sin[NS][r], dy = sin[NS + 1][r];
-            const float dh = dy + dh_dir[r] + acc0[r] + acc1[r];
+            const float hp = sin[NS][r];
+            const float dh = dh4[r];
             float dg[G], dhd, dcp;
             pk_cell_bwd<CELL>(act, s, hp, 0.f, msk[r], dh, dc_car[r], dg, dhd, dcp);
             dh_dir[r] = rvf[r] != 0.f ? dhd : 0.f;
@@ -428,18 +536,31 @@ __global__ __launch_bounds__(256, 1) void rec2f_bwd_kernel(R2Args a) {
     }
 #define PK_FOBL(E) flush_outputs_e(0, E)
     PK_EDGE_DISPATCH(PK_FOBL);
+    if (LN) {  // my unit's share of d gamma / d beta over this cluster's rows and all steps: one owner per (cluster, unit)
+        accg += __shfl_xor(accg, 16, 64);
+        accg += __shfl_xor(accg, 32, 64);
+        accb += __shfl_xor(accb, 16, 64);
+        accb += __shfl_xor(accb, 32, 64);
+        if (lane < 16) {
+            a.lnpart[(long)(a.ln_cg0 + c) * KPAD + unit] = accg;
+            a.lnpart[(long)(a.ln_ncg + a.ln_cg0 + c) * KPAD + unit] = accb;
+        }
+    }
 }
 
 typedef void (*Rec2fKernel)(R2Args);
+// (the LayerNorm variants exist with the run-time activation only: no shipped recipe normalises h_t)
 template <int CELL>
-Rec2fKernel pickf_fwd(int act) {
-    return act == PK_ACT_RELU ? rec2f_fwd_kernel<CELL, PK_ACT_RELU> : act == PK_ACT_TANH ? rec2f_fwd_kernel<CELL, PK_ACT_TANH>
-                                                                                         : rec2f_fwd_kernel<CELL, -1>;
+Rec2fKernel pickf_fwd(int act, bool ln) {
+    if (ln) return rec2f_fwd_kernel<CELL, -1, true>;
+    return act == PK_ACT_RELU ? rec2f_fwd_kernel<CELL, PK_ACT_RELU, false>
+         : act == PK_ACT_TANH ? rec2f_fwd_kernel<CELL, PK_ACT_TANH, false> : rec2f_fwd_kernel<CELL, -1, false>;
 }
 template <int CELL>
-Rec2fKernel pickf_bwd(int act) {
-    return act == PK_ACT_RELU ? rec2f_bwd_kernel<CELL, PK_ACT_RELU> : act == PK_ACT_TANH ? rec2f_bwd_kernel<CELL, PK_ACT_TANH>
-                                                                                         : rec2f_bwd_kernel<CELL, -1>;
+Rec2fKernel pickf_bwd(int act, bool ln) {
+    if (ln) return rec2f_bwd_kernel<CELL, -1, true>;
+    return act == PK_ACT_RELU ? rec2f_bwd_kernel<CELL, PK_ACT_RELU, false>
+         : act == PK_ACT_TANH ? rec2f_bwd_kernel<CELL, PK_ACT_TANH, false> : rec2f_bwd_kernel<CELL, -1, false>;
 }
 
 int grant_lds(Rec2fKernel k, size_t lds) {
@@ -469,7 +590,8 @@ int64_t pk_rec2f_exchange_floats(int cell, int T, int B, int bidir, int H) {
 }
 
 int pk_rec2f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int H, const float* P, const float* pscale,
-                 const float* pshift, const float* U, const float* mask, float mask_scalar, float* Y, float* S, float* Yx) {
+                 const float* pshift, const float* U, const float* mask, float mask_scalar, float* Y, float* S, float* Yx,
+                 const PkLnHost* ln) {
     int rc = pk_rec2_check("pk_rec_fwd (fp32, persistent)", pk_rec2f_covers(cell, H), cell, T, B, bidir, H);
     if (rc) return rc;
     const int ndir = 1 + bidir, R = B * ndir, Hp = (H + 7) & ~7;
@@ -489,13 +611,16 @@ int pk_rec2f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     rc = pk_rec2_host_setup(a, false, cell);
     if (rc) return rc;
     PK_CHECK_HIP(hipMemsetAsync(Yx, 0xFF, (size_t)T * B * y_pitch * 4, st));  // the mailbox: every dword "not written yet"
+    rc = pk_rec2_ln_setup(st, a, pl, ln, false);
+    if (rc) return rc;
     const int G = pk_cell_gates(cell);
-    const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_f32(KPAD) * 4 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell)) * 1024) + 16;
-    const Rec2fKernel k = cell == PK_CELL_LIGRU ? pickf_fwd<PK_CELL_LIGRU>(act) : pickf_fwd<PK_CELL_RNN>(act);
+    const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_f32(KPAD) * 4 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell) + (ln ? 1 : 0)) * 1024) + 16;
+    const Rec2fKernel k = cell == PK_CELL_LIGRU ? pickf_fwd<PK_CELL_LIGRU>(act, ln != nullptr) : pickf_fwd<PK_CELL_RNN>(act, ln != nullptr);
     rc = grant_lds(k, lds);
     if (rc) return rc;
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
+        a.ln_cg0 = l * pl.C;
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_fwd (fp32, persistent)");
@@ -507,7 +632,7 @@ int pk_rec2f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
 }
 
 int pk_rec2f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
-                 float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, float* dGx) {
+                 float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, float* dGx, const PkLnHost* ln) {
     int rc = pk_rec2_check("pk_rec_bwd (fp32, persistent)", pk_rec2f_covers(cell, H), cell, T, B, bidir, H);
     if (rc) return rc;
     const int ndir = 1 + bidir, R = B * ndir, Hp = (H + 7) & ~7, G = pk_cell_gates(cell);
@@ -527,13 +652,16 @@ int pk_rec2f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     rc = pk_rec2_host_setup(a, true, cell);
     if (rc) return rc;
     PK_CHECK_HIP(hipMemsetAsync(dGx, 0xFF, (size_t)ndir * T * B * g_pitch * 4, st));
+    rc = pk_rec2_ln_setup(st, a, pl, ln, true);
+    if (rc) return rc;
     const size_t atile = (size_t)RMAX * pk_r2_lda_f32(G * KPAD) * 4;
-    const size_t lds = (2 * atile > 100 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(pk_cell_saved(cell) + 2 + G) * 1024) + 16;
-    const Rec2fKernel k = cell == PK_CELL_LIGRU ? pickf_bwd<PK_CELL_LIGRU>(act) : pickf_bwd<PK_CELL_RNN>(act);
+    const size_t lds = (2 * atile > 100 * 1024 ? 1 : 2) * atile + 4 * ((size_t)(pk_cell_saved(cell) + 2 + (ln ? 1 : 0) + G) * 1024) + 16;
+    const Rec2fKernel k = cell == PK_CELL_LIGRU ? pickf_bwd<PK_CELL_LIGRU>(act, ln != nullptr) : pickf_bwd<PK_CELL_RNN>(act, ln != nullptr);
     rc = grant_lds(k, lds);
     if (rc) return rc;
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
+        a.ln_cg0 = l * pl.C;
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_bwd (fp32, persistent)");
@@ -541,5 +669,5 @@ int pk_rec2f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
         hipLaunchKernelGGL(k, dim3(pl.C * pl.Pn), dim3(256), lds, st, a);
         PK_LAUNCH_CHECK();
     }
-    return 0;
+    return pk_rec2_ln_finish(st, a, ln);
 }

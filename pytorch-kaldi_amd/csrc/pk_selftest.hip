@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include "pk_common.h"
+#define PK_REC2_PRECISE 1  // (no fast-math gate functions: only dpp_row_sum is used from this header)
+#include "pk_rec2_common.h"
 
 namespace {
 
@@ -140,6 +142,31 @@ extern "C" int pk_selftest_permlane(void* stream, int* h_bad_count) {
         if (((l >> 4) & 1) != 0) continue;  // the odd rows hold the same pairs again; only the even rows publish
         if (h[l * 2] != 1000u + l || h[l * 2 + 1] != 1000u + l + 16) ++bad;
     }
+    *h_bad_count = bad;
+    return 0;
+}
+
+// The DPP row all-reduce of the per-step LayerNorm exchange (pk_rec2_common.h::dpp_row_sum): every lane of a 16-lane
+// row ends with the exact sum of the row's 16 integers-as-floats, bit-identical on all 16 lanes.
+namespace {
+__global__ void dpp_row_sum_kernel(float* out) {
+    const float x = (float)(1 + (threadIdx.x & 15)) + 100.f * (float)(threadIdx.x >> 4);
+    out[threadIdx.x] = dpp_row_sum(x);
+}
+}  // namespace
+
+extern "C" int pk_selftest_dpp_row_sum(void* stream, int* h_bad_count) {
+    hipStream_t st = pk_stream(stream);
+    float h[64], *d;
+    PK_CHECK_HIP(hipMalloc((void**)&d, sizeof(h)));
+    hipLaunchKernelGGL(dpp_row_sum_kernel, dim3(1), dim3(64), 0, st, d);
+    PK_LAUNCH_CHECK();
+    PK_CHECK_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st));
+    PK_CHECK_HIP(hipStreamSynchronize(st));
+    (void)hipFree(d);
+    int bad = 0;
+    for (int l = 0; l < 64; ++l)
+        if (h[l] != 136.f + 1600.f * (float)(l >> 4)) ++bad;
     *h_bad_count = bad;
     return 0;
 }

@@ -1003,9 +1003,20 @@ def log_softmax(x):
 # One recurrent layer: projections + (BatchNorm) + time loop, both directions.
 # neural_networks.py:412-481 (LSTM), 589-653 (GRU), 1092-1153 (liGRU), ...
 # ----------------------------------------------------------------------------
+def ln_persistent_ok(cell, H):
+    """Per-step LayerNorm of h_t inside the persistent time loop: the second-generation kernels - liGRU / RNN / LSTM in
+    perf mode, liGRU / RNN in fp32 (LSTM's first-generation fp32 kernels do not have it).  PK_REC_LN_PERSIST=0 sends such
+    layers back to the step-wise algorithm."""
+    if os.environ.get("PK_REC_LN_PERSIST", "1") == "0" or H < 2:
+        return False
+    if bf16_mode():
+        return cell in ("liGRU", "RNN", "LSTM")
+    return cell in ("liGRU", "RNN") and os.environ.get("PK_REC_F32_GEN", "")[:1] != "1"
+
+
 def choose_rec_algo(cell, H, use_ln):
     want = settings.rec_algo
-    ok = cell in ("liGRU", "RNN", "LSTM") and H <= 576 and not use_ln
+    ok = cell in ("liGRU", "RNN", "LSTM") and H <= 576 and (not use_ln or ln_persistent_ok(cell, H))
     # the first-generation exact-fp32 kernels exchange pairs of fp32 values: LSTM always, liGRU / RNN when
     # PK_REC_F32_GEN=1 keeps them (the library reads the same switch, pk_rec_persist.hip::use_gen2_f32)
     if not bf16_mode() and (cell == "LSTM" or os.environ.get("PK_REC_F32_GEN", "")[:1] == "1"):
@@ -1063,6 +1074,9 @@ def _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, Yb=None, dGb=N
                       beta=0.0 if d == 0 else 1.0, splitk=_splitk_bf(_tiles_bf(H, H), TB))
 
 
+LN_EPS = 1e-6  # the reference's LayerNorm(features, eps=1e-6), neural_networks.py:23-27
+
+
 class RecLayerFn(torch.autograd.Function):
     """y, bn_mean, bn_var = f(x, Wcat, bcat, Ucat, gamma, beta, mask)
 
@@ -1108,25 +1122,36 @@ class RecLayerFn(torch.autograd.Function):
             pshift = bcat.contiguous() if bcat is not None else torch.zeros(GH, device=x.device)
         Y = _new(T, B, ndir * H, like=x2)
         S = _new(ndir, TB, NS * H, like=x2)
-        work = _new(int(lib.pk_rec_work_floats(CELL[cell], T, B, int(bidir), H)), like=x2)
         use_ln = ln_gamma is not None
         algo = choose_rec_algo(cell, H, use_ln)
         prec = PREC[settings.precision]
         if algo == REC_PERSISTENT:
             _lib.raise_if_persist_failed()
         LNS = None
-        if use_ln:  # per-step LayerNorm of h_t: saved [mean, 1/(std+eps), pre-LN h] per (step, row)
+        n_work = int(lib.pk_rec_work_floats(CELL[cell], T, B, int(bidir), H))
+        n_lnwork = 0
+        if use_ln:  # per-step LayerNorm of h_t: statistics and pre-LN h of every (step, row), saved for backward
             ln_gamma, ln_beta = ln_gamma.contiguous(), ln_beta.contiguous()
-            LNS = _new(T, ndir * B, H + 2, like=x2)
+            LNS = _new(int(lib.pk_rec_ln_saved_floats(T, B, int(bidir), H)), like=x2)
+            if algo == REC_PERSISTENT:  # + the row-statistics exchange of the persistent kernels
+                n_lnwork = int(lib.pk_rec_ln_work_floats(T, B, int(bidir), H))
+        work = _new(n_work + (0 if bf else n_lnwork), like=x2)
         Yb = None
         if bf and algo == REC_PERSISTENT:
             # perf mode: second-generation persistent kernel; its bf16 exchange buffer Yb is also the
             # k-major operand of the dU GEMM in backward (nothing is converted afterwards)
             Hp = _up(H, 8)
             Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
-            rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
-                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1],
-                                     2 if settings.self_fill else 0)
+            if use_ln:
+                lnwork = _new(n_lnwork, like=x2)
+                rc = lib.pk_rec_fwd_bf16_ln(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
+                                            _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(ln_gamma), _p(ln_beta),
+                                            LN_EPS, _p(Y), _p(S), _p(LNS), _p(Yb), Yb.shape[1],
+                                            2 if settings.self_fill else 0, _p(lnwork))
+            else:
+                rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
+                                         _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb),
+                                         Yb.shape[1], 2 if settings.self_fill else 0)
             _lib.check(rc, "pk_rec_fwd_bf16")
         else:
             rc = lib.pk_rec_fwd(_stream(), algo, prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
@@ -1161,18 +1186,29 @@ class RecLayerFn(torch.autograd.Function):
         dY = dY.contiguous()
         dP2 = _new(ndir, TB, GH, like=dY)
         dU = _new(GH, H, like=dY)
-        work = _new(int(lib.pk_rec_work_floats(CELL[cell], T, B, int(bidir), H)), like=dY)
+        bf = ctx.bf
+        n_lnwork = 0
+        if ln_gamma is not None and ctx.algo == REC_PERSISTENT:
+            n_lnwork = int(lib.pk_rec_ln_work_floats(T, B, int(bidir), H))
+        work = _new(int(lib.pk_rec_work_floats(CELL[cell], T, B, int(bidir), H)) + (0 if ctx.Yb is not None else n_lnwork),
+                    like=dY)
         dlg = dlb = None
         if ln_gamma is not None:
             dlg, dlb = _new(H, like=dY), _new(H, like=dY)
-        bf = ctx.bf
         dGb = None
         if ctx.Yb is not None:
             Hp = _up(H, 8)
             dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16)
-            rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
-                                     float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dP2), _p(dGb), dGb.shape[1],
-                                     2 if settings.self_fill else 0)
+            if ln_gamma is not None:
+                lnwork = _new(n_lnwork, like=dY)
+                rc = lib.pk_rec_bwd_bf16_ln(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
+                                            float(mask_scalar), _p(ln_gamma), LN_EPS, _p(Y), _p(S), _p(LNS), _p(dY),
+                                            _p(dP2), _p(dGb), dGb.shape[1], 2 if settings.self_fill else 0, _p(lnwork),
+                                            _p(dlg), _p(dlb))
+            else:
+                rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
+                                         float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dP2), _p(dGb), dGb.shape[1],
+                                         2 if settings.self_fill else 0)
             _lib.check(rc, "pk_rec_bwd_bf16")
         else:
             rc = lib.pk_rec_bwd(_stream(), ctx.algo, ctx.prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat),

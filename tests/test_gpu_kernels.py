@@ -32,6 +32,15 @@ def test_permlane16_swap_lane_mapping():
     assert bad.value == 0
 
 
+def test_dpp_row_sum_reaches_every_lane():
+    """The 16-lane all-reduce the per-step LayerNorm of the persistent recurrences sums its row statistics with."""
+    lib = _lib.load()
+    bad = ctypes.c_int(-1)
+    _lib.check(lib.pk_selftest_dpp_row_sum(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(bad)),
+               "pk_selftest_dpp_row_sum")
+    assert bad.value == 0
+
+
 def test_single_hip_runtime():
     """libpk_amd.so must bind to the HIP runtime torch already mapped (one runtime per
     process): exactly one libamdhip64 in /proc/self/maps."""

@@ -38,8 +38,8 @@ def _check_case(case, algo):
     g = Golden(case)
     m = g.meta
     if any(s.strip().lower() == "true" for k, v in m["options"].items() if k.endswith("_use_laynorm")
-           for s in v.split(",")) and m["arch_class"] in PERSISTENT_OK + ("GRU", "minimalGRU") and algo == "persistent":
-        pytest.skip("per-step LayerNorm runs in the step-wise algorithm")
+           for s in v.split(",")) and m["arch_class"] in ("LSTM", "GRU", "minimalGRU") and algo == "persistent":
+        pytest.skip("per-step LayerNorm inside the persistent loop: liGRU / RNN in fp32 (LSTM: perf mode only)")
     pre = {"liGRU": "ligru", "LSTM": "lstm", "GRU": "gru", "minimalGRU": "minimalgru", "RNN": "rnn"}.get(m["arch_class"])
     if algo == "persistent" and m["arch_class"] == "LSTM" and any(int(h) % 2 for h in m["options"][pre + "_lay"].split(",")):
         pytest.skip("LSTM's exact-fp32 persistent kernels exchange pairs of fp32 values: odd layer widths run step-wise")
@@ -593,3 +593,75 @@ def test_full_geometry_value_for_value(kind, pre, act, T, prec):
     if report is not None:  # the engine's own pattern differs from the oracle's only where a_t is rounding noise
         for flipped, total, worst_a in report:
             assert flipped < (2e-4 if prec == "fp32" else 2e-2) * total, report
+
+
+# --------------------------------------------------------------------------------
+# per-step LayerNorm of h_t inside the persistent time loop (the row statistics cross the 9 workgroups of a cluster)
+# --------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("kind,pre,act,bidir,B,T", [("liGRU", "ligru", "relu", True, 24, 12), ("RNN", "rnn", "tanh", False, 37, 9),
+                                                     ("LSTM", "lstm", "tanh", True, 11, 10), ("liGRU", "ligru", "relu", True, 128, 6)])
+def test_per_step_layernorm_in_the_persistent_loop(kind, pre, act, bidir, B, T, prec):
+    """`*_use_laynorm=True` (neural_networks.py:466-467, :1138-1139, :1444-1445) at the recipes' width H = 550: every
+    cluster is 9 workgroups whose waves exchange the rows' partial sums inside each step.  Compared with the oracle
+    (fp32 at 1e-4; perf mode against the oracle's bf16-operand model at 5e-3 / 2e-2) and - fp32 - with the engine's own
+    step-wise algorithm, which the reference-generated `*_ln*` fixtures grade."""
+    import contextlib
+
+    from engine_util import F_amd, nn_amd
+
+    if kind == "LSTM" and prec == "fp32":
+        pytest.skip("LSTM's exact-fp32 persistent kernels (first generation) do not normalise h_t: step-wise")
+    D, H = 40, 550
+    opts = _rec_opts(pre, [H, H], act, bn=False, bidir=bidir)
+    opts[pre + "_use_laynorm"] = "True,True"
+    torch.manual_seed(99)
+    net = getattr(nn_amd, kind)(opts, D)
+    with torch.no_grad():  # LayerNorm parameters away from (1, 0)
+        for name, q in net.named_parameters():
+            if name.startswith("ln.") and name.endswith("gamma"):
+                q.mul_(1.0 + 0.3 * torch.randn_like(q))
+            if name.startswith("ln.") and name.endswith("beta"):
+                q.add_(0.2 * torch.randn_like(q))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T, B, D, generator=g)
+    masks = O.make_drop_masks(kind, opts, B, "train", generator=g)
+    cot = torch.randn(T, B, net.out_dim, generator=g)
+    osd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    log = [] if act == "relu" else None
+    with (O.bf16_operands() if prec == "bf16" else contextlib.nullcontext()):
+        yo = O.recurrent_forward(kind, opts, osd, xo, training=True, to_do="train", drop_masks=masks, kink_log=log)
+        (yo * cot).sum().backward()
+    ref = {k: v.grad for k, v in osd.items() if v.requires_grad and v.grad is not None}
+    F_amd.set_precision(prec)
+    net.cuda().train()
+    runs = {}
+    for algo in (("persistent", "stepwise") if prec == "fp32" else ("persistent",)):
+        F_amd.set_rec_algo(algo)
+        report = F_amd.set_forced_kinks(log) if log is not None else None
+        try:
+            net.zero_grad(set_to_none=True)
+            xe = x.clone().cuda().requires_grad_(True)
+            ye = net(xe, drop_masks=masks)
+            (ye * cot.cuda()).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            F_amd.set_forced_kinks(None)
+        runs[algo] = (ye.detach().cpu(), xe.grad.cpu(),
+                      {k: (q.grad.detach().cpu() if q.grad is not None else None) for k, q in net.named_parameters()})
+    otol, gtol = (TOL, TOL) if prec == "fp32" else (5e-3, 2e-2)
+    ye, dxe, got = runs["persistent"]
+    e_y, e_x = rel_err(ye, yo), rel_err(dxe, xo.grad)
+    worst = check_grads(got, ref, None, gtol)
+    print("\nper-step LayerNorm, persistent, %s %s: y %.2e, dx %.2e, worst parameter gradient %.2e" % (kind, prec, e_y, e_x, worst))
+    assert e_y < otol, e_y
+    assert e_x < gtol, e_x
+    assert any(k.startswith("ln.") and v is not None and float(v.abs().max()) > 0 for k, v in got.items())
+    if "stepwise" in runs:
+        ys, dxs, gs = runs["stepwise"]
+        assert rel_err(ye, ys) < 2e-5 and rel_err(dxe, dxs) < 2e-5
+        for k, v in gs.items():
+            if v is not None:
+                assert rel_err(got[k], v) < 5e-5, k

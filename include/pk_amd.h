@@ -298,6 +298,16 @@ int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, 
 int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
                       float mask_scalar, const float* Y, const float* S, const float* dY, uint16_t* dGb, int64_t g_pitch,
                       int prefilled);
+/* ... with per-step LayerNorm of h_t (GRU neural_networks.py:638-639, minimalGRU :1299-1300): a third exchange in the
+ * step, of the rows' partial sums; arguments as pk_rec_fwd_bf16_ln / pk_rec_bwd_bf16_ln. */
+int pk_rec2p_fwd_bf16_ln(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
+                         const float* pscale, const float* pshift, const float* U, const float* mask, float mask_scalar,
+                         const float* ln_gamma, const float* ln_beta, float ln_eps, float* Y, float* S, float* LNS,
+                         uint16_t* Yb, uint16_t* Xb, int64_t y_pitch, int prefilled, float* lnwork);
+int pk_rec2p_bwd_bf16_ln(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
+                         float mask_scalar, const float* ln_gamma, float ln_eps, const float* Y, const float* S,
+                         const float* LNS, const float* dY, uint16_t* dGb, int64_t g_pitch, int prefilled, float* lnwork,
+                         float* dln_gamma, float* dln_beta);
 unsigned pk_persist2_error_count(void);
 void pk_persist2_error_reset(void);
 

@@ -73,6 +73,10 @@ SIGNATURES = {
     "pk_gemm_bf16_auto_splitk_cus": (c_int, [c_int, c_int, c_int, c_int]),
     "pk_rec_fwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, P, c_int64, c_int]),
     "pk_rec_bwd_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, P, c_int64, c_int]),
+    "pk_rec2p_fwd_bf16_ln": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, c_float, P, P, P,
+                                     P, P, c_int64, c_int, P]),
+    "pk_rec2p_bwd_bf16_ln": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, c_float, P, P, P, P, P,
+                                     c_int64, c_int, P, P, P]),
     "pk_rec_fwd_bf16_ln": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P, c_float, P, P, P,
                                    P, c_int64, c_int, P]),
     "pk_rec_bwd_bf16_ln": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, c_float, P, P, P, P, P, P,

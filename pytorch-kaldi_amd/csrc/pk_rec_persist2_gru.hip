@@ -22,7 +22,9 @@ namespace {
 // forward
 // ============================================================================
 // ACT: compile-time activation (relu / tanh) or -1 = run-time a.act, as in pk_rec_persist2.hip
-template <int CELL, int ACT>
+// LN: per-step LayerNorm of h_t (neural_networks.py:638-639, :1299-1300) - a third exchange in the step, of the rows'
+// partial sums (ln_row_allreduce, pk_rec2_common.h), between the blend and the publish of h_t.
+template <int CELL, int ACT, bool LN = false>
 __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr bool TR = false;  // no phase trace in the two-phase kernels
@@ -31,7 +33,8 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
     constexpr int LDA = pk_r2_lda_bf16(KPAD);
     constexpr int ATILE = RMAX * LDA * 2;
     constexpr int NCH = (RMAX * (KPAD / 8) + 255) / 256;
-    constexpr int WAVE_LDS = (G + 1 + G) * 1024 + 512;  // P stage | Y | saved z(,r),a | bf16 publish patch
+    constexpr int NF = G + 1 + G + (LN ? 1 : 0);
+    constexpr int WAVE_LDS = NF * 1024 + 512;  // P stage | Y | saved z(,r),a (| pre-LN h) | bf16 publish patch
     constexpr int LDS_TRASH = 2 * ATILE + 4 * WAVE_LDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // tile(phase 1) | tile(phase 2) | 4 x WAVE_LDS | trash
 
@@ -131,10 +134,22 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
     float* patchP = reinterpret_cast<float*>(wl);                  // [G][256]
     float* patchY = reinterpret_cast<float*>(wl + G * 1024);       // [256]
     float* patchS = reinterpret_cast<float*>(wl + (G + 1) * 1024); // [G][256]: z(,r), a
-    unsigned short* patchB = reinterpret_cast<unsigned short*>(wl + (2 * G + 1) * 1024);
+    float* patchL = reinterpret_cast<float*>(wl + (2 * G + 1) * 1024);  // (LN only)
+    unsigned short* patchB = reinterpret_cast<unsigned short*>(wl + NF * 1024);
     const __amdgpu_buffer_rsrc_t rsY = make_rsrc(a.Yb, szYb);
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(a.Xb, szYb);
     float* trash = a.trash + (tid & 63) * 4;
+    // ---- per-step LayerNorm state (as in pk_rec_persist2.hip)
+    const LnSlots ls = LN ? ln_slots(a, c, p, wave, lane, T) : LnSlots();
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(LN ? (const void*)a.lnx : (const void*)a.Yb, LN ? ls.size : 0u);
+    const float gam = (LN && unit_ok) ? a.ln_gamma[unit] : 0.f, bet = (LN && unit_ok) ? a.ln_beta[unit] : 0.f;
+    const float invH = 1.0f / (float)H, inv_nm1 = 1.0f / (float)(H - 1);
+    float piv[4] = {0.f, 0.f, 0.f, 0.f};
+    pk_f32x2 st_val = {0.f, 0.f};
+    const int st_row = kq * 4 + (lane & 3);
+    const bool st_ok = LN && p == 0 && wave == 0 && (lane & 15) < 4 && st_row < nrows;
+    float* const st_base = st_ok ? a.lnstat + (long)(n_base + st_row) * 2 : trash;
+    const long st_step = st_ok ? (long)a.R * 2 : 0;
 
     f32x4 pv[G];
     auto load_proj = [&](int tt, auto E) {
@@ -149,6 +164,10 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
         st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchY, lane));
 #pragma unroll
         for (int k = 0; k < G; ++k) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, patch_get_vec(patchS + k * 256, lane));
+        if (LN) {
+            st4<EE>(a.lnh, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchL, lane));
+            *reinterpret_cast<pk_f32x2*>(st_base + (long)tt * st_step) = st_val;
+        }
     };
 #define PKG_LP0(E) load_proj(0, E)
     PK_EDGE_DISPATCH(PKG_LP0);
@@ -262,7 +281,38 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
             hprev[r] = h;
             hv[r] = h;
             av[r] = at;
-            patchB[(kq * 4 + r) * 16 + (lane & 15)] = to_bf_pub(h);
+            if (!LN) patchB[(kq * 4 + r) * 16 + (lane & 15)] = to_bf_pub(h);
+        }
+        if (LN) {
+            float la[4], lb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = hv[r] - piv[r];
+                la[r] = rvf[r] != 0.f ? d : 0.f;
+                lb[r] = rvf[r] != 0.f ? d * d : 0.f;
+            }
+            unsigned po[3];
+            ls.poll_at(t, po);
+            dead = ln_row_allreduce<fast>(rsx, ls.pub_at(t), po, la, lb, a.err, a.spin_limit, lane, dead);
+            patch_put_cd(patchL, kq, lane, hv);  // the pre-LN value, saved for backward
+            float mu4[4], ri4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float md = la[r] * invH;
+                const float mu = piv[r] + md;
+                const float var = fmaxf((lb[r] - la[r] * md) * inv_nm1, 0.f);
+                const float ri = 1.0f / (sqrtf(var) + a.ln_eps);
+                const float hn = rvf[r] != 0.f ? gam * ((hv[r] - mu) * ri) + bet : 0.f;
+                hv[r] = hn;
+                hprev[r] = hn;
+                piv[r] = mu;
+                mu4[r] = mu;
+                ri4[r] = ri;
+                patchB[(kq * 4 + r) * 16 + (lane & 15)] = to_bf_pub(hn);
+            }
+            const int u3 = lane & 3;
+            st_val[0] = u3 == 0 ? mu4[0] : u3 == 1 ? mu4[1] : u3 == 2 ? mu4[2] : mu4[3];
+            st_val[1] = u3 == 0 ? ri4[0] : u3 == 1 ? ri4[1] : u3 == 2 ? ri4[2] : ri4[3];
         }
         PK_LDS_ORDER();
         {
@@ -287,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
 // ============================================================================
 // backward
 // ============================================================================
-template <int CELL, int ACT>
+template <int CELL, int ACT, bool LN = false>
 __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr bool TR = false;  // no phase trace in the two-phase kernels
@@ -298,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
     constexpr int BTILE = RMAX * LDB * 2, ATILE = RMAX * LDA * 2;
     constexpr int NCHB = (RMAX * G1 * (KPAD / 8) + 255) / 256;
     constexpr int NCHA = (RMAX * (KPAD / 8) + 255) / 256;
-    constexpr int NIN = G + 2;                   // saved z(,r),a | h_{t-1} | dY
+    constexpr int NIN = G + 2 + (LN ? 1 : 0);    // saved z(,r),a | h_{t-1} | dY (| pre-LN h_t)
     constexpr int WAVE_LDS = NIN * 1024 + G * 512;
     constexpr int LDS_TRASH = BTILE + ATILE + 4 * WAVE_LDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -416,6 +466,7 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
         for (int k = 0; k < G; ++k) iv[k] = ld4<EE>(a.S, vS0 + ts * vSs + k * H, vnv);
         iv[G] = ld4<EE>(a.Y, vY0 + tp * vYs, t > 0 ? vnv : 0);
         iv[G + 1] = ld4<EE>(a.dY, vY0 + ts * vYs, vnv);
+        if (LN) iv[G + 2] = ld4<EE>(a.lnh, vY0 + ts * vYs, vnv);
         if (t == 0) iv[G] = f32x4{0.f, 0.f, 0.f, 0.f};  // h_{-1} = 0
     };
     auto load_step = [&](int t) {
@@ -423,6 +474,25 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
         PK_EDGE_DISPATCH(PKG_LS);
     };
     load_step(T - 1);
+    // ---- per-step LayerNorm state (as in pk_rec_persist2.hip)
+    const LnSlots ls = LN ? ln_slots(a, c, p, wave, lane, T) : LnSlots();
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(LN ? (const void*)a.lnx : (const void*)a.dGb, LN ? ls.size : 0u);
+    const float gam = (LN && unit_ok) ? a.ln_gamma[unit] : 0.f;
+    const float invH = 1.0f / (float)H, inv_nm1 = 1.0f / (float)(H - 1);
+    float accg = 0.f, accb = 0.f;
+    pk_f32x2 stn[4];
+    long st_off[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = kq * 4 + r;
+        st_off[r] = (LN && row < nrows) ? (long)(n_base + row) * 2 : 0;
+        stn[r] = pk_f32x2{0.f, 1.f};
+    }
+    auto load_stats = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stn[r] = *reinterpret_cast<const pk_f32x2*>(a.lnstat + (long)t * a.R * 2 + st_off[r]);
+    };
+    if (LN) load_stats(T - 1);
     const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     auto fill_slab = [&](int tt, auto FASTC) {  // my G chunks of the slab that step tt will publish
         const unsigned off = pbase + (pk_ok ? (unsigned)(pdir ? (T - 1 - tt) : tt) * TS : 0u);
@@ -453,11 +523,18 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
                         : poll_to_lds<NCHB, false>(rs, goff, clB, smem, a.err, a.spin_limit, lane, dead, retries);
         }
         PK_TRACE(1);
+        float mu4[4], ri4[4];  // this step's row statistics (the loads are a whole step old)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            mu4[r] = stn[r][0];
+            ri4[r] = stn[r][1];
+        }
 #pragma unroll
         for (int k = 0; k < NIN; ++k) patch_put_vec(patchI + k * 256, lane, iv[k]);
         if (t < T - 1) PK_BARRIER_LDS();
         else PK_LDS_ORDER();
         if (t > 0) load_step(t - 1);
+        if (LN && t > 0) load_stats(t - 1);
         if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) {
             if (fast) fill_slab(t - PK_R2_FILL_AHEAD, BoolC<1>());
             else fill_slab(t - PK_R2_FILL_AHEAD, BoolC<0>());
@@ -478,10 +555,36 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
 #pragma unroll
         for (int k = 0; k < NIN; ++k) patch_get_cd(patchI + k * 256, kq, lane, sin[k]);
         float da[4], dzp[4], dhd[4];
+        float dh4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh4[r] = sin[G + 1][r] + dh_dir[r] + acc0[r] + acc1[r];
+        if (LN) {  // through the LayerNorm first (see pk_rec_persist2.hip)
+            float la[4], lb[4], dd[4], gg[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = rvf[r] != 0.f;
+                dd[r] = sin[G + 2][r] - mu4[r];
+                gg[r] = dh4[r] * gam;
+                la[r] = ok ? gg[r] : 0.f;
+                lb[r] = ok ? gg[r] * dd[r] : 0.f;
+                accg += ok ? dh4[r] * (dd[r] * ri4[r]) : 0.f;
+                accb += ok ? dh4[r] : 0.f;
+            }
+            unsigned po[3];
+            ls.poll_at(it, po);
+            dead = fast ? ln_row_allreduce<true>(rsx, ls.pub_at(it), po, la, lb, a.err, a.spin_limit, lane, dead)
+                        : ln_row_allreduce<false>(rsx, ls.pub_at(it), po, la, lb, a.err, a.spin_limit, lane, dead);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sd = 1.0f / ri4[r] - a.ln_eps;
+                const float k2 = ri4[r] * ri4[r] * lb[r] * inv_nm1 / sd;
+                dh4[r] = ri4[r] * (gg[r] - la[r] * invH) - k2 * dd[r];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float z = sin[0][r], at = sin[G1][r], hp = sin[G][r];
-            const float dh = sin[G + 1][r] + dh_dir[r] + acc0[r] + acc1[r];
+            const float dh = dh4[r];
             const float cand = pk_act(act, at) * msk[r];
             const bool ok = rvf[r] != 0.f;
             dzp[r] = ok ? dh * (hp - cand) * z * (1.f - z) : 0.f;
@@ -544,6 +647,16 @@ __global__ __launch_bounds__(256, 1) void rec2g_bwd_kernel(R2Args a) {
             else pub_store<false>(rs, og, o);
         }
         PK_TRACE(5);
+    }
+    if (LN) {  // my unit's share of d gamma / d beta over this cluster's rows and all steps
+        accg += __shfl_xor(accg, 16, 64);
+        accg += __shfl_xor(accg, 32, 64);
+        accb += __shfl_xor(accb, 16, 64);
+        accb += __shfl_xor(accb, 32, 64);
+        if (lane < 16) {
+            a.lnpart[(long)(a.ln_cg0 + c) * KPAD + unit] = accg;
+            a.lnpart[(long)(a.ln_ncg + a.ln_cg0 + c) * KPAD + unit] = accb;
+        }
     }
 }
 
@@ -835,12 +948,12 @@ inline bool bwd_gen3() {
     return g == 3;
 }
 size_t granted_lds3[2][3] = {{0, 0, 0}, {0, 0, 0}};
+size_t granted_ln[2][2] = {{0, 0}, {0, 0}};  // [fwd / bwd][GRU / minimalGRU]: the LayerNorm variants (run-time activation only)
 
-}  // namespace
-
-extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
-                                 const float* pscale, const float* pshift, const float* U, const float* mask,
-                                 float mask_scalar, float* Y, float* S, uint16_t* Yb, uint16_t* Xb, int64_t y_pitch, int prefilled) {
+int rec2p_fwd_impl(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
+                   const float* pscale, const float* pshift, const float* U, const float* mask,
+                   float mask_scalar, float* Y, float* S, uint16_t* Yb, uint16_t* Xb, int64_t y_pitch, int prefilled,
+                   const PkLnHost* ln) {
     int rc = pk_rec2_check("pk_rec2p_fwd_bf16", cell == PK_CELL_GRU || cell == PK_CELL_MINGRU, cell, T, B, bidir, H);
     if (rc) return rc;
     hipStream_t st = pk_stream(stream);
@@ -862,15 +975,20 @@ extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, 
     a.self_fill = prefilled == 2 ? 1 : 0;  // (prefilled: see pk_rec_fwd_bf16)
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Yb, 0xFF, (size_t)T * B * y_pitch * 2, st));
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(Xb, 0xFF, (size_t)T * B * y_pitch * 2, st));
-    const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(2 * G + 1) * 1024 + 512) + 16;
+    rc = pk_rec2_ln_setup(st, a, pl, ln, false);
+    if (rc) return rc;
+    const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(2 * G + 1 + (ln ? 1 : 0)) * 1024 + 512) + 16;
     const int slot = cell == PK_CELL_GRU ? 0 : 1;
-    const Rec2gKernel fn = cell == PK_CELL_GRU ? pick_fwd<PK_CELL_GRU>(act) : pick_fwd<PK_CELL_MINGRU>(act);
-    if (granted_lds[0][slot][act_slot(act)] < lds) {
+    const Rec2gKernel fn = ln ? (cell == PK_CELL_GRU ? rec2g_fwd_kernel<PK_CELL_GRU, -1, true> : rec2g_fwd_kernel<PK_CELL_MINGRU, -1, true>)
+                              : (cell == PK_CELL_GRU ? pick_fwd<PK_CELL_GRU>(act) : pick_fwd<PK_CELL_MINGRU>(act));
+    size_t& granted = ln ? granted_ln[0][slot] : granted_lds[0][slot][act_slot(act)];
+    if (granted < lds) {
         PK_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        granted_lds[0][slot][act_slot(act)] = lds;
+        granted = lds;
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
+        a.ln_cg0 = l * pl.C;
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
@@ -882,9 +1000,9 @@ extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, 
     return 0;
 }
 
-extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
-                                 const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
-                                 uint16_t* dGb, int64_t g_pitch, int prefilled) {
+int rec2p_bwd_impl(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
+                   const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
+                   uint16_t* dGb, int64_t g_pitch, int prefilled, const PkLnHost* ln) {
     int rc = pk_rec2_check("pk_rec2p_bwd_bf16", cell == PK_CELL_GRU || cell == PK_CELL_MINGRU, cell, T, B, bidir, H);
     if (rc) return rc;
     hipStream_t st = pk_stream(stream);
@@ -905,19 +1023,23 @@ extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, 
     if (rc) return rc;
     a.self_fill = prefilled == 2 ? 1 : 0;
     if (!prefilled) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
-    const bool g3 = bwd_gen3();
+    rc = pk_rec2_ln_setup(st, a, pl, ln, true);
+    if (rc) return rc;
+    const bool g3 = bwd_gen3() && !ln;  // (the LayerNorm variant exists in the second-generation kernel)
     const size_t tiles = (size_t)RMAX * pk_r2_lda_bf16(G1 * KPAD) * 2 + (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2;
-    const size_t lds = g3 ? tiles + 32 : tiles + 4 * ((size_t)(G + 2) * 1024 + (size_t)G * 512) + 16;
+    const size_t lds = g3 ? tiles + 32 : tiles + 4 * ((size_t)(G + 2 + (ln ? 1 : 0)) * 1024 + (size_t)G * 512) + 16;
     const int slot = cell == PK_CELL_GRU ? 0 : 1;
-    const Rec2gKernel fn = g3 ? (cell == PK_CELL_GRU ? pick_bwd3<PK_CELL_GRU>(act) : pick_bwd3<PK_CELL_MINGRU>(act))
+    const Rec2gKernel fn = ln ? (cell == PK_CELL_GRU ? rec2g_bwd_kernel<PK_CELL_GRU, -1, true> : rec2g_bwd_kernel<PK_CELL_MINGRU, -1, true>)
+                         : g3 ? (cell == PK_CELL_GRU ? pick_bwd3<PK_CELL_GRU>(act) : pick_bwd3<PK_CELL_MINGRU>(act))
                               : (cell == PK_CELL_GRU ? pick_bwd<PK_CELL_GRU>(act) : pick_bwd<PK_CELL_MINGRU>(act));
-    size_t& granted = g3 ? granted_lds3[slot][act_slot(act)] : granted_lds[1][slot][act_slot(act)];
+    size_t& granted = ln ? granted_ln[1][slot] : g3 ? granted_lds3[slot][act_slot(act)] : granted_lds[1][slot][act_slot(act)];
     if (granted < lds) {
         PK_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         granted = lds;
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
+        a.ln_cg0 = l * pl.C;
         rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
@@ -926,5 +1048,39 @@ extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, 
         hipLaunchKernelGGL(fn, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
     }
-    return 0;
+    return pk_rec2_ln_finish(st, a, ln);
+}
+
+}  // namespace
+
+extern "C" int pk_rec2p_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
+                                 const float* pscale, const float* pshift, const float* U, const float* mask,
+                                 float mask_scalar, float* Y, float* S, uint16_t* Yb, uint16_t* Xb, int64_t y_pitch, int prefilled) {
+    return rec2p_fwd_impl(stream, cell, act, T, B, bidir, H, P, pscale, pshift, U, mask, mask_scalar, Y, S, Yb, Xb, y_pitch,
+                          prefilled, nullptr);
+}
+extern "C" int pk_rec2p_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
+                                 const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
+                                 uint16_t* dGb, int64_t g_pitch, int prefilled) {
+    return rec2p_bwd_impl(stream, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dGb, g_pitch, prefilled, nullptr);
+}
+// ... with per-step LayerNorm of h_t (GRU: neural_networks.py:638-639, minimalGRU: :1299-1300); arguments as
+// pk_rec_fwd_bf16_ln / pk_rec_bwd_bf16_ln
+extern "C" int pk_rec2p_fwd_bf16_ln(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* P,
+                                    const float* pscale, const float* pshift, const float* U, const float* mask,
+                                    float mask_scalar, const float* ln_gamma, const float* ln_beta, float ln_eps, float* Y,
+                                    float* S, float* LNS, uint16_t* Yb, uint16_t* Xb, int64_t y_pitch, int prefilled,
+                                    float* lnwork) {
+    PK_REQUIRE(ln_gamma && ln_beta && LNS && lnwork, "pk_rec2p_fwd_bf16_ln: null LayerNorm argument");
+    const PkLnHost ln = {ln_gamma, ln_beta, ln_eps, LNS, lnwork, nullptr, nullptr};
+    return rec2p_fwd_impl(stream, cell, act, T, B, bidir, H, P, pscale, pshift, U, mask, mask_scalar, Y, S, Yb, Xb, y_pitch,
+                          prefilled, &ln);
+}
+extern "C" int pk_rec2p_bwd_bf16_ln(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
+                                    const float* mask, float mask_scalar, const float* ln_gamma, float ln_eps, const float* Y,
+                                    const float* S, const float* LNS, const float* dY, uint16_t* dGb, int64_t g_pitch,
+                                    int prefilled, float* lnwork, float* dln_gamma, float* dln_beta) {
+    PK_REQUIRE(ln_gamma && LNS && lnwork && dln_gamma && dln_beta, "pk_rec2p_bwd_bf16_ln: null LayerNorm argument");
+    const PkLnHost ln = {ln_gamma, nullptr, ln_eps, const_cast<float*>(LNS), lnwork, dln_gamma, dln_beta};
+    return rec2p_bwd_impl(stream, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dGb, g_pitch, prefilled, &ln);
 }

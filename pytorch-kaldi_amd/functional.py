@@ -1010,13 +1010,15 @@ def ln_persistent_ok(cell, H):
     if os.environ.get("PK_REC_LN_PERSIST", "1") == "0" or H < 2:
         return False
     if bf16_mode():
-        return cell in ("liGRU", "RNN", "LSTM")
+        return cell in ("liGRU", "RNN", "LSTM", "GRU", "minimalGRU")
     return cell in ("liGRU", "RNN") and os.environ.get("PK_REC_F32_GEN", "")[:1] != "1"
 
 
 def choose_rec_algo(cell, H, use_ln):
     want = settings.rec_algo
     ok = cell in ("liGRU", "RNN", "LSTM") and H <= 576 and (not use_ln or ln_persistent_ok(cell, H))
+    if cell in ("GRU", "minimalGRU"):  # the two-phase persistent kernels are perf-mode only; on this (general) path they
+        ok = H <= 576 and use_ln and ln_persistent_ok(cell, H)  # serve the layers that normalise h_t
     # the first-generation exact-fp32 kernels exchange pairs of fp32 values: LSTM always, liGRU / RNN when
     # PK_REC_F32_GEN=1 keeps them (the library reads the same switch, pk_rec_persist.hip::use_gen2_f32)
     if not bf16_mode() and (cell == "LSTM" or os.environ.get("PK_REC_F32_GEN", "")[:1] == "1"):
@@ -1137,12 +1139,21 @@ class RecLayerFn(torch.autograd.Function):
                 n_lnwork = int(lib.pk_rec_ln_work_floats(T, B, int(bidir), H))
         work = _new(n_work + (0 if bf else n_lnwork), like=x2)
         Yb = None
+        ctx.Xb = None
         if bf and algo == REC_PERSISTENT:
             # perf mode: second-generation persistent kernel; its bf16 exchange buffer Yb is also the
             # k-major operand of the dU GEMM in backward (nothing is converted afterwards)
             Hp = _up(H, 8)
             Yb = torch.empty(TB, _up(ndir * Hp, 64), device=x.device, dtype=torch.bfloat16)
-            if use_ln:
+            two_phase = cell in ("GRU", "minimalGRU")
+            if use_ln and two_phase:
+                lnwork = _new(n_lnwork, like=x2)
+                ctx.Xb = torch.empty_like(Yb)  # second mailbox of the two-phase cells: r*h (GRU) / z*h (minimalGRU)
+                rc = lib.pk_rec2p_fwd_bf16_ln(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
+                                              _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(ln_gamma), _p(ln_beta),
+                                              LN_EPS, _p(Y), _p(S), _p(LNS), _p(Yb), _p(ctx.Xb), Yb.shape[1],
+                                              2 if settings.self_fill else 0, _p(lnwork))
+            elif use_ln:
                 lnwork = _new(n_lnwork, like=x2)
                 rc = lib.pk_rec_fwd_bf16_ln(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
                                             _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(ln_gamma), _p(ln_beta),
@@ -1199,7 +1210,16 @@ class RecLayerFn(torch.autograd.Function):
         if ctx.Yb is not None:
             Hp = _up(H, 8)
             dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16)
-            if ln_gamma is not None:
+            if ctx.Xb is not None:  # two-phase cells (with per-step LayerNorm): the gate gradients come back as bf16 only
+                lnwork = _new(n_lnwork, like=dY)
+                rc = lib.pk_rec2p_bwd_bf16_ln(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
+                                              float(mask_scalar), _p(ln_gamma), LN_EPS, _p(Y), _p(S), _p(LNS), _p(dY),
+                                              _p(dGb), dGb.shape[1], 2 if settings.self_fill else 0, _p(lnwork),
+                                              _p(dlg), _p(dlb))
+                flat = dP2.view(ndir * TB, GH)
+                for g_ in range(G):
+                    flat[:, g_ * H:(g_ + 1) * H].copy_(dGb[:, g_ * Hp:g_ * Hp + H])
+            elif ln_gamma is not None:
                 lnwork = _new(n_lnwork, like=dY)
                 rc = lib.pk_rec_bwd_bf16_ln(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
                                             float(mask_scalar), _p(ln_gamma), LN_EPS, _p(Y), _p(S), _p(LNS), _p(dY),
@@ -1216,8 +1236,8 @@ class RecLayerFn(torch.autograd.Function):
                                 None if bf else _p(dU), _p(dlg), _p(dlb), _p(work))
             _lib.check(rc, "pk_rec_bwd")
         if bf:
-            _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, ctx.Yb, dGb)
-            ctx.Yb = None
+            _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, ctx.Yb, dGb, ctx.Xb)
+            ctx.Yb = ctx.Xb = None
         g1 = dP2[0]
         g2 = dP2[1] if bidir else None
         dgamma = dbeta = dbias = None

@@ -600,7 +600,8 @@ def test_full_geometry_value_for_value(kind, pre, act, T, prec):
 # --------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("kind,pre,act,bidir,B,T", [("liGRU", "ligru", "relu", True, 24, 12), ("RNN", "rnn", "tanh", False, 37, 9),
-                                                     ("LSTM", "lstm", "tanh", True, 11, 10), ("liGRU", "ligru", "relu", True, 128, 6)])
+                                                     ("LSTM", "lstm", "tanh", True, 11, 10), ("liGRU", "ligru", "relu", True, 128, 6),
+                                                     ("GRU", "gru", "tanh", True, 19, 8), ("minimalGRU", "minimalgru", "tanh", False, 40, 7)])
 def test_per_step_layernorm_in_the_persistent_loop(kind, pre, act, bidir, B, T, prec):
     """`*_use_laynorm=True` (neural_networks.py:466-467, :1138-1139, :1444-1445) at the recipes' width H = 550: every
     cluster is 9 workgroups whose waves exchange the rows' partial sums inside each step.  Compared with the oracle
@@ -610,8 +611,9 @@ def test_per_step_layernorm_in_the_persistent_loop(kind, pre, act, bidir, B, T, 
 
     from engine_util import F_amd, nn_amd
 
-    if kind == "LSTM" and prec == "fp32":
-        pytest.skip("LSTM's exact-fp32 persistent kernels (first generation) do not normalise h_t: step-wise")
+    if kind in ("LSTM", "GRU", "minimalGRU") and prec == "fp32":
+        pytest.skip("fp32: LSTM's first-generation persistent kernels do not normalise h_t, GRU / minimalGRU have no fp32 "
+                    "persistent kernels: step-wise")
     D, H = 40, 550
     opts = _rec_opts(pre, [H, H], act, bn=False, bidir=bidir)
     opts[pre + "_use_laynorm"] = "True,True"

@@ -202,6 +202,9 @@ __device__ __forceinline__ void epilogue(const BArgs& p, const f32x4 (&acc)[4][4
 // STAGES = 2: LDS double buffer, one barrier per k-tile, 2 workgroups per CU (64 KB each).
 // STAGES = 1: single buffer, two barriers per k-tile, 3-4 workgroups per CU (32 KB each): the overlap of
 //             loads and MFMA comes from the co-resident workgroups instead of from the software pipeline.
+// (A ring of four buffers with three k-tiles in flight was tried for the small-batch shapes - 8 workgroups on 8 CUs - and
+// changed nothing: 128 rows x 1024 x 1024 stayed at 16-25 us.  Those launches are bound by what ONE CU can pull through
+// its memory pipe (~32 GB/s each), not by exposed latency: see gemm_bf16s_kernel, which spreads them over 32+ CUs.)
 template <bool A_KC, bool B_KC, int STAGES>
 __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 4) void gemm_bf16x_kernel(BArgs p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [STAGES][A 16 KB | B 16 KB]
@@ -276,14 +279,16 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 4) void gemm_bf16x_kernel(BA
 }
 
 // ============================================================================
-// One MLP layer of a small batch in ONE launch (round 3): z = x W^T + b on bf16 operands, BatchNorm1d in training mode
-// over the batch, activation, drop mask, and the bf16 copy the next layer's GEMM reads.
-// Reference: neural_networks.py:139-148 (`drop(act(bn(wx(x))))`, the order every shipped MLP recipe takes).
+// Small-batch products (round 3): M <= 128 rows, both operands k-contiguous - an MLP layer, an output layer or a SincNet
+// fully-connected layer at batch 128.  On the 128 x 128 tile such a product is 8 workgroups on 8 CUs, and a CU pulls
+// ~32 GB/s through its memory pipe whatever the software pipeline does (two stages, four stages and one stage all took
+// 16-25 us for 128 x 1024 x 1024, 33 us with the layer epilogue below).  Here a workgroup owns ALL rows of 32 output
+// columns: 32-61 workgroups, each re-reading the 128-row A panel from L2 (256 KB) next to its 64 KB of B.
 //
-// With M <= 128 rows the whole batch sits in ONE row tile, so a workgroup that owns 128 output columns holds every row
-// of those columns in its accumulators: the batch statistics are a reduction inside the workgroup (two passes over the
-// registers: mean, then centred second moment - nothing cancels) and the normalised, activated, masked layer output
-// leaves together with z, the statistics and the running-statistics update.  Replaces seven launches of the unfused
+// FUSED: one MLP layer in ONE launch - z = x W^T + b, BatchNorm1d in training mode over the batch, activation, drop
+// mask, and the bf16 copy the next layer's GEMM reads (neural_networks.py:139-148, `drop(act(bn(wx(x))))`).  With every
+// row of its columns in the accumulators of one workgroup the batch statistics are a reduction inside it (two passes
+// over the registers: mean, then centred second moment - nothing cancels): replaces seven launches of the unfused
 // pipeline (GEMM, 2 x statistics, finalize, affine + activation, mask, bf16 conversion of the next layer's input).
 // ============================================================================
 struct BnActArgs {
@@ -296,137 +301,203 @@ struct BnActArgs {
     int act;
 };
 
-template <int STAGES>
-__global__ __launch_bounds__(256, STAGES == 2 ? 2 : 4) void gemm_bf16x_bnact_kernel(BArgs p, BnActArgs q) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [STAGES][A 16 KB | B 16 KB]
+constexpr int SN = 32;                    // columns per workgroup
+constexpr int SSTAGE = 16384 + SN * 128;  // bytes per stage: A 128 x 64 | B 32 x 64
+
+// k-contiguous tile image of ROWS rows x 64 k (the [row][8 slots] image of stage<true>, ROWS * 8 chunks of 16 bytes)
+template <int ROWS>
+__device__ __forceinline__ void stage_kc_rows(const unsigned short* __restrict__ base, long ld, int r0, int rmax, int k0, int kmax,
+                                              const unsigned short* zeros, unsigned char* buf, int tid, int wave) {
+    static_assert(ROWS * 8 == 256, "one 16-byte chunk per thread");
+    const int row = tid >> 3, ps = tid & 7;
+    const int ks = ps ^ swz_kc(row);
+    int gr = r0 + row;
+    gr = gr < rmax ? gr : rmax - 1;
+    const int gk = k0 + ks * 8;
+    const unsigned long long src = sel_addr(gk < kmax, base + (long)gr * ld + gk, zeros);
+    glds16(reinterpret_cast<const void*>(src), buf + (wave * 64) * 16);
+}
+
+// k-major tile image of 64 k x 32 columns: [64 k][4 slots of 8 columns] = 256 chunks, one per thread (B stored [K][ldb],
+// n contiguous: the dX product of a layer, dz . W).  No swizzle: the four k-rows a 16-lane group of the transpose read
+// touches are 256 contiguous bytes.
+__device__ __forceinline__ void stage_km32(const unsigned short* __restrict__ base, long ld, int c0, int cmax, int k0, int kmax,
+                                           const unsigned short* zeros, unsigned char* buf, int tid, int wave) {
+    const int kr = tid >> 2, cs = tid & 3;
+    int gc = c0 + cs * 8;
+    if (gc >= cmax) gc = (cmax - 1) & ~7;  // chunk entirely out of range: any in-range chunk (never stored)
+    const int gk = k0 + kr;
+    const unsigned long long src = sel_addr(gk < kmax, base + (long)gk * ld + gc, zeros);
+    glds16(reinterpret_cast<const void*>(src), buf + (wave * 64) * 16);
+}
+__device__ __forceinline__ bf16x8 frag_km32(const unsigned char* buf, int sub, int kk, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int col = sub + (i & 3) * 4;
+    bf16x8 out;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int kr = kk * 32 + g * 8 + h * 4 + (i >> 2);
+        const unsigned char* a = buf + kr * 64 + col * 2;
+        const s4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)a);
+        out[4 * h + 0] = v[0];
+        out[4 * h + 1] = v[1];
+        out[4 * h + 2] = v[2];
+        out[4 * h + 3] = v[3];
+    }
+    return out;
+}
+
+// sum over the 16 lanes of a DPP row (quad_perm x 2, row_half_mirror, row_mirror): every lane ends with the total
+__device__ __forceinline__ float dpp16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+template <bool FUSED, bool B_KC = true>
+__global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(BArgs p, BnActArgs q) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [2][A 16 KB | B 4 KB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tn = blockIdx.x;
-    if (tn >= p.tiles_n) return;
-    const int m0 = 0, n0 = tn * TN;
+    const int n0 = blockIdx.x * SN;
     const int nk = (p.K + TK - 1) / TK;
-    f32x4 acc[4][4];
+    f32x4 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto fetch = [&](int kt, unsigned char* buf) {
         const int k0 = kt * TK;
-        stage<true>(p.A, p.lda, m0, p.M, k0, p.K, p.zeros, buf, tid, wave);
-        stage<true>(p.B, p.ldb, n0, p.N, k0, p.K, p.zeros, buf + 16384, tid, wave);
+        stage<true>(p.A, p.lda, 0, p.M, k0, p.K, p.zeros, buf, tid, wave);
+        if (B_KC) stage_kc_rows<SN>(p.B, p.ldb, n0, p.N, k0, p.K, p.zeros, buf + 16384, tid, wave);
+        else stage_km32(p.B, p.ldb, n0, p.N, k0, p.K, p.zeros, buf + 16384, tid, wave);
     };
-    if (STAGES == 2) {
-        if (nk > 0) fetch(0, smem);
+    if (nk > 0) fetch(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        unsigned char* cur = smem + (kt & 1) * SSTAGE;
+        if (kt + 1 < nk) fetch(kt + 1, smem + ((kt + 1) & 1) * SSTAGE);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = frag<true>(cur, wave * 32 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = B_KC ? frag<true>(cur + 16384, j * 16, kk, lane) : frag_km32(cur + 16384, j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    for (int kt = 0; kt < nk; ++kt) {
-        unsigned char* cur = smem + (STAGES == 2 ? (kt & 1) * 32768 : 0);
-        if (STAGES == 2) {
-            if (kt + 1 < nk) fetch(kt + 1, smem + ((kt + 1) & 1) * 32768);
-        } else {
-            fetch(kt, cur);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = frag<true>(cur, wm * 64 + i * 16, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = frag<true>(cur + 16384, wn * 64 + j * 16, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-        }
-        if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    // ---- epilogue.  acc[i][j][r]: row = wm*64 + i*16 + (lane & 15), column = n0 + wn*64 + j*16 + (lane >> 4)*4 + r
-    float* red = reinterpret_cast<float*>(smem);  // [pass 2][wn 2][wm 2][64 columns] (all waves are past the main loop)
+    // acc[i][j][r]: row = wave*32 + i*16 + (lane & 15), column = n0 + j*16 + (lane >> 4)*4 + r
     const int kq = lane >> 4, lr = lane & 15;
-    const int cbase = n0 + wn * 64 + kq * 4;
-    bool rok[4];
+    const int cbase = n0 + kq * 4;
+    if (!FUSED) {
+        const bool vec_ok = (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rok[i] = wm * 64 + i * 16 + lr < p.M;
-    float bv[4][4];
+        for (int i = 0; i < 2; ++i) {
+            const int row = wave * 32 + i * 16 + lr;
+            if (row >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 2; ++j) {
+                const int col = cbase + j * 16;
+                float* dst = p.C + (long)row * p.ldc + col;
+                if (vec_ok && col + 3 < p.N) {
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = p.alpha * acc[i][j][r] + (p.bias ? p.bias[col + r] : 0.f);
+                    if (p.beta != 0.f) {
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] += p.beta * c[r];
+                    }
+                    *reinterpret_cast<f32x4*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (col + r >= p.N) continue;
+                        float o = p.alpha * acc[i][j][r] + (p.bias ? p.bias[col + r] : 0.f);
+                        if (p.beta != 0.f) o += p.beta * dst[r];
+                        dst[r] = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---- the layer epilogue
+    float* red = reinterpret_cast<float*>(smem);  // [pass 2][wave 4][32 columns] (all waves are past the main loop)
+    bool rok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) rok[i] = wave * 32 + i * 16 + lr < p.M;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = cbase + j * 16 + r;
-            bv[j][r] = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+            const float bv = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][j][r] += bv;
         }
+    // sum over the 128 rows of every one of my 8 columns: over i in registers, over the 16 lanes of a DPP row, over the
+    // four waves through LDS (every wave adds the four partial sums in the same order: bit-identical totals)
+    auto column_total = [&](float (&s)[2][4], int pass) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] += bv[j][r];
-    // sum over the wave's 64 rows of every one of my 16 columns: over i in registers, over the 16 lanes of a lane row
-    // by xor-shuffles (masks 1, 2, 4, 8 stay inside a group of 16 lanes), over the two row halves through LDS
-    auto column_total = [&](float (&s)[4][4], int pass) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = s[j][r];
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
-                s[j][r] = v;
-            }
-        float* mine = red + ((pass * 2 + wn) * 2 + wm) * 64;
+            for (int r = 0; r < 4; ++r) s[j][r] = dpp16_sum(s[j][r]);
+        float* mine = red + (pass * 4 + wave) * SN;
         if (lr == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mine[j * 16 + kq * 4 + r] = s[j][r];
         }
         __syncthreads();
-        const float* other = red + ((pass * 2 + wn) * 2 + (wm ^ 1)) * 64;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                // (row half 0 first on both sides: the two waves of a column range end with bit-identical totals)
-                const float mv = s[j][r], ov = other[j * 16 + kq * 4 + r];
-                s[j][r] = wm == 0 ? mv + ov : ov + mv;
+                const int c = j * 16 + kq * 4 + r;
+                s[j][r] = ((red[(pass * 4 + 0) * SN + c] + red[(pass * 4 + 1) * SN + c]) + red[(pass * 4 + 2) * SN + c]) +
+                          red[(pass * 4 + 3) * SN + c];
             }
     };
-    float mean[4][4], var[4][4];
+    float mean[2][4], var[2][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float t = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) t += rok[i] ? acc[i][j][r] : 0.f;
+            for (int i = 0; i < 2; ++i) t += rok[i] ? acc[i][j][r] : 0.f;
             mean[j][r] = t;
         }
     column_total(mean, 0);
     const float invM = 1.0f / (float)p.M;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             mean[j][r] *= invM;
             float t = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 2; ++i) {
                 const float d = acc[i][j][r] - mean[j][r];
                 t += rok[i] ? d * d : 0.f;
             }
             var[j][r] = t;
         }
     column_total(var, 1);
-    float sc[4][4], sh[4][4];
+    float sc[2][4], sh[2][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int col = cbase + j * 16 + r;
@@ -436,7 +507,7 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 4) void gemm_bf16x_bnact_ker
             const float g = (q.gamma != nullptr && cok) ? q.gamma[col] : 1.f, b = (q.beta != nullptr && cok) ? q.beta[col] : 0.f;
             sc[j][r] = g * inv;
             sh[j][r] = b - mean[j][r] * sc[j][r];
-            if (wm == 0 && lr == 0 && cok) {  // one lane per column: the statistics backward needs, the running statistics
+            if (wave == 0 && lr == 0 && cok) {  // one lane per column: the statistics backward needs, the running statistics
                 q.mean[col] = mean[j][r];
                 q.var[col] = var[j][r];
                 if (q.rmean != nullptr) {
@@ -446,11 +517,11 @@ __global__ __launch_bounds__(256, STAGES == 2 ? 2 : 4) void gemm_bf16x_bnact_ker
             }
         }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wm * 64 + i * 16 + lr;
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + lr;
         if (row >= p.M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const int col = cbase + j * 16;
             if (col >= p.N) continue;  // (N is a multiple of 4 on this path: a lane's four columns are in or out together)
             const f32x4 z = acc[i][j];
@@ -898,7 +969,7 @@ extern "C" int pk_cvt_bf16(void* stream, const float* src, int64_t ld_src, int64
 // PK_GEMM_TILE=128|256 / pk_gemm_bf16_set_tile() force one of them.
 static int g_gemm_tile_forced = -1;
 extern "C" void pk_gemm_bf16_set_tile(int tile) { g_gemm_tile_forced = (tile == 128 || tile == 256) ? tile : 0; }
-static int gemm_tile_for(int M, int N, int a_kc, int b_kc) {
+static int gemm_tile_for(int M, int N, int a_kc, int b_kc, int K = 1 << 30) {
     int& forced = g_gemm_tile_forced;
     if (forced < 0) {
         const char* e = getenv("PK_GEMM_TILE");
@@ -914,7 +985,15 @@ static int gemm_tile_for(int M, int N, int a_kc, int b_kc) {
         rows256 = (e && atoi(e) == 0) ? 0 : 1;
     }
     if (rows256 && a_kc && M >= 16384 && N >= 1024) return 256;
-    return (!a_kc && !b_kc && M >= 1024 && N >= 1024) ? 256 : 128;
+    if (!a_kc && !b_kc && M >= 1024 && N >= 1024) {
+        // a weight gradient over a short reduction (an MLP layer at batch 128: 1024 x 1024 over K = 128) has no split-K to
+        // fill the chip with: 16 workgroups of 256-tiles each read-modify-write 256 KB of the fp32 gradient on their own
+        // (17 us measured); the 128-tile puts the same traffic on 64 CUs
+        const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+        if (K < 2048 && tiles256 < 64) return 128;
+        return 256;
+    }
+    return 128;
 }
 
 // kept for callers that sized split-K from the tile height (rows of the block tile of a k-contiguous shape)
@@ -961,7 +1040,7 @@ static int gemm_bf16_impl(void* stream, int M, int N, int K, float alpha, const 
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.bias = bias;
     p.stats = stats;
-    const int tile = gemm_tile_for(M, N, a_kc, b_kc);
+    const int tile = gemm_tile_for(M, N, a_kc, b_kc, K);
     PK_REQUIRE(stats == nullptr || (tile == 256 && a_kc && b_kc && splitk <= 1 && beta == 0.f), "pk_gemm_bf16_stats: internal: shape not covered");
     p.tiles_m = (M + tile - 1) / tile;
     p.tiles_n = (N + tile - 1) / tile;
@@ -984,6 +1063,21 @@ static int gemm_bf16_impl(void* stream, int M, int N, int K, float alpha, const 
     p.ws = splitk > 1 ? workspace : nullptr;
     p.items = splitk * p.tiles_m * p.tiles_n;
     p.per_xcd = (p.items + 7) / 8;
+    {   // small-batch products: all rows of 32 columns per workgroup (gemm_bf16s_kernel); PK_GEMM_SKINNY=0 keeps the 128-tile
+        static int skinny_on = -1;
+        if (skinny_on < 0) {
+            const char* e = getenv("PK_GEMM_SKINNY");
+            skinny_on = (e && e[0] == '0') ? 0 : 1;
+        }
+        if (skinny_on && !g_gemm_tile_forced && a_kc && M <= TM && N >= 4 * SN && splitk == 1 && stats == nullptr) {
+            BnActArgs q = {};
+            const dim3 sgrid((unsigned)((N + SN - 1) / SN));
+            if (b_kc) hipLaunchKernelGGL((gemm_bf16s_kernel<false, true>), sgrid, dim3(256), 2 * SSTAGE, st, p, q);
+            else hipLaunchKernelGGL((gemm_bf16s_kernel<false, false>), sgrid, dim3(256), 2 * SSTAGE, st, p, q);
+            PK_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (tile == 256) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -1068,7 +1162,7 @@ extern "C" int pk_gemm_bf16_stats(void* stream, int M, int N, int K, float alpha
                           fused ? stats : nullptr);
 }
 
-// One perf-mode MLP layer of a batch of up to 128 rows in one launch: see gemm_bf16x_bnact_kernel.
+// One perf-mode MLP layer of a batch of up to 128 rows in one launch: see gemm_bf16s_kernel<true>.
 // xb [M][ldx] / wb [N][ldw] bf16 (k-contiguous), z / a / y fp32 [M][N] (y null = no mask: the layer output is a),
 // yb bf16 [M][ldyb] (ldyb >= N, both multiples of 8), mean / var [N] (biased batch statistics, saved for backward).
 // pk_linear_bn_act_bf16_covers says whether a shape takes this path.
@@ -1105,12 +1199,7 @@ extern "C" int pk_linear_bn_act_bf16(void* stream, int M, int N, int K, const ui
     q.eps = eps; q.momentum = momentum; q.unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
     q.rmean = running_mean; q.rvar = running_var; q.mean = mean; q.var = var;
     q.zout = z; q.aout = a; q.yout = y; q.yb = (unsigned short*)yb; q.ldyb = ldyb; q.act = act;
-    static bool attr_done = false;
-    if (!attr_done) {
-        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_bnact_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((gemm_bf16x_bnact_kernel<2>), dim3((unsigned)p.tiles_n), dim3(256), 65536, st, p, q);
+    hipLaunchKernelGGL((gemm_bf16s_kernel<true>), dim3((unsigned)((N + SN - 1) / SN)), dim3(256), 2 * SSTAGE, st, p, q);
     PK_LAUNCH_CHECK();
     return 0;
 }

@@ -838,7 +838,11 @@ extern "C" int pk_logsoftmax_fwd(void* stream, const float* x, int64_t rows, int
 // but a wave walks its rows one dependent HBM round trip after the other, so short rows (a 48-class head: one load per
 // lane and row) need many waves to hide that: 64 000 x 48 took 284 us with 31 rows per wave, ~20 us with 4
 static inline long lsm_bf16_blocks(int64_t rows, int64_t N) {
-    const long rows_per_wave = N <= 64 ? 4 : N <= 256 ? 8 : N <= 1024 ? 16 : 31;
+    long rows_per_wave = N <= 64 ? 4 : N <= 256 ? 8 : N <= 1024 ? 16 : 31;
+    // a small batch (an MLP step of 128 frames) must not queue its rows behind one another: 128 x 1944 on 8 waves of 16
+    // rows took 55 us; at least ~512 waves before a wave gets a second row
+    const long spread = rows / 512 > 0 ? rows / 512 : 1;
+    if (rows_per_wave > spread) rows_per_wave = spread;
     long b = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
     if (b > 4096) b = 4096;
     if (b < 1) b = 1;
@@ -894,6 +898,7 @@ extern "C" int pk_nll_logsoftmax_bwd_bf16(void* stream, const float* y, const in
 
 static inline long nll_err_blocks(int64_t rows) {
     long b = (rows + 31) / 32;  // >= 8 rows per wave
+    if (rows < 16384) b = (rows + 3) / 4;  // small batches: a row per wave (128 x 1944 on 16 waves of 8 rows took 21 us)
     if (b > 1024) b = 1024;
     if (b < 1) b = 1;
     return b;

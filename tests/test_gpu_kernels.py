@@ -376,6 +376,13 @@ BF_GEMM_SHAPES = [
     (640, 900, 136, 1, 0, 1),
     (1100, 1104, 6400, 0, 0, 4),
     (1938, 1100, 5000, 0, 0, 3),
+    # small-batch products: the four-stage ring of the 128-tile (<= 64 tiles, K >= 256, k-contiguous A)
+    (128, 1024, 1024, 1, 1, 1),
+    (128, 1024, 440, 1, 1, 1),
+    (128, 1024, 1000, 1, 0, 1),
+    (100, 1944, 264, 1, 1, 1),
+    (77, 136, 3000, 1, 0, 1),
+    (1024, 1024, 128, 0, 0, 1),
 ]
 
 

@@ -61,6 +61,8 @@ SIGNATURES = {
     "pk_nll_logsoftmax_bwd_bf16": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64, P, P]),
     "pk_rec_num_saved": (c_int, [c_int]),
     "pk_rec_num_gates": (c_int, [c_int]),
+    "pk_bn_act_bwd_small_covers": (c_int, [c_int64, c_int64]),
+    "pk_bn_act_bwd_small": (c_int, [P, P, P, P, c_int, P, P, P, c_float, P, c_int64, c_int64, P, c_int64, P, P, P, P, P]),
     "pk_rec_work_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "pk_rec_ln_saved_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "pk_rec_ln_work_floats": (c_int64, [c_int, c_int, c_int, c_int]),
@@ -232,8 +234,37 @@ class Profiler:
                 for k, v in acc.items()}
 
 
+class _TracedLib:
+    """PK_DEBUG_CALLS=1 (fault hunting): every entry point that takes a stream prints its name before the call and the
+    device is synchronised behind it - the last name on stderr is the launch a memory fault belongs to."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        sig = SIGNATURES.get(name)
+        if sig is None or not sig[1] or sig[1][0] is not P:
+            return fn
+
+        def traced(*a):
+            import sys
+
+            import torch
+
+            sys.stderr.write("[pk] %s\n" % name)
+            sys.stderr.flush()
+            rc = fn(*a)
+            torch.cuda.synchronize()
+            return rc
+
+        return traced
+
+
 def load():  # noqa: F811 - same name on purpose: every caller goes through the switch
     lib = _raw_load()
     if _profiler is not None:
         return _TimedLib(lib, _profiler)
+    if os.environ.get("PK_DEBUG_CALLS", "0") == "1":
+        return _TracedLib(lib)
     return lib

@@ -754,6 +754,91 @@ extern "C" int pk_bn_bwd_apply(void* stream, const float* g, const float* g2, in
     return 0;
 }
 
+// ---- backward of drop(act(bn(z))) for a SMALL batch (M <= 128 rows) in one launch: the activation / mask backward
+// (pk_act_bwd), the two BatchNorm reductions (pk_bn_bwd_reduce: two launches), the BatchNorm backward itself
+// (pk_bn_bwd_apply) and the bf16 conversion of its result (pk_cvt_bf16) - five launches of ~4.5 us each on a 128-frame
+// MLP step whose arithmetic is 128 x 1024 elements.  A workgroup owns 32 columns and all M rows: thread (column, row
+// group) keeps its g and xhat in registers between the reduction and the second pass.
+//   g = dy * mask * act'(a);  sum_g = sum_rows g;  sum_gx = sum_rows g * xhat;
+//   dz = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M)      (neural_networks.py:139-148 backwards)
+// dzb: bf16 [M][ldb] (ldb >= N; pad columns zero: the GEMM operand), dz: fp32 [M][N] or null.  sum_g / sum_gx [N] are
+// written; acc_beta / acc_gamma (null or [N]): += the same sums (the parameters' .grad, accumulated in place).
+constexpr int SB_COLS = 32, SB_RG = 8, SB_ROWS = 16;  // 8 row groups x 16 rows = 128 rows at most
+__global__ __launch_bounds__(256) void bn_act_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ a,
+                                                                const float* __restrict__ mask, int act,
+                                                                const float* __restrict__ z, const float* __restrict__ mean,
+                                                                const float* __restrict__ var, float eps,
+                                                                const float* __restrict__ gamma, int M, int N,
+                                                                unsigned short* __restrict__ dzb, long ldb,
+                                                                float* __restrict__ dz, float* __restrict__ sum_g,
+                                                                float* __restrict__ sum_gx, float* __restrict__ acc_beta,
+                                                                float* __restrict__ acc_gamma) {
+    __shared__ float sh[2][SB_RG][SB_COLS];
+    const int cx = threadIdx.x & (SB_COLS - 1), rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * SB_COLS + cx;
+    const bool cok = c < N;
+    const float mu = cok ? mean[c] : 0.f;
+    const float inv = cok ? 1.0f / sqrtf(var[c] + eps) : 0.f;
+    float gv[SB_ROWS], xh[SB_ROWS];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < SB_ROWS; ++k) {
+        const int r = rg + k * SB_RG;
+        float g = 0.f, x = 0.f;
+        if (cok && r < M) {
+            const long o = (long)r * N + c;
+            g = dy[o];
+            if (mask) g *= mask[o];
+            g *= pk_act_grad_from_out(act, a[o]);
+            x = (z[o] - mu) * inv;
+        }
+        gv[k] = g;
+        xh[k] = x;
+        s0 += g;
+        s1 += g * x;
+    }
+    sh[0][rg][cx] = s0;
+    sh[1][rg][cx] = s1;
+    __syncthreads();
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < SB_RG; ++k) {  // every thread of a column adds the eight partial sums in the same order
+        t0 += sh[0][k][cx];
+        t1 += sh[1][k][cx];
+    }
+    if (rg == 0 && cok) {
+        sum_g[c] = t0;
+        sum_gx[c] = t1;
+        if (acc_beta) acc_beta[c] += t0;
+        if (acc_gamma) acc_gamma[c] += t1;
+    }
+    const float ga = (gamma && cok) ? gamma[c] : 1.f;
+    const float invM = 1.0f / (float)M;
+    const float k0 = t0 * invM, k1 = t1 * invM;
+#pragma unroll
+    for (int k = 0; k < SB_ROWS; ++k) {
+        const int r = rg + k * SB_RG;
+        if (r >= M) continue;
+        const float d = cok ? ga * inv * (gv[k] - k0 - xh[k] * k1) : 0.f;
+        if (c < ldb) dzb[(long)r * ldb + c] = pk_f2bf(d);  // (columns N .. ldb-1: zero padding)
+        if (dz && cok) dz[(long)r * N + c] = d;
+    }
+}
+
+extern "C" int pk_bn_act_bwd_small_covers(int64_t M, int64_t N) { return M >= 1 && M <= SB_RG * SB_ROWS && N >= 1; }
+extern "C" int pk_bn_act_bwd_small(void* stream, const float* dy, const float* a, const float* mask, int act, const float* z,
+                                   const float* mean, const float* var, float eps, const float* gamma, int64_t M, int64_t N,
+                                   uint16_t* dzb, int64_t ldb, float* dz, float* sum_g, float* sum_gx, float* acc_beta,
+                                   float* acc_gamma) {
+    PK_REQUIRE(pk_bn_act_bwd_small_covers(M, N), "pk_bn_act_bwd_small: up to %d rows (got %ld x %ld)", SB_RG * SB_ROWS, (long)M, (long)N);
+    PK_REQUIRE(dy && a && z && mean && var && dzb && sum_g && sum_gx && ldb >= N, "pk_bn_act_bwd_small: null argument or short pitch");
+    hipLaunchKernelGGL(bn_act_bwd_small_kernel, dim3((unsigned)((ldb + SB_COLS - 1) / SB_COLS)), dim3(256), 0, pk_stream(stream), dy, a,
+                       mask, act, z, mean, var, eps, gamma, (int)M, (int)N, (unsigned short*)dzb, (long)ldb, dz, sum_g, sum_gx,
+                       acc_beta, acc_gamma);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int pk_colsum(void* stream, const float* g, const float* g2, int64_t ldg, int64_t M, int64_t N,
                          float* partial, float* out) {
     hipStream_t st = pk_stream(stream);

@@ -152,6 +152,31 @@ def set_forced_decisions(relu=None, pool=None):
     return _Decisions.report
 
 
+class _Ahead:
+    """Masks of the nn.Dropout calls a forward is about to make, drawn together (masks_ahead)."""
+    queue = []
+
+
+def masks_ahead(specs, device):
+    """specs: [(rows, cols, p)] in call order.  A feed-forward stack at batch 128 is launch-bound: instead of two
+    launches per nn.Dropout call (Bernoulli draw, scale) the masks of all calls with the same p are drawn as ONE flat
+    tensor - two launches per distinct p; dropout_mask() then hands out its slices in order.  (Same distribution,
+    another use of the device generator's stream than call-by-call draws.)"""
+    _Ahead.queue = []
+    if _Drops.queue is not None or len(specs) < 2:
+        return
+    out = [None] * len(specs)
+    for p in sorted(set(q for _, _, q in specs)):
+        idx = [i for i, sp in enumerate(specs) if sp[2] == p]
+        sizes = [_up(specs[i][0] * specs[i][1], 4) for i in idx]  # 16-byte aligned slices
+        flat = torch.empty(sum(sizes), device=device, dtype=torch.float32).bernoulli_(1.0 - p).div_(1.0 - p)
+        o = 0
+        for i, n in zip(idx, sizes):
+            out[i] = flat[o:o + specs[i][0] * specs[i][1]].view(specs[i][0], specs[i][1])
+            o += n
+    _Ahead.queue = [(tuple(sp[:2]), sp[2], m) for sp, m in zip(specs, out)]
+
+
 def dropout_mask(like, p):
     """The Bernoulli(1-p) / (1-p) mask of one nn.Dropout call on a tensor shaped `like` (device RNG)."""
     if _Drops.queue is not None:
@@ -159,6 +184,11 @@ def dropout_mask(like, p):
         if tuple(m.shape) != tuple(like.shape):
             raise _lib.PkError("forced dropout mask %s for a %s tensor" % (tuple(m.shape), tuple(like.shape)))
         return m.to(device=like.device, dtype=torch.float32) / (1.0 - p)
+    if _Ahead.queue:
+        shape, q, m = _Ahead.queue.pop(0)
+        if shape == tuple(like.shape) and q == p and m.device == like.device:
+            return m
+        _Ahead.queue = []  # the forward took another route than announced: back to call-by-call draws
     return torch.empty_like(like).bernoulli_(1.0 - p).div_(1.0 - p)
 
 
@@ -334,6 +364,15 @@ def side_targets_ok(params):
     call join_side() first)."""
     return (settings.wgrad_side and bf16_mode() and params is not None and len(params) > 0
             and all(getattr(q, "_pk_flat", False) and q.grad is not None and q.requires_grad for q in params))
+
+
+def direct_grads_ok(params):
+    """Small-batch layers (an MLP step of 128 frames is launch-bound): a gradient may be ACCUMULATED into the parameter's
+    pre-allocated flat .grad by the kernel that produces it, on the current stream, instead of being returned to autograd
+    (whose AccumulateGrad node is one more add launch per parameter).  Same conditions as the side-stream weight
+    gradients, and only while no data-parallel reducer listens for gradient hooks.  PK_DIRECT_GRADS=0 turns it off."""
+    return (_Side.listener is None and os.environ.get("PK_DIRECT_GRADS", "1") != "0" and torch.is_grad_enabled() is False
+            and side_targets_ok(params))
 
 
 _DEBUG_SKIP_SIDE = os.environ.get("PK_DEBUG_SKIP_SIDE", "0") == "1"  # timing experiments only: drops the weight-gradient work
@@ -514,6 +553,9 @@ def _linear_bwd_bf16(ctx, dyb, xb, wb, like):
             if side:  # off the dependency chain: accumulate into the flat .grad on the side stream (beta = 1)
                 side_launch(lambda: gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0,
                                               splitk=sk), (dyb, xb), [wp])
+            elif M <= 512 and wp is not None and wp.is_contiguous() and direct_grads_ok([wp]):
+                # small batch: straight into the flat .grad on this stream (no AccumulateGrad add behind it)
+                gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0, splitk=sk)
             else:
                 dw = _new(N, K, like=like)
                 gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K, splitk=sk)
@@ -860,6 +902,7 @@ class LinearBnActFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.in_shape = x.shape
         ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None
+        ctx.bnparams = [gamma, beta] if (isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter)) else None
         ctx.mark_non_differentiable(yb)
         return y, yb
 
@@ -870,17 +913,32 @@ class LinearBnActFn(torch.autograd.Function):
         eps, act = ctx.cfg
         M, N, K = ctx.dims
         dy2 = _rows2d(dy.contiguous())
+        sum_g, sum_gx = _new(N, like=z), _new(N, like=z)
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if lib.pk_bn_act_bwd_small_covers(M, N) == 1 and os.environ.get("PK_MLP_FUSED_BWD", "1") != "0":
+            # one launch: activation / mask backward, both BatchNorm reductions, BatchNorm backward, the bf16 operand
+            direct = ctx.bnparams is not None and direct_grads_ok(ctx.bnparams)
+            dzb = torch.empty(M, _up(N, 64), device=z.device, dtype=torch.bfloat16)
+            dz = _new(M, N, like=z) if need_db else None
+            _lib.check(lib.pk_bn_act_bwd_small(_stream(), _p(dy2), _p(a), _p(mask), ACT[act], _p(z), _p(mean), _p(var), eps,
+                                               _p(gamma), M, N, _p(dzb), dzb.shape[1], _p(dz), _p(sum_g), _p(sum_gx),
+                                               _p(ctx.bnparams[1].grad) if direct else None,
+                                               _p(ctx.bnparams[0].grad) if direct else None), "pk_bn_act_bwd_small")
+            dx, dw = _linear_bwd_bf16(ctx, dzb, xb, wb, z)
+            db = colsum(dz) if need_db else None
+            if direct:
+                return dx, dw, db, None, None, None, None, None, None, None, None, None
+            return dx, dw, db, sum_gx, sum_g, None, None, None, None, None, None, None
         g = _new(M, N, like=z)
         _lib.check(lib.pk_act_bwd(_stream(), _p(dy2), _p(a), _p(mask), ACT[act], M * N, _p(g)), "pk_act_bwd")
         part = _new(int(lib.pk_bn_partial_floats(M, N)), like=z)
-        sum_g, sum_gx = _new(N, like=z), _new(N, like=z)
         _lib.check(lib.pk_bn_bwd_reduce(_stream(), _p(g), None, N, _p(z), N, M, N, _p(mean), _p(var), eps, _p(part), _p(sum_g),
                                         _p(sum_gx)), "pk_bn_bwd_reduce")
         dz = _new(M, N, like=z)
         _lib.check(lib.pk_bn_bwd_apply(_stream(), _p(g), None, N, _p(z), N, M, N, _p(mean), _p(var), eps, _p(gamma), _p(sum_g),
                                        _p(sum_gx), float(M), _p(dz), N), "pk_bn_bwd_apply")
         dx, dw = _linear_bwd_bf16(ctx, cvt_bf16(dz), xb, wb, dz)
-        db = colsum(dz) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = colsum(dz) if need_db else None
         return dx, dw, db, sum_gx, sum_g, None, None, None, None, None, None, None
 
 
@@ -891,12 +949,13 @@ def linear_bn_act_ok(x, weight, training, use_bn, act):
             and _lib.load().pk_linear_bn_act_bf16_covers(x.shape[0], weight.shape[0], x.shape[1]) == 1)
 
 
-def linear_bn_act(x, weight, bias, bn, act, mask):
+def linear_bn_act(x, weight, bias, bn, act, mask, count=True):
     """-> y = mask * act(bn(x W^T + b)); y._pk_yb = its bf16 copy (what the next layer's GEMM reads)."""
     twin = getattr(x, "_pk_yb", None)
     xb = twin[0] if (twin is not None and twin[1] == x._version and twin[0].shape[0] == x.shape[0]) else None
-    with torch.no_grad():
-        bn.num_batches_tracked += 1
+    if count:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
     y, yb = LinearBnActFn.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
                                 act, mask, xb)
     y._pk_yb = (yb, y._version)

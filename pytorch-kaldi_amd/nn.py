@@ -178,6 +178,12 @@ class MLP(nn.Module):
             x = self.ln0(x)
         if self.dnn_use_batchnorm_inp:
             x = F_.norm_act_drop(x, self.bn0, True, self.training, "linear")
+        if self.training and x.dim() == 2 and x.is_cuda:
+            # a 128-frame step is launch-bound: all dropout masks of the stack in two launches per distinct p, and the
+            # batch counters of the one-launch layers in one
+            F_.masks_ahead([(x.shape[0], self.dnn_lay[i], self.dnn_drop[i]) for i in range(self.N_dnn_lay)
+                            if self.dnn_drop[i] > 0.0], x.device)
+        counted = []
         for i in range(self.N_dnn_lay):
             if (self.dnn_act[i] == "softmax" and not self.dnn_use_laynorm[i] and not self.dnn_use_batchnorm[i]
                     and not (self.training and self.dnn_drop[i] > 0.0)
@@ -191,13 +197,17 @@ class MLP(nn.Module):
                 mask = None
                 if self.training and self.dnn_drop[i] > 0.0:
                     mask = F_.dropout_mask(torch.empty(x.shape[0], self.dnn_lay[i], device=x.device), self.dnn_drop[i])
-                x = F_.linear_bn_act(x, self.wx[i].weight, self.wx[i].bias, self.bn[i], self.dnn_act[i], mask)
+                x = F_.linear_bn_act(x, self.wx[i].weight, self.wx[i].bias, self.bn[i], self.dnn_act[i], mask, count=False)
+                counted.append(self.bn[i].num_batches_tracked)
                 continue
             z = F_.linear(x, self.wx[i].weight, self.wx[i].bias)
             if self.dnn_use_laynorm[i]:
                 z = self.ln[i](z)
             x = _apply_act_drop(z, self.bn[i], bool(self.dnn_use_batchnorm[i]), self.training, self.dnn_act[i],
                                 self.dnn_drop[i])
+        if counted:
+            with torch.no_grad():
+                torch._foreach_add_(counted, 1)
         return x
 
 

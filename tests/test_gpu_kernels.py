@@ -41,6 +41,26 @@ def test_dpp_row_sum_reaches_every_lane():
     assert bad.value == 0
 
 
+def test_grouped_dropout_masks():
+    """masks_ahead draws the masks of a stack's nn.Dropout calls together (two launches per distinct p); dropout_mask then
+    hands them out in call order and falls back to a fresh draw when the forward takes another route."""
+    dev = torch.device("cuda")
+    specs = [(128, 1024, 0.15), (128, 1024, 0.15), (128, 512, 0.3), (128, 1024, 0.15)]
+    torch.manual_seed(5)
+    F_.masks_ahead(specs, dev)
+    got = [F_.dropout_mask(torch.empty(r, c, device=dev), p) for r, c, p in specs]
+    assert F_._Ahead.queue == []
+    for (r, c, p), m in zip(specs, got):
+        assert tuple(m.shape) == (r, c) and m.data_ptr() % 16 == 0
+        vals = torch.unique(m).cpu()
+        assert all(abs(float(v)) < 1e-12 or abs(float(v) - 1.0 / (1.0 - p)) < 1e-6 for v in vals)
+        assert abs(float(m.mean()) - 1.0) < 0.02
+    assert not torch.equal(got[0], got[1])
+    F_.masks_ahead(specs, dev)
+    m = F_.dropout_mask(torch.empty(7, 9, device=dev), 0.5)  # not what was announced: a fresh draw, the queue is dropped
+    assert tuple(m.shape) == (7, 9) and F_._Ahead.queue == []
+
+
 def test_single_hip_runtime():
     """libpk_amd.so must bind to the HIP runtime torch already mapped (one runtime per
     process): exactly one libamdhip64 in /proc/self/maps."""

@@ -667,3 +667,53 @@ def test_per_step_layernorm_in_the_persistent_loop(kind, pre, act, bidir, B, T, 
         for k, v in gs.items():
             if v is not None:
                 assert rel_err(got[k], v) < 5e-5, k
+
+
+# --------------------------------------------------------------------------------
+# the small-batch (launch-bound) MLP step: one-launch layers, one-launch BatchNorm / activation backward, gradients
+# accumulated into the flat .grad by the kernels that produce them
+# --------------------------------------------------------------------------------
+def test_small_batch_mlp_step_direct_gradients(monkeypatch):
+    """TIMIT_MLP at its batch size (128 frames, 440 -> 1024 x 4 -> softmax head) in perf mode with flat parameters: the
+    backward pass with its small-batch shortcuts on (one launch for activation / BatchNorm backward, PK_MLP_FUSED_BWD;
+    weight and BatchNorm gradients accumulated into the flat .grad by the kernels that produce them, PK_DIRECT_GRADS)
+    must leave the gradients of the node-by-node backward through autograd's AccumulateGrad - same forward, same saved
+    tensors; the fp32 operation order inside the BatchNorm backward differs, which flips the bf16 rounding of a few
+    entries of dz per layer (measured 7e-4 at the bottom layer; two different forward kernels are 2e-2 apart, the bf16
+    noise floor of this stack) - twice in a row (the second step lands on zeroed gradients again)."""
+    from engine_util import F_amd, nn_amd
+
+    optim_ = importlib.import_module("pytorch-kaldi_amd.optim")
+    opts = {"dnn_lay": "1024,1024,1024,1024,200", "dnn_drop": "0.15,0.15,0.15,0.15,0.0", "dnn_use_laynorm_inp": "False",
+            "dnn_use_batchnorm_inp": "False", "dnn_use_batchnorm": "True,True,True,True,False",
+            "dnn_use_laynorm": "False,False,False,False,False", "dnn_act": "relu,relu,relu,relu,softmax"}
+    g = torch.Generator().manual_seed(8)
+    xs = [torch.randn(128, 440, generator=g).cuda() for _ in range(2)]
+    labs = [torch.randint(0, 200, (128,), generator=g).cuda() for _ in range(2)]
+    F_amd.set_precision("bf16")
+    results = {}
+    for mode in ("plain", "direct"):
+        for k in ("PK_MLP_FUSED_BWD", "PK_DIRECT_GRADS"):
+            monkeypatch.setenv(k, "0" if mode == "plain" else "1")
+        torch.manual_seed(3)
+        net = nn_amd.MLP(opts, 440).cuda().train()
+        flat = optim_.FlatParams(net)
+        grads = []
+        for x, lab in zip(xs, labs):
+            masks = [(torch.rand(128, 1024, generator=torch.Generator().manual_seed(50 + i)) > 0.15).float() for i in range(4)]
+            F_amd.set_forced_dropout([m.cuda() for m in masks])
+            try:
+                flat.zero_grad()
+                loss = torch.nn.functional.nll_loss(net(x), lab)
+                loss.backward()
+                torch.cuda.synchronize()
+            finally:
+                F_amd.set_forced_dropout(None)
+            grads.append({k: q.grad.detach().clone() for k, q in net.named_parameters()})
+        results[mode] = grads
+    for step in range(2):
+        for k, ref in results["plain"][step].items():
+            if float(ref.abs().max()) < 1e-6:  # (the bias in front of a BatchNorm: its gradient is rounding noise around 0)
+                continue
+            got = results["direct"][step][k]
+            assert rel_err(got, ref) < 4e-3, (step, k, rel_err(got, ref))

@@ -367,6 +367,20 @@ int pk_linear_bn_act_bf16(void* stream, int M, int N, int K, const uint16_t* xb,
                           const float* bias, const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, int act, const float* mask, float* z, float* a,
                           float* y, uint16_t* yb, int64_t ldyb, float* mean, float* var);
+/* ---- perf-mode convolutions (pk_conv_bf16.hip): F.conv1d + F.max_pool1d of the SincNet / CNN stacks
+ * (neural_networks.py:1546-1552, :1655-1661, :1805-1813) as an implicit GEMM on v_mfma_f32_16x16x32_bf16 - x, w and the
+ * un-pooled output gradient enter as bf16, accumulation in fp32; same tensors and arg-max convention as
+ * pk_conv1d_pool_fwd / _bwd (the exact-fp32 kernels of the parity mode).  pk_conv_bf16_covers: pool widths that divide
+ * 48, up to 128 output channels.  work: pk_conv_bf16_work_floats(..., backward) floats of scratch per call.  The bias
+ * gradient is not produced here (a column sum of dy). */
+int pk_conv1d_pool_dgrad(void* stream, const float* w, const float* dy, const int32_t* argmax, int B, int Cin, int L, int Cout,
+                         int K, int pool, float* dx, float* work); /* exact-fp32 data gradient alone; work >= pk_conv_fwd_work_floats */
+int pk_conv_bf16_covers(int Cin, int Cout, int K, int pool);
+int64_t pk_conv_bf16_work_floats(int B, int Cin, int L, int Cout, int K, int pool, int backward);
+int pk_conv1d_pool_fwd_bf16(void* stream, const float* x, const float* w, const float* bias, int B, int Cin, int L, int Cout,
+                            int K, int pool, float* y, int32_t* argmax, float* work);
+int pk_conv1d_pool_bwd_bf16(void* stream, const float* x, const float* w, const float* dy, const int32_t* argmax, int B,
+                            int Cin, int L, int Cout, int K, int pool, float* dw, float* dx, float* work);
 int pk_selftest_mfma(void* stream, int* h_bad_count);
 /* v_permlane16_swap_b32 lane mapping the third-generation persistent recurrences rely on when they assemble a 16-byte
  * publish chunk from two lanes (pk_rec_persist3.hip) */

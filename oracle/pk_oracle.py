@@ -128,22 +128,29 @@ def flip_time(x):
 # The HIP engine's "bf16" mode computes the SAME algorithm with the operands of every GEMM - projections, the
 # recurrent h_{t-1}.U^T, Linear layers, and in backward dY.W, dY^T.x, dgates.U, dgates^T.h - rounded to bf16
 # (round-to-nearest-even, v_cvt_pk_bf16_f32) and the products accumulated in fp32; everything element-wise (gates,
-# BatchNorm, LayerNorm, softmax, state) stays fp32.  `with bf16_operands():` makes every matrix product of this oracle
+# BatchNorm, LayerNorm, softmax, state) stays fp32; with `bf16_operands(conv=True)` the convolutions of the SincNet / CNN
+# stacks too (x, w and the un-pooled output gradient as bf16: the engine's opt-in pk_conv_bf16.hip).
+# `with bf16_operands():` makes every matrix product of this oracle
 # do exactly that, so a test can separate (i) "the engine implements the bf16-operand algorithm" (engine vs this model:
 # tight) from (ii) "how far the bf16-operand algorithm is from the reference's fp32 results on this network" (this
 # model vs the golden arrays: intrinsic, network-dependent).
 # ----------------------------------------------------------------------------
-_EMUL = {"bf16": False}
+_EMUL = {"bf16": False, "conv": False}
 
 
 class bf16_operands:
+    """conv=True: the convolutions take bf16 operands too (the engine with PK_CONV_BF16=1)."""
+
+    def __init__(self, conv=False):
+        self.conv = conv
+
     def __enter__(self):
-        self.prev = _EMUL["bf16"]
-        _EMUL["bf16"] = True
+        self.prev = (_EMUL["bf16"], _EMUL["conv"])
+        _EMUL["bf16"], _EMUL["conv"] = True, self.conv
         return self
 
     def __exit__(self, *exc):
-        _EMUL["bf16"] = self.prev
+        _EMUL["bf16"], _EMUL["conv"] = self.prev
 
 
 def _rb(t):
@@ -166,6 +173,33 @@ class _Bf16Linear(torch.autograd.Function):
         dx = gb.matmul(wb)
         dw = gb.reshape(-1, gb.shape[-1]).t().matmul(xb.reshape(-1, xb.shape[-1]))
         return dx, dw
+
+
+class _Bf16Conv(torch.autograd.Function):
+    """conv1d(round(x), round(w)) in fp32; backward dx = conv_transpose(round(g), round(w)), dw = corr(round(g), round(x))
+    - the engine's perf-mode convolutions (pk_conv_bf16.hip): x, w and the un-pooled output gradient enter as bf16."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xb, wb = _rb(x), _rb(w)
+        ctx.save_for_backward(xb, wb)
+        return F.conv1d(xb, wb)
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, wb = ctx.saved_tensors
+        gb = _rb(g)
+        dx = torch.nn.grad.conv1d_input(xb.shape, wb, gb) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv1d_weight(xb, wb.shape, gb) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def _conv1d(x, w, b=None):
+    """F.conv1d - the one place a convolution operand enters (bf16-operand model: see _Bf16Conv)."""
+    if _EMUL["bf16"] and _EMUL["conv"]:
+        y = _Bf16Conv.apply(x, w)
+        return y if b is None else y + b.view(1, -1, 1)
+    return F.conv1d(x, w, b)
 
 
 def _mm(x, w):
@@ -444,8 +478,8 @@ def conv_stack_forward(kind, options, sd, x, training=True, drop_masks=None, kin
                                  int(_opt(options, "sinc_sample_rate")),
                                  int(_opt(options, "sinc_min_low_hz")),
                                  int(_opt(options, "sinc_min_band_hz")))
-                return F.conv1d(v, w)
-            return F.conv1d(v, sd["conv.%d.weight" % i], sd["conv.%d.bias" % i])
+                return _conv1d(v, w)
+            return _conv1d(v, sd["conv.%d.weight" % i], sd["conv.%d.bias" % i])
 
         m = None if drop_masks is None else drop_masks[i]
         kp = None if kinks is None else kinks[i]

@@ -616,3 +616,16 @@ extern "C" int pk_conv1d_pool_bwd(void* stream, const float* x, const float* w, 
     }
     return 0;
 }
+
+// The data gradient alone (exact fp32): dx [B,Cin,L] from dy + argmax.  The perf-mode path (pk_conv_bf16.hip) uses it for
+// layers with very few input channels (SincNet's first layer: one - a matrix-vector product per position, where an MFMA
+// tile would be 15/16 padding).  work: >= pk_conv_fwd_work_floats(Cin, Cout, K) floats.
+extern "C" int pk_conv1d_pool_dgrad(void* stream, const float* w, const float* dy, const int32_t* argmax, int B, int Cin, int L,
+                                    int Cout, int K, int pool, float* dx, float* work) {
+    hipStream_t st = pk_stream(stream);
+    PK_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && K > 0 && pool > 0 && L >= K && dx && work, "pk_conv1d_pool_dgrad: bad argument");
+    const int Lc = L - K + 1, Lp = Lc / pool;
+    PK_REQUIRE(Lp > 0, "pk_conv1d_pool_dgrad: empty output");
+    return Cin < 4 ? launch_conv_tile<1, 8, false, 1>(st, dy, argmax, w, work, nullptr, B, Cin, Cout, K, Lc, L, pool, dx, nullptr, Lp)
+                   : launch_conv_tile<16, 4, false, 1>(st, dy, argmax, w, work, nullptr, B, Cin, Cout, K, Lc, L, pool, dx, nullptr, Lp);
+}

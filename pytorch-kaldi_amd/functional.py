@@ -1610,9 +1610,20 @@ class ConvPoolFn(torch.autograd.Function):
         Lp = (L - K + 1) // pool
         y = _new(B, Cout, Lp, like=x)
         arg = torch.empty(B, Cout, Lp, device=x.device, dtype=torch.int32)
-        work = _new(int(lib.pk_conv_fwd_work_floats(Cin, Cout, K)), like=x)
-        _lib.check(lib.pk_conv1d_pool_fwd(_stream(), _p(x), _p(w), _p(bias), B, Cin, L, Cout, K, pool, _p(y),
-                                          ctypes.c_void_p(arg.data_ptr()), _p(work)), "pk_conv1d_pool_fwd")
+        # perf mode, opt-in (PK_CONV_BF16=1): the implicit-GEMM kernels on the matrix pipe (bf16 operands).  Not the default
+        # yet: on timit_sincnet they are worth 4 % of the step (forward 0.40 vs 0.70 ms, data gradient 0.21 vs 0.40, but
+        # the filter gradient is no faster than the fp32 kernel), and the recipe-scale SincNet fixture grades 7.4e-3
+        # against the bf16-operand model where the fp32 convolutions hold 5e-3
+        ctx.conv_bf = (bf16_mode() and os.environ.get("PK_CONV_BF16", "0") == "1"
+                       and lib.pk_conv_bf16_covers(Cin, Cout, K, pool) == 1)
+        if ctx.conv_bf:
+            work = _new(int(lib.pk_conv_bf16_work_floats(B, Cin, L, Cout, K, pool, 0)), like=x)
+            _lib.check(lib.pk_conv1d_pool_fwd_bf16(_stream(), _p(x), _p(w), _p(bias), B, Cin, L, Cout, K, pool, _p(y),
+                                                   ctypes.c_void_p(arg.data_ptr()), _p(work)), "pk_conv1d_pool_fwd_bf16")
+        else:
+            work = _new(int(lib.pk_conv_fwd_work_floats(Cin, Cout, K)), like=x)
+            _lib.check(lib.pk_conv1d_pool_fwd(_stream(), _p(x), _p(w), _p(bias), B, Cin, L, Cout, K, pool, _p(y),
+                                              ctypes.c_void_p(arg.data_ptr()), _p(work)), "pk_conv1d_pool_fwd")
         if _Decisions.pool is not None:
             # test mode: backward routes dy to another run's arg-max positions (absolute index = window start + offset)
             fpool, off = _Decisions.pool.pop(0)
@@ -1636,6 +1647,21 @@ class ConvPoolFn(torch.autograd.Function):
         dw = torch.empty_like(w)
         db = _new(Cout, like=x) if ctx.has_bias else None
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        if ctx.conv_bf:
+            work = _new(int(lib.pk_conv_bf16_work_floats(B, Cin, L, Cout, K, pool, 1)), like=x)
+            dx_mfma = dx
+            if dx is not None and Cin < 8:
+                # a layer with a handful of input channels (SincNet's first: one): its data gradient is a matrix-vector
+                # product per position - the exact-fp32 kernel, not an MFMA tile that is 15/16 padding
+                wk = _new(int(lib.pk_conv_fwd_work_floats(Cin, Cout, K)), like=x)
+                _lib.check(lib.pk_conv1d_pool_dgrad(_stream(), _p(w), _p(dy), ctypes.c_void_p(arg.data_ptr()), B, Cin, L, Cout,
+                                                    K, pool, _p(dx), _p(wk)), "pk_conv1d_pool_dgrad")
+                dx_mfma = None
+            _lib.check(lib.pk_conv1d_pool_bwd_bf16(_stream(), _p(x), _p(w), _p(dy), ctypes.c_void_p(arg.data_ptr()), B, Cin,
+                                                   L, Cout, K, pool, _p(dw), _p(dx_mfma), _p(work)), "pk_conv1d_pool_bwd_bf16")
+            if db is not None:
+                db = dy.sum(dim=(0, 2))
+            return dx, dw, db, None
         part = _new(int(lib.pk_conv_partial_floats(B, Cin, L, Cout, K, pool)), like=x)
         _lib.check(lib.pk_conv1d_pool_bwd(_stream(), _p(x), _p(w), _p(dy), ctypes.c_void_p(arg.data_ptr()), B, Cin, L,
                                           Cout, K, pool, _p(dw), _p(db), _p(dx), _p(part)), "pk_conv1d_pool_bwd")

@@ -86,9 +86,9 @@ def oracle_params(nns):
                 for k, v in net.state_dict().items()} for n, net in nns.items()}
 
 
-def oracle_run(O, g, sds, emulate=False, forced=False):
+def oracle_run(O, g, sds, emulate=False, forced=False, force_pool=True, conv_bf16=False):
     """The oracle on the fixture's batch (CPU): outs dict, gradients left in sds.  forced: differentiate on the
-    reference run's discrete decisions (ReLU patterns, pooling arg-max) instead of this run's own."""
+    reference run's discrete decisions (ReLU patterns, pooling arg-max when force_pool) instead of this run's own."""
     import contextlib
 
     m = g.meta
@@ -97,9 +97,9 @@ def oracle_run(O, g, sds, emulate=False, forced=False):
     if forced:
         rp = {tag: pat for tag, pat in relu_patterns(g)}
         pi = {}
-        for tag, pool, off in pool_offsets(g):
+        for tag, pool, off in (pool_offsets(g) if force_pool else []):
             pi[tag] = (torch.arange(off.shape[-1]) * pool)[None, None, :] + off.long()
-    with (O.bf16_operands() if emulate else contextlib.nullcontext()):
+    with (O.bf16_operands(conv=conv_bf16) if emulate else contextlib.nullcontext()):
         outs = O.recipe_forward(m["model"], m["options"], m["arch_dict"], sds, g.t("inp"), m["fea_dict"], m["lab_dict"],
                                 rec_masks=rec_masks(g), drop_masks=dm, relu_patterns=rp or None, pool_idx=pi or None)
         outs["loss_final"].backward()

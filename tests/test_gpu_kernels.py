@@ -230,6 +230,62 @@ def test_conv_pool(B, Cin, L, Cout, K, pool):
     assert rel_err(be.grad, br.grad) < 1e-5
 
 
+def _rb64(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _Bf16ConvRef(torch.autograd.Function):
+    """fp64 evaluation of the bf16-operand convolution: x, w and the output gradient rounded to bf16."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xb, wb = _rb64(x), _rb64(w)
+        ctx.save_for_backward(xb, wb)
+        return TF.conv1d(xb, wb)
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, wb = ctx.saved_tensors
+        gb = _rb64(g)
+        return torch.nn.grad.conv1d_input(xb.shape, wb, gb), torch.nn.grad.conv1d_weight(xb, wb.shape, gb)
+
+
+@pytest.mark.parametrize("B,Cin,L,Cout,K,pool", CONV_SHAPES + [(128, 1, 3200, 128, 129, 3), (16, 128, 1024, 60, 5, 3),
+                                                               (5, 60, 112, 60, 3, 2)])
+def test_conv_pool_bf16(B, Cin, L, Cout, K, pool, monkeypatch):
+    """The opt-in perf-mode convolutions (PK_CONV_BF16=1, pk_conv_bf16.hip: implicit GEMM on the bf16 matrix pipe, eight
+    shifted copies of the staged window) against an fp64 evaluation of the same bf16-operand algorithm: outputs, arg-max
+    routing, dx, dw, db."""
+    monkeypatch.setenv("PK_CONV_BF16", "1")
+    lib = _lib.load()
+    if lib.pk_conv_bf16_covers(Cin, Cout, K, pool) != 1:
+        pytest.skip("layer not covered by the bf16 kernels (pool width / channel count): fp32 kernels")
+    g = torch.Generator().manual_seed(B + Cin + L)
+    x = torch.randn(B, Cin, L, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / (Cin * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    Lp = (L - K + 1) // pool
+    cot = torch.randn(B, Cout, Lp, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = TF.max_pool1d(_Bf16ConvRef.apply(xr, wr) + br.view(1, -1, 1), pool)
+    (yr * cot.double()).sum().backward()
+    F_.set_precision("bf16")
+    try:
+        xe, we, be = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+        ye = F_.conv1d_pool(xe, we, be, pool)
+        (ye * cot.cuda()).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        F_.set_precision("fp32")
+    assert rel_err(ye, yr) < 2e-5
+    # (an arg-max that flips between the fp32 and the fp64 accumulation re-routes one element of dz: 1 / sqrt(N) of a norm)
+    # (layers with fewer than 8 input channels take their data gradient from the exact-fp32 kernel: it differs from this
+    # bf16-rounded reference by the rounding itself, measured 2.4e-3)
+    assert rel_err(xe.grad, xr.grad) < (2e-3 if Cin >= 8 else 1e-2)
+    assert rel_err(we.grad, wr.grad) < 2e-3
+    assert rel_err(be.grad, br.grad) < 2e-5
+
+
 def test_optimizers_match_torch():
     lib = _lib.load()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -28,6 +28,7 @@ bf16 mode is graded in two steps:
 """
 import configparser
 import importlib
+import os
 import math
 
 import numpy as np
@@ -470,6 +471,12 @@ def test_recipe_scale_golden(case, prec):
     # and ONE re-routed element of a 4 M-element layer moves that layer's parameter gradient by 5e-4 of its norm; the
     # reference's own fp32 gradients sit 1.4e-2 from an fp64 evaluation for the same reason - both measured)
     relus, pools = SU.relu_patterns(g), SU.pool_offsets(g)
+    conv_bf16 = prec == "bf16" and bool(pools) and os.environ.get("PK_CONV_BF16", "0") == "1"
+    if conv_bf16:
+        # opt-in bf16 convolutions: the conv outputs sit ~1e-2 from the reference's, so the reference's arg-max positions
+        # / ReLU patterns are no longer (near-)decisions of THIS run and forcing them would change VALUES by that noise:
+        # the engine and the bf16-operand model both take their own (they run the same function)
+        relus, pools = [], []
     decisions = F_amd.set_forced_decisions([pt for _, pt in relus] if relus else None,
                                            [(pool, off) for _, pool, off in pools] if pools else None)
     inp = g.t("inp").cuda()
@@ -496,7 +503,7 @@ def test_recipe_scale_golden(case, prec):
         for kind, (diff, total) in flips.items():  # the engine's own decisions differ only where values tie at fp32 resolution
             assert diff <= 2e-5 * total + 2, (kind, diff, total)
         return
-    oouts = SU.oracle_run(O, g, init, emulate=True, forced=True)
+    oouts = SU.oracle_run(O, g, init, emulate=True, forced=not conv_bf16, force_pool=not conv_bf16, conv_bf16=conv_bf16)
     st = m["strides"]
     rep = {}
     for k in m["out_keys"]:

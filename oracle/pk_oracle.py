@@ -139,7 +139,8 @@ _EMUL = {"bf16": False, "conv": False}
 
 
 class bf16_operands:
-    """conv=True: the convolutions take bf16 operands too (the engine with PK_CONV_BF16=1)."""
+    """conv=True: the convolutions of layers with at least 8 input channels take bf16 operands too (the engine with
+    PK_CONV_BF16=1); conv="all": every convolution (PK_CONV_BF16=2)."""
 
     def __init__(self, conv=False):
         self.conv = conv
@@ -196,7 +197,7 @@ class _Bf16Conv(torch.autograd.Function):
 
 def _conv1d(x, w, b=None):
     """F.conv1d - the one place a convolution operand enters (bf16-operand model: see _Bf16Conv)."""
-    if _EMUL["bf16"] and _EMUL["conv"]:
+    if _EMUL["bf16"] and _EMUL["conv"] and (x.shape[1] >= 8 or _EMUL["conv"] == "all"):  # (the engine's rule: layers with >= 8 input channels)
         y = _Bf16Conv.apply(x, w)
         return y if b is None else y + b.view(1, -1, 1)
     return F.conv1d(x, w, b)

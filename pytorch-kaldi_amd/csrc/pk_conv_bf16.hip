@@ -31,11 +31,18 @@ __device__ __forceinline__ unsigned short f2bf(float f) { return pk_f2bf(f); }
 // The eight shifted copies of one staged row (copy_c[j] = x[j + c], rows of `xpitch` elements): work item T takes the
 // samples 4T .. 4T+6 (its own four and the next three) and writes, for every copy, the 8-byte word that starts inside its
 // own four: word m = T - (c >> 2) of copy c holds x[4T + (c & 3) .. + 3].  (8 ds_write_b64 per four samples.)
-template <typename F>
-__device__ __forceinline__ void stage_row_copies(unsigned short* base, int xpitch, int T, F sample) {
+// ptr_of(s): a VALID address for sample s (clamped), ok_of(s): whether the sample exists (else zero).  All seven loads
+// are issued before any is used (the empty asm consumes them together): written as `ok ? *p : 0` the compiler puts every
+// load under its own branch with its own s_waitcnt vmcnt(0) - seven dependent round trips per work item.
+template <typename P, typename V>
+__device__ __forceinline__ void stage_row_copies(unsigned short* base, int xpitch, int T, P ptr_of, V ok_of) {
+    float raw[7];
+#pragma unroll
+    for (int e = 0; e < 7; ++e) raw[e] = *ptr_of(4 * T + e);
+    asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]));
     unsigned short h[7];
 #pragma unroll
-    for (int e = 0; e < 7; ++e) h[e] = f2bf(sample(4 * T + e));
+    for (int e = 0; e < 7; ++e) h[e] = f2bf(ok_of(4 * T + e) ? raw[e] : 0.f);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int m = T - (c >> 2), d = c & 3;
@@ -107,14 +114,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         // ---- stage the input window of the chunk: eight shifted bf16 copies per channel
         if (FWD) {
             const int w4 = a.wlen >> 2;
+#pragma unroll 2
             for (int i = tid; i < a.ICC * w4; i += 256) {
                 const int ic = i / w4, T = i - ic * w4;
                 const float* row = a.in + ((long)b * a.NIC + ic0 + (ic < nic ? ic : 0)) * a.Lin;
                 const bool cok = ic < nic;
-                stage_row_copies(xs + (size_t)ic * 8 * a.xpitch, a.xpitch, T, [&](int s) {
-                    const int l = in0 + s;
-                    return (cok && l >= 0 && l < a.Lin) ? row[l] : 0.f;
-                });
+                stage_row_copies(xs + (size_t)ic * 8 * a.xpitch, a.xpitch, T,
+                                 [&](int s) { return row + min(max(in0 + s, 0), a.Lin - 1); },
+                                 [&](int s) { return cok && in0 + s >= 0 && in0 + s < a.Lin; });
             }
         } else {
             // dz = dy routed to the arg-max positions: zero the copies, then scatter
@@ -124,26 +131,55 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             const int lpa = max(in0, 0) / a.pool;
             const int lpb = min(a.Lp - 1, (in0 + a.wlen - 1) / a.pool);
             const int nlp = lpb - lpa + 1;
-            for (int i = tid; i < nic * nlp; i += 256) {
-                const int ic = i / nlp, lp = lpa + (i - ic * nlp);
-                const long o = ((long)b * a.NIC + ic0 + ic) * a.Lp + lp;
-                const int s = a.amax[o] - in0;
-                if (s >= 0 && s < a.wlen) {
-                    const unsigned short h = f2bf(a.in[o]);
-                    unsigned short* base = xs + (size_t)ic * 8 * a.xpitch;
+            // (eight (dy, arg-max) pairs per thread in flight: one at a time the loop was a chain of global round trips)
+            for (int i0 = tid; i0 < nic * nlp; i0 += 256 * 8) {
+                float v[8];
+                int sidx[8], icv[8];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        if (s - c >= 0) base[c * a.xpitch + (s - c)] = h;
+                for (int e = 0; e < 8; ++e) {
+                    const int i = min(i0 + e * 256, nic * nlp - 1);  // (clamped: the loads are unconditional, see stage_row_copies)
+                    const int ic = i / nlp, lp = lpa + (i - ic * nlp);
+                    const long o = ((long)b * a.NIC + ic0 + ic) * a.Lp + lp;
+                    sidx[e] = a.amax[o];
+                    v[e] = a.in[o];
+                    icv[e] = ic;
+                }
+                asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sidx[e] = (i0 + e * 256 < nic * nlp) ? sidx[e] - in0 : -1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int s = sidx[e];
+                    if (s >= 0 && s < a.wlen) {
+                        const unsigned short h = f2bf(v[e]);
+                        unsigned short* base = xs + (size_t)icv[e] * 8 * a.xpitch;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if (s - c >= 0) base[c * a.xpitch + (s - c)] = h;
+                    }
                 }
             }
         }
         // ---- stage the chunk's weights: rows of rc elements (16-byte pieces)
         {
-            const int pieces = rc >> 3;
-            for (int i = tid; i < a.NB * 16 * pieces; i += 256) {
-                const int row = i / pieces, pc = i - row * pieces;
-                const uint4 v = *reinterpret_cast<const uint4*>(a.wb + (size_t)row * a.Rp + (size_t)ic0 * a.Kt + pc * 8);
-                *reinterpret_cast<uint4*>(ws + (size_t)row * a.wpitch + pc * 8) = v;
+            const int pieces = rc >> 3, total = a.NB * 16 * pieces;
+            for (int i0 = tid; i0 < total; i0 += 256 * 4) {  // four 16-byte pieces per thread in flight
+                uint4 v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = min(i0 + e * 256, total - 1);
+                    const int row = i / pieces, pc = i - row * pieces;
+                    v[e] = *reinterpret_cast<const uint4*>(a.wb + (size_t)row * a.Rp + (size_t)ic0 * a.Kt + pc * 8);
+                }
+                asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = i0 + e * 256;
+                    if (i < total) {
+                        const int row = i / pieces, pc = i - row * pieces;
+                        *reinterpret_cast<uint4*>(ws + (size_t)row * a.wpitch + pc * 8) = v[e];
+                    }
+                }
             }
         }
         __syncthreads();
@@ -279,14 +315,14 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(ConvWArgs a) {
             // x window copies of the chunk
             {
                 const int w4 = a.xlen >> 2;
+#pragma unroll 2
                 for (int i = tid; i < a.ICC * w4; i += 256) {
                     const int ic = i / w4, T = i - ic * w4;
                     const float* row = a.x + ((long)b * a.Cin + ic0 + (ic < nic ? ic : 0)) * a.L;
                     const bool cok = ic < nic;
-                    stage_row_copies(xs + (size_t)ic * 8 * a.xpitch, a.xpitch, T, [&](int s) {
-                        const int l = p0 + s;
-                        return (cok && l < a.L) ? row[l] : 0.f;
-                    });
+                    stage_row_copies(xs + (size_t)ic * 8 * a.xpitch, a.xpitch, T,
+                                     [&](int s) { return row + min(p0 + s, a.L - 1); },
+                                     [&](int s) { return cok && p0 + s < a.L; });
                 }
             }
             __syncthreads();
@@ -294,11 +330,24 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(ConvWArgs a) {
                 const int lpa = p0 / a.pool;
                 const int lpb = min(a.Lp - 1, (p0 + TPW - 1) / a.pool);
                 const int nlp = lpb - lpa + 1;
-                for (int i = tid; i < a.Cout * nlp; i += 256) {
-                    const int co = i / nlp, lp = lpa + (i - co * nlp);
-                    const long o = ((long)b * a.Cout + co) * a.Lp + lp;
-                    const int s = a.amax[o] - p0;
-                    if (s >= 0 && s < TPW) zs[(size_t)co * a.zpitch + s] = f2bf(a.dy[o]);
+                for (int i0 = tid; i0 < a.Cout * nlp; i0 += 256 * 8) {  // eight pairs per thread in flight (see conv_mfma_kernel)
+                    float v[8];
+                    int sidx[8], cov[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int i = min(i0 + e * 256, a.Cout * nlp - 1);
+                        const int co = i / nlp, lp = lpa + (i - co * nlp);
+                        const long o = ((long)b * a.Cout + co) * a.Lp + lp;
+                        sidx[e] = a.amax[o];
+                        v[e] = a.dy[o];
+                        cov[e] = co;
+                    }
+                    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sidx[e] = (i0 + e * 256 < a.Cout * nlp) ? sidx[e] - p0 : -1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (sidx[e] >= 0 && sidx[e] < TPW) zs[(size_t)cov[e] * a.zpitch + sidx[e]] = f2bf(v[e]);
                 }
             }
             __syncthreads();

@@ -1610,11 +1610,14 @@ class ConvPoolFn(torch.autograd.Function):
         Lp = (L - K + 1) // pool
         y = _new(B, Cout, Lp, like=x)
         arg = torch.empty(B, Cout, Lp, device=x.device, dtype=torch.int32)
-        # perf mode, opt-in (PK_CONV_BF16=1): the implicit-GEMM kernels on the matrix pipe (bf16 operands).  Not the default
-        # yet: on timit_sincnet they are worth 4 % of the step (forward 0.40 vs 0.70 ms, data gradient 0.21 vs 0.40, but
-        # the filter gradient is no faster than the fp32 kernel), and the recipe-scale SincNet fixture grades 7.4e-3
-        # against the bf16-operand model where the fp32 convolutions hold 5e-3
-        ctx.conv_bf = (bf16_mode() and os.environ.get("PK_CONV_BF16", "0") == "1"
+        # perf mode, opt-in: the implicit-GEMM kernels on the matrix pipe (bf16 operands, pk_conv_bf16.hip).  PK_CONV_BF16=1:
+        # layers with at least 8 input channels, =2: every covered layer; default 0: the exact-fp32 kernels.  Measured on
+        # timit_sincnet with =2: 3.36 vs 3.91 ms per step - but with the raw waveform and the 129-tap sinc filters rounded
+        # to bf16 the recipe-scale fixture's worst parameter gradient sits 30 % from the reference's (bf16-operand model
+        # vs reference), and the network's own noise floor exceeds the fixed grading limits: not a
+        # default until the first layer's treatment is settled
+        mode = os.environ.get("PK_CONV_BF16", "0")
+        ctx.conv_bf = (bf16_mode() and mode in ("1", "2") and (Cin >= 8 or mode == "2")
                        and lib.pk_conv_bf16_covers(Cin, Cout, K, pool) == 1)
         if ctx.conv_bf:
             work = _new(int(lib.pk_conv_bf16_work_floats(B, Cin, L, Cout, K, pool, 0)), like=x)

@@ -91,3 +91,13 @@ def check_grads(got_by_name, ref_by_name, meta, tol, zero_tol=1e-4):
         worst = max(worst, e)
         assert e < tol, (k, e)
     return worst
+
+
+def conv_bf16_on():
+    """Which of the engine's perf-mode convolutions take bf16 operands (pk_conv_bf16.hip): False = none (default),
+    True = layers with at least 8 input channels (PK_CONV_BF16=1), "all" (PK_CONV_BF16=2).  The bf16-operand model of the oracle is
+    switched the same way: O.bf16_operands(conv=conv_bf16_on())."""
+    import os
+
+    mode = os.environ.get("PK_CONV_BF16", "0")
+    return True if mode == "1" else ("all" if mode == "2" else False)

@@ -86,7 +86,7 @@ def oracle_params(nns):
                 for k, v in net.state_dict().items()} for n, net in nns.items()}
 
 
-def oracle_run(O, g, sds, emulate=False, forced=False, force_pool=True, conv_bf16=False):
+def oracle_run(O, g, sds, emulate=False, forced=False, force_pool=True, conv_bf16=False, inp_noise=0.0):
     """The oracle on the fixture's batch (CPU): outs dict, gradients left in sds.  forced: differentiate on the
     reference run's discrete decisions (ReLU patterns, pooling arg-max when force_pool) instead of this run's own."""
     import contextlib
@@ -99,8 +99,14 @@ def oracle_run(O, g, sds, emulate=False, forced=False, force_pool=True, conv_bf1
         pi = {}
         for tag, pool, off in (pool_offsets(g) if force_pool else []):
             pi[tag] = (torch.arange(off.shape[-1]) * pool)[None, None, :] + off.long()
+    inp = g.t("inp")
+    if inp_noise:  # the features (not the label columns) perturbed at fp32-rounding level: the model's own noise floor
+        nfea = inp.shape[-1] - len(m["lab_dict"])
+        inp = inp.clone()
+        gen = torch.Generator().manual_seed(99)
+        inp[..., :nfea] *= 1.0 + inp_noise * torch.randn(inp[..., :nfea].shape, generator=gen)
     with (O.bf16_operands(conv=conv_bf16) if emulate else contextlib.nullcontext()):
-        outs = O.recipe_forward(m["model"], m["options"], m["arch_dict"], sds, g.t("inp"), m["fea_dict"], m["lab_dict"],
+        outs = O.recipe_forward(m["model"], m["options"], m["arch_dict"], sds, inp, m["fea_dict"], m["lab_dict"],
                                 rec_masks=rec_masks(g), drop_masks=dm, relu_patterns=rp or None, pool_idx=pi or None)
         outs["loss_final"].backward()
     return outs

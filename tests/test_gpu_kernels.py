@@ -253,10 +253,10 @@ class _Bf16ConvRef(torch.autograd.Function):
 @pytest.mark.parametrize("B,Cin,L,Cout,K,pool", CONV_SHAPES + [(128, 1, 3200, 128, 129, 3), (16, 128, 1024, 60, 5, 3),
                                                                (5, 60, 112, 60, 3, 2)])
 def test_conv_pool_bf16(B, Cin, L, Cout, K, pool, monkeypatch):
-    """The opt-in perf-mode convolutions (PK_CONV_BF16=1, pk_conv_bf16.hip: implicit GEMM on the bf16 matrix pipe, eight
+    """The perf-mode convolutions (pk_conv_bf16.hip: implicit GEMM on the bf16 matrix pipe, eight
     shifted copies of the staged window) against an fp64 evaluation of the same bf16-operand algorithm: outputs, arg-max
     routing, dx, dw, db."""
-    monkeypatch.setenv("PK_CONV_BF16", "1")
+    monkeypatch.setenv("PK_CONV_BF16", "2")  # every covered layer, also those with fewer than 8 input channels
     lib = _lib.load()
     if lib.pk_conv_bf16_covers(Cin, Cout, K, pool) != 1:
         pytest.skip("layer not covered by the bf16 kernels (pool width / channel count): fp32 kernels")

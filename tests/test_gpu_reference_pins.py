@@ -35,7 +35,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import Golden, analytically_zero, grad_err, list_cases, rel_err
+from golden_util import conv_bf16_on, Golden, analytically_zero, grad_err, list_cases, rel_err
 
 pytestmark = pytest.mark.gpu
 U_BF16 = 2.0 ** -9
@@ -62,7 +62,7 @@ def emulate_module(g):
         if sd[k].is_floating_point() and "running" not in k:
             sd[k].requires_grad_(True)
     x = g.t("x").clone().requires_grad_(True)
-    with O.bf16_operands():
+    with O.bf16_operands(conv=conv_bf16_on()):
         y = O.arch_forward(m["arch_class"], m["options"], sd, x, training=m["training"], to_do=m["to_do"],
                            drop_masks=g.masks() or None)
         dx = grads = None
@@ -471,11 +471,11 @@ def test_recipe_scale_golden(case, prec):
     # and ONE re-routed element of a 4 M-element layer moves that layer's parameter gradient by 5e-4 of its norm; the
     # reference's own fp32 gradients sit 1.4e-2 from an fp64 evaluation for the same reason - both measured)
     relus, pools = SU.relu_patterns(g), SU.pool_offsets(g)
-    conv_bf16 = prec == "bf16" and bool(pools) and os.environ.get("PK_CONV_BF16", "0") == "1"
+    conv_bf16 = prec == "bf16" and bool(pools) and conv_bf16_on()
     if conv_bf16:
-        # opt-in bf16 convolutions: the conv outputs sit ~1e-2 from the reference's, so the reference's arg-max positions
-        # / ReLU patterns are no longer (near-)decisions of THIS run and forcing them would change VALUES by that noise:
-        # the engine and the bf16-operand model both take their own (they run the same function)
+        # bf16 convolutions: the conv outputs sit ~1e-2 from the reference's, so the reference's arg-max positions / ReLU
+        # patterns are no longer (near-)decisions of THIS run and forcing them would change VALUES by that noise: the
+        # engine and the bf16-operand model both take their own (they run the same function)
         relus, pools = [], []
     decisions = F_amd.set_forced_decisions([pt for _, pt in relus] if relus else None,
                                            [(pool, off) for _, pool, off in pools] if pools else None)
@@ -505,11 +505,23 @@ def test_recipe_scale_golden(case, prec):
         return
     oouts = SU.oracle_run(O, g, init, emulate=True, forced=not conv_bf16, force_pool=not conv_bf16, conv_bf16=conv_bf16)
     st = m["strides"]
+    # With bf16 convolutions the model's OWN noise floor on this network is above the engine-vs-model limits: a 1e-6
+    # relative perturbation of the waveform (what another fp32 summation order amounts to) moves the trunk's output
+    # by 8e-3 (bf16 rounding flips through four conv + LayerNorm layers and the MLP; measured on the host).  The limits
+    # are therefore taken as max(fixed limit, 2 x that floor), per tensor, from a second model run.
+    noisy_out, noisy = {}, None
+    if conv_bf16:
+        noisy = SU.oracle_params(nns)
+        nouts = SU.oracle_run(O, g, noisy, emulate=True, forced=False, force_pool=False, conv_bf16=conv_bf16, inp_noise=1e-6)
+        noisy_out = {k: nouts[k].detach() for k in m["out_keys"]}
     rep = {}
     for k in m["out_keys"]:
         s_ = st["out/%s/stride" % k]
-        rep[k] = _two_step(k, SU.rows(outs[k].reshape(-1, outs[k].shape[-1]), s_),
-                           SU.rows(oouts[k].detach().reshape(-1, oouts[k].shape[-1]), s_), g.t("out/%s/rows" % k), TIGHT_OUT)
+        mrows = SU.rows(oouts[k].detach().reshape(-1, oouts[k].shape[-1]), s_)
+        tight = TIGHT_OUT
+        if conv_bf16:
+            tight = max(tight, 2.0 * rel_err(SU.rows(noisy_out[k].reshape(-1, noisy_out[k].shape[-1]), s_), mrows))
+        rep[k] = _two_step(k, SU.rows(outs[k].reshape(-1, outs[k].shape[-1]), s_), mrows, g.t("out/%s/rows" % k), tight)
     lref, lo = float(g.t("loss_final")), float(oouts["loss_final"].detach())
     assert abs(float(outs["loss_final"]) - lo) < TIGHT_OUT * lref
     assert abs(float(outs["loss_final"]) - lref) < model_bound(abs(lo - lref) / lref) * lref
@@ -518,7 +530,10 @@ def test_recipe_scale_golden(case, prec):
     for name, k, key, gr, ref_rows, ref_ck in SU.grad_items(g, grads_of):
         s_ = st[key + "/stride"]
         frac = float(ref_rows.double().norm()) / ref_ck[0]
-        worst = max(worst, _two_step((name, k), SU.rows(gr, s_), SU.rows(init[name][k].grad, s_), ref_rows, TIGHT_GRAD,
+        tight = TIGHT_GRAD
+        if conv_bf16:
+            tight = max(tight, 2.0 * grad_err(SU.rows(noisy[name][k].grad, s_), SU.rows(init[name][k].grad, s_), gtot * frac))
+        worst = max(worst, _two_step((name, k), SU.rows(gr, s_), SU.rows(init[name][k].grad, s_), ref_rows, tight,
                                      gtot * frac), key=lambda t: t[2])
     print("\n%s [bf16]: outputs (engine-vs-model, model-vs-ref, engine-vs-ref) %s; worst gradient %s; decisions that bf16 "
           "rounding changed (differing, of): %s"

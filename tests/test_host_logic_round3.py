@@ -124,7 +124,7 @@ def test_oracle_bf16_convolution_model():
     w = (torch.randn(6, 4, 7, generator=g, dtype=torch.float64) / 5).requires_grad_(True)
     b = torch.randn(6, generator=g, dtype=torch.float64).requires_grad_(True)
     cot = torch.randn(3, 6, 44, generator=g, dtype=torch.float64).to(torch.bfloat16).double()  # bf16-exact cotangent
-    with O.bf16_operands(conv=True):
+    with O.bf16_operands(conv="all"):  # (4 input channels: below the engine's default threshold of 8)
         y = O._conv1d(x, w, b)
         (y * cot).sum().backward()
     xb = x.detach().to(torch.bfloat16).double().requires_grad_(True)
@@ -134,6 +134,9 @@ def test_oracle_bf16_convolution_model():
     assert torch.allclose(y, yr, rtol=0, atol=1e-12)
     assert torch.allclose(x.grad, xb.grad, rtol=0, atol=1e-12) and torch.allclose(w.grad, wb.grad, rtol=0, atol=1e-12)
     assert torch.allclose(b.grad, cot.sum((0, 2)), rtol=0, atol=1e-12)
-    with O.bf16_operands():  # the default model leaves convolutions in full precision (the engine's default)
+    with O.bf16_operands():  # without conv= the model leaves convolutions in full precision (the engine's default)
         y2 = O._conv1d(x.detach(), w.detach(), b.detach())
     assert torch.allclose(y2, TF.conv1d(x.detach(), w.detach(), b.detach()), rtol=0, atol=0)
+    with O.bf16_operands(conv=True):  # the default rule leaves a 4-channel layer exact as well
+        y3 = O._conv1d(x.detach(), w.detach(), b.detach())
+    assert torch.equal(y3, y2)

@@ -67,6 +67,7 @@ def parse():
                     help="one GPU: run the whole data-parallel path anyway - a ONE-rank RCCL communicator, the bucketed "
                          "reducer forced on (a one-rank sum is the identity: losses must equal the plain run bit for bit)")
     ap.add_argument("--dump-losses", default=None, help="write the loss of every timed step to this file (JSON list)")
+    ap.add_argument("--only-forward-mode", action="store_true", help="print only the forward_mode sub-record (eval-mode forward)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: every rank joins, one all-reduce, rank 0 prints {\"n_gpus\": world} (tests)")
     return ap.parse_args()
@@ -608,6 +609,40 @@ def launch_check(rank, world):
         dist.destroy_process_group()
 
 
+def forward_mode(args, steps=30, warmup=3):
+    """The validation / forward chunks of the same recipe (core.py:616-642 with to_do = valid): module.eval(),
+    torch.no_grad(), forward_model on the same resident batch - running BatchNorm statistics folded into the projection
+    scale / shift, the (1 - p) dropout scalar, no saved tensors, loss and error computed, nothing differentiated."""
+    tr = Trainer(args, 0, 1)
+    for n in tr.nns.values():
+        n.eval()
+    rcp = tr.rcp
+
+    def step(i):
+        inp = tr.batches[i % len(tr.batches)]
+        with torch.no_grad():
+            outs = tr.U.forward_model(rcp["fea_dict"], rcp["lab_dict"], rcp["arch_dict"], rcp["model"], tr.nns, tr.costs, inp,
+                                      tr.inp_out_dict, tr.T, tr.B, "valid", [])
+        return outs["loss_final"]
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        last = step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    frames = tr.T * tr.B if rcp["seq"] else tr.B
+    rec = {"dtype": args.prec, "ms_per_step": round(dt / steps * 1e3, 3), "value": round(frames * steps / dt, 1),
+           "unit": "frames/s", "steps": steps, "warmup": warmup, "loss_final": round(float(last), 5),
+           "note": "to_do = valid on the same batch: eval-mode modules under torch.no_grad(), forward_model with its cost "
+                   "lines, no backward, no optimizer (the validation / forward chunks of a recipe)"}
+    release(tr)
+    return rec
+
+
 def sub_record(rec, extra=()):
     keep = ("dtype", "ms_per_step", "value", "unit", "steps", "warmup", "roofline", "entry_points_ms_per_step",
             "whole_step_tflops", "regions_ms_per_step") + tuple(extra)
@@ -638,6 +673,9 @@ def main():
     rank, world, _ = DP.init_from_env()
     if args.launch_check:
         launch_check(rank, world)
+        return
+    if args.only_forward_mode:
+        print(json.dumps(forward_mode(args)), flush=True)
         return
     if world != args.gpus and world > 1:
         args.gpus = world
@@ -675,6 +713,10 @@ def main():
             out["reference_caller"] = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
             F_.settings.fused_cost = True
+        try:  # (2b) the forward-only chunks of the same recipe (validation / decoding passes)
+            out["forward_mode"] = forward_mode(args)
+        except Exception as e:
+            out["forward_mode"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # (3) the other BASELINE configurations, batch 128 per GPU: perf mode (median of 3 regions) and parity mode
         out["other_configs"] = []
         for recipe, steps, warmup in OTHER_CONFIGS:

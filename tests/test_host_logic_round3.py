@@ -140,3 +140,34 @@ def test_oracle_bf16_convolution_model():
     with O.bf16_operands(conv=True):  # the default rule leaves a 4-channel layer exact as well
         y3 = O._conv1d(x.detach(), w.detach(), b.detach())
     assert torch.equal(y3, y2)
+
+
+def test_direct_gradients_only_without_a_reducer_and_inside_backward(monkeypatch):
+    """functional.direct_grads_ok: kernels may accumulate into the flat .grad themselves only when the parameters are
+    flat-bucket views with a pre-allocated gradient, autograd is not recording (a plain backward pass), no data-parallel
+    reducer listens for gradient hooks, and PK_DIRECT_GRADS is not 0."""
+    monkeypatch.delenv("PK_DIRECT_GRADS", raising=False)
+    old = F_.settings.precision
+    q = torch.nn.Parameter(torch.zeros(4, 3))
+    q.grad = torch.zeros(4, 3)
+    q._pk_flat = True
+    plain = torch.nn.Parameter(torch.zeros(4, 3))
+    plain.grad = torch.zeros(4, 3)
+    try:
+        F_.set_precision("bf16")
+        monkeypatch.setattr(F_._Side, "listener", None)
+        assert not F_.direct_grads_ok([q])            # autograd is recording: not inside a backward pass
+        with torch.no_grad():
+            assert F_.direct_grads_ok([q])
+            assert not F_.direct_grads_ok([plain])    # not a flat-bucket parameter
+            assert not F_.direct_grads_ok([q, plain])
+            monkeypatch.setattr(F_._Side, "listener", lambda params: None)
+            assert not F_.direct_grads_ok([q])        # a reducer counts gradient hooks: everything goes through autograd
+            monkeypatch.setattr(F_._Side, "listener", None)
+            monkeypatch.setenv("PK_DIRECT_GRADS", "0")
+            assert not F_.direct_grads_ok([q])
+            monkeypatch.delenv("PK_DIRECT_GRADS")
+            F_.set_precision("fp32")
+            assert not F_.direct_grads_ok([q])        # parity mode: node by node
+    finally:
+        F_.set_precision(old)

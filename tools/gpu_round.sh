@@ -8,6 +8,11 @@ set -u
 tag=${1:-rXX}
 out=gpurun_out/$tag
 mkdir -p "$out"
+# a box whose GPU faults on its first touch (seen in round 3: 'Memory access fault' inside the first .cuda() of a process,
+# before any kernel of this library ran) burns minutes on core dumps: stop at once
+if ! timeout 90 python -c "import torch; x = torch.zeros(1 << 20).cuda() + 1; torch.cuda.synchronize(); print('gpu ok', float(x.sum()))"; then
+    echo "BAD BOX: first GPU touch failed"; exit 0
+fi
 if [ "${2:-}" != "skip-tests" ]; then
     timeout 1500 python -m pytest tests -q -m gpu > "$out/pytest_gpu.log" 2>&1
     echo "pytest rc=$? $(tail -1 "$out/pytest_gpu.log")"

@@ -409,6 +409,9 @@ int pk_rec2_check_residency(const void* kernel, int threads, size_t lds, int gri
 // third generation (pk_rec_persist3.hip: swapped MFMA operands): the backward pass of liGRU / RNN by default (PK_REC_GEN*)
 int pk_rec3_covers(int cell, int backward);
 int pk_rec3_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act, bool backward, bool traced);
+// fifth generation (pk_rec_split.hip: role-split workgroups - compute / poll / I/O waves): PK_REC_GEN* = 5
+int pk_recs_covers(int cell, int backward);
+int pk_recs_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act, bool backward, bool traced, bool delay_forced);
 // eight-wave LSTM kernels (pk_rec_persist2_lstm.hip): on unless PK_LSTM_WAVES=4; the launch loop over pl.launches
 int pk_rec2l_enabled();
 int pk_rec2l_launch(hipStream_t st, R2Args& a, const Plan2& pl, int act, bool backward);

@@ -932,6 +932,7 @@ static int rec_fwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
     if (rc) return rc;
     // (per-step LayerNorm lives in the four-wave second-generation kernels of this file, for every cell)
     if (lstm8 && !ln) return pk_rec2l_launch(st, a, pl, act, false);
+    if (!ln && pk_recs_covers(cell, 0)) return pk_recs_launch(st, a, pl, cell, act, false, traced(cell, act), g2_poll_delay >= 0);
     if (!ln && pk_rec3_covers(cell, 0)) return pk_rec3_launch(st, a, pl, cell, act, false, traced(cell, act));
     const int G = pk_cell_gates(cell);
     const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell) + (ln ? 1 : 0)) * 1024 + 512) + 16;
@@ -1003,6 +1004,7 @@ static int rec_bwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
     rc = pk_rec2_ln_setup(st, a, pl, ln, true);
     if (rc) return rc;
     if (lstm8 && !ln) return pk_rec2l_launch(st, a, pl, act, true);
+    if (!ln && pk_recs_covers(cell, 1)) return pk_recs_launch(st, a, pl, cell, act, true, traced(cell, act), g2_poll_delay >= 0);
     if (!ln && pk_rec3_covers(cell, 1)) return pk_rec3_launch(st, a, pl, cell, act, true, traced(cell, act));
     const size_t atile = (size_t)RMAX * pk_r2_lda_bf16(G * KPAD) * 2;
     const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0) + (ln ? 1 : 0);

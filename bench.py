@@ -182,20 +182,25 @@ def algorithmic_flops(rcp, T, B):
 
 
 def rec_launch_bytes(rcp, T, B, entry):
-    """Algorithmic HBM bytes of one persistent recurrent launch (bidirectional, fp32 tensors, bf16 exchange)."""
+    """Algorithmic HBM bytes of one persistent recurrent launch (bidirectional, fp32 tensors, bf16 exchange).  The two-phase
+    cells (GRU / minimalGRU, pk_rec2p_*: pk_rec_persist2_gru.hip) save their G gate tensors and publish a second bf16
+    exchange buffer (Xb: r*h / z*h, the k-major operand of the dU_h GEMM) in the forward pass."""
     a1 = rcp["cfg"]["architecture1"]
     kind = a1["arch_class"]
-    if kind not in ("liGRU", "LSTM", "RNN") or entry not in ("pk_rec_fwd_bf16", "pk_rec_bwd_bf16"):
+    two_phase = kind in ("GRU", "minimalGRU")
+    if kind not in ("liGRU", "LSTM", "RNN", "GRU", "minimalGRU"):
         return None
-    G = {"liGRU": 2, "LSTM": 4, "RNN": 1}[kind]
-    NS = {"liGRU": 2, "LSTM": 5, "RNN": 1}[kind]
-    H = int(a1[{"liGRU": "ligru", "LSTM": "lstm", "RNN": "rnn"}[kind] + "_lay"].split(",")[0])
+    if entry not in (("pk_rec2p_fwd_bf16", "pk_rec2p_bwd_bf16") if two_phase else ("pk_rec_fwd_bf16", "pk_rec_bwd_bf16")):
+        return None
+    G = {"liGRU": 2, "LSTM": 4, "RNN": 1, "GRU": 3, "minimalGRU": 2}[kind]
+    NS = {"liGRU": 2, "LSTM": 5, "RNN": 1, "GRU": 3, "minimalGRU": 2}[kind]  # fp32 tensors saved per direction
+    H = int(a1[{"liGRU": "ligru", "LSTM": "lstm", "RNN": "rnn", "GRU": "gru", "minimalGRU": "minimalgru"}[kind] + "_lay"].split(",")[0])
     Hp = (H + 7) // 8 * 8
     rows = T * B
-    if "fwd" in entry:  # read P; write Y, S (both directions) and the bf16 copy Yb
-        return rows * G * H * 4 + rows * 2 * H * 4 + 2 * rows * NS * H * 4 + rows * 2 * Hp * 2
-    # read S, Y (h_{t-1}) and dY; write the bf16 gate gradients of both directions
-    return 2 * rows * NS * H * 4 + 2 * rows * 2 * H * 4 + 2 * rows * G * Hp * 2
+    if "fwd" in entry:  # read P; write Y, S (both directions) and the bf16 copy Yb (+ Xb)
+        return rows * G * H * 4 + rows * 2 * H * 4 + 2 * rows * NS * H * 4 + rows * 2 * Hp * 2 * (2 if two_phase else 1)
+    # read S, Y (h_{t-1}) and dY (+ the bf16 r*h / z*h of the two-phase cells); write the bf16 gate gradients of both directions
+    return 2 * rows * NS * H * 4 + 2 * rows * 2 * H * 4 + 2 * rows * G * Hp * 2 + (rows * 2 * Hp * 2 if two_phase else 0)
 
 
 def profile_entry_points(tr, steps=2):
@@ -331,6 +336,8 @@ def cpu_baseline(args, rcp_name, full=False):
             fs = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_full_shape.json")))
             if fs.get("recipe", "timit_ligru") == rcp_name:
                 rec["full_shape"] = {k: fs[k] for k in ("value", "unit", "cores", "T", "B", "seconds", "sample") if k in fs}
+                rec["full_shape"]["measured_in_run"] = False  # a constant quoted from the file below, NOT timed by this run
+                rec["full_shape"]["source"] = "profiles/r03_cpu_full_shape.json (bench.py --cpu-full on a GPU box's host, round 3)"
         except (OSError, ValueError):
             pass
     return rec

@@ -60,6 +60,46 @@ __device__ __forceinline__ u32x4 s_pack_chunk(unsigned lo, unsigned hi) {  // se
 }
 __device__ __forceinline__ unsigned s_pack2(float x, float y) { return (unsigned)to_bf_pub(x) | ((unsigned)to_bf_pub(y) << 16); }
 
+// 16-byte access of the I/O wave: EDGY = false: no wave of this workgroup straddles H (straight-line code);
+// EDGY = true: the wave-uniform edge class e decides (0 = one 16-byte access, 1 = two 8-byte halves, 2 = element by element)
+template <bool EDGY>
+__device__ __forceinline__ f32x4 s_ld4(const float* base, unsigned off, int nv, int e) {
+    if constexpr (!EDGY) {
+        return ld4<0>(base, off, nv);
+    } else {
+        if (e == 0) return ld4<0>(base, off, nv);
+        if (e == 1) return ld4<1>(base, off, nv);
+        return ld4<2>(base, off, nv);
+    }
+}
+template <bool EDGY>
+__device__ __forceinline__ void s_st4(float* base, unsigned off, int nv, int e, float* trash, f32x4 v) {
+    if constexpr (!EDGY) {
+        st4<0>(base, off, nv, trash, v);
+    } else {
+        if (e == 0) st4<0>(base, off, nv, trash, v);
+        else if (e == 1) st4<1>(base, off, nv, trash, v);
+        else st4<2>(base, off, nv, trash, v);
+    }
+}
+// The polling waves start their poll when the workgroup's own compute waves have published (LDS flag words, one per
+// compute wave, = number of steps published): a poll issued at that moment reaches L2 together with the stores of the
+// other workgroups of the cluster, which run in lock step with this one - the hand-off then costs ONE round trip.  (A
+// fixed idle time instead lets every workgroup's re-polls fall at a random phase of a ~1 800-clock round trip; the
+// cluster then advances at the pace of the unluckiest workgroup: measured 6 480 instead of 5 440 clocks per step.)
+// (the flag words are read with an inline-asm LDS load: a volatile C++ access through a generic pointer compiles to
+// flat_load / flat_store + s_waitcnt vmcnt(0), i.e. it would wait for the wave's global-memory queue)
+__device__ __forceinline__ void s_wait_published(const unsigned char* flags, unsigned want, int spin_limit) {
+    const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)flags;
+    for (int spins = 0; spins < spin_limit; ++spins) {
+        u32x4 f;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(f) : "v"(addr) : "memory");
+        const unsigned m01 = f[0] < f[1] ? f[0] : f[1], m23 = f[2] < f[3] ? f[2] : f[3];
+        if ((m01 < m23 ? m01 : m23) >= want) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 #define PKS_TRACE_AT(TID, slot)                                                              \
     do {                                                                                     \
         if (TR && a.trace != nullptr && blockIdx.x == 0 && tid == (TID)) a.trace[(long)step_idx * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
@@ -95,6 +135,7 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
     const unsigned szYb = (unsigned)T * TS;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.Yb, szYb);
     const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    unsigned char* const pub_flags = smem + LDS_TRASH + 16;  // unsigned [4]: steps published per compute wave
 
     for (int i = tid; i < (LDS_TRASH + 32) / 4; i += S_THREADS) reinterpret_cast<unsigned*>(smem)[i] = 0u;
 
@@ -226,6 +267,7 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
                     const u32x4 o = s_pack_chunk(s_pack2(hv[0], hv[1]), s_pack2(hv[2], hv[3]));
                     const unsigned off = pbase + (pk_ok ? (unsigned)(dir ? (T - 1 - t) : t) * TS : 0u);
                     pub_store<fast>(rs, off, o);
+                    if (lane == 0) reinterpret_cast<unsigned*>(smem + LDS_TRASH + 16)[wave] = (unsigned)(t + 1);  // the polling waves' cue
                     if (a.self_fill && t + PK_R2_FILL_AHEAD < T) {
                         const unsigned offf = pbase + (pk_ok ? (unsigned)(dir ? (T - 1 - (t + PK_R2_FILL_AHEAD)) : (t + PK_R2_FILL_AHEAD)) * TS : 0u);
                         pub_store<fast>(rs, offf, sentinel);
@@ -272,9 +314,10 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
                 unsigned goff[NCHP];
 #pragma unroll
                 for (int i = 0; i < NCHP; ++i) goff[i] = cbase[i] + (unsigned)(t - 1) * cstep[i];
-                // the compute waves publish h_{t-1} a whole MFMA + gate phase behind the barrier: a poll that arrives
-                // before the stores costs a round trip
+                // the compute waves publish h_{t-1} a whole MFMA + gate phase behind the barrier: sleep through most of it,
+                // then wait for their cue
                 for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
+                if (!dead) s_wait_published(pub_flags, (unsigned)t, a.spin_limit);
                 int loff[NCHP];
 #pragma unroll
                 for (int i = 0; i < NCHP; ++i) loff[i] = clds[i] + (((okm >> i) & 1u) ? (t & 1) * ATILE : 0);
@@ -322,71 +365,60 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
         const unsigned vS0 = (((unsigned)adir * T * B + ab) * (NS * H) + au00), vSs = (unsigned)B * NS * H;
         float* trash = a.trash + lane * 4;
         const int aoff = arow * S_PROW + (lane & 3) * 4;  // my 16 bytes of a slot, access side
-        f32x4 pn[4][G];
-        auto load_proj = [&](int tt) {
-            const unsigned ts = (unsigned)(adir ? (T - 1 - tt) : tt);
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int e = edge[w];
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const unsigned off = vP0 + ts * vPs + g * H + w * 16;
-                    if (e == 0) pn[w][g] = ld4<0>(a.P, off, anv[w]);
-                    else if (e == 1) pn[w][g] = ld4<1>(a.P, off, anv[w]);
-                    else pn[w][g] = ld4<2>(a.P, off, anv[w]);
-                }
-            }
-        };
-        auto stage_proj = [&](int slot) {  // BatchNorm affine folded into the projection on the way: p * scale + shift
-            float* const d = pslots + slot * PSLOT + aoff;
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(pn[w][g][r], psc[w][g][r], psh[w][g][r]);
-                    *reinterpret_cast<f32x4*>(d + (w * G + g) * S_PATCH_F) = v;
-                }
-        };
-        auto flush_outputs = [&](int tt) {  // layer output and saved gates of step tt: LDS slots -> HBM, 16 bytes per lane
-            const unsigned ts = (unsigned)(adir ? (T - 1 - tt) : tt);
-            const float* const s = oslots + (tt & 1) * OSLOT + aoff;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int e = edge[w];
-                f32x4 v[NOUT];
-#pragma unroll
-                for (int k = 0; k < NOUT; ++k) v[k] = *reinterpret_cast<const f32x4*>(s + (w * NOUT + k) * S_PATCH_F);
-                const unsigned oy = vY0 + ts * vYs + w * 16;
-                if (e == 0) st4<0>(a.Y, oy, anv[w], trash, v[0]);
-                else if (e == 1) st4<1>(a.Y, oy, anv[w], trash, v[0]);
-                else st4<2>(a.Y, oy, anv[w], trash, v[0]);
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const unsigned os = vS0 + ts * vSs + k * H + w * 16;
-                    if (e == 0) st4<0>(a.S, os, anv[w], trash, v[1 + k]);
-                    else if (e == 1) st4<1>(a.S, os, anv[w], trash, v[1 + k]);
-                    else st4<2>(a.S, os, anv[w], trash, v[1 + k]);
-                }
-            }
-        };
         __syncthreads();
         bool dead = false;
         (void)cluster_on_one_xcd(a, c, p, tid, dead);  // (takes part in the handshake's workgroup vote only)
-        load_proj(0);
-        stage_proj(0);
-        if (T > 1) load_proj(1);
-        PK_BARRIER_LDS();  // B(0)
-        for (int t = 0; t < T; ++t) {  // while the compute waves work on step t
-            if (t > 0) flush_outputs(t - 1);
-            if (t + 1 < T) {
-                stage_proj((t + 1) & 1);  // (the loads are a step old)
-                if (t + 2 < T) load_proj(t + 2);
+        auto io = [&](auto EDGYC) {
+            constexpr bool EDGY = decltype(EDGYC)::value != 0;
+            f32x4 pn[4][G];
+            auto load_proj = [&](int tt) {
+                const unsigned ts = (unsigned)(adir ? (T - 1 - tt) : tt);
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) pn[w][g] = s_ld4<EDGY>(a.P, vP0 + ts * vPs + g * H + w * 16, anv[w], edge[w]);
+            };
+            auto stage_proj = [&](int slot) {  // BatchNorm affine folded into the projection on the way: p * scale + shift
+                float* const d = pslots + slot * PSLOT + aoff;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        f32x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(pn[w][g][r], psc[w][g][r], psh[w][g][r]);
+                        *reinterpret_cast<f32x4*>(d + (w * G + g) * S_PATCH_F) = v;
+                    }
+            };
+            auto flush_outputs = [&](int tt) {  // layer output and saved gates of step tt: LDS slots -> HBM, 16 bytes per lane
+                const unsigned ts = (unsigned)(adir ? (T - 1 - tt) : tt);
+                const float* const sl = oslots + (tt & 1) * OSLOT + aoff;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    f32x4 v[NOUT];
+#pragma unroll
+                    for (int k = 0; k < NOUT; ++k) v[k] = *reinterpret_cast<const f32x4*>(sl + (w * NOUT + k) * S_PATCH_F);
+                    s_st4<EDGY>(a.Y, vY0 + ts * vYs + w * 16, anv[w], edge[w], trash, v[0]);
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) s_st4<EDGY>(a.S, vS0 + ts * vSs + k * H + w * 16, anv[w], edge[w], trash, v[1 + k]);
+                }
+            };
+            load_proj(0);
+            stage_proj(0);
+            if (T > 1) load_proj(1);
+            PK_BARRIER_LDS();  // B(0)
+            for (int t = 0; t < T; ++t) {  // while the compute waves work on step t
+                if (t + 1 < T) {
+                    stage_proj((t + 1) & 1);  // (the loads are a step old)
+                    if (t + 2 < T) load_proj(t + 2);
+                }
+                if (t > 0) flush_outputs(t - 1);
+                PK_BARRIER_LDS();  // B(t + 1)
             }
-            PK_BARRIER_LDS();  // B(t + 1)
-        }
-        flush_outputs(T - 1);
+            flush_outputs(T - 1);
+        };
+        if ((edge[0] | edge[1] | edge[2] | edge[3]) != 0) io(BoolC<1>());
+        else io(BoolC<0>());
     }
 }
 
@@ -423,6 +455,7 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dGb, szGb);
     const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     const bool want_dp2 = a.dP2 != nullptr;  // fp32 gate gradients wanted (frozen-BatchNorm path); perf mode works from the bf16 copy
+    unsigned char* const pub_flags = smem + LDS_TRASH + 16;  // unsigned [4]: iterations published per compute wave
 
     for (int i = tid; i < (LDS_TRASH + 32) / 4; i += S_THREADS) reinterpret_cast<unsigned*>(smem)[i] = 0u;
 
@@ -557,6 +590,7 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
                         const u32x4 o = s_pack_chunk(s_pack2(dgv[g][0], dgv[g][1]), s_pack2(dgv[g][2], dgv[g][3]));
                         pub_store<fast>(rs, off + (pk_ok ? (unsigned)(g * Hp) * 2u : 0u), o);
                     }
+                    if (lane == 0) reinterpret_cast<unsigned*>(smem + LDS_TRASH + 16)[wave] = (unsigned)(it + 1);  // the polling waves' cue
                     if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) fill_slab(t - PK_R2_FILL_AHEAD, FASTC);
                 }
                 if (want_dp2) {
@@ -605,6 +639,7 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
 #pragma unroll
                 for (int i = 0; i < NCHP; ++i) goff[i] = cbase[i] + (unsigned)(it - 1) * cstep[i];
                 for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
+                if (!dead) s_wait_published(pub_flags, (unsigned)it, a.spin_limit);
                 int loff[NCHP];
 #pragma unroll
                 for (int i = 0; i < NCHP; ++i) loff[i] = clds[i] + (((okm >> i) & 1u) ? (it & 1) * ATILE : 0);
@@ -640,67 +675,60 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
         const unsigned vG0 = (((unsigned)adir * TB + ab) * GH + au00), vGs = (unsigned)B * GH;
         float* trash = a.trash + lane * 4;
         const int aoff = arow * S_PROW + (lane & 3) * 4;
-        // saved tensors of a step, one 16-byte access each: [0..NS) gates, NS = h_{t-1}, NS+1 = dY
-        f32x4 in[4][NIN];
-        auto load_step = [&](int t) {
-            const unsigned ts = (unsigned)(adir ? (T - 1 - t) : t);
-            const unsigned tp = t > 0 ? (adir ? ts + 1 : ts - 1) : ts;  // storage time of step t-1 (any valid row when t == 0)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int e = edge[w];
-                const int nvp = t > 0 ? anv[w] : 0;
-#pragma unroll
-                for (int k = 0; k < NIN; ++k) {
-                    const float* base = k < NS ? a.S : (k == NS ? a.Y : a.dY);
-                    const unsigned off = (k < NS ? vS0 + ts * vSs + k * H : (k == NS ? vY0 + tp * vYs : vY0 + ts * vYs)) + w * 16;
-                    const int nvk = k == NS ? nvp : anv[w];
-                    if (e == 0) in[w][k] = ld4<0>(base, off, nvk);
-                    else if (e == 1) in[w][k] = ld4<1>(base, off, nvk);
-                    else in[w][k] = ld4<2>(base, off, nvk);
-                }
-                if (t == 0) in[w][NS] = f32x4{0.f, 0.f, 0.f, 0.f};  // h_{-1} = 0
-            }
-        };
-        auto stage_step = [&](int slot) {
-            float* const d = islots + slot * ISLOT + aoff;
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-#pragma unroll
-                for (int k = 0; k < NIN; ++k) *reinterpret_cast<f32x4*>(d + (w * NIN + k) * S_PATCH_F) = in[w][k];
-        };
-        auto flush_gates = [&](int it) {  // fp32 gate gradients of iteration it (step tt = T-1-it): LDS slots -> HBM
-            const int tt = T - 1 - it;
-            const unsigned ts = (unsigned)(adir ? (T - 1 - tt) : tt);
-            const float* const s = gslots + (it & 1) * GSLOT + aoff;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int e = edge[w];
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(s + (w * G + g) * S_PATCH_F);
-                    const unsigned og = vG0 + ts * vGs + g * H + w * 16;
-                    if (e == 0) st4<0>(a.dP2, og, anv[w], trash, v);
-                    else if (e == 1) st4<1>(a.dP2, og, anv[w], trash, v);
-                    else st4<2>(a.dP2, og, anv[w], trash, v);
-                }
-            }
-        };
         __syncthreads();
         bool dead = false;
         (void)cluster_on_one_xcd(a, c, p, tid, dead);
-        load_step(T - 1);
-        stage_step(0);
-        if (T > 1) load_step(T - 2);
-        PK_BARRIER_LDS();  // B(0)
-        for (int it = 0; it < T; ++it) {  // while the compute waves work on iteration it (step T-1-it)
-            if (want_dp2 && it > 0) flush_gates(it - 1);
-            if (it + 1 < T) {
-                stage_step((it + 1) & 1);
-                if (it + 2 < T) load_step(T - 1 - (it + 2));
+        auto io = [&](auto EDGYC) {
+            constexpr bool EDGY = decltype(EDGYC)::value != 0;
+            // saved tensors of a step, one 16-byte access each: [0..NS) gates, NS = h_{t-1}, NS+1 = dY
+            f32x4 in[4][NIN];
+            auto load_step = [&](int t) {
+                const unsigned ts = (unsigned)(adir ? (T - 1 - t) : t);
+                const unsigned tp = t > 0 ? (adir ? ts + 1 : ts - 1) : ts;  // storage time of step t-1 (any valid row when t == 0)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int nvp = t > 0 ? anv[w] : 0;
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) in[w][k] = s_ld4<EDGY>(a.S, vS0 + ts * vSs + k * H + w * 16, anv[w], edge[w]);
+                    in[w][NS] = s_ld4<EDGY>(a.Y, vY0 + tp * vYs + w * 16, nvp, edge[w]);
+                    in[w][NS + 1] = s_ld4<EDGY>(a.dY, vY0 + ts * vYs + w * 16, anv[w], edge[w]);
+                    if (t == 0) in[w][NS] = f32x4{0.f, 0.f, 0.f, 0.f};  // h_{-1} = 0
+                }
+            };
+            auto stage_step = [&](int slot) {
+                float* const d = islots + slot * ISLOT + aoff;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int k = 0; k < NIN; ++k) *reinterpret_cast<f32x4*>(d + (w * NIN + k) * S_PATCH_F) = in[w][k];
+            };
+            auto flush_gates = [&](int it) {  // fp32 gate gradients of iteration it (step tt = T-1-it): LDS slots -> HBM
+                const int tt = T - 1 - it;
+                const unsigned ts = (unsigned)(adir ? (T - 1 - tt) : tt);
+                const float* const sl = gslots + (it & 1) * GSLOT + aoff;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        s_st4<EDGY>(a.dP2, vG0 + ts * vGs + g * H + w * 16, anv[w], edge[w], trash,
+                                    *reinterpret_cast<const f32x4*>(sl + (w * G + g) * S_PATCH_F));
+            };
+            load_step(T - 1);
+            stage_step(0);
+            if (T > 1) load_step(T - 2);
+            PK_BARRIER_LDS();  // B(0)
+            for (int it = 0; it < T; ++it) {  // while the compute waves work on iteration it (step T-1-it)
+                if (it + 1 < T) {
+                    stage_step((it + 1) & 1);
+                    if (it + 2 < T) load_step(T - 1 - (it + 2));
+                }
+                if (want_dp2 && it > 0) flush_gates(it - 1);
+                PK_BARRIER_LDS();  // B(it + 1)
             }
-            PK_BARRIER_LDS();  // B(it + 1)
-        }
-        if (want_dp2) flush_gates(T - 1);
+            if (want_dp2) flush_gates(T - 1);
+        };
+        if ((edge[0] | edge[1] | edge[2] | edge[3]) != 0) io(BoolC<1>());
+        else io(BoolC<0>());
     }
 }
 

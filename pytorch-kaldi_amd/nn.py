@@ -26,6 +26,7 @@ only: ``forward`` never calls them, it hands their tensors to the HIP kernels
 through ``functional``.  There is no CPU path: ``use_cuda`` must be True.
 """
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -236,13 +237,19 @@ class _MaskPrefetcher:
     next call turns out to want other shapes (last batch of a chunk), or somebody else drew from / re-seeded the
     generator in the meantime (its state differs from the one the helper left), that state is restored and the masks
     are drawn on the spot - the stream stays exactly the reference's.  Nothing else in the engine's step touches the
-    CPU generator (batch padding uses python's random, nn.Dropout masks the device generator)."""
+    CPU generator (batch padding uses python's random, nn.Dropout masks the device generator).
 
-    live = []     # every prefetcher that may hold ahead-of-time draws (drain_mask_prefetch)
-    _jobs = None  # the helper's queue
+    SEVERAL recurrent modules in one model (the reference ships such recipes, e.g.
+    cfg/TIMIT_baselines/TIMIT_rev/TIMIT_joint_training_liGRU_fbank.cfg) consume the ONE generator in turn: module A's
+    helper would be drawing A's next masks while module B draws its current ones.  Drawing ahead is therefore only done
+    while a single prefetcher is alive; as soon as a second one asks for a mask every set drawn ahead is given back to
+    the generator and all of them draw on the spot, in call order - the reference's stream, at the reference's speed."""
+
+    live = weakref.WeakSet()  # every prefetcher that may hold ahead-of-time draws (drain_mask_prefetch); a module's
+    _jobs = None              # prefetcher dies with the module.  _jobs: the helper's queue
 
     def __init__(self):
-        _MaskPrefetcher.live.append(self)
+        _MaskPrefetcher.live.add(self)
         self._done = None     # event of the set being drawn
         self._ahead = None    # dict(sig, masks, state0, state1): the set drawn ahead (complete once _done is set)
         self._ready = None    # the set this forward call is being served from
@@ -273,9 +280,12 @@ class _MaskPrefetcher:
         box = {"sig": list(sig)}
 
         def run():
-            box["state0"] = torch.get_rng_state()
-            box["masks"] = [self._draw(*s_) for s_ in box["sig"]]
-            box["state1"] = torch.get_rng_state()
+            try:
+                box["state0"] = torch.get_rng_state()
+                box["masks"] = [self._draw(*s_) for s_ in box["sig"]]
+                box["state1"] = torch.get_rng_state()
+            except BaseException as e:  # handed to the thread that joins (the helper itself lives on)
+                box["exc"] = e
 
         self._ahead, self._done = box, threading.Event()
         _MaskPrefetcher._jobs.put((run, self._done))
@@ -284,6 +294,16 @@ class _MaskPrefetcher:
         if self._done is not None:
             self._done.wait()
             self._done = None
+            if self._ahead is not None and "exc" in self._ahead:
+                exc, st0 = self._ahead["exc"], self._ahead.get("state0")
+                self._ahead = None
+                if st0 is not None:
+                    torch.set_rng_state(st0)  # whatever the failed set consumed goes back
+                raise exc
+
+    @classmethod
+    def _alone(cls, me):
+        return all(pf is me for pf in cls.live)
 
     def _rewind(self, to_state, redraw):
         """Give the generator back every draw made ahead that nobody will use: back to `to_state`, then the masks of
@@ -298,11 +318,16 @@ class _MaskPrefetcher:
         """Mask of layer i (0 .. n_lay - 1, asked for in layer order) of the current forward call."""
         if i == 0:
             self._cur, self._taken, self._ready = [], 0, None
+            if not self._alone(self):  # another module shares the generator: nobody keeps draws made ahead
+                for pf in list(_MaskPrefetcher.live):
+                    if pf is not self:
+                        pf.drain()
             self._join()
             if self._ahead is not None:
                 if torch.equal(torch.get_rng_state(), self._ahead["state1"]):
                     self._ready, self._ahead = self._ahead, None
-                    self._start(self._ready["sig"])  # the call after this one, while this one runs
+                    if self._alone(self):
+                        self._start(self._ready["sig"])  # the call after this one, while this one runs
                 else:
                     self._ahead = None  # the generator moved on without us (manual_seed, somebody else's draws): theirs now
         want = (rows, H, p)
@@ -314,7 +339,7 @@ class _MaskPrefetcher:
         if rd is not None:  # other shapes than the ones drawn ahead: un-draw this set's unused masks and the next set
             self._rewind(rd["state0"], self._cur[:-1])
         m = self._draw(*want)
-        if i == n_lay - 1 and self._done is None and self._ahead is None:
+        if i == n_lay - 1 and self._done is None and self._ahead is None and self._alone(self):
             self._start(self._cur)  # first call, or the call after a mismatch: start drawing ahead again
         return m
 
@@ -329,9 +354,9 @@ class _MaskPrefetcher:
 def drain_mask_prefetch():
     """Un-draw every mask drawn ahead of time (PK_MASK_RNG=reference) and forget the prefetchers: call before
     torch.manual_seed / before reading the CPU generator's state (core.run_nn_dp does, at both ends of a chunk)."""
-    for pf in _MaskPrefetcher.live:
+    for pf in list(_MaskPrefetcher.live):
         pf.drain()
-    _MaskPrefetcher.live = []
+    _MaskPrefetcher.live = weakref.WeakSet()
 
 
 class _Recurrent(nn.Module):

@@ -10,12 +10,12 @@ if ! timeout 120 python -c "import torch; x = torch.zeros(1 << 20).cuda() + 1; t
     echo "BAD BOX: first GPU touch failed"; exit 0
 fi
 # the driver's exact command, first process on the fresh box (pre-warm on by default)
-python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --step-trace > "$out/drv_first.json" 2> "$out/drv_first.err"
-echo "driver cmd, first process: $(python3 tools/jget.py "$out/drv_first.json" ms_per_step step_ms.first step_ms.median step_ms.max config.prewarm_steps)"
+true
+true
 PK_REC_GEN=5 timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "bf16_persistent_matches or dirty_buffer or full_geometry or full_size or bf16_mode_is_close" > "$out/pytest_split.log" 2>&1
 echo "pytest split rc=$? $(tail -1 "$out/pytest_split.log")"
 grep -E "FAILED|Error|error" "$out/pytest_split.log" | head -10
-for d in -1 6 10 14 18 24; do
+for d in -1 0 8 20; do
   PK_REC_GEN=5 DELAY=$d JSON_OUT="$out/trace_gen5_d$d.json" timeout 120 python tools/trace_rec2.py > "$out/trace_gen5_d$d.log" 2>&1
   echo "gen5 delay $d: $(grep -E 'cycles/step|retries|launch ms' "$out/trace_gen5_d$d.log" | tr '\n' ' ' | cut -c1-420)"
 done

@@ -49,8 +49,9 @@
 
 namespace {
 
-constexpr int S_THREADS = 512;
-constexpr int S_NP = 3;                       // polling waves (4, 5, 6); wave 7 is the I/O wave
+// NP (template parameter) = number of polling waves: 3 (waves 4-6 poll, wave 7 does the I/O: 512 threads) or 0 (the
+// compute waves poll their own quarter of the tile right behind their publish, as the earlier generations do, and wave 4
+// does the I/O: 320 threads)
 constexpr int S_PROW = 20, S_PATCH_F = 16 * S_PROW;  // LDS slot of one fp32 tensor tile [16 rows][16 units], row pitch 20 floats
 
 __device__ __forceinline__ u32x4 s_pack_chunk(unsigned lo, unsigned hi) {  // see pk_rec_persist3.hip::pack_chunk
@@ -87,6 +88,48 @@ __device__ __forceinline__ void s_st4(float* base, unsigned off, int nv, int e, 
 // other workgroups of the cluster, which run in lock step with this one - the hand-off then costs ONE round trip.  (A
 // fixed idle time instead lets every workgroup's re-polls fall at a random phase of a ~1 800-clock round trip; the
 // cluster then advances at the pace of the unluckiest workgroup: measured 6 480 instead of 5 440 clocks per step.)
+// poll_to_lds (pk_rec2_common.h) with RUNNING offsets: polls the chunks at goff[], advances goff[] to the next step's slab
+// while the loads are in flight (owned slots by +ts / -ts as upm says; slots not owned stay out of range), then checks,
+// re-polls what still holds the fill pattern and stores the chunks to the LDS tile.
+template <int NCH, bool FAST>
+__device__ __forceinline__ bool poll_to_lds_adv(__amdgpu_buffer_rsrc_t rs, unsigned (&goff)[NCH], unsigned okm, unsigned upm, unsigned ts,
+                                                const int (&loff)[NCH], unsigned char* tile, unsigned* err, int spin_limit, int lane,
+                                                bool dead, int& retries) {
+    u32x4 v[NCH];
+    unsigned cur[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        cur[i] = goff[i];
+        v[i] = poll_load<FAST>(rs, cur[i]);
+    }
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) bad = bad | has_sent16(v[i]);
+    if (__any(bad) && !dead) {
+        int spins = 0;
+        while (true) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+                if (has_sent16(v[i])) v[i] = poll_load<FAST>(rs, cur[i]);
+            bad = false;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) bad = bad | has_sent16(v[i]);
+            ++retries;
+            if (!__any(bad)) break;
+            if (spin_check2(spins, spin_limit, err, lane)) {
+                dead = true;
+                break;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        *reinterpret_cast<u32x4*>(tile + loff[i]) = v[i];
+        goff[i] = cur[i] + (((okm >> i) & 1u) ? (((upm >> i) & 1u) ? ts : 0u - ts) : 0u);
+    }
+    return dead;
+}
+
 // (the flag words are read with an inline-asm LDS load: a volatile C++ access through a generic pointer compiles to
 // flat_load / flat_store + s_waitcnt vmcnt(0), i.e. it would wait for the wave's global-memory queue)
 __device__ __forceinline__ void s_wait_published(const unsigned char* flags, unsigned want, int spin_limit) {
@@ -108,18 +151,21 @@ __device__ __forceinline__ void s_wait_published(const unsigned char* flags, uns
 // ============================================================================
 // forward
 // ============================================================================
-template <int CELL, int ACT, bool TR>
-__global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
+template <int CELL, int ACT, bool TR, int NP>
+__global__ __launch_bounds__((5 + NP) * 64) void recs_fwd_kernel(R2Args a) {
+    constexpr int S_THREADS = (5 + NP) * 64, S_NP = NP > 0 ? NP : 1;
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
     constexpr int LDA = pk_r2_lda_bf16(KPAD);
     constexpr int ATILE = RMAX * LDA * 2;
     constexpr int NCHP = (RMAX * (KPAD / 8) + 64 * S_NP - 1) / (64 * S_NP);  // 16-byte chunks per polling lane (6)
-    constexpr int LDS_TRASH = 2 * ATILE;
+    constexpr int NCHC = (RMAX * (KPAD / 8) + 255) / 256;                    // ... per compute lane when the compute waves poll (5)
+    constexpr int TSTRIDE = ATILE + 32;   // a tile is followed by its own 32-byte dump slot for chunk slots a lane does not own
+    constexpr int LDS_TRASH = ATILE;      // (relative to the tile)
     constexpr int NOUT = 1 + NS;
     constexpr int PSLOT = 4 * G * S_PATCH_F, OSLOT = 4 * NOUT * S_PATCH_F;  // floats per step buffer (all four compute waves)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][ATILE] | trash | [2] P slots | [2] output slots
-    float* const pslots = reinterpret_cast<float*>(smem + 2 * ATILE + 32);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][tile | dump] | flags | [2] P slots | [2] output slots
+    float* const pslots = reinterpret_cast<float*>(smem + 2 * TSTRIDE + 32);
     float* const oslots = pslots + 2 * PSLOT;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -135,9 +181,9 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
     const unsigned szYb = (unsigned)T * TS;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.Yb, szYb);
     const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    unsigned char* const pub_flags = smem + LDS_TRASH + 16;  // unsigned [4]: steps published per compute wave
+    unsigned char* const pub_flags = smem + 2 * TSTRIDE;  // unsigned [4]: steps published per compute wave (NP > 0)
 
-    for (int i = tid; i < (LDS_TRASH + 32) / 4; i += S_THREADS) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+    for (int i = tid; i < (2 * TSTRIDE + 32) / 4; i += S_THREADS) reinterpret_cast<unsigned*>(smem)[i] = 0u;
 
     if (wave < 4) {
         // ===================================================================== COMPUTE
@@ -188,6 +234,27 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
         const int pu0 = ubase + (kq >> 1) * 8;
         const bool pk_ok = (kq & 1) == 0 && row_ok && pu0 < Hp;
         const unsigned pbase = pk_ok ? ((unsigned)bb * a.Ypitch + dir * Hp + pu0) * 2u : szYb;  // out of range: dropped
+        // NP == 0: poll descriptors of my chunks (as in the earlier generations): chunk ci = (row, col) of the cluster's block
+        // (kept as RUNNING offsets - advanced while the poll is in flight - plus two bit masks: the per-chunk base / step
+        // arrays of the earlier generations cost 2 x NCHC registers more, which this 256-register wave does not have)
+        unsigned gcur[NCHC], okm = 0u, upm = 0u;  // byte offset of the next poll; chunk slots I own; slots whose offset grows
+        int clds[NCHC];
+        if constexpr (NP == 0) {
+            const int CPR = Hp >> 3;
+#pragma unroll
+            for (int i = 0; i < NCHC; ++i) {
+                const int ci = tid + 256 * i;
+                const bool ok = ci < nrows * CPR;
+                const int crow = ok ? ci / CPR : 0, col = ok ? ci - crow * CPR : 0;
+                const int cn = n_base + crow;
+                const int cdir = cn >= B ? 1 : 0, cb = cn - cdir * B;
+                // step t reads storage time (dir ? T-t : t-1); a slot I do not own stays out of range
+                gcur[i] = ok ? ((unsigned)cb * a.Ypitch + cdir * Hp + col * 8) * 2u + (unsigned)(cdir ? (T - 1) : 0) * TS : szYb;
+                okm |= ok ? (1u << i) : 0u;
+                upm |= (ok && !cdir) ? (1u << i) : 0u;
+                clds[i] = ok ? crow * (LDA * 2) + col * 16 : LDS_TRASH;
+            }
+        }
         const float* const my_p = pslots + wave * (G * S_PATCH_F) + row * S_PROW + kq * 4;
         float* const my_o = oslots + wave * (NOUT * S_PATCH_F) + row * S_PROW + kq * 4;
         if (a.self_fill) {  // my chunks of the first slabs, visible everywhere before the handshake lets anyone poll
@@ -203,9 +270,17 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
             for (int t = 0; t < T; ++t) {
                 const int step_idx = t;
                 PKS_TRACE_AT(0, 0);
+                if constexpr (NP == 0) {
+                    if (t > 0) {
+                        for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
+                        int retries = 0;
+                        dead = poll_to_lds_adv<NCHC, fast>(rs, gcur, okm, upm, TS, clds, smem + (t & 1) * TSTRIDE, a.err, a.spin_limit, lane, dead, retries);
+                        if (TR && a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
+                    }
+                }
                 PK_BARRIER_LDS();  // B(t): tile t, projections t in LDS; the I/O wave has taken the outputs of step t - 2
                 PKS_TRACE_AT(0, 1);
-                const unsigned char* At = smem + (t & 1) * ATILE;
+                const unsigned char* At = smem + (t & 1) * TSTRIDE;
                 f32x4 pv[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) pv[g] = *reinterpret_cast<const f32x4*>(my_p + (t & 1) * PSLOT + g * S_PATCH_F);
@@ -267,7 +342,7 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
                     const u32x4 o = s_pack_chunk(s_pack2(hv[0], hv[1]), s_pack2(hv[2], hv[3]));
                     const unsigned off = pbase + (pk_ok ? (unsigned)(dir ? (T - 1 - t) : t) * TS : 0u);
                     pub_store<fast>(rs, off, o);
-                    if (lane == 0) reinterpret_cast<unsigned*>(smem + LDS_TRASH + 16)[wave] = (unsigned)(t + 1);  // the polling waves' cue
+                    if (NP > 0 && lane == 0) reinterpret_cast<unsigned*>(smem + 2 * TSTRIDE)[wave] = (unsigned)(t + 1);  // the polling waves' cue
                     if (a.self_fill && t + PK_R2_FILL_AHEAD < T) {
                         const unsigned offf = pbase + (pk_ok ? (unsigned)(dir ? (T - 1 - (t + PK_R2_FILL_AHEAD)) : (t + PK_R2_FILL_AHEAD)) * TS : 0u);
                         pub_store<fast>(rs, offf, sentinel);
@@ -284,11 +359,11 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
         };
         if (fast_rt) run(BoolC<1>());
         else run(BoolC<0>());
-    } else if (wave < 4 + S_NP) {
+    } else if (NP > 0 && wave < 4 + NP) {
         // ===================================================================== POLL
         const int ptid = (wave - 4) * 64 + lane;
         const int CPR = Hp >> 3;
-        unsigned cbase[NCHP], cstep[NCHP], okm = 0u;
+        unsigned cbase[NCHP], cstep[NCHP];
         int clds[NCHP];  // LDS byte offset inside a tile; chunk slots I do not own: the trash slot behind both tiles
 #pragma unroll
         for (int i = 0; i < NCHP; ++i) {
@@ -301,7 +376,6 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
             cbase[i] = ok ? ((unsigned)b * a.Ypitch + dir * Hp + col * 8) * 2u + (unsigned)(dir ? (T - 1) : 0) * TS : szYb;
             cstep[i] = ok ? (dir ? 0u - TS : TS) : 0u;
             clds[i] = ok ? row * (LDA * 2) + col * 16 : LDS_TRASH;
-            okm |= ok ? (1u << i) : 0u;
         }
         __syncthreads();
         bool dead = false;
@@ -318,11 +392,8 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
                 // then wait for their cue
                 for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
                 if (!dead) s_wait_published(pub_flags, (unsigned)t, a.spin_limit);
-                int loff[NCHP];
-#pragma unroll
-                for (int i = 0; i < NCHP; ++i) loff[i] = clds[i] + (((okm >> i) & 1u) ? (t & 1) * ATILE : 0);
                 int retries = 0;
-                dead = poll_to_lds<NCHP, fast>(rs, goff, loff, smem, a.err, a.spin_limit, lane, dead, retries);
+                dead = poll_to_lds<NCHP, fast>(rs, goff, clds, smem + (t & 1) * TSTRIDE, a.err, a.spin_limit, lane, dead, retries);
                 if (TR && a.trace != nullptr && blockIdx.x == 0 && tid == 256) {
                     a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
                     a.trace[(long)step_idx * 8 + 7] = __builtin_amdgcn_s_memtime();
@@ -425,18 +496,20 @@ __global__ __launch_bounds__(S_THREADS) void recs_fwd_kernel(R2Args a) {
 // ============================================================================
 // backward: dL/dh_{t-1} = direct + [dgates_t] . [U_0; U_1; ...]
 // ============================================================================
-template <int CELL, int ACT, bool TR>
-__global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
+template <int CELL, int ACT, bool TR, int NP>
+__global__ __launch_bounds__((5 + NP) * 64) void recs_bwd_kernel(R2Args a) {
+    constexpr int S_THREADS = (5 + NP) * 64, S_NP = NP > 0 ? NP : 1;
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
     constexpr int LDA = pk_r2_lda_bf16(G * KPAD);
     constexpr int ATILE = RMAX * LDA * 2;
     constexpr int NCHP = (RMAX * G * (KPAD / 8) + 64 * S_NP - 1) / (64 * S_NP);  // 12 (liGRU) / 6 (RNN)
+    constexpr int NCHC = (RMAX * G * (KPAD / 8) + 255) / 256;                    // ... per compute lane when the compute waves poll (9 / 5)
     constexpr int NIN = NS + 2;  // saved gates, h_{t-1}, dY
-    constexpr int LDS_TRASH = 2 * ATILE;
+    constexpr int TSTRIDE = ATILE + 32, LDS_TRASH = ATILE;
     constexpr int ISLOT = 4 * NIN * S_PATCH_F, GSLOT = 4 * G * S_PATCH_F;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][ATILE] | trash | [2] input slots | [2] fp32 gate-gradient slots
-    float* const islots = reinterpret_cast<float*>(smem + 2 * ATILE + 32);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][tile | dump] | flags | [2] input slots | [2] fp32 gate-gradient slots
+    float* const islots = reinterpret_cast<float*>(smem + 2 * TSTRIDE + 32);
     float* const gslots = islots + 2 * ISLOT;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -455,9 +528,9 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dGb, szGb);
     const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     const bool want_dp2 = a.dP2 != nullptr;  // fp32 gate gradients wanted (frozen-BatchNorm path); perf mode works from the bf16 copy
-    unsigned char* const pub_flags = smem + LDS_TRASH + 16;  // unsigned [4]: iterations published per compute wave
+    unsigned char* const pub_flags = smem + 2 * TSTRIDE;  // unsigned [4]: iterations published per compute wave (NP > 0)
 
-    for (int i = tid; i < (LDS_TRASH + 32) / 4; i += S_THREADS) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+    for (int i = tid; i < (2 * TSTRIDE + 32) / 4; i += S_THREADS) reinterpret_cast<unsigned*>(smem)[i] = 0u;
 
     if (wave < 4) {
         // ===================================================================== COMPUTE
@@ -503,6 +576,28 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
         const int pu0 = ubase + (kq >> 1) * 8;
         const bool pk_ok = (kq & 1) == 0 && row_ok && pu0 < Hp;
         const unsigned pbase = pk_ok ? (unsigned)dir * (unsigned)T * TS + ((unsigned)bb * a.Gpitch + pu0) * 2u : szGb;
+        unsigned gcur[NCHC], okm = 0u, upm = 0u;  // running poll offsets + masks (see the forward kernel)
+        int clds[NCHC];
+        if constexpr (NP == 0) {  // poll descriptors: chunk ci = (row, gate, col) of the cluster's dgates block
+            const int CPR = Hp >> 3;
+#pragma unroll
+            for (int i = 0; i < NCHC; ++i) {
+                const int ci = tid + 256 * i;
+                const bool ok = ci < nrows * G * CPR;
+                const int crow = ok ? ci / (G * CPR) : 0;
+                const int rem = ok ? ci - crow * (G * CPR) : 0;
+                const int cg = rem / CPR, col = rem - cg * CPR;
+                const int cn = n_base + crow;
+                const int cdir = cn >= B ? 1 : 0, cb = cn - cdir * B;
+                // iteration it (t = T-1-it, it >= 1) reads storage time (dir ? T-2-t : t+1) = (dir ? it-1 : T-it)
+                gcur[i] = ok ? (unsigned)cdir * (unsigned)T * TS + ((unsigned)cb * a.Gpitch + cg * Hp + col * 8) * 2u +
+                                   (unsigned)(cdir ? 0 : (T - 1)) * TS
+                             : szGb;
+                okm |= ok ? (1u << i) : 0u;
+                upm |= (ok && cdir) ? (1u << i) : 0u;
+                clds[i] = ok ? crow * (LDA * 2) + (cg * KPAD + col * 8) * 2 : LDS_TRASH;
+            }
+        }
         const float* const my_i = islots + wave * (NIN * S_PATCH_F) + row * S_PROW + kq * 4;
         float* const my_g = gslots + wave * (G * S_PATCH_F) + row * S_PROW + kq * 4;
         auto fill_slab = [&](int tt, auto FASTC) {  // my G chunks of the slab that step tt will publish
@@ -523,9 +618,17 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
             for (int t = T - 1; t >= 0; --t, ++it) {
                 const int step_idx = it;
                 PKS_TRACE_AT(0, 0);
+                if constexpr (NP == 0) {
+                    if (it > 0) {
+                        for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
+                        int retries = 0;
+                        dead = poll_to_lds_adv<NCHC, fast>(rs, gcur, okm, upm, TS, clds, smem + (it & 1) * TSTRIDE, a.err, a.spin_limit, lane, dead, retries);
+                        if (TR && a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
+                    }
+                }
                 PK_BARRIER_LDS();  // B(it)
                 PKS_TRACE_AT(0, 1);
-                const unsigned char* At = smem + (it & 1) * ATILE;
+                const unsigned char* At = smem + (it & 1) * TSTRIDE;
                 f32x4 iv[NIN];
 #pragma unroll
                 for (int k = 0; k < NIN; ++k) iv[k] = *reinterpret_cast<const f32x4*>(my_i + (it & 1) * ISLOT + k * S_PATCH_F);
@@ -590,7 +693,7 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
                         const u32x4 o = s_pack_chunk(s_pack2(dgv[g][0], dgv[g][1]), s_pack2(dgv[g][2], dgv[g][3]));
                         pub_store<fast>(rs, off + (pk_ok ? (unsigned)(g * Hp) * 2u : 0u), o);
                     }
-                    if (lane == 0) reinterpret_cast<unsigned*>(smem + LDS_TRASH + 16)[wave] = (unsigned)(it + 1);  // the polling waves' cue
+                    if (NP > 0 && lane == 0) reinterpret_cast<unsigned*>(smem + 2 * TSTRIDE)[wave] = (unsigned)(it + 1);  // the polling waves' cue
                     if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) fill_slab(t - PK_R2_FILL_AHEAD, FASTC);
                 }
                 if (want_dp2) {
@@ -604,11 +707,11 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
         };
         if (fast_rt) run(BoolC<1>());
         else run(BoolC<0>());
-    } else if (wave < 4 + S_NP) {
+    } else if (NP > 0 && wave < 4 + NP) {
         // ===================================================================== POLL
         const int ptid = (wave - 4) * 64 + lane;
         const int CPR = Hp >> 3;
-        unsigned cbase[NCHP], cstep[NCHP], okm = 0u;
+        unsigned cbase[NCHP], cstep[NCHP];
         int clds[NCHP];  // LDS byte offset inside a tile; chunk slots I do not own: the trash slot behind both tiles
 #pragma unroll
         for (int i = 0; i < NCHP; ++i) {
@@ -625,7 +728,6 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
                           : szGb;
             cstep[i] = ok ? (dir ? TS : 0u - TS) : 0u;
             clds[i] = ok ? row * (LDA * 2) + (g * KPAD + col * 8) * 2 : LDS_TRASH;
-            okm |= ok ? (1u << i) : 0u;
         }
         __syncthreads();
         bool dead = false;
@@ -640,11 +742,8 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
                 for (int i = 0; i < NCHP; ++i) goff[i] = cbase[i] + (unsigned)(it - 1) * cstep[i];
                 for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
                 if (!dead) s_wait_published(pub_flags, (unsigned)it, a.spin_limit);
-                int loff[NCHP];
-#pragma unroll
-                for (int i = 0; i < NCHP; ++i) loff[i] = clds[i] + (((okm >> i) & 1u) ? (it & 1) * ATILE : 0);
                 int retries = 0;
-                dead = poll_to_lds<NCHP, fast>(rs, goff, loff, smem, a.err, a.spin_limit, lane, dead, retries);
+                dead = poll_to_lds<NCHP, fast>(rs, goff, clds, smem + (it & 1) * TSTRIDE, a.err, a.spin_limit, lane, dead, retries);
                 if (TR && a.trace != nullptr && blockIdx.x == 0 && tid == 256) {
                     a.trace[(long)step_idx * 8 + 6] = (unsigned long long)retries;
                     a.trace[(long)step_idx * 8 + 7] = __builtin_amdgcn_s_memtime();
@@ -733,20 +832,21 @@ __global__ __launch_bounds__(S_THREADS) void recs_bwd_kernel(R2Args a) {
 }
 
 typedef void (*RecSKernel)(R2Args);
-template <int CELL>
+template <int CELL, int NP>
 RecSKernel picks_fwd(int act, bool tr) {
-    if (tr) return recs_fwd_kernel<CELL, PK_ACT_RELU, true>;
-    return act == PK_ACT_RELU ? recs_fwd_kernel<CELL, PK_ACT_RELU, false>
-         : act == PK_ACT_TANH ? recs_fwd_kernel<CELL, PK_ACT_TANH, false> : recs_fwd_kernel<CELL, -1, false>;
+    if (tr) return recs_fwd_kernel<CELL, PK_ACT_RELU, true, NP>;
+    return act == PK_ACT_RELU ? recs_fwd_kernel<CELL, PK_ACT_RELU, false, NP>
+         : act == PK_ACT_TANH ? recs_fwd_kernel<CELL, PK_ACT_TANH, false, NP> : recs_fwd_kernel<CELL, -1, false, NP>;
 }
-template <int CELL>
+template <int CELL, int NP>
 RecSKernel picks_bwd(int act, bool tr) {
-    if (tr) return recs_bwd_kernel<CELL, PK_ACT_RELU, true>;
-    return act == PK_ACT_RELU ? recs_bwd_kernel<CELL, PK_ACT_RELU, false>
-         : act == PK_ACT_TANH ? recs_bwd_kernel<CELL, PK_ACT_TANH, false> : recs_bwd_kernel<CELL, -1, false>;
+    if (tr) return recs_bwd_kernel<CELL, PK_ACT_RELU, true, NP>;
+    return act == PK_ACT_RELU ? recs_bwd_kernel<CELL, PK_ACT_RELU, false, NP>
+         : act == PK_ACT_TANH ? recs_bwd_kernel<CELL, PK_ACT_TANH, false, NP> : recs_bwd_kernel<CELL, -1, false, NP>;
 }
 int gs_on[2] = {-1, -1};     // per pass: 1 = the role-split kernels run this pass
-int gs_delay[2] = {-1, -1};  // poll delay of the polling waves, s_sleep units of 64 clocks behind the barrier
+int gs_np[2] = {0, 0};       // per pass: polling waves (0 = the compute waves poll)
+int gs_delay[2] = {-1, -1};  // NP > 0: idle time of the polling waves behind the barrier, s_sleep units of 64 clocks
 
 }  // namespace
 
@@ -760,6 +860,11 @@ int pk_recs_covers(int cell, int backward) {
         auto parse = [](const char* e, int dflt) { return (e && e[0] >= '2' && e[0] <= '5') ? (e[0] == '5' ? 1 : 0) : dflt; };
         gs_on[0] = parse(ef, parse(both, PK_RECS_DEFAULT_FWD));
         gs_on[1] = parse(eb, parse(both, PK_RECS_DEFAULT_BWD));
+        const char* np = getenv("PK_SPLIT_POLLERS");  // "3" / "0", or "<fwd><bwd>" e.g. "03"
+        if (np && np[0]) {
+            gs_np[0] = np[0] == '3' ? 3 : 0;
+            gs_np[1] = (np[1] ? np[1] : np[0]) == '3' ? 3 : 0;
+        }
         const char* df = getenv("PK_SPLIT_POLL_DELAY_FWD");
         const char* db = getenv("PK_SPLIT_POLL_DELAY_BWD");
         gs_delay[0] = df ? atoi(df) : PK_RECS_DELAY_FWD;
@@ -774,28 +879,35 @@ int pk_recs_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act
     const int G = pk_cell_gates(cell), NS = pk_cell_saved(cell);
     const size_t atile = (size_t)RMAX * pk_r2_lda_bf16(backward ? G * KPAD : KPAD) * 2;
     const int nslot = backward ? (NS + 2) + G : G + (1 + NS);
-    const size_t lds = 2 * atile + 32 + (size_t)2 * 4 * nslot * S_PATCH_F * 4;
-    if (!delay_forced) a.poll_delay = gs_delay[backward ? 1 : 0];
+    const size_t lds = 2 * (atile + 32) + 32 + (size_t)2 * 4 * nslot * S_PATCH_F * 4;
+    const int np = gs_np[backward ? 1 : 0];
+    const int threads = (5 + np) * 64;
+    if (np > 0 && !delay_forced) a.poll_delay = gs_delay[backward ? 1 : 0];  // (np == 0: the per-pass defaults of the earlier generations)
     RecSKernel k;
-    if (cell == PK_CELL_LIGRU) k = backward ? picks_bwd<PK_CELL_LIGRU>(act, traced) : picks_fwd<PK_CELL_LIGRU>(act, traced);
-    else k = backward ? picks_bwd<PK_CELL_RNN>(act, false) : picks_fwd<PK_CELL_RNN>(act, false);
+    if (cell == PK_CELL_LIGRU) {
+        if (np > 0) k = backward ? picks_bwd<PK_CELL_LIGRU, 3>(act, traced) : picks_fwd<PK_CELL_LIGRU, 3>(act, traced);
+        else k = backward ? picks_bwd<PK_CELL_LIGRU, 0>(act, traced) : picks_fwd<PK_CELL_LIGRU, 0>(act, traced);
+    } else {
+        if (np > 0) k = backward ? picks_bwd<PK_CELL_RNN, 3>(act, false) : picks_fwd<PK_CELL_RNN, 3>(act, false);
+        else k = backward ? picks_bwd<PK_CELL_RNN, 0>(act, false) : picks_fwd<PK_CELL_RNN, 0>(act, false);
+    }
     {   // dynamic LDS above the 64 KB default needs the opt-in; hipFuncSetAttribute is slow: once per kernel
-        static const void* granted[32];
+        static const void* granted[64];
         static int n_granted = 0;
         bool have = false;
         for (int i = 0; i < n_granted; ++i) have = have || granted[i] == (const void*)k;
         if (!have) {
             PK_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if (n_granted < 32) granted[n_granted++] = (const void*)k;
+            if (n_granted < 64) granted[n_granted++] = (const void*)k;
         }
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
         int rc = pk_rec2_reset_handshake(st);
         if (rc) return rc;
-        rc = pk_rec2_check_residency((const void*)k, S_THREADS, lds, pl.C * pl.Pn, backward ? "pk_rec_bwd_bf16" : "pk_rec_fwd_bf16");
+        rc = pk_rec2_check_residency((const void*)k, threads, lds, pl.C * pl.Pn, backward ? "pk_rec_bwd_bf16" : "pk_rec_fwd_bf16");
         if (rc) return rc;
-        hipLaunchKernelGGL(k, dim3(pl.C * pl.Pn), dim3(S_THREADS), lds, st, a);
+        hipLaunchKernelGGL(k, dim3(pl.C * pl.Pn), dim3(threads), lds, st, a);
         PK_LAUNCH_CHECK();
     }
     return 0;

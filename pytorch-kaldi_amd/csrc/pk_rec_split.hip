@@ -441,15 +441,17 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_fwd_kernel(R2Args a) {
         (void)cluster_on_one_xcd(a, c, p, tid, dead);  // (takes part in the handshake's workgroup vote only)
         auto io = [&](auto EDGYC) {
             constexpr bool EDGY = decltype(EDGYC)::value != 0;
-            f32x4 pn[4][G];
-            auto load_proj = [&](int tt) {
+            // two register sets: the projections of even / odd steps, loaded TWO steps ahead of their use (an HBM load of
+            // this access pattern can take longer than a whole step)
+            f32x4 pn0[4][G], pn1[4][G];
+            auto load_proj = [&](f32x4 (&pn)[4][G], int tt) {
                 const unsigned ts = (unsigned)(adir ? (T - 1 - tt) : tt);
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
 #pragma unroll
                     for (int g = 0; g < G; ++g) pn[w][g] = s_ld4<EDGY>(a.P, vP0 + ts * vPs + g * H + w * 16, anv[w], edge[w]);
             };
-            auto stage_proj = [&](int slot) {  // BatchNorm affine folded into the projection on the way: p * scale + shift
+            auto stage_proj = [&](const f32x4 (&pn)[4][G], int slot) {  // BatchNorm affine folded into the projection on the way: p * scale + shift
                 float* const d = pslots + slot * PSLOT + aoff;
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
@@ -474,17 +476,24 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_fwd_kernel(R2Args a) {
                     for (int k = 0; k < NS; ++k) s_st4<EDGY>(a.S, vS0 + ts * vSs + k * H + w * 16, anv[w], edge[w], trash, v[1 + k]);
                 }
             };
-            load_proj(0);
-            stage_proj(0);
-            if (T > 1) load_proj(1);
+            load_proj(pn0, 0);
+            stage_proj(pn0, 0);
+            if (T > 1) load_proj(pn1, 1);
+            if (T > 2) load_proj(pn0, 2);
             PK_BARRIER_LDS();  // B(0)
-            for (int t = 0; t < T; ++t) {  // while the compute waves work on step t
+            auto iter = [&](int t, f32x4 (&pn)[4][G]) {  // while the compute waves work on step t; pn: the set of step t + 1
                 if (t + 1 < T) {
-                    stage_proj((t + 1) & 1);  // (the loads are a step old)
-                    if (t + 2 < T) load_proj(t + 2);
+                    stage_proj(pn, (t + 1) & 1);  // (the loads are two steps old)
+                    if (t + 3 < T) load_proj(pn, t + 3);
                 }
                 if (t > 0) flush_outputs(t - 1);
+                if (TR && NP == 0 && a.trace != nullptr && blockIdx.x == 0 && lane == 0 && t + 1 < T)
+                    a.trace[(long)(t + 1) * 8 + 7] = __builtin_amdgcn_s_memtime();  // my arrival at B(t + 1)
                 PK_BARRIER_LDS();  // B(t + 1)
+            };
+            for (int t = 0; t < T; t += 2) {
+                iter(t, pn1);
+                if (t + 1 < T) iter(t + 1, pn0);
             }
             flush_outputs(T - 1);
         };
@@ -780,8 +789,8 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_bwd_kernel(R2Args a) {
         auto io = [&](auto EDGYC) {
             constexpr bool EDGY = decltype(EDGYC)::value != 0;
             // saved tensors of a step, one 16-byte access each: [0..NS) gates, NS = h_{t-1}, NS+1 = dY
-            f32x4 in[4][NIN];
-            auto load_step = [&](int t) {
+            f32x4 in0[4][NIN], in1[4][NIN];  // the saved tensors of even / odd iterations, loaded two iterations ahead
+            auto load_step = [&](f32x4 (&in)[4][NIN], int t) {
                 const unsigned ts = (unsigned)(adir ? (T - 1 - t) : t);
                 const unsigned tp = t > 0 ? (adir ? ts + 1 : ts - 1) : ts;  // storage time of step t-1 (any valid row when t == 0)
 #pragma unroll
@@ -794,7 +803,7 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_bwd_kernel(R2Args a) {
                     if (t == 0) in[w][NS] = f32x4{0.f, 0.f, 0.f, 0.f};  // h_{-1} = 0
                 }
             };
-            auto stage_step = [&](int slot) {
+            auto stage_step = [&](const f32x4 (&in)[4][NIN], int slot) {
                 float* const d = islots + slot * ISLOT + aoff;
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
@@ -812,17 +821,24 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_bwd_kernel(R2Args a) {
                         s_st4<EDGY>(a.dP2, vG0 + ts * vGs + g * H + w * 16, anv[w], edge[w], trash,
                                     *reinterpret_cast<const f32x4*>(sl + (w * G + g) * S_PATCH_F));
             };
-            load_step(T - 1);
-            stage_step(0);
-            if (T > 1) load_step(T - 2);
+            load_step(in0, T - 1);
+            stage_step(in0, 0);
+            if (T > 1) load_step(in1, T - 2);
+            if (T > 2) load_step(in0, T - 3);
             PK_BARRIER_LDS();  // B(0)
-            for (int it = 0; it < T; ++it) {  // while the compute waves work on iteration it (step T-1-it)
+            auto iter = [&](int it, f32x4 (&in)[4][NIN]) {  // while the compute waves work on iteration it; in: the set of iteration it + 1
                 if (it + 1 < T) {
-                    stage_step((it + 1) & 1);
-                    if (it + 2 < T) load_step(T - 1 - (it + 2));
+                    stage_step(in, (it + 1) & 1);
+                    if (it + 3 < T) load_step(in, T - 1 - (it + 3));
                 }
                 if (want_dp2 && it > 0) flush_gates(it - 1);
+                if (TR && NP == 0 && a.trace != nullptr && blockIdx.x == 0 && lane == 0 && it + 1 < T)
+                    a.trace[(long)(it + 1) * 8 + 7] = __builtin_amdgcn_s_memtime();  // my arrival at B(it + 1)
                 PK_BARRIER_LDS();  // B(it + 1)
+            };
+            for (int it = 0; it < T; it += 2) {
+                iter(it, in1);
+                if (it + 1 < T) iter(it + 1, in0);
             }
             if (want_dp2) flush_gates(T - 1);
         };

@@ -54,6 +54,10 @@ for tag, tr in (("fwd", tr_f.cpu()), ("bwd", tr_b.cpu())):
     for i, n in enumerate(names[:5]):
         print("   %-24s mean %8.0f  median %8.0f" % (n, d[:, i].mean(), d[:, i].median()))
     print("   poll retries per step: mean %.2f  max %d" % (tr[:, 6].mean(), int(tr[:, 6].max())))
+    if float(tr[:, 7].abs().sum()) > 0:  # role-split kernels: slot 7 = a helper wave's time stamp of the step
+        lead = tr[:, 1] - tr[:, 7]       # barrier release seen by compute wave 0 minus the helper's stamp
+        print("   helper stamp -> barrier release: mean %8.0f  median %8.0f  p10 %8.0f" % (lead.mean(), lead.median(), lead.quantile(0.1)))
+        summary.setdefault(tag + "_helper_lead", {"mean": float(lead.mean()), "median": float(lead.median())})
     tail = tr[1:, 0] - tr[:-1, 5]
     print("   %-24s mean %8.0f  median %8.0f" % (names[5], tail.mean(), tail.median()))
     summary[tag] = {"cycles_per_step_mean": float(step.mean()), "cycles_per_step_median": float(step.median()),

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Role-split recurrences, second look: is the I/O wave what the step waits for?  (slot 7 of the phase trace = its arrival at
-# the step's barrier; NP = 0)
+# the step's barrier; NP = 0)  Plus: which host op launches which kernel in an eager timit_mlp / timit_sincnet step.
 set -u
 tag=${1:-r04e}
 out=gpurun_out/$tag
@@ -23,4 +23,8 @@ for i in 1 2; do
     ms=$(env $v timeout 200 python bench.py --no-extras --no-cpu-baseline --steps 40 --prewarm-s 0.5 2>/dev/null | python3 tools/jget.py /dev/stdin ms_per_step loss_final)
     echo "$v  $ms" | tee -a "$out/ab.txt"
   done
+done
+for r in timit_mlp timit_sincnet; do
+  timeout 200 python tools/step_ops_profile.py $r > "$out/ops_$r.txt" 2> "$out/ops_$r.err"
+  echo "ops $r: $(grep -c ' us ' "$out/ops_$r.txt") kernels"
 done

@@ -151,12 +151,14 @@ int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* g1, int64_t
 /* Backward of drop(act(bn(z))) for a batch of up to 128 rows in ONE launch (an MLP layer at the recipes' batch size;
  * neural_networks.py:139-148 backwards): g = dy * mask * act'(a), sum_g / sum_gx [N] = the BatchNorm reductions
  * (d beta, d gamma), dz = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M) as bf16 [M][ldb] (pad columns zero) and,
- * when dz != NULL, fp32 [M][N].  acc_beta / acc_gamma (NULL or [N]): the sums are also added to these in place. */
+ * when dz != NULL, fp32 [M][N].  acc_beta / acc_gamma (NULL or [N]): the sums are also added to these in place.
+ * db / acc_bias (NULL or [N]): the column sums of dz (gradient of the Linear bias in front of the BatchNorm,
+ * neural_networks.py:120) written / accumulated in place. */
 int pk_bn_act_bwd_small_covers(int64_t M, int64_t N);
 int pk_bn_act_bwd_small(void* stream, const float* dy, const float* a, const float* mask, int act, const float* z,
                         const float* mean, const float* var, float eps, const float* gamma, int64_t M, int64_t N,
                         uint16_t* dzb, int64_t ldb, float* dz, float* sum_g, float* sum_gx, float* acc_beta,
-                        float* acc_gamma);
+                        float* acc_gamma, float* db, float* acc_bias);
 /* column sums of g (+g2): bias gradient when there is no BatchNorm. */
 int pk_colsum(void* stream, const float* g, const float* g2, int64_t ldg, int64_t M, int64_t N, float* partial,
               float* out);

@@ -67,7 +67,7 @@ SIGNATURES = {
     "pk_conv1d_pool_fwd_bf16": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "pk_conv1d_pool_bwd_bf16": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "pk_bn_act_bwd_small_covers": (c_int, [c_int64, c_int64]),
-    "pk_bn_act_bwd_small": (c_int, [P, P, P, P, c_int, P, P, P, c_float, P, c_int64, c_int64, P, c_int64, P, P, P, P, P]),
+    "pk_bn_act_bwd_small": (c_int, [P, P, P, P, c_int, P, P, P, c_float, P, c_int64, c_int64, P, c_int64, P, P, P, P, P, P, P]),
     "pk_rec_work_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int]),
     "pk_rec_ln_saved_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "pk_rec_ln_work_floats": (c_int64, [c_int, c_int, c_int, c_int]),

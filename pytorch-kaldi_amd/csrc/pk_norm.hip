@@ -763,6 +763,9 @@ extern "C" int pk_bn_bwd_apply(void* stream, const float* g, const float* g2, in
 //   dz = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M)      (neural_networks.py:139-148 backwards)
 // dzb: bf16 [M][ldb] (ldb >= N; pad columns zero: the GEMM operand), dz: fp32 [M][N] or null.  sum_g / sum_gx [N] are
 // written; acc_beta / acc_gamma (null or [N]): += the same sums (the parameters' .grad, accumulated in place).
+// db / acc_bias (null or [N]): the column sums of dz - the gradient of the Linear bias IN FRONT of the BatchNorm, which the
+// reference always creates (neural_networks.py:120) and differentiates (analytically zero; what autograd delivers is the
+// rounding residue of this very sum) - written / accumulated here instead of by two more launches (pk_colsum).
 constexpr int SB_COLS = 32, SB_RG = 8, SB_ROWS = 16;  // 8 row groups x 16 rows = 128 rows at most
 __global__ __launch_bounds__(256) void bn_act_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ a,
                                                                 const float* __restrict__ mask, int act,
@@ -772,7 +775,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_small_kernel(const float* __re
                                                                 unsigned short* __restrict__ dzb, long ldb,
                                                                 float* __restrict__ dz, float* __restrict__ sum_g,
                                                                 float* __restrict__ sum_gx, float* __restrict__ acc_beta,
-                                                                float* __restrict__ acc_gamma) {
+                                                                float* __restrict__ acc_gamma, float* __restrict__ db,
+                                                                float* __restrict__ acc_bias) {
     __shared__ float sh[2][SB_RG][SB_COLS];
     const int cx = threadIdx.x & (SB_COLS - 1), rg = threadIdx.x >> 5;
     const int c = blockIdx.x * SB_COLS + cx;
@@ -815,13 +819,27 @@ __global__ __launch_bounds__(256) void bn_act_bwd_small_kernel(const float* __re
     const float ga = (gamma && cok) ? gamma[c] : 1.f;
     const float invM = 1.0f / (float)M;
     const float k0 = t0 * invM, k1 = t1 * invM;
+    float s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < SB_ROWS; ++k) {
         const int r = rg + k * SB_RG;
         if (r >= M) continue;
         const float d = cok ? ga * inv * (gv[k] - k0 - xh[k] * k1) : 0.f;
+        s2 += d;
         if (c < ldb) dzb[(long)r * ldb + c] = pk_f2bf(d);  // (columns N .. ldb-1: zero padding)
         if (dz && cok) dz[(long)r * N + c] = d;
+    }
+    if (db != nullptr || acc_bias != nullptr) {  // (uniform over the grid)
+        __syncthreads();  // everyone has read sh[0] / sh[1]
+        sh[0][rg][cx] = s2;
+        __syncthreads();
+        if (rg == 0 && cok) {
+            float t2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < SB_RG; ++k) t2 += sh[0][k][cx];
+            if (db) db[c] = t2;
+            if (acc_bias) acc_bias[c] += t2;
+        }
     }
 }
 
@@ -829,12 +847,12 @@ extern "C" int pk_bn_act_bwd_small_covers(int64_t M, int64_t N) { return M >= 1 
 extern "C" int pk_bn_act_bwd_small(void* stream, const float* dy, const float* a, const float* mask, int act, const float* z,
                                    const float* mean, const float* var, float eps, const float* gamma, int64_t M, int64_t N,
                                    uint16_t* dzb, int64_t ldb, float* dz, float* sum_g, float* sum_gx, float* acc_beta,
-                                   float* acc_gamma) {
+                                   float* acc_gamma, float* db, float* acc_bias) {
     PK_REQUIRE(pk_bn_act_bwd_small_covers(M, N), "pk_bn_act_bwd_small: up to %d rows (got %ld x %ld)", SB_RG * SB_ROWS, (long)M, (long)N);
     PK_REQUIRE(dy && a && z && mean && var && dzb && sum_g && sum_gx && ldb >= N, "pk_bn_act_bwd_small: null argument or short pitch");
     hipLaunchKernelGGL(bn_act_bwd_small_kernel, dim3((unsigned)((ldb + SB_COLS - 1) / SB_COLS)), dim3(256), 0, pk_stream(stream), dy, a,
                        mask, act, z, mean, var, eps, gamma, (int)M, (int)N, (unsigned short*)dzb, (long)ldb, dz, sum_g, sum_gx,
-                       acc_beta, acc_gamma);
+                       acc_beta, acc_gamma, db, acc_bias);
     PK_LAUNCH_CHECK();
     return 0;
 }

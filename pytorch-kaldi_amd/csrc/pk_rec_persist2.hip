@@ -810,6 +810,14 @@ int pk_rec2_host_setup(R2Args& a, bool backward, int cell) {
     a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe;
     a.trash = g2_trash; a.poll_delay = g2_poll_delay >= 0 ? g2_poll_delay : default_poll_delay(backward, cell);
     a.helper_delay = 0;
+    {   // role-split kernels (pk_rec_split.hip): which compute wave writes the phase trace (diagnostics)
+        static int tw = -1;
+        if (tw < 0) {
+            const char* e = getenv("PK_TRACE_WAVE");
+            tw = e ? (atoi(e) & 3) : 0;
+        }
+        if (g2_trace != nullptr) a.helper_delay = tw;
+    }
     a.empty_step = g2_empty_step;
     a.self_fill = 0;
     {   // PK_REC_FLUSH_LATE=1: the third-generation kernels issue a step's output stores / next-step loads behind its MFMA

@@ -143,9 +143,10 @@ __device__ __forceinline__ void s_wait_published(const unsigned char* flags, uns
     }
 }
 
+// (the traced compute wave is a.helper_delay - PK_TRACE_WAVE, 0..3: the waves share their SIMDs with different helpers)
 #define PKS_TRACE_AT(TID, slot)                                                              \
     do {                                                                                     \
-        if (TR && a.trace != nullptr && blockIdx.x == 0 && tid == (TID)) a.trace[(long)step_idx * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        if (TR && a.trace != nullptr && blockIdx.x == 0 && tid == (TID) + 64 * a.helper_delay) a.trace[(long)step_idx * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
 // ============================================================================
@@ -267,6 +268,7 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_fwd_kernel(R2Args a) {
         const bool fast_rt = __builtin_amdgcn_readfirstlane((int)(cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0)) != 0;
         auto run = [&](auto FASTC) {
             constexpr bool fast = decltype(FASTC)::value != 0;
+            if (a.flush_late == 0) __builtin_amdgcn_s_setprio(3);  // the helper wave on my SIMD takes the issue slots I leave (PK_REC_FLUSH_LATE=1: A/B)
             for (int t = 0; t < T; ++t) {
                 const int step_idx = t;
                 PKS_TRACE_AT(0, 0);
@@ -623,6 +625,7 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_bwd_kernel(R2Args a) {
         const bool fast_rt = __builtin_amdgcn_readfirstlane((int)(cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0)) != 0;
         auto run = [&](auto FASTC) {
             constexpr bool fast = decltype(FASTC)::value != 0;
+            if (a.flush_late == 0) __builtin_amdgcn_s_setprio(3);
             int it = 0;
             for (int t = T - 1; t >= 0; --t, ++it) {
                 const int step_idx = it;

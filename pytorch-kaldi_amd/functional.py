@@ -903,6 +903,7 @@ class LinearBnActFn(torch.autograd.Function):
         ctx.in_shape = x.shape
         ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None
         ctx.bnparams = [gamma, beta] if (isinstance(gamma, torch.nn.Parameter) and isinstance(beta, torch.nn.Parameter)) else None
+        ctx.bparam = bias if isinstance(bias, torch.nn.Parameter) else None
         ctx.mark_non_differentiable(yb)
         return y, yb
 
@@ -919,13 +920,16 @@ class LinearBnActFn(torch.autograd.Function):
             # one launch: activation / mask backward, both BatchNorm reductions, BatchNorm backward, the bf16 operand
             direct = ctx.bnparams is not None and direct_grads_ok(ctx.bnparams)
             dzb = torch.empty(M, _up(N, 64), device=z.device, dtype=torch.bfloat16)
-            dz = _new(M, N, like=z) if need_db else None
+            # the bias gradient (column sums of dz) comes out of the same launch: into the flat .grad when that is allowed,
+            # else as a tensor for autograd
+            direct_b = need_db and ctx.bparam is not None and direct_grads_ok([ctx.bparam])
+            db = _new(N, like=z) if (need_db and not direct_b) else None
             _lib.check(lib.pk_bn_act_bwd_small(_stream(), _p(dy2), _p(a), _p(mask), ACT[act], _p(z), _p(mean), _p(var), eps,
-                                               _p(gamma), M, N, _p(dzb), dzb.shape[1], _p(dz), _p(sum_g), _p(sum_gx),
+                                               _p(gamma), M, N, _p(dzb), dzb.shape[1], None, _p(sum_g), _p(sum_gx),
                                                _p(ctx.bnparams[1].grad) if direct else None,
-                                               _p(ctx.bnparams[0].grad) if direct else None), "pk_bn_act_bwd_small")
+                                               _p(ctx.bnparams[0].grad) if direct else None, _p(db),
+                                               _p(ctx.bparam.grad) if direct_b else None), "pk_bn_act_bwd_small")
             dx, dw = _linear_bwd_bf16(ctx, dzb, xb, wb, z)
-            db = colsum(dz) if need_db else None
             if direct:
                 return dx, dw, db, None, None, None, None, None, None, None, None, None
             return dx, dw, db, sum_gx, sum_g, None, None, None, None, None, None, None

@@ -369,6 +369,17 @@ int pk_linear_bn_act_bf16(void* stream, int M, int N, int K, const uint16_t* xb,
                           const float* bias, const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, int act, const float* mask, float* z, float* a,
                           float* y, uint16_t* yb, int64_t ldyb, float* mean, float* var);
+/* The same layer in two launches that cover the chip (round 4: a launch of the one-launch form is as long as its
+ * 320 KB per-workgroup footprint takes through ONE CU's memory pipe): the product split along K into fp32 slabs
+ * ws[splitk][M][N] - splitk = pk_gemm_bf16_small_splitk(M, N, K), >= 2 - then the layer epilogue straight from the
+ * slabs.  pk_gemm_bf16_small_splitk also sizes the split of any small-batch pk_gemm_bf16 call (M <= 128 rows,
+ * k-contiguous A; 1 = not worth splitting). */
+int pk_gemm_bf16_small_splitk(int M, int N, int K);
+int pk_linear_bn_act_bf16_sk(void* stream, int M, int N, int K, const uint16_t* xb, int64_t ldx, const uint16_t* wb,
+                             int64_t ldw, const float* bias, const float* gamma, const float* beta, float eps,
+                             float momentum, float* running_mean, float* running_var, int act, const float* mask,
+                             float* z, float* a, float* y, uint16_t* yb, int64_t ldyb, float* mean, float* var,
+                             int splitk, float* ws);
 /* ---- perf-mode convolutions (pk_conv_bf16.hip): F.conv1d + F.max_pool1d of the SincNet / CNN stacks
  * (neural_networks.py:1546-1552, :1655-1661, :1805-1813) as an implicit GEMM on v_mfma_f32_16x16x32_bf16 - x, w and the
  * un-pooled output gradient enter as bf16, accumulation in fp32; same tensors and arg-max convention as

@@ -119,6 +119,9 @@ SIGNATURES = {
     "pk_linear_bn_act_bf16_covers": (c_int, [c_int64, c_int64, c_int64]),
     "pk_linear_bn_act_bf16": (c_int, [P, c_int, c_int, c_int, P, c_int64, P, c_int64, P, P, P, c_float, c_float, P, P, c_int, P,
                                       P, P, P, P, c_int64, P, P]),
+    "pk_gemm_bf16_small_splitk": (c_int, [c_int, c_int, c_int]),
+    "pk_linear_bn_act_bf16_sk": (c_int, [P, c_int, c_int, c_int, P, c_int64, P, c_int64, P, P, P, c_float, c_float, P, P, c_int, P,
+                                         P, P, P, P, c_int64, P, P, c_int, P]),
     "pk_selftest_mfma": (c_int, [P, ctypes.POINTER(c_int)]),
     "pk_selftest_permlane": (c_int, [P, ctypes.POINTER(c_int)]),
     "pk_selftest_dpp_row_sum": (c_int, [P, ctypes.POINTER(c_int)]),

@@ -546,6 +546,283 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16s_kernel(BArgs p, BnActArgs q
     }
 }
 
+
+// ============================================================================
+// Small-batch products, round 4: cut the per-workgroup footprint until the grid covers the chip.
+//
+// A launch of the kernels above is as long as its LARGEST per-workgroup footprint divided by what one CU pulls through
+// its memory pipe (~26 GB/s, MI355X_MICROARCH.md: 10-11 B/clk/CU): all 128 rows x 32 columns over K = 1024 is 320 KB
+// per workgroup on 32 CUs - 12-18 us for 0.27 GFLOP (profiles/r03_timit_mlp_kernel_stats.csv), whatever the pipeline
+// depth (the k-tiles of one workgroup arrive one L2 round trip after the other).  Three kernels replace that shape:
+//   gemm_bf16sk_kernel     the same 128 x 32 column tile, the reduction SPLIT over blockIdx.y: <= SK_TILES k-tiles per
+//                          workgroup, every tile's LDS-DMA issued before the first wait (40-80 KB footprints, 200-500
+//                          workgroups); fp32 slabs [split][M][N] summed by splitk_reduce_bf_kernel or by
+//   linear_bn_act_epi_kernel  the MLP layer epilogue (bias, batch statistics, BatchNorm, activation, mask, bf16 copy) read
+//                          straight from the slabs: 16 columns x all rows per workgroup;
+//   gemm_bf16_t64_kernel   weight gradients of such a layer, C[n][k] (+)= sum_m dz[m][n] x[m][k] with the batch as the
+//                          (short) reduction: 64 x 64 output tiles (64 KB footprints on 256 workgroups instead of 192 KB
+//                          on 64).
+// ============================================================================
+constexpr int SK_TILES = 4;
+template <bool B_KC>
+__global__ __launch_bounds__(256) void gemm_bf16sk_kernel(BArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [SK_TILES][A 16 KB | B 4 KB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * SN, split = blockIdx.y;
+    const int k_lo = split * p.k_per_split;
+    int k_hi = k_lo + p.k_per_split;
+    k_hi = k_hi < p.K ? k_hi : p.K;
+    const int nk = (k_hi - k_lo + TK - 1) / TK;  // <= SK_TILES (host)
+#pragma unroll
+    for (int t = 0; t < SK_TILES; ++t) {
+        if (t < nk) {
+            unsigned char* buf = smem + t * SSTAGE;
+            const int k0 = k_lo + t * TK;
+            stage<true>(p.A, p.lda, 0, p.M, k0, k_hi, p.zeros, buf, tid, wave);
+            if (B_KC) stage_kc_rows<SN>(p.B, p.ldb, n0, p.N, k0, k_hi, p.zeros, buf + 16384, tid, wave);
+            else stage_km32(p.B, p.ldb, n0, p.N, k0, k_hi, p.zeros, buf + 16384, tid, wave);
+        }
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const unsigned char* cur = smem + t * SSTAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = frag<true>(cur, wave * 32 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = B_KC ? frag<true>(cur + 16384, j * 16, kk, lane) : frag_km32(cur + 16384, j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    // acc[i][j][r]: row = wave*32 + i*16 + (lane & 15), column = n0 + j*16 + (lane >> 4)*4 + r  -> my slab of p.ws
+    float* slab = p.ws + (long)split * p.M * p.N;
+    const bool vec_ok = (p.N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 32 + i * 16 + (lane & 15);
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + j * 16 + (lane >> 4) * 4;
+            float* dst = slab + (long)row * p.N + col;
+            if (vec_ok && col + 3 < p.N) {
+                *reinterpret_cast<f32x4*>(dst) = acc[i][j];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (col + r < p.N) dst[r] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// Sum of one float4 per lane over the lanes that share (lane & 3): the 16 row groups of a wave in the 4-columns-per-thread
+// layout of the epilogue kernels below
+__device__ __forceinline__ f32x4 rows16_sum(f32x4 v) {
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], off, 64);
+    return v;
+}
+
+// The MLP layer epilogue on split-K slabs (see gemm_bf16s_kernel<true> for the arithmetic - same two-pass statistics, same
+// outputs): a workgroup owns EP_COLS columns and all M <= 128 rows; thread = (4 consecutive columns, row group rg of 64),
+// rows rg and rg + 64.
+constexpr int EP_COLS = 16;
+__global__ __launch_bounds__(256) void linear_bn_act_epi_kernel(const float* __restrict__ ws, int splits, int M, int N,
+                                                                 const float* __restrict__ bias, BnActArgs q) {
+    __shared__ float red[2][4][EP_COLS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = (tid & 3) * 4, rg = tid >> 2;
+    const int col = blockIdx.x * EP_COLS + c4;
+    const bool cok = col < N;  // (N is a multiple of 4: a thread's four columns are in or out together)
+    const long slab = (long)M * N;
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr && cok) bv = *reinterpret_cast<const f32x4*>(bias + col);
+    f32x4 v[2];
+    bool rok[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = rg + 64 * k;
+        rok[k] = cok && r < M;
+        v[k] = bv;
+        if (rok[k]) {
+            const float* src = ws + (long)r * N + col;
+            for (int s_ = 0; s_ < splits; ++s_) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(src + s_ * slab);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[k][e] += t[e];
+            }
+        }
+    }
+    auto column_total = [&](f32x4 t, int pass) -> f32x4 {
+        t = rows16_sum(t);
+        if (lane < 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[pass][wave][c4 + e] = t[e];
+        }
+        __syncthreads();
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ((red[pass][0][c4 + e] + red[pass][1][c4 + e]) + red[pass][2][c4 + e]) + red[pass][3][c4 + e];
+        return o;
+    };
+    const float invM = 1.0f / (float)M;
+    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] += rok[k] ? v[k][e] : 0.f;
+    f32x4 mean = column_total(t, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) mean[e] *= invM;
+    t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[k][e] - mean[e];
+            t[e] += rok[k] ? d * d : 0.f;
+        }
+    f32x4 var = column_total(t, 1);
+    float sc[4], sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        var[e] *= invM;
+        const float inv = 1.0f / sqrtf(var[e] + q.eps);
+        const float g = (q.gamma != nullptr && cok) ? q.gamma[col + e] : 1.f, b = (q.beta != nullptr && cok) ? q.beta[col + e] : 0.f;
+        sc[e] = g * inv;
+        sh[e] = b - mean[e] * sc[e];
+    }
+    if (rg == 0 && cok) {  // one thread per four columns: the statistics backward needs, the running statistics
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            q.mean[col + e] = mean[e];
+            q.var[col + e] = var[e];
+            if (q.rmean != nullptr) {
+                q.rmean[col + e] = (1.f - q.momentum) * q.rmean[col + e] + q.momentum * mean[e];
+                q.rvar[col + e] = (1.f - q.momentum) * q.rvar[col + e] + q.momentum * (var[e] * q.unbias);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!rok[k]) continue;
+        const int r = rg + 64 * k;
+        const long o = (long)r * N + col;
+        f32x4 av, yv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[e] = pk_act(q.act, v[k][e] * sc[e] + sh[e]);
+        *reinterpret_cast<f32x4*>(q.zout + o) = v[k];
+        *reinterpret_cast<f32x4*>(q.aout + o) = av;
+        yv = av;
+        if (q.mask != nullptr) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(q.mask + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) yv[e] = av[e] * mk[e];
+            *reinterpret_cast<f32x4*>(q.yout + o) = yv;
+        }
+        uint2 pk;
+        pk.x = pk_pack_bf2(yv[0], yv[1]);
+        pk.y = pk_pack_bf2(yv[2], yv[3]);
+        *reinterpret_cast<uint2*>(q.yb + (long)r * q.ldyb + col) = pk;
+    }
+}
+
+// C[M][N] = alpha * sum_k A[k][m] B[k][n] (+ beta C): both operands k-major, short reduction (the batch of an MLP step):
+// one 64 x 64 output tile per workgroup (2 x 2 waves of 32 x 32), the operands as [64 k][32 columns] images (stage_km32 /
+// frag_km32), up to T64_TILES k-tiles in flight before the first wait.
+constexpr int T64_TILES = 2, T64_STAGE = 4 * 4096;  // per k-tile: A columns 0-31 | 32-63 | B columns 0-31 | 32-63
+__global__ __launch_bounds__(256) void gemm_bf16_t64_kernel(BArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // [T64_TILES][T64_STAGE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int nk = (p.K + TK - 1) / TK;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int kt, unsigned char* buf) {
+        const int k0 = kt * TK;
+        stage_km32(p.A, p.lda, m0, p.M, k0, p.K, p.zeros, buf, tid, wave);
+        stage_km32(p.A, p.lda, m0 + 32 < p.M ? m0 + 32 : m0, p.M, k0, p.K, p.zeros, buf + 4096, tid, wave);
+        stage_km32(p.B, p.ldb, n0, p.N, k0, p.K, p.zeros, buf + 8192, tid, wave);
+        stage_km32(p.B, p.ldb, n0 + 32 < p.N ? n0 + 32 : n0, p.N, k0, p.K, p.zeros, buf + 12288, tid, wave);
+    };
+    for (int base = 0; base < nk; base += T64_TILES) {
+#pragma unroll
+        for (int t = 0; t < T64_TILES; ++t)
+            if (base + t < nk) fetch(base + t, smem + t * T64_STAGE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < T64_TILES; ++t) {
+            if (base + t >= nk) break;
+            const unsigned char* cur = smem + t * T64_STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = frag_km32(cur + wm * 4096, i * 16, kk, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = frag_km32(cur + 8192 + wn * 4096, j * 16, kk, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();  // everyone is done reading before the next group of tiles lands
+    }
+    // acc[i][j][r]: row = m0 + wm*32 + i*16 + (lane & 15), column = n0 + wn*32 + j*16 + (lane >> 4)*4 + r
+    const bool vec_ok = (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + wm * 32 + i * 16 + (lane & 15);
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 32 + j * 16 + (lane >> 4) * 4;
+            float* dst = p.C + (long)row * p.ldc + col;
+            if (vec_ok && col + 3 < p.N) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = p.alpha * acc[i][j][r] + (p.bias ? p.bias[col + r] : 0.f);
+                if (p.beta != 0.f) {
+                    const f32x4 c = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] += p.beta * c[r];
+                }
+                *reinterpret_cast<f32x4*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (col + r >= p.N) continue;
+                    float o = p.alpha * acc[i][j][r] + (p.bias ? p.bias[col + r] : 0.f);
+                    if (p.beta != 0.f) o += p.beta * dst[r];
+                    dst[r] = o;
+                }
+            }
+        }
+    }
+}
+
 // ============================================================================
 // 256 x 256 x 64 block tile, 8 waves, eight phases per pair of k-tiles.
 //
@@ -1069,6 +1346,34 @@ static int gemm_bf16_impl(void* stream, int M, int N, int K, float alpha, const 
             const char* e = getenv("PK_GEMM_SKINNY");
             skinny_on = (e && e[0] == '0') ? 0 : 1;
         }
+        if (skinny_on && !g_gemm_tile_forced && a_kc && M <= TM && splitk > 1 && p.k_per_split <= SK_TILES * TK && stats == nullptr) {
+            // the reduction split over the grid (round 4): slabs, then the existing reduce
+            static bool attr_done = false;
+            if (!attr_done) {
+                PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16sk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_TILES * SSTAGE));
+                PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16sk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_TILES * SSTAGE));
+                attr_done = true;
+            }
+            const dim3 sgrid((unsigned)((N + SN - 1) / SN), (unsigned)splitk);
+            if (b_kc) hipLaunchKernelGGL((gemm_bf16sk_kernel<true>), sgrid, dim3(256), SK_TILES * SSTAGE, st, p);
+            else hipLaunchKernelGGL((gemm_bf16sk_kernel<false>), sgrid, dim3(256), SK_TILES * SSTAGE, st, p);
+            PK_LAUNCH_CHECK();
+            const long total = (long)M * N;
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_bf_kernel, dim3(blocks), dim3(256), 0, st, workspace, splitk, M, N, alpha, beta,
+                               bias, C, (long)ldc);
+            PK_LAUNCH_CHECK();
+            return 0;
+        }
+        if (skinny_on && !g_gemm_tile_forced && !a_kc && !b_kc && splitk == 1 && K <= 512 && stats == nullptr &&
+            (long)((M + TM - 1) / TM) * ((N + TN - 1) / TN) <= 192 && M >= 64 && N >= 64) {
+            // a weight gradient over a short reduction: 64 x 64 tiles put the same read-modify-write on four times the CUs
+            const dim3 tgrid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+            hipLaunchKernelGGL(gemm_bf16_t64_kernel, tgrid, dim3(256), T64_TILES * T64_STAGE, st, p);
+            PK_LAUNCH_CHECK();
+            return 0;
+        }
         if (skinny_on && !g_gemm_tile_forced && a_kc && M <= TM && N >= 4 * SN && splitk == 1 && stats == nullptr) {
             BnActArgs q = {};
             const dim3 sgrid((unsigned)((N + SN - 1) / SN));
@@ -1160,6 +1465,72 @@ extern "C" int pk_gemm_bf16_stats(void* stream, int M, int N, int K, float alpha
     *row_blocks = fused ? (M + 255) / 256 : 0;
     return gemm_bf16_impl(stream, M, N, K, alpha, A, lda, a_kc, B, ldb, b_kc, 0.f, C, ldc, bias, 1, nullptr,
                           fused ? stats : nullptr);
+}
+
+// Split of the reduction for a small-batch product (M <= 128 rows, k-contiguous A): enough (column tile, split) workgroups
+// to cover the chip, at most SK_TILES k-tiles per workgroup; 1 = the product is too small to be worth a second launch.
+extern "C" int pk_gemm_bf16_small_splitk(int M, int N, int K) {
+    if (M < 1 || M > TM || N < 1 || K < 2 * TK) return 1;
+    const int col_tiles = (N + SN - 1) / SN;
+    int s = 256 / col_tiles;               // workgroups ~ CUs
+    const int need = (K + SK_TILES * TK - 1) / (SK_TILES * TK);  // the LDS holds SK_TILES k-tiles
+    if (s < need) s = need;
+    if (s > 16) s = 16;
+    const int tiles = (K + TK - 1) / TK;
+    if (s > tiles) s = tiles;
+    if (s < 2) return 1;
+    int kps = ((K + s - 1) / s + TK - 1) / TK * TK;  // what gemm_bf16_impl will use
+    if (kps > SK_TILES * TK) return 1;
+    return (K + kps - 1) / kps;
+}
+
+// One perf-mode MLP layer (see pk_linear_bn_act_bf16) in TWO launches that cover the chip: the product split along K into
+// fp32 slabs ws[splitk][M][N] (splitk from pk_gemm_bf16_small_splitk, >= 2), then the layer epilogue straight from the slabs.
+extern "C" int pk_linear_bn_act_bf16_sk(void* stream, int M, int N, int K, const uint16_t* xb, int64_t ldx, const uint16_t* wb,
+                                        int64_t ldw, const float* bias, const float* gamma, const float* beta, float eps,
+                                        float momentum, float* running_mean, float* running_var, int act, const float* mask,
+                                        float* z, float* a, float* y, uint16_t* yb, int64_t ldyb, float* mean, float* var,
+                                        int splitk, float* ws) {
+    PK_REQUIRE(pk_linear_bn_act_bf16_covers(M, N, K), "pk_linear_bn_act_bf16_sk: needs 2 <= M <= 128 rows and N a multiple of 8 (got %d x %d)", M, N);
+    PK_REQUIRE((ldx % 8) == 0 && (ldw % 8) == 0 && ((uintptr_t)xb & 15) == 0 && ((uintptr_t)wb & 15) == 0 && ldx >= ((K + 7) & ~7) &&
+                   ldw >= ((K + 7) & ~7),
+               "pk_linear_bn_act_bf16_sk: operands need 16-byte aligned bases and pitches that are multiples of 8 elements");
+    PK_REQUIRE(z && a && yb && mean && var && (mask == nullptr || y != nullptr) && ldyb >= N && (ldyb % 4) == 0,
+               "pk_linear_bn_act_bf16_sk: null output or bad pitch");
+    PK_REQUIRE((((uintptr_t)z | (uintptr_t)a | (uintptr_t)y | (uintptr_t)mask | (uintptr_t)ws | (uintptr_t)bias) & 15) == 0 && ((uintptr_t)yb & 7) == 0,
+               "pk_linear_bn_act_bf16_sk: fp32 matrices need 16-byte aligned bases");
+    PK_REQUIRE(splitk >= 2 && ws != nullptr, "pk_linear_bn_act_bf16_sk: needs splitk >= 2 and a workspace of splitk x M x N floats");
+    int kps = ((K + splitk - 1) / splitk + TK - 1) / TK * TK;
+    PK_REQUIRE(kps <= SK_TILES * TK, "pk_linear_bn_act_bf16_sk: %d splits of K = %d exceed %d k-tiles per workgroup", splitk, K, SK_TILES);
+    splitk = (K + kps - 1) / kps;
+    hipStream_t st = pk_stream(stream);
+    BArgs p;
+    p.M = M; p.N = N; p.K = K;
+    p.alpha = 1.f; p.beta = 0.f;
+    p.A = xb; p.lda = ldx; p.B = wb; p.ldb = ldw;
+    p.C = z; p.ldc = N; p.bias = nullptr;
+    p.stats = nullptr; p.ws = ws;
+    p.tiles_m = 1; p.tiles_n = (N + TN - 1) / TN;
+    p.k_per_split = kps;
+    p.items = p.tiles_n; p.per_xcd = (p.items + 7) / 8;
+    static void* zp = nullptr;
+    if (zp == nullptr) PK_CHECK_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)));
+    p.zeros = (const unsigned short*)zp;
+    static bool attr_done = false;
+    if (!attr_done) {
+        PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16sk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_TILES * SSTAGE));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16sk_kernel<true>), dim3((unsigned)((N + SN - 1) / SN), (unsigned)splitk), dim3(256), SK_TILES * SSTAGE, st, p);
+    PK_LAUNCH_CHECK();
+    BnActArgs q;
+    q.gamma = gamma; q.beta = beta; q.mask = mask;
+    q.eps = eps; q.momentum = momentum; q.unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
+    q.rmean = running_mean; q.rvar = running_var; q.mean = mean; q.var = var;
+    q.zout = z; q.aout = a; q.yout = y; q.yb = (unsigned short*)yb; q.ldyb = ldyb; q.act = act;
+    hipLaunchKernelGGL(linear_bn_act_epi_kernel, dim3((unsigned)((N + EP_COLS - 1) / EP_COLS)), dim3(256), 0, st, ws, splitk, M, N, bias, q);
+    PK_LAUNCH_CHECK();
+    return 0;
 }
 
 // One perf-mode MLP layer of a batch of up to 128 rows in one launch: see gemm_bf16s_kernel<true>.

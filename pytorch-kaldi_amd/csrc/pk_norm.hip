@@ -766,7 +766,16 @@ extern "C" int pk_bn_bwd_apply(void* stream, const float* g, const float* g2, in
 // db / acc_bias (null or [N]): the column sums of dz - the gradient of the Linear bias IN FRONT of the BatchNorm, which the
 // reference always creates (neural_networks.py:120) and differentiates (analytically zero; what autograd delivers is the
 // rounding residue of this very sum) - written / accumulated here instead of by two more launches (pk_colsum).
-constexpr int SB_COLS = 32, SB_RG = 8, SB_ROWS = 16;  // 8 row groups x 16 rows = 128 rows at most
+// Round 4: a workgroup owns 16 columns (was 32: twice the workgroups - the launch is as long as one workgroup's footprint
+// takes through its CU's memory pipe) and a thread four consecutive columns of rows rg and rg + 64 (16-byte accesses).
+constexpr int SB_COLS = 16, SB_RG = 64, SB_ROWS = 2;  // 64 row groups x 2 rows = 128 rows at most
+__device__ __forceinline__ f32x4 sb_rows16_sum(f32x4 v) {  // over the lanes that share (lane & 3): the 16 row groups of a wave
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], off, 64);
+    return v;
+}
 __global__ __launch_bounds__(256) void bn_act_bwd_small_kernel(const float* __restrict__ dy, const float* __restrict__ a,
                                                                 const float* __restrict__ mask, int act,
                                                                 const float* __restrict__ z, const float* __restrict__ mean,
@@ -777,68 +786,124 @@ __global__ __launch_bounds__(256) void bn_act_bwd_small_kernel(const float* __re
                                                                 float* __restrict__ sum_gx, float* __restrict__ acc_beta,
                                                                 float* __restrict__ acc_gamma, float* __restrict__ db,
                                                                 float* __restrict__ acc_bias) {
-    __shared__ float sh[2][SB_RG][SB_COLS];
-    const int cx = threadIdx.x & (SB_COLS - 1), rg = threadIdx.x >> 5;
-    const int c = blockIdx.x * SB_COLS + cx;
-    const bool cok = c < N;
-    const float mu = cok ? mean[c] : 0.f;
-    const float inv = cok ? 1.0f / sqrtf(var[c] + eps) : 0.f;
-    float gv[SB_ROWS], xh[SB_ROWS];
-    float s0 = 0.f, s1 = 0.f;
+    __shared__ float sh[3][4][SB_COLS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = (tid & 3) * 4, rg = tid >> 2;
+    const int c = blockIdx.x * SB_COLS + c4;
+    const bool vec = (N & 3) == 0 && (ldb & 3) == 0;  // (else: element by element)
+    bool cok[4];
+    float mu[4], inv[4], ga[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        cok[e] = c + e < N;
+        mu[e] = cok[e] ? mean[c + e] : 0.f;
+        inv[e] = cok[e] ? 1.0f / sqrtf(var[c + e] + eps) : 0.f;
+        ga[e] = (gamma && cok[e]) ? gamma[c + e] : 1.f;
+    }
+    f32x4 gv[SB_ROWS], xh[SB_ROWS];
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < SB_ROWS; ++k) {
         const int r = rg + k * SB_RG;
-        float g = 0.f, x = 0.f;
-        if (cok && r < M) {
+        f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f}, x = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r < M && cok[0]) {
             const long o = (long)r * N + c;
-            g = dy[o];
-            if (mask) g *= mask[o];
-            g *= pk_act_grad_from_out(act, a[o]);
-            x = (z[o] - mu) * inv;
+            f32x4 d, av, zv, mk = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (vec) {
+                d = *reinterpret_cast<const f32x4*>(dy + o);
+                av = *reinterpret_cast<const f32x4*>(a + o);
+                zv = *reinterpret_cast<const f32x4*>(z + o);
+                if (mask) mk = *reinterpret_cast<const f32x4*>(mask + o);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    d[e] = cok[e] ? dy[o + e] : 0.f;
+                    av[e] = cok[e] ? a[o + e] : 0.f;
+                    zv[e] = cok[e] ? z[o + e] : 0.f;
+                    if (mask) mk[e] = cok[e] ? mask[o + e] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                g[e] = cok[e] ? d[e] * mk[e] * pk_act_grad_from_out(act, av[e]) : 0.f;
+                x[e] = cok[e] ? (zv[e] - mu[e]) * inv[e] : 0.f;
+            }
         }
         gv[k] = g;
         xh[k] = x;
-        s0 += g;
-        s1 += g * x;
-    }
-    sh[0][rg][cx] = s0;
-    sh[1][rg][cx] = s1;
-    __syncthreads();
-    float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < SB_RG; ++k) {  // every thread of a column adds the eight partial sums in the same order
-        t0 += sh[0][k][cx];
-        t1 += sh[1][k][cx];
+        for (int e = 0; e < 4; ++e) {
+            s0[e] += g[e];
+            s1[e] += g[e] * x[e];
+        }
     }
-    if (rg == 0 && cok) {
-        sum_g[c] = t0;
-        sum_gx[c] = t1;
-        if (acc_beta) acc_beta[c] += t0;
-        if (acc_gamma) acc_gamma[c] += t1;
+    s0 = sb_rows16_sum(s0);
+    s1 = sb_rows16_sum(s1);
+    if (lane < 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sh[0][wave][c4 + e] = s0[e];
+            sh[1][wave][c4 + e] = s1[e];
+        }
     }
-    const float ga = (gamma && cok) ? gamma[c] : 1.f;
+    __syncthreads();
+    float t0[4], t1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // every thread of a column adds the four partial sums in the same order
+        t0[e] = ((sh[0][0][c4 + e] + sh[0][1][c4 + e]) + sh[0][2][c4 + e]) + sh[0][3][c4 + e];
+        t1[e] = ((sh[1][0][c4 + e] + sh[1][1][c4 + e]) + sh[1][2][c4 + e]) + sh[1][3][c4 + e];
+    }
+    if (rg == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (!cok[e]) continue;
+            sum_g[c + e] = t0[e];
+            sum_gx[c + e] = t1[e];
+            if (acc_beta) acc_beta[c + e] += t0[e];
+            if (acc_gamma) acc_gamma[c + e] += t1[e];
+        }
+    }
     const float invM = 1.0f / (float)M;
-    const float k0 = t0 * invM, k1 = t1 * invM;
-    float s2 = 0.f;
+    f32x4 s2 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < SB_ROWS; ++k) {
         const int r = rg + k * SB_RG;
         if (r >= M) continue;
-        const float d = cok ? ga * inv * (gv[k] - k0 - xh[k] * k1) : 0.f;
-        s2 += d;
-        if (c < ldb) dzb[(long)r * ldb + c] = pk_f2bf(d);  // (columns N .. ldb-1: zero padding)
-        if (dz && cok) dz[(long)r * N + c] = d;
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            d[e] = cok[e] ? ga[e] * inv[e] * (gv[k][e] - t0[e] * invM - xh[k][e] * (t1[e] * invM)) : 0.f;
+            s2[e] += d[e];
+        }
+        if (vec && c + 3 < ldb) {
+            uint2 pk;
+            pk.x = pk_pack_bf2(d[0], d[1]);
+            pk.y = pk_pack_bf2(d[2], d[3]);
+            *reinterpret_cast<uint2*>(dzb + (long)r * ldb + c) = pk;  // (columns N .. ldb-1: zero padding)
+            if (dz && cok[0]) *reinterpret_cast<f32x4*>(dz + (long)r * N + c) = d;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (c + e < ldb) dzb[(long)r * ldb + c + e] = pk_f2bf(d[e]);
+                if (dz && cok[e]) dz[(long)r * N + c + e] = d[e];
+            }
+        }
     }
     if (db != nullptr || acc_bias != nullptr) {  // (uniform over the grid)
-        __syncthreads();  // everyone has read sh[0] / sh[1]
-        sh[0][rg][cx] = s2;
-        __syncthreads();
-        if (rg == 0 && cok) {
-            float t2 = 0.f;
+        s2 = sb_rows16_sum(s2);
+        if (lane < 4) {
 #pragma unroll
-            for (int k = 0; k < SB_RG; ++k) t2 += sh[0][k][cx];
-            if (db) db[c] = t2;
-            if (acc_bias) acc_bias[c] += t2;
+            for (int e = 0; e < 4; ++e) sh[2][wave][c4 + e] = s2[e];
+        }
+        __syncthreads();
+        if (rg == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (!cok[e]) continue;
+                const float t2 = ((sh[2][0][c4 + e] + sh[2][1][c4 + e]) + sh[2][2][c4 + e]) + sh[2][3][c4 + e];
+                if (db) db[c + e] = t2;
+                if (acc_bias) acc_bias[c + e] += t2;
+            }
         }
     }
 }

@@ -276,11 +276,18 @@ def cvt_bf16(x2, nseg=1, seglen=None, segpad=None):
     return out
 
 
+_SMALL_SPLITK = os.environ.get("PK_SMALL_SPLITK", "1") != "0"
+
+
 def gemm_bf16(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, alpha=1.0, beta=0.0, bias=None, splitk=1):
     """C[M,N] fp32 = alpha * A.B + beta*C + bias on bf16 operands (see include/pk_amd.h: pk_gemm_bf16).
     A / B may be tensors or (tensor, element_offset) pairs."""
     lib = _lib.load()
     ws = None
+    if splitk == 1 and a_kc and M <= 128 and _SMALL_SPLITK:
+        # a small-batch product is as slow as its largest per-workgroup footprint: the reduction is split over the grid
+        # (pk_gemm_bf16_small_splitk: 1 = not worth a second launch)
+        splitk = int(lib.pk_gemm_bf16_small_splitk(M, N, K))
     if splitk > 1:
         ws = torch.empty(splitk * M * N, device=C.device, dtype=torch.float32)
 
@@ -656,6 +663,10 @@ def linear_log_softmax(x, weight, bias=None):
         wb_plain = cvt_bf16(w)
         if tw is None:
             xb, xseg, wb = _cvt_bf16_shared(x2), None, wb_plain
+        elif tw[1][0] == 1 and tw[0].shape[1] == wb_plain.shape[1]:
+            # one segment at the weight copy's own pitch (the bf16 copy an MLP layer published): nothing is re-pitched -
+            # the plain path (one weight copy; the weight gradient goes straight into .grad, no segment copies)
+            xb, xseg, wb = tw[0], None, wb_plain
         else:
             xb, xseg = tw
             wb = cvt_bf16(w, *xseg)
@@ -678,6 +689,7 @@ class HeadNllFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, y, lab, xb, wb, xseg, ignore_index):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)  # (no zero tensor for the statistics output in backward)
         ctx.xseg = xseg
         M, N = y.shape
         lab = lab.contiguous()
@@ -698,6 +710,8 @@ class HeadNllFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _d4):
         lib = _lib.load()
+        if dloss is None:
+            return (None,) * 9
         xb, wb, y, lab, out4 = ctx.saved_tensors
         M, N, K = ctx.dims
         dl = dloss.contiguous().float()
@@ -877,6 +891,7 @@ class LinearBnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, act, mask, xb):
         _need_gpu(x, weight, bias, gamma, beta, mask)
+        ctx.set_materialize_grads(False)  # no zero tensor for the (non-differentiable) bf16 twin in backward: one fill launch less
         lib = _lib.load()
         x2 = _rows2d(x)
         M, K = x2.shape
@@ -888,10 +903,19 @@ class LinearBnActFn(torch.autograd.Function):
         y = _new(M, N, like=x2) if mask is not None else a
         yb = torch.empty(M, N, device=x2.device, dtype=torch.bfloat16)
         mean, var = _new(N, like=x2), _new(N, like=x2)
-        _lib.check(lib.pk_linear_bn_act_bf16(_stream(), M, N, K, _p(xb), xb.shape[1], _p(wb), wb.shape[1], _p(bias), _p(gamma),
-                                             _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var),
-                                             ACT[act], _p(mask), _p(z), _p(a), _p(y) if mask is not None else None, _p(yb), N,
-                                             _p(mean), _p(var)), "pk_linear_bn_act_bf16")
+        sk = int(lib.pk_gemm_bf16_small_splitk(M, N, K)) if _SMALL_SPLITK else 1
+        if sk > 1:  # the product split along K over the whole chip, then the layer epilogue from the slabs
+            ws = torch.empty(sk * M * N, device=x2.device, dtype=torch.float32)
+            _lib.check(lib.pk_linear_bn_act_bf16_sk(_stream(), M, N, K, _p(xb), xb.shape[1], _p(wb), wb.shape[1], _p(bias),
+                                                    _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
+                                                    _p(running_var), ACT[act], _p(mask), _p(z), _p(a),
+                                                    _p(y) if mask is not None else None, _p(yb), N, _p(mean), _p(var), sk, _p(ws)),
+                       "pk_linear_bn_act_bf16_sk")
+        else:
+            _lib.check(lib.pk_linear_bn_act_bf16(_stream(), M, N, K, _p(xb), xb.shape[1], _p(wb), wb.shape[1], _p(bias), _p(gamma),
+                                                 _p(beta), float(eps), float(momentum), _p(running_mean), _p(running_var),
+                                                 ACT[act], _p(mask), _p(z), _p(a), _p(y) if mask is not None else None, _p(yb), N,
+                                                 _p(mean), _p(var)), "pk_linear_bn_act_bf16")
         if _Decisions.relu is not None and act == "relu":  # test mode (see NormActDropFn)
             pat = _Decisions.relu.pop(0).to(a.device).reshape(M, N)
             _Decisions.report.append(("relu", int(((a > 0) != pat).sum()), M * N))
@@ -910,6 +934,8 @@ class LinearBnActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dyb):
         lib = _lib.load()
+        if dy is None:
+            return (None,) * 12
         xb, wb, z, gamma, mean, var, a, mask = ctx.saved_tensors
         eps, act = ctx.cfg
         M, N, K = ctx.dims

@@ -459,6 +459,16 @@ BF_GEMM_SHAPES = [
     (100, 1944, 264, 1, 1, 1),
     (77, 136, 3000, 1, 0, 1),
     (1024, 1024, 128, 0, 0, 1),
+    # round 4: the reduction of a small-batch product split over the grid (pk_gemm_bf16_small_splitk: output layers with 48
+    # / 1938 columns, their input gradient over K = 1938, a two-row batch), weight gradients over a short reduction on
+    # 64 x 64 tiles (ragged rows / columns / reduction)
+    (128, 48, 1024, 1, 1, 1),
+    (128, 1024, 1938, 1, 0, 1),
+    (2, 64, 512, 1, 1, 1),
+    (128, 3300, 1024, 1, 0, 1),
+    (1938, 1024, 128, 0, 0, 1),
+    (100, 72, 37, 0, 0, 1),
+    (1024, 3300, 128, 0, 0, 1),
 ]
 
 
@@ -775,3 +785,88 @@ def test_output_layers_on_one_input_share_their_input_gradient():
     for got, ref in zip(res[True], res[False]):
         assert rel_err(got, ref) < 1e-6
     assert rel_err(res[True][1], 2 * res[True][0]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,act,masked", [(128, 1024, 1024, "relu", True), (128, 1024, 440, "relu", True), (37, 200, 520, "tanh", False),
+                                             (2, 8, 128, "relu", False), (128, 1024, 3300, "relu", True)])
+def test_small_batch_layer_two_launch_form_matches_the_one_launch_form(M, N, K, act, masked):
+    """pk_linear_bn_act_bf16_sk (product split along K over the whole chip + layer epilogue from the slabs) against
+    pk_linear_bn_act_bf16 (one launch): same outputs up to the fp32 summation order of the split reduction."""
+    import importlib
+
+    _lib = importlib.import_module("pytorch-kaldi_amd._lib")
+    lib = _lib.load()
+    sk = int(lib.pk_gemm_bf16_small_splitk(M, N, K))
+    assert sk >= 2
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias, gamma, beta = torch.randn(N, generator=g).cuda(), (1 + 0.1 * torch.randn(N, generator=g)).cuda(), torch.randn(N, generator=g).cuda()
+    mask = ((torch.rand(M, N, generator=g) > 0.15).float() / 0.85).cuda() if masked else None
+    xb, wb = F_.cvt_bf16(x), F_.cvt_bf16(w)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    outs = []
+    for form in (0, 1):
+        z, a, y = (torch.empty(M, N).cuda() for _ in range(3))
+        yb = torch.empty(M, N, dtype=torch.bfloat16).cuda()
+        mean, var = torch.empty(N).cuda(), torch.empty(N).cuda()
+        rm, rv = torch.zeros(N).cuda(), torch.ones(N).cuda()
+        args = [st, M, N, K, p(xb), xb.shape[1], p(wb), wb.shape[1], p(bias), p(gamma), p(beta), 1e-5, 0.05, p(rm), p(rv), F_.ACT[act],
+                p(mask), p(z), p(a), p(y) if masked else None, p(yb), N, p(mean), p(var)]
+        if form == 0:
+            _lib.check(lib.pk_linear_bn_act_bf16(*args), "one launch")
+        else:
+            ws = torch.empty(sk * M * N).cuda()
+            _lib.check(lib.pk_linear_bn_act_bf16_sk(*args, sk, p(ws)), "two launches")
+        torch.cuda.synchronize()
+        outs.append((z, a, y if masked else a, yb.float(), mean, var, rm, rv))
+    for i, (u, v) in enumerate(zip(*outs)):
+        assert rel_err(v, u.double()) < (8e-3 if i == 3 else 2e-5), (i, rel_err(v, u.double()))
+    # and against the arithmetic itself (fp64, bf16-rounded operands)
+    zr = _bf_round(x.cpu()) @ _bf_round(w.cpu()).t() + bias.cpu().double()
+    mu, vr = zr.mean(0), zr.var(0, unbiased=False)
+    ar = (zr - mu) / (vr + 1e-5).sqrt() * gamma.cpu().double() + beta.cpu().double()
+    ar = ar.clamp_min(0) if act == "relu" else ar.tanh()
+    assert rel_err(outs[1][0], zr) < 2e-5 and rel_err(outs[1][1], ar) < 1e-4 and rel_err(outs[1][4], mu) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,act,masked", [(128, 1024, "relu", True), (37, 200, "tanh", False), (2, 8, "relu", False), (100, 50, "relu", True),
+                                           (128, 3300, "relu", True)])
+def test_bn_act_bwd_small_against_the_arithmetic(M, N, act, masked):
+    """pk_bn_act_bwd_small (activation / mask backward, both BatchNorm reductions, BatchNorm backward, bf16 operand, bias
+    gradient) against an fp64 evaluation of neural_networks.py:139-148 backwards; N = 50 takes the element-by-element path."""
+    import importlib
+
+    _lib = importlib.import_module("pytorch-kaldi_amd._lib")
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3 * M + N)
+    z = torch.randn(M, N, generator=g)
+    gamma = 1 + 0.1 * torch.randn(N, generator=g)
+    mean, var = z.double().mean(0), z.double().var(0, unbiased=False)
+    xh = (z.double() - mean) / (var + 1e-5).sqrt()
+    pre = xh * gamma.double() + 0.3
+    a = pre.clamp_min(0) if act == "relu" else pre.tanh()
+    mask = ((torch.rand(M, N, generator=g) > 0.15).float() / 0.85) if masked else None
+    dy = torch.randn(M, N, generator=g)
+    gg = dy.double() * (mask.double() if masked else 1.0) * ((a > 0).double() if act == "relu" else 1 - a * a)
+    sg, sgx = gg.sum(0), (gg * xh).sum(0)
+    dz = gamma.double() / (var + 1e-5).sqrt() * (gg - sg / M - xh * sgx / M)
+    ldb = (N + 63) // 64 * 64
+    dev = lambda t: None if t is None else t.float().cuda()
+    zc, ac, mc, dyc, gc, mnc, vrc = dev(z), dev(a), dev(mask), dev(dy), dev(gamma), dev(mean), dev(var)
+    dzb = torch.full((M, ldb), 7.0, dtype=torch.bfloat16).cuda()
+    dzf, s_g, s_gx, db = torch.empty(M, N).cuda(), torch.empty(N).cuda(), torch.empty(N).cuda(), torch.empty(N).cuda()
+    accb, accg, accbias = torch.ones(N).cuda(), torch.ones(N).cuda(), torch.ones(N).cuda()
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.pk_bn_act_bwd_small(st, p(dyc), p(ac), p(mc), F_.ACT[act], p(zc), p(mnc), p(vrc), 1e-5, p(gc), M, N, p(dzb), ldb,
+                                       p(dzf), p(s_g), p(s_gx), p(accb), p(accg), p(db), p(accbias)), "pk_bn_act_bwd_small")
+    torch.cuda.synchronize()
+    assert rel_err(dzf, dz) < 2e-5 and rel_err(dzb[:, :N].float(), dz) < 6e-3
+    assert float(dzb[:, N:].float().abs().max()) == 0.0 if ldb > N else True
+    assert rel_err(s_g, sg) < 2e-5 and rel_err(s_gx, sgx) < 2e-5
+    assert rel_err(accb - 1, sg) < 2e-5 and rel_err(accg - 1, sgx) < 2e-5
+    assert float((db - dzf.sum(0)).abs().max()) < 1e-4 * float(dzf.abs().max()) * M and float((accbias - 1 - db).abs().max()) < 1e-5

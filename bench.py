@@ -104,6 +104,8 @@ class Trainer:
             flats = None
         else:
             self.opts = self.OPT.fused_optimizer_init(self.nns, rcp["cfg"], rcp["arch_dict"])
+            for o in self.opts.values():
+                o.zero_in_step = True  # (as core.run_nn_dp sets it: zero_grad() runs in front of every backward pass)
             flats = {k: o.flat for k, o in self.opts.items()}
         # 8 MB buckets: the recurrent stack's 31.7 MB of gradients leave in 4 pieces while BPTT of the lower layers runs
         self.reducer = self.DP.GradReducer(self.nns, flats=flats, bucket_bytes=8 << 20, overlap=args.overlap,

@@ -349,6 +349,15 @@ int pk_sgd_step(void* stream, float* p, const float* g, float* momentum_buf, int
 /* torch.optim.Adam as utils.py:2130-2146 builds it; step counts from 1; max_exp_avg_sq NULL unless amsgrad. */
 int pk_adam_step(void* stream, float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
                  int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step);
+/* The same three steps (kind: 0 RMSprop - h0 alpha, h1 eps; 1 SGD - h0 momentum, s0 its buffer or NULL; 2 Adam - h0 / h1 betas,
+ * h2 eps, s0 / s1 moments, s2 amsgrad maximum or NULL; step counts from 1) on a flat bucket whose length and pointers are
+ * multiples of 4 elements, with two things done on the way out: zero_grad != 0 leaves g zeroed (the zero_grad() of the next
+ * step has nothing left to do), and the bf16 copies of the 2-D weights that the perf-mode GEMMs read are refreshed - segs
+ * (device, [nseg][5] int64, ascending: first element in the bucket, rows, columns (multiple of 4), pitch of the copy, first
+ * element of the copy in `shadow`), or NULL / 0. */
+int pk_fused_step(void* stream, int kind, float* p, float* g, float* s0, float* s1, float* s2, int64_t n, float lr, float h0,
+                  float h1, float h2, float weight_decay, int step, int zero_grad, const int64_t* segs, int nseg,
+                  uint16_t* shadow);
 
 /* persistent-recurrence health: number of spin time-outs since the last reset
  * (host-mapped counter, readable without a device sync). */

@@ -114,6 +114,7 @@ SIGNATURES = {
     "pk_rmsprop_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_float]),
     "pk_sgd_step": (c_int, [P, P, P, P, c_int64, c_float, c_float, c_float, c_int]),
     "pk_adam_step": (c_int, [P, P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int]),
+    "pk_fused_step": (c_int, [P, c_int, P, P, P, P, P, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_int, P, c_int, P]),
     "pk_persist_error_count": (ctypes.c_uint, []),
     "pk_persist_error_reset": (None, []),
     "pk_linear_bn_act_bf16_covers": (c_int, [c_int64, c_int64, c_int64]),

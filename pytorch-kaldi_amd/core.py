@@ -261,6 +261,8 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
     inp_out_dict = fea_dict
     nns, costs = model_init(inp_out_dict, model, config, arch_dict, use_cuda, False, to_do)
     optimizers = fused_optimizer_init(nns, config, arch_dict)
+    for o_ in optimizers.values():
+        o_.zero_in_step = True  # this loop zeroes the gradients in front of every backward pass and never reads them behind step()
     for net in nns.keys():
         pt_file_arch = config[arch_dict[net][0]]["arch_pretrain_file"]
         if pt_file_arch != "none":

@@ -258,10 +258,32 @@ def _up(n, m):
     return (n + m - 1) // m * m
 
 
-def cvt_bf16(x2, nseg=1, seglen=None, segpad=None):
+def weight_bf16(w):
+    """The bf16 copy of a 2-D weight at the plain pitch (what cvt_bf16(w) gives).  A weight that lives in an
+    optim.FlatParams buffer gets a PERSISTENT copy which the fused optimizer step refreshes on its way out
+    (pk_fused_step): the per-layer conversion launch of every step is gone.  The copy is trusted only while the weight's
+    version counter stands where it stood when the copy was made (the fused step writes through raw pointers and does not
+    move it; load_state_dict / any torch in-place op does, and the copy is then redone)."""
+    sh = getattr(w, "_pk_shadow", None)
+    if sh is not None:
+        view, version, alive = sh
+        if alive() is not None:
+            if w._version == version:
+                return view
+            cvt_bf16(w.detach(), out=view)  # somebody rewrote the weight through torch: resynchronise
+            w._pk_shadow = (view, w._version, alive)
+            return view
+    owner = getattr(w, "_pk_owner", None)
+    owner = owner() if owner is not None else None
+    if owner is not None and w.is_contiguous():
+        owner.want_shadow(w)  # from the next optimizer step on
+    return cvt_bf16(w.contiguous())
+
+
+def cvt_bf16(x2, nseg=1, seglen=None, segpad=None, out=None):
     """fp32 [rows, cols] (unit column stride) -> bf16 [rows, pitch]; the columns are `nseg` segments of
     `seglen`, each placed at a pitch of `segpad` (multiple of 8 so that every segment starts 16-byte
-    aligned); padding is zero.  pitch = nseg*segpad rounded up to 64."""
+    aligned); padding is zero.  pitch = nseg*segpad rounded up to 64.  out: write into this [rows, pitch] bf16 tensor."""
     lib = _lib.load()
     rows, cols = x2.shape
     if seglen is None:
@@ -270,7 +292,9 @@ def cvt_bf16(x2, nseg=1, seglen=None, segpad=None):
         segpad = _up(seglen, 8)
     assert nseg * seglen == cols and x2.stride(1) == 1
     pitch = _up(nseg * segpad, 64)
-    out = torch.empty(rows, pitch, device=x2.device, dtype=torch.bfloat16)
+    if out is None:
+        out = torch.empty(rows, pitch, device=x2.device, dtype=torch.bfloat16)
+    assert tuple(out.shape) == (rows, pitch) and out.dtype == torch.bfloat16 and out.is_contiguous()
     _lib.check(lib.pk_cvt_bf16(_stream(), _p(x2), x2.stride(0), rows, nseg, seglen, segpad, _p(out), pitch),
                "pk_cvt_bf16")
     return out
@@ -660,7 +684,7 @@ def linear_log_softmax(x, weight, bias=None):
         w = weight.contiguous()
         x2 = _rows2d(x)
         tw = input_twin(x2)
-        wb_plain = cvt_bf16(w)
+        wb_plain = weight_bf16(weight)
         if tw is None:
             xb, xseg, wb = _cvt_bf16_shared(x2), None, wb_plain
         elif tw[1][0] == 1 and tw[0].shape[1] == wb_plain.shape[1]:
@@ -896,7 +920,7 @@ class LinearBnActFn(torch.autograd.Function):
         x2 = _rows2d(x)
         M, K = x2.shape
         N = weight.shape[0]
-        wb = cvt_bf16(weight.contiguous())
+        wb = weight_bf16(weight)
         if xb is None:
             xb = cvt_bf16(x2)
         z, a = _new(M, N, like=x2), _new(M, N, like=x2)

@@ -17,8 +17,8 @@ would still move them - and ``state_dict()`` has no entry for them, exactly like
 torch's "skip grad=None".
 """
 import ctypes
-
 import os
+import weakref
 
 import torch
 
@@ -77,11 +77,50 @@ class FlatParams:
                 p.data = self.flat[o:o + n].view(p.shape)
                 p.grad = self.grad[o:o + n].view(p.shape)
                 p._pk_flat = True  # functional.side_targets_ok: weight gradients may accumulate here from a side stream
+                p._pk_owner = weakref.ref(self)  # functional.weight_bf16: who keeps this weight's bf16 copy fresh
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._clean = False      # the gradient buffer is known to be all zeros (the fused step zeroed it on its way out)
+        self._shadow_req = set() # parameters whose bf16 copy the perf-mode GEMMs asked for (functional.weight_bf16)
+        self._shadow_have = ()   # ... the ones a copy exists for, in buffer order
+        self.shadow = self.shadow_segs = None
+
+    # ---- bf16 copies of 2-D weights, refreshed by the fused optimizer step itself (pk_fused_step) -------------------
+    def want_shadow(self, p):
+        i = self._index.get(id(p))
+        if i is not None and not self.unused[i] and p.dim() == 2 and p.shape[1] % 4 == 0 and p.is_cuda:
+            self._shadow_req.add(i)
+
+    def build_shadows(self):
+        """(Re)build the copies for everything asked for so far: one bf16 buffer, a weight's rows at a pitch of its
+        columns rounded up to 64 (what functional.cvt_bf16 gives), weights in buffer order back to back; pad columns
+        stay zero.  Allocates: call outside a HIP-graph capture (FusedOptimizer.step does, in the eager warm-up steps)."""
+        from . import functional as F_
+        want = tuple(sorted(self._shadow_req, key=lambda i: self.offsets[i]))
+        if want == self._shadow_have:
+            return
+        rows = []
+        soff = 0
+        for i in want:
+            p = self.params[i]
+            pitch = (p.shape[1] + 63) // 64 * 64
+            rows.append((self.offsets[i], p.shape[0], p.shape[1], pitch, soff))
+            soff += p.shape[0] * pitch
+        self.shadow = torch.zeros(max(soff, 8), device=self.flat.device, dtype=torch.bfloat16)
+        self.shadow_segs = torch.tensor(rows, dtype=torch.int64, device=self.flat.device).reshape(-1, 5)
+        self._shadow_have = want
+        for i, (_o, r, c, pitch, so) in zip(want, rows):
+            p = self.params[i]
+            view = self.shadow[so:so + r * pitch].view(r, pitch)
+            F_.cvt_bf16(p.detach(), out=view)
+            p._pk_shadow = (view, p._version, weakref.ref(self.shadow))
 
     def zero_grad(self):
         from .functional import join_side
         join_side()
-        self.grad.zero_()
+        if self._clean:
+            self._clean = False  # (whatever comes next may write gradients)
+        else:
+            self.grad.zero_()
         for p, o in zip(self.params, self.offsets):  # keep .grad aliased to the flat buffer
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
@@ -120,6 +159,10 @@ class FusedOptimizer:
                 self.bufs["max_exp_avg_sq"] = z()
         self.steps = 0
         self.param_groups = [{"lr": lr}]  # run_nn overrides the LR through param_groups (core.py:533-535)
+        # True: step() leaves the flat gradient zeroed (and the following zero_grad() skips its fill launch).  For loops
+        # that call zero_grad() in front of every backward pass anyway - core.run_nn_dp, bench.py - and never read .grad
+        # behind step(); off by default (torch.optim leaves .grad alone).  PK_OPT_ZERO_IN_STEP=0 turns it off everywhere.
+        self.zero_in_step = False
 
     @property
     def state(self):  # the (first) flat state buffer; kept for callers that only need "the" state
@@ -137,6 +180,24 @@ class FusedOptimizer:
         lr = float(self.param_groups[0]["lr"])
         f = self.flat
         ptr = lambda k: self.bufs[k].data_ptr() if k in self.bufs else None
+        if f.n_active % 4 == 0 and os.environ.get("PK_FUSED_STEP", "1") != "0":
+            # one launch that also zeroes the gradient (zero_in_step) and refreshes the bf16 copies of the weights
+            if f._shadow_req and not torch.cuda.is_current_stream_capturing():
+                f.build_shadows()
+            nseg = len(f._shadow_have)
+            zero = bool(self.zero_in_step) and os.environ.get("PK_OPT_ZERO_IN_STEP", "1") != "0"
+            kind = {"rmsprop": 0, "sgd": 1, "adam": 2}[self.kind]
+            h = {"rmsprop": (self.alpha, self.eps, 0.0), "sgd": (self.momentum, 0.0, 0.0),
+                 "adam": (self.betas[0], self.betas[1], self.eps)}[self.kind]
+            s0 = ptr("square_avg") if kind == 0 else ptr("momentum_buffer") if kind == 1 else ptr("exp_avg")
+            rc = lib.pk_fused_step(_stream(), kind, f.flat.data_ptr(), f.grad.data_ptr(), s0, ptr("exp_avg_sq"),
+                                   ptr("max_exp_avg_sq"), f.n_active, lr, h[0], h[1], h[2], self.weight_decay, self.steps + 1,
+                                   int(zero), f.shadow_segs.data_ptr() if nseg else None, nseg,
+                                   f.shadow.data_ptr() if nseg else None)
+            _lib.check(rc, "fused optimizer step")
+            f._clean = zero
+            self.steps += 1
+            return
         if self.kind == "rmsprop":
             rc = lib.pk_rmsprop_step(_stream(), f.flat.data_ptr(), f.grad.data_ptr(), ptr("square_avg"), f.n_active, lr,
                                      self.alpha, self.eps, self.weight_decay)

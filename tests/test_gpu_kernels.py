@@ -865,8 +865,83 @@ def test_bn_act_bwd_small_against_the_arithmetic(M, N, act, masked):
     _lib.check(lib.pk_bn_act_bwd_small(st, p(dyc), p(ac), p(mc), F_.ACT[act], p(zc), p(mnc), p(vrc), 1e-5, p(gc), M, N, p(dzb), ldb,
                                        p(dzf), p(s_g), p(s_gx), p(accb), p(accg), p(db), p(accbias)), "pk_bn_act_bwd_small")
     torch.cuda.synchronize()
-    assert rel_err(dzf, dz) < 2e-5 and rel_err(dzb[:, :N].float(), dz) < 6e-3
+    tol = 2e-5 if M > 2 else 1e-4  # (two rows: xhat = +-1 up to eps, the backward cancels to rounding level)
+    assert rel_err(dzf, dz) < tol and rel_err(dzb[:, :N].float(), dz) < 6e-3
     assert float(dzb[:, N:].float().abs().max()) == 0.0 if ldb > N else True
     assert rel_err(s_g, sg) < 2e-5 and rel_err(s_gx, sgx) < 2e-5
     assert rel_err(accb - 1, sg) < 2e-5 and rel_err(accg - 1, sgx) < 2e-5
     assert float((db - dzf.sum(0)).abs().max()) < 1e-4 * float(dzf.abs().max()) * M and float((accbias - 1 - db).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_fused_step_matches_torch_zeroes_the_gradient_and_refreshes_the_bf16_copies():
+    """pk_fused_step (round 4) against torch.optim for the three optimizers, with its two side jobs: the gradient is zero
+    afterwards, and the bf16 copies of the 2-D weights named in the segment table equal bf16(new weights) at their pitch
+    (pad columns stay zero, everything outside the named weights stays untouched)."""
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(14)
+    n = 64 * 300
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) for _ in range(3)]
+    # two "weights" inside the bucket: [40 x 100] at element 128 (pitch 128) and [7 x 64] at element 6400 (pitch 64)
+    segs = torch.tensor([[128, 40, 100, 128, 0], [6400, 7, 64, 64, 40 * 128]], dtype=torch.int64).cuda()
+    for kind, mk in ((0, lambda q: torch.optim.RMSprop([q], lr=4e-4, alpha=0.95, eps=1e-8, weight_decay=1e-4)),
+                     (1, lambda q: torch.optim.SGD([q], lr=0.08, momentum=0.9, weight_decay=1e-4)),
+                     (2, lambda q: torch.optim.Adam([q], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, amsgrad=True))):
+        pr = p0.clone().requires_grad_(True)
+        opt = mk(pr)
+        pe = p0.clone().cuda()
+        s0, s1, s2 = (torch.zeros(n).cuda() for _ in range(3))
+        shadow = torch.zeros(40 * 128 + 7 * 64 + 64, dtype=torch.bfloat16).cuda()
+        shadow[-64:] = 3.0
+        h = [(0.95, 1e-8, 0.0), (0.9, 0.0, 0.0), (0.9, 0.999, 1e-8)][kind]
+        for i, gr in enumerate(grads):
+            pr.grad = gr.clone()
+            opt.step()
+            ge = gr.cuda()
+            _lib.check(lib.pk_fused_step(st, kind, pe.data_ptr(), ge.data_ptr(), s0.data_ptr(), s1.data_ptr(), s2.data_ptr(), n,
+                                         [4e-4, 0.08, 1e-3][kind], h[0], h[1], h[2], 1e-4, i + 1, int(i != 1), segs.data_ptr(), 2,
+                                         shadow.data_ptr()), "fused step")
+            torch.cuda.synchronize()
+            assert float(ge.abs().max()) == (0.0 if i != 1 else float(gr.abs().max()))
+        assert rel_err(pe, pr) < 1e-6
+        w1 = pe[128:128 + 4000].view(40, 100)
+        c1 = shadow[:40 * 128].view(40, 128)
+        assert torch.equal(c1[:, :100], w1.to(torch.bfloat16)) and float(c1[:, 100:].float().abs().max()) == 0.0
+        w2 = pe[6400:6400 + 448].view(7, 64)
+        assert torch.equal(shadow[40 * 128:40 * 128 + 448].view(7, 64), w2.to(torch.bfloat16))
+        assert float((shadow[-64:].float() - 3.0).abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_weight_copies_kept_by_the_optimizer_follow_every_way_a_weight_changes():
+    """functional.weight_bf16: after the first optimizer step a flat 2-D weight has a persistent bf16 copy; it equals
+    bf16(weight) after fused steps (raw-pointer writes), after a torch in-place change (version counter) and after
+    load_state_dict."""
+    optim_ = importlib.import_module("pytorch-kaldi_amd.optim")
+    lin = torch.nn.Linear(100, 40).cuda()
+    flat = optim_.FlatParams(lin)
+    opt = optim_.FusedOptimizer(flat, "sgd", 0.1)
+    opt.zero_in_step = True
+    w = lin.weight
+    first = F_.weight_bf16(w)          # no copy yet: a fresh conversion, and the request is noted
+    assert getattr(w, "_pk_shadow", None) is None
+    for step in range(3):
+        opt.zero_grad()
+        w.grad.add_(torch.randn_like(w))
+        opt.step()
+        torch.cuda.synchronize()
+        assert float(flat.grad.abs().max()) == 0.0
+        view = F_.weight_bf16(w)
+        assert view.data_ptr() == w._pk_shadow[0].data_ptr() and view.shape == (40, 128)
+        assert torch.equal(view[:, :100], w.detach().to(torch.bfloat16)) and float(view[:, 100:].float().abs().max()) == 0.0
+    assert not torch.equal(first[:, :100], view[:, :100])
+    with torch.no_grad():
+        w.mul_(0.5)
+    assert torch.equal(F_.weight_bf16(w)[:, :100], w.detach().to(torch.bfloat16))
+    sd = {k: v.clone() + 1.0 for k, v in lin.state_dict().items()}
+    lin.load_state_dict(sd)
+    assert torch.equal(F_.weight_bf16(w)[:, :100], w.detach().to(torch.bfloat16))
+    opt.zero_grad()                       # (the gradient was left clean by the last step: no fill, still zero)
+    assert float(flat.grad.abs().max()) == 0.0

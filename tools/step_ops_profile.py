@@ -45,8 +45,9 @@ for t, op, kern, dur, stack in rows:
     seen.add(key)
     n += 1
     stock = kern.startswith("void at::") or "rocclr" in kern or kern.startswith("at::")
-    count[(op, kern.split("(")[0][:70], stack)] += 1 if stock else 0
-    print("%3d %-34s %-70s %6.1f us  %s" % (n, op[:34], kern.split("(")[0][:70], dur, stack))
+    short = kern.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
+    count[(op, short, stack)] += 1 if stock else 0
+    print("%3d %-34s %-70s %6.1f us  %s" % (n, op[:34], short, dur, stack))
 print("\n---- stock torch launches by (op, kernel, frames)")
 for (op, kern, stack), c in count.most_common():
     if c:

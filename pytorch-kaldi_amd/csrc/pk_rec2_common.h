@@ -46,7 +46,7 @@ struct R2Args {
     float ln_eps;
     float* lnh;      // pre-LN h_t, same layout as Y ([T][B][YH], storage time)
     float* lnstat;   // [T][R][2]: mean, 1 / (std + eps) of (step t, row n)
-    float* lnx;      // row-statistics exchange [T][ln_ncg][4 row quads][4 * Pn slots][8 floats], 0xFF-filled before the launch
+    float* lnx;      // row-statistics exchange [T + 1][ln_ncg][4 row quads][4 * Pn slots][8 floats], 0xFF-filled before the launch
     float* lnpart;   // backward: [2][ln_ncg][KPAD] per-cluster partial sums of d gamma, d beta
     int ln_cg0;      // global index of this launch's first cluster
     int ln_ncg;      // clusters over all launches
@@ -250,7 +250,7 @@ __device__ __forceinline__ LnSlots ln_slots(const R2Args& a, int c, int p, int w
     LnSlots s;
     const unsigned nslot = 4u * (unsigned)a.Pn, kq = (unsigned)lane >> 4, u = (unsigned)lane & 15u;
     s.slab = (unsigned)a.ln_ncg * 4u * nslot * 32u;
-    s.size = (unsigned)T * s.slab;
+    s.size = (unsigned)(T + 1) * s.slab;  // (slab T: the first step's extra exchange, forward kernels)
     const unsigned base = (((unsigned)(a.ln_cg0 + c) * 4u + kq) * nslot) * 32u;
     s.pub_ok = u == 0u;
     s.pub = base + ((unsigned)p * 4u + (unsigned)wave) * 32u;

@@ -287,6 +287,23 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
             if (!LN) patchB[(kq * 4 + r) * 16 + (lane & 15)] = to_bf_pub(h);
         }
         if (LN) {
+            if (t == 0) {
+                // first step: there is no previous mean to pivot the one-pass variance on (a pivot of 0 costs eps * (mean /
+                // std)^2 of relative accuracy) - one more exchange, this step only, gives the row's own mean first: the
+                // reference's two-pass form (neural_networks.py:23-33).  It uses the extra slab behind the T step slabs.
+                float ma[4], mb[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ma[r] = rvf[r] != 0.f ? hv[r] : 0.f;
+                    mb[r] = 0.f;
+                }
+                unsigned po0[3];
+                ls.poll_at(T, po0);
+                dead = fast ? ln_row_allreduce<true>(rsx, ls.pub_at(T), po0, ma, mb, a.err, a.spin_limit, lane, dead)
+                            : ln_row_allreduce<false>(rsx, ls.pub_at(T), po0, ma, mb, a.err, a.spin_limit, lane, dead);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) piv[r] = ma[r] * invH;
+            }
             float la[4], lb[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -738,7 +755,7 @@ extern "C" int64_t pk_rec_ln_saved_floats(int T, int B, int bidir, int H) {
     const int64_t step = (int64_t)T * R * (H + 2);                           // step-wise algorithm: [mean, rinv, pre-LN h] rows
     return pers > step ? pers : step;
 }
-static int64_t ln_exchange_floats(int T, const Plan2& pl) { return (int64_t)T * pl.launches * pl.C * 4 * (4 * pl.Pn) * 8; }
+static int64_t ln_exchange_floats(int T, const Plan2& pl) { return (int64_t)(T + 1) * pl.launches * pl.C * 4 * (4 * pl.Pn) * 8; }
 extern "C" int64_t pk_rec_ln_work_floats(int T, int B, int bidir, int H) {
     Plan2 pl;
     if (T <= 0 || B <= 0 || H <= 0 || H > KPAD || pk_rec2_make_plan(B * (1 + bidir), H, pl) != 0) return 0;

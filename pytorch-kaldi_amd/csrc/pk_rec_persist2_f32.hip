@@ -234,6 +234,23 @@ __global__ __launch_bounds__(256, 1) void rec2f_fwd_kernel(R2Args a) {
         }
         if (LN) {
             // h_t = gamma * (x - mean) / (std + eps) + beta over the row's H units, unbiased std (neural_networks.py:23-33)
+            if (t == 0) {
+                // first step: there is no previous mean to pivot the one-pass variance on (a pivot of 0 costs eps * (mean /
+                // std)^2 of relative accuracy) - one more exchange, this step only, gives the row's own mean first: the
+                // reference's two-pass form (neural_networks.py:23-33).  It uses the extra slab behind the T step slabs.
+                float ma[4], mb[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ma[r] = rvf[r] != 0.f ? hv[r] : 0.f;
+                    mb[r] = 0.f;
+                }
+                unsigned po0[3];
+                ls.poll_at(T, po0);
+                dead = fast ? ln_row_allreduce<true>(rsx, ls.pub_at(T), po0, ma, mb, a.err, a.spin_limit, lane, dead)
+                            : ln_row_allreduce<false>(rsx, ls.pub_at(T), po0, ma, mb, a.err, a.spin_limit, lane, dead);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) piv[r] = ma[r] * invH;
+            }
             float la[4], lb[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -191,10 +191,10 @@ int pk_logsoftmax_bwd_bf16(void* stream, const float* dy, const float* y, int64_
  * in one pass over the log-posteriors y [rows][N], N <= 2048, labels int64 on the device.
  * out4 (device) = { mean of -y[r][lab[r]] over the rows whose label is not ignore_index, error rate over all rows,
  * number of counted rows, number of labels outside [0, N) (the caller raises on it) }.
- * partial: pk_nll_err_partial_floats(rows) floats. */
+ * partial: pk_nll_err_partial_floats(rows) floats.  * loss_out (NULL or one float): a second copy of out4[0]; bad_acc (NULL or one float): += out4[3] in place. */
 int64_t pk_nll_err_partial_floats(int64_t rows);
 int pk_nll_err_fwd(void* stream, const float* y, const int64_t* lab, int64_t ignore_index, int64_t rows, int64_t N,
-                   float* partial, float* out4);
+                   float* partial, float* out4, float* loss_out, float* bad_acc);
 /* ... and its backward joined with the LogSoftmax backward: the one-hot gradient of the mean NLL is never written;
  * dz = (dloss / count) * (exp(y) - onehot(lab)) as bf16 plus its column sums.  dloss, count: device scalars. */
 int pk_nll_logsoftmax_bwd_bf16(void* stream, const float* y, const int64_t* lab, const float* dloss, const float* count,

@@ -623,8 +623,11 @@ __global__ __launch_bounds__(256) void nll_err_partial_kernel(const float* __res
 }
 
 // out[0] = mean loss over the counted rows, out[1] = error rate over all rows, out[2] = counted rows, out[3] = bad labels
+// loss_out (null or one float): a second copy of the loss (the differentiable output of functional.HeadNllFn: no device
+// copy launch for it); bad_acc (null or one float): += the bad labels, in place (the chunk's persistent counter).
 __global__ __launch_bounds__(256) void nll_err_final_kernel(const float* __restrict__ partial, long nw, long rows,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, float* __restrict__ loss_out,
+                                                             float* __restrict__ bad_acc) {
     __shared__ float sh[4][4];
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     for (long w = threadIdx.x; w < nw; w += 256) {
@@ -649,6 +652,8 @@ __global__ __launch_bounds__(256) void nll_err_final_kernel(const float* __restr
         out[1] = t[1] / (float)rows;
         out[2] = t[2];
         out[3] = t[3];
+        if (loss_out != nullptr) loss_out[0] = out[0];
+        if (bad_acc != nullptr) bad_acc[0] += t[3];
     }
 }
 
@@ -1075,7 +1080,7 @@ static inline long nll_err_blocks(int64_t rows) {
 extern "C" int64_t pk_nll_err_partial_floats(int64_t rows) { return nll_err_blocks(rows) * 4 * 4; }
 
 extern "C" int pk_nll_err_fwd(void* stream, const float* y, const int64_t* lab, int64_t ignore_index, int64_t rows, int64_t N,
-                              float* partial, float* out4) {
+                              float* partial, float* out4, float* loss_out, float* bad_acc) {
     PK_REQUIRE(rows > 0 && N >= 1 && N <= 2048, "pk_nll_err_fwd: needs rows of 1..2048 columns");
     PK_REQUIRE(y && lab && partial && out4, "pk_nll_err_fwd: null argument");
     hipStream_t st = pk_stream(stream);
@@ -1087,7 +1092,7 @@ extern "C" int pk_nll_err_fwd(void* stream, const float* y, const int64_t* lab, 
     else if (N <= 1024) hipLaunchKernelGGL((nll_err_partial_kernel<16>), grid, dim3(256), 0, st, y, l, (long)ignore_index, (long)rows, (long)N, partial);
     else hipLaunchKernelGGL((nll_err_partial_kernel<32>), grid, dim3(256), 0, st, y, l, (long)ignore_index, (long)rows, (long)N, partial);
     PK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nll_err_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks * 4, (long)rows, out4);
+    hipLaunchKernelGGL(nll_err_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks * 4, (long)rows, out4, loss_out, bad_acc);
     PK_LAUNCH_CHECK();
     return 0;
 }

@@ -718,9 +718,12 @@ class HeadNllFn(torch.autograd.Function):
         M, N = y.shape
         lab = lab.contiguous()
         out4 = _new(4, like=y)
+        loss = torch.empty((), device=y.device, dtype=torch.float32)  # the differentiable output: written by the same launch
         part = _new(int(lib.pk_nll_err_partial_floats(M)), like=y)
-        _lib.check(lib.pk_nll_err_fwd(_stream(), _p(y), _p(lab), int(ignore_index), M, N, _p(part), _p(out4)),
-                   "pk_nll_err_fwd")
+        # bad labels are counted IN PLACE into the device's persistent counter by the same launch (HIP-graph safe; the loss
+        # of such a batch is NaN; the count is reported at the next point where the host waits for the GPU anyway)
+        _lib.check(lib.pk_nll_err_fwd(_stream(), _p(y), _p(lab), int(ignore_index), M, N, _p(part), _p(out4), _p(loss),
+                                      _p(label_check_counter(y.device))), "pk_nll_err_fwd")
         ctx.save_for_backward(xb, wb, y, lab, out4)
         ctx.dx_share = _dx_share_key(x) if (_DxShare.on and x.is_contiguous()) else None
         ctx.dims = (M, N, x.shape[-1])
@@ -729,7 +732,7 @@ class HeadNllFn(torch.autograd.Function):
         ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None
         ctx.ignore_index = int(ignore_index)
         ctx.mark_non_differentiable(out4)
-        return out4[0].clone(), out4
+        return loss, out4
 
     @staticmethod
     def backward(ctx, dloss, _d4):
@@ -780,8 +783,7 @@ def note_label_check(stats):
     """Accumulate the bad-label count of one head_nll call IN PLACE into the persistent device scalar (no host sync
     here; the loss of such a batch is NaN - pk_nll_err_fwd - and the count is reported at the next point where the host
     waits for the GPU anyway).  In place, so that a HIP-graph replay of the step keeps counting."""
-    with torch.no_grad():
-        label_check_counter(stats.device).add_(stats[3])
+    del stats  # (round 4: pk_nll_err_fwd accumulates the count itself - HeadNllFn passes the counter)
 
 
 def raise_if_bad_labels():

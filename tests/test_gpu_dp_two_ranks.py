@@ -111,7 +111,9 @@ def test_benchmarked_step_with_the_reducer_forced_on_for_50_steps(tmp_path):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PK_DP_TRACE="1" if mode == "forced" else "0")
         for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
-        cmd = [sys.executable, bench, "--steps", "50", "--warmup", "2", "--no-extras", "--no-cpu-baseline", "--dump-losses", out]
+        # (--prewarm-s 0: the time-based pre-warm would run a different number of steps in the two runs)
+            cmd = [sys.executable, bench, "--steps", "50", "--warmup", "2", "--prewarm-s", "0", "--no-extras", "--no-cpu-baseline",
+                   "--dump-losses", out]
         if mode == "forced":
             cmd.append("--force-reducer")
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)

@@ -410,6 +410,10 @@ int pk_selftest_permlane(void* stream, int* h_bad_count);
 /* the DPP row sum (quad_perm x2, row_half_mirror, row_mirror) of the per-step LayerNorm exchange in the persistent
  * recurrences: every lane of a 16-lane row must end with the row's total */
 int pk_selftest_dpp_row_sum(void* stream, int* h_bad_count);
+/* test aid: `blocks` workgroups (one per CU: 64 KB of LDS each) that copy a private 64 KB slice of buf (blocks x 16384
+ * floats) through LDS for `usec` microseconds on `stream` - a stand-in for a collective's ring kernel next to the persistent
+ * recurrences. */
+int pk_selftest_cu_hog(void* stream, int blocks, int usec, float* buf);
 
 /* ---- chunk loader pieces (next row): binary Kaldi matrix tables and the whole-chunk transforms
  * of data_io.load_chunk.  Host memory; plain files (the reference reads through Kaldi pipes, which stay outside).

@@ -126,6 +126,7 @@ SIGNATURES = {
     "pk_selftest_mfma": (c_int, [P, ctypes.POINTER(c_int)]),
     "pk_selftest_permlane": (c_int, [P, ctypes.POINTER(c_int)]),
     "pk_selftest_dpp_row_sum": (c_int, [P, ctypes.POINTER(c_int)]),
+    "pk_selftest_cu_hog": (c_int, [P, c_int, c_int, P]),
 }
 
 

@@ -170,3 +170,32 @@ extern "C" int pk_selftest_dpp_row_sum(void* stream, int* h_bad_count) {
     *h_bad_count = bad;
     return 0;
 }
+
+// A stand-in for a collective's ring kernel running next to the persistent recurrences (tests/test_gpu_dp_two_ranks.py:
+// the one multi-GPU hazard a single-GPU box can reproduce - somebody else's long-running workgroups on CUs the clusters
+// of a persistent launch would like to have): `blocks` workgroups, one per CU (64 KB of LDS each), copy their private
+// 64 KB slice of `buf` through LDS round and round until `usec` microseconds have passed (constant 100 MHz clock).
+namespace {
+__global__ __launch_bounds__(256) void cu_hog_kernel(float* buf, long ticks) {
+    __shared__ float lds[16384];
+    float* mine = buf + (long)blockIdx.x * 16384;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned rounds = 0;
+    while ((long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) {
+        for (int i = threadIdx.x; i < 16384; i += 256) lds[i] = mine[i] + 1.0f;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16384; i += 256) mine[i] = lds[(i + 64) & 16383];
+        __syncthreads();
+        ++rounds;
+    }
+    if (threadIdx.x == 0) mine[0] = (float)rounds;
+}
+}  // namespace
+
+extern "C" int pk_selftest_cu_hog(void* stream, int blocks, int usec, float* buf) {
+    PK_REQUIRE(blocks >= 1 && blocks <= 256 && usec >= 1 && usec <= 2000000 && buf != nullptr,
+               "pk_selftest_cu_hog: 1..256 workgroups, up to 2 s, a buffer of blocks x 16384 floats");
+    hipLaunchKernelGGL(cu_hog_kernel, dim3(blocks), dim3(256), 0, pk_stream(stream), buf, (long)usec * 100);
+    PK_LAUNCH_CHECK();
+    return 0;
+}

@@ -61,7 +61,7 @@ class GradReducer:
     not fire, e.g. parameters that received no gradient this step).
     """
 
-    def __init__(self, modules, bucket_bytes=32 << 20, flats=None, group=None, overlap=True, force=False):
+    def __init__(self, modules, bucket_bytes=32 << 20, flats=None, group=None, overlap=True, force=False, wire=None):
         """overlap=True (default): a bucket's all-reduce is launched as soon as every gradient in it has been produced,
         while BPTT of the lower layers still runs.  Gradients arrive two ways: through autograd (BatchNorm / bias
         gradients: post-accumulate-grad hooks) and - in perf mode - from the weight-gradient GEMMs that
@@ -69,7 +69,11 @@ class GradReducer:
         (functional.set_side_listener reports them).  The all-reduce is enqueued from the SIDE stream, behind those
         GEMMs, so the main stream (the backward dependency chain) never waits for a weight gradient.
         overlap=False: every bucket is reduced in finish(), after backward.  force: build buckets on one rank too
-        (tests: the whole path runs over a one-rank RCCL communicator)."""
+        (tests: the whole path runs over a one-rank RCCL communicator).
+        wire: "fp32" (default) or "bf16" (PK_DP_WIRE): the format a bucket travels in.  bf16 halves the payload of the
+        ring (26.8-62.5 MB per step and rank at the BASELINE configurations; xGMI is per-link bound): every
+        rank's share is rounded once (2^-9 relative) and the ring adds in bf16; the fp32 flat gradient is overwritten with
+        the widened sum.  Graded against the fp32 wire in tests/test_dp_gloo.py."""
         self.group = group
         self.overlap = overlap
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -82,6 +86,9 @@ class GradReducer:
         # PK_DP_TRACE=1: HIP events at every bucket's hand-over to the all-reduce and around finish(): timeline() then
         # says how far ahead of the end of backward each bucket left and how much of the exchange finish() still waited for
         self.trace = os.environ.get("PK_DP_TRACE", "0") == "1"
+        self.wire = wire or os.environ.get("PK_DP_WIRE", "fp32")
+        if self.wire not in ("fp32", "bf16"):
+            raise ValueError("GradReducer: wire format %r (fp32 or bf16)" % (self.wire,))
         self._ev = []
         self._timelines = []
         if self.world == 1 and not force:
@@ -194,13 +201,21 @@ class GradReducer:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self._mark(("bucket", b["idx"], buf.numel() * buf.element_size()), side)
-                buf.div_(self.world)
-                h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                h = self._reduce(b, buf)
         else:
             self._mark(("bucket", b["idx"], buf.numel() * buf.element_size()))
-            buf.div_(self.world)
-            h = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            h = self._reduce(b, buf)
         self.handles.append((h, b))
+
+    def _reduce(self, b, buf):
+        buf.div_(self.world)
+        if self.wire == "bf16":
+            w = buf.to(torch.bfloat16)
+            b["wire"] = (w, buf)
+            if w.is_cuda:
+                w.record_stream(torch.cuda.current_stream())
+            return dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Call after backward(): completes every bucket and re-arms for the next step."""
@@ -214,6 +229,9 @@ class GradReducer:
         join_side()  # the side stream's weight gradients (and the reductions enqueued behind them) before anything reads .grad
         for h, b in self.handles:
             h.wait()
+            if "wire" in b:  # the widened sum back into the fp32 bucket
+                w, buf = b.pop("wire")
+                buf.copy_(w)
             if b["flat"] is None:
                 buf, grads = b.pop("packed")
                 o = 0

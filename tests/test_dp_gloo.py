@@ -36,7 +36,7 @@ def _grouped(net):
     return net
 
 
-def _worker(rank, world, port, use_flat, bucket_bytes, out, overlap=True):
+def _worker(rank, world, port, use_flat, bucket_bytes, out, overlap=True, wire="fp32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     DP = importlib.import_module("pytorch-kaldi_amd.dp")
@@ -55,7 +55,7 @@ def _worker(rank, world, port, use_flat, bucket_bytes, out, overlap=True):
         for i in (0, 2, 4):
             assert off[id(net[i].bias)] == off[id(net[i].weight)] + net[i].weight.numel()
         assert off[id(net[0].weight)] < off[id(net[2].weight)] < off[id(net[4].weight)] < off[id(net.unused)] < f.n_active
-    red = DP.GradReducer({"net": net}, bucket_bytes=bucket_bytes, flats=flats, overlap=overlap)
+    red = DP.GradReducer({"net": net}, bucket_bytes=bucket_bytes, flats=flats, overlap=overlap, wire=wire)
     x, y = _batch()
     for step in range(2):  # two steps: buckets must re-arm
         if flats:
@@ -91,6 +91,28 @@ def test_two_rank_allreduce_equals_shard_average(tmp_path, use_flat, bucket_byte
     for k, v in ref.items():
         assert torch.allclose(got[k], v / world, rtol=1e-6, atol=1e-7), k
     assert got["unused"] is None or float(got["unused"].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("use_flat,overlap", [(True, True), (False, False), ("grouped", True)])
+def test_bf16_wire_is_the_fp32_exchange_up_to_bf16_rounding(tmp_path, use_flat, overlap):
+    """GradReducer(wire="bf16") (PK_DP_WIRE): the buckets travel as bf16 - every rank's share rounded once, the sum formed
+    in bf16 - and come back widened into the fp32 gradients.  Against the fp32 wire on the same two shards: within
+    2^-7 of each tensor's largest entry (the shares and their sum are rounded to 2^-9 relative each; a share can be larger than the
+    sum), and not bit-identical (the switch does something)."""
+    world = 2
+    outs = {}
+    for wire in ("fp32", "bf16"):
+        out = str(tmp_path / (wire + ".pt"))
+        mp.spawn(_worker, args=(world, _free_port(), use_flat, 128, out, overlap, wire), nprocs=world, join=True)
+        outs[wire] = torch.load(out)
+    differs = False
+    for k, v in outs["fp32"].items():
+        if v is None or float(v.abs().max()) == 0.0:
+            continue
+        d = float((outs["bf16"][k] - v).abs().max())
+        assert d <= 2.0 ** -7 * float(v.abs().max()), (k, d)
+        differs = differs or d > 0.0
+    assert differs
 
 
 def test_shard_batch_shapes():

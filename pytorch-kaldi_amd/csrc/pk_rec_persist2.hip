@@ -888,7 +888,7 @@ extern "C" int pk_rec_plan_cus(int R, int H) {
 extern "C" void pk_persist2_set_mode(int force_safe) { g2_force_safe = force_safe ? 1 : 0; }
 extern "C" void pk_persist2_set_poll_delay(int units) { g2_poll_delay = units; }  // < 0: back to the per-pass defaults
 extern "C" void pk_persist2_set_trace(void* dev_buf) { g2_trace = (unsigned long long*)dev_buf; }
-extern "C" void pk_persist2_set_empty_step(int on) { g2_empty_step = on ? 1 : 0; }
+extern "C" void pk_persist2_set_empty_step(int on) { g2_empty_step = on; }  // 1: no arithmetic; 2 (role-split kernels): no HBM traffic either
 extern "C" unsigned pk_persist2_error_count(void) { return g2_err_host ? *g2_err_host : 0u; }
 extern "C" void pk_persist2_error_reset(void) {
     if (g2_err_host) *g2_err_host = 0u;

@@ -483,12 +483,13 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_fwd_kernel(R2Args a) {
             if (T > 1) load_proj(pn1, 1);
             if (T > 2) load_proj(pn0, 2);
             PK_BARRIER_LDS();  // B(0)
+            const bool no_io = TR && a.empty_step == 2;  // diagnostics (EMPTY=2): no HBM traffic at all from this CU (results are garbage)
             auto iter = [&](int t, f32x4 (&pn)[4][G]) {  // while the compute waves work on step t; pn: the set of step t + 1
                 if (t + 1 < T) {
                     stage_proj(pn, (t + 1) & 1);  // (the loads are two steps old)
-                    if (t + 3 < T) load_proj(pn, t + 3);
+                    if (t + 3 < T && !no_io) load_proj(pn, t + 3);
                 }
-                if (t > 0) flush_outputs(t - 1);
+                if (t > 0 && !no_io) flush_outputs(t - 1);
                 if (TR && NP == 0 && a.trace != nullptr && blockIdx.x == 0 && lane == 0 && t + 1 < T)
                     a.trace[(long)(t + 1) * 8 + 7] = __builtin_amdgcn_s_memtime();  // my arrival at B(t + 1)
                 PK_BARRIER_LDS();  // B(t + 1)
@@ -829,10 +830,11 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_bwd_kernel(R2Args a) {
             if (T > 1) load_step(in1, T - 2);
             if (T > 2) load_step(in0, T - 3);
             PK_BARRIER_LDS();  // B(0)
+            const bool no_io = TR && a.empty_step == 2;  // diagnostics (EMPTY=2): no HBM traffic at all from this CU
             auto iter = [&](int it, f32x4 (&in)[4][NIN]) {  // while the compute waves work on iteration it; in: the set of iteration it + 1
                 if (it + 1 < T) {
                     stage_step(in, (it + 1) & 1);
-                    if (it + 3 < T) load_step(in, T - 1 - (it + 3));
+                    if (it + 3 < T && !no_io) load_step(in, T - 1 - (it + 3));
                 }
                 if (want_dp2 && it > 0) flush_gates(it - 1);
                 if (TR && NP == 0 && a.trace != nullptr && blockIdx.x == 0 && lane == 0 && it + 1 < T)

@@ -625,9 +625,9 @@ def test_head_nll_declines_what_it_does_not_cover():
         bad[2] = 7
         loss, stats = F_.head_nll(y, bad)
         assert bool(torch.isnan(loss))   # a label outside [0, classes) poisons the loss (torch: device-side assert) ...
-        F_.note_label_check(stats)
-        F_.note_label_check(stats)       # ... and is counted in place (a HIP-graph replay keeps counting)
-        assert float(F_.label_check_counter("cuda")) == 2.0
+        loss, stats = F_.head_nll(y, bad)  # ... and is counted in place by the same launch (a HIP-graph replay keeps counting)
+        F_.note_label_check(stats)         # (round 4: a no-op, kept for callers of the round-3 protocol)
+        assert float(F_.label_check_counter("cuda")) == 2.0 and float(stats[3]) == 1.0
         with pytest.raises(_lib.PkError):
             F_.raise_if_bad_labels()
         assert float(F_.label_check_counter("cuda")) == 0.0

@@ -842,7 +842,7 @@ int pk_rec2_host_setup(R2Args& a, bool backward, int cell) {
         static int fl = -1;
         if (fl < 0) {
             const char* e = getenv("PK_REC_FLUSH_LATE");
-            fl = (e && e[0] == '1') ? 1 : 0;
+            fl = e ? atoi(e) : 0;  // (third generation: 1 = late; role-split kernels: bit 0 no priorities, bit 1 nt stores, bit 2 nt loads)
         }
         a.flush_late = fl;
     }

@@ -63,9 +63,11 @@ __device__ __forceinline__ unsigned s_pack2(float x, float y) { return (unsigned
 
 // 16-byte access of the I/O wave: EDGY = false: no wave of this workgroup straddles H (straight-line code);
 // EDGY = true: the wave-uniform edge class e decides (0 = one 16-byte access, 1 = two 8-byte halves, 2 = element by element)
+// (nt: streaming cache policy for tensors that are read / written exactly once - PK_REC_FLUSH_LATE bit 1 = stores, bit 2 = loads)
 template <bool EDGY>
-__device__ __forceinline__ f32x4 s_ld4(const float* base, unsigned off, int nv, int e) {
+__device__ __forceinline__ f32x4 s_ld4(const float* base, unsigned off, int nv, int e, bool nt = false) {
     if constexpr (!EDGY) {
+        if (nt) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + (nv == 4 ? off : 0u)));
         return ld4<0>(base, off, nv);
     } else {
         if (e == 0) return ld4<0>(base, off, nv);
@@ -74,9 +76,10 @@ __device__ __forceinline__ f32x4 s_ld4(const float* base, unsigned off, int nv, 
     }
 }
 template <bool EDGY>
-__device__ __forceinline__ void s_st4(float* base, unsigned off, int nv, int e, float* trash, f32x4 v) {
+__device__ __forceinline__ void s_st4(float* base, unsigned off, int nv, int e, float* trash, f32x4 v, bool nt = false) {
     if constexpr (!EDGY) {
-        st4<0>(base, off, nv, trash, v);
+        if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(nv == 4 ? base + off : trash));
+        else st4<0>(base, off, nv, trash, v);
     } else {
         if (e == 0) st4<0>(base, off, nv, trash, v);
         else if (e == 1) st4<1>(base, off, nv, trash, v);
@@ -268,7 +271,7 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_fwd_kernel(R2Args a) {
         const bool fast_rt = __builtin_amdgcn_readfirstlane((int)(cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0)) != 0;
         auto run = [&](auto FASTC) {
             constexpr bool fast = decltype(FASTC)::value != 0;
-            if (a.flush_late == 0) __builtin_amdgcn_s_setprio(3);  // the helper wave on my SIMD takes the issue slots I leave (PK_REC_FLUSH_LATE=1: A/B)
+            if ((a.flush_late & 1) == 0) __builtin_amdgcn_s_setprio(3);  // the helper wave on my SIMD takes the issue slots I leave (PK_REC_FLUSH_LATE=1: A/B)
             for (int t = 0; t < T; ++t) {
                 const int step_idx = t;
                 PKS_TRACE_AT(0, 0);
@@ -289,7 +292,7 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_fwd_kernel(R2Args a) {
                 f32x4 acc[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const bool empty = TR && a.empty_step != 0;
+                const bool empty = TR && a.empty_step != 0 && a.empty_step < 6;  // (6, 7: full arithmetic, doctored I/O)
                 const bool mm = t > 0 && !empty;
                 const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
                 constexpr int PKD = 4;
@@ -446,12 +449,14 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_fwd_kernel(R2Args a) {
             // two register sets: the projections of even / odd steps, loaded TWO steps ahead of their use (an HBM load of
             // this access pattern can take longer than a whole step)
             f32x4 pn0[4][G], pn1[4][G];
+            const bool nt_st = (a.flush_late & 2) != 0, nt_ld = (a.flush_late & 4) != 0;
             auto load_proj = [&](f32x4 (&pn)[4][G], int tt) {
+                if (TR && a.empty_step >= 5) tt = tt & 3;  // diagnostics: the same few rows again and again (cache hits)
                 const unsigned ts = (unsigned)(adir ? (T - 1 - tt) : tt);
 #pragma unroll
                 for (int w = 0; w < 4; ++w)
 #pragma unroll
-                    for (int g = 0; g < G; ++g) pn[w][g] = s_ld4<EDGY>(a.P, vP0 + ts * vPs + g * H + w * 16, anv[w], edge[w]);
+                    for (int g = 0; g < G; ++g) pn[w][g] = s_ld4<EDGY>(a.P, vP0 + ts * vPs + g * H + w * 16, anv[w], edge[w], nt_ld);
             };
             auto stage_proj = [&](const f32x4 (&pn)[4][G], int slot) {  // BatchNorm affine folded into the projection on the way: p * scale + shift
                 float* const d = pslots + slot * PSLOT + aoff;
@@ -473,9 +478,9 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_fwd_kernel(R2Args a) {
                     f32x4 v[NOUT];
 #pragma unroll
                     for (int k = 0; k < NOUT; ++k) v[k] = *reinterpret_cast<const f32x4*>(sl + (w * NOUT + k) * S_PATCH_F);
-                    s_st4<EDGY>(a.Y, vY0 + ts * vYs + w * 16, anv[w], edge[w], trash, v[0]);
+                    s_st4<EDGY>(a.Y, vY0 + ts * vYs + w * 16, anv[w], edge[w], trash, v[0], nt_st);
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) s_st4<EDGY>(a.S, vS0 + ts * vSs + k * H + w * 16, anv[w], edge[w], trash, v[1 + k]);
+                    for (int k = 0; k < NS; ++k) s_st4<EDGY>(a.S, vS0 + ts * vSs + k * H + w * 16, anv[w], edge[w], trash, v[1 + k], nt_st);
                 }
             };
             load_proj(pn0, 0);
@@ -483,13 +488,14 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_fwd_kernel(R2Args a) {
             if (T > 1) load_proj(pn1, 1);
             if (T > 2) load_proj(pn0, 2);
             PK_BARRIER_LDS();  // B(0)
-            const bool no_io = TR && a.empty_step == 2;  // diagnostics (EMPTY=2): no HBM traffic at all from this CU (results are garbage)
+            // diagnostics (results are garbage): EMPTY=2 no HBM traffic at all from this CU, 3 = loads only, 4 = stores only
+            const bool no_ld = TR && (a.empty_step == 2 || a.empty_step == 4), no_st = TR && (a.empty_step == 2 || a.empty_step == 3 || a.empty_step == 7);
             auto iter = [&](int t, f32x4 (&pn)[4][G]) {  // while the compute waves work on step t; pn: the set of step t + 1
                 if (t + 1 < T) {
                     stage_proj(pn, (t + 1) & 1);  // (the loads are two steps old)
-                    if (t + 3 < T && !no_io) load_proj(pn, t + 3);
+                    if (t + 3 < T && !no_ld) load_proj(pn, t + 3);
                 }
-                if (t > 0 && !no_io) flush_outputs(t - 1);
+                if (t > 0 && !no_st) flush_outputs(t - 1);
                 if (TR && NP == 0 && a.trace != nullptr && blockIdx.x == 0 && lane == 0 && t + 1 < T)
                     a.trace[(long)(t + 1) * 8 + 7] = __builtin_amdgcn_s_memtime();  // my arrival at B(t + 1)
                 PK_BARRIER_LDS();  // B(t + 1)
@@ -626,7 +632,7 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_bwd_kernel(R2Args a) {
         const bool fast_rt = __builtin_amdgcn_readfirstlane((int)(cluster_on_one_xcd(a, c, p, tid, dead) && a.force_safe == 0)) != 0;
         auto run = [&](auto FASTC) {
             constexpr bool fast = decltype(FASTC)::value != 0;
-            if (a.flush_late == 0) __builtin_amdgcn_s_setprio(3);
+            if ((a.flush_late & 1) == 0) __builtin_amdgcn_s_setprio(3);
             int it = 0;
             for (int t = T - 1; t >= 0; --t, ++it) {
                 const int step_idx = it;
@@ -646,7 +652,7 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_bwd_kernel(R2Args a) {
 #pragma unroll
                 for (int k = 0; k < NIN; ++k) iv[k] = *reinterpret_cast<const f32x4*>(my_i + (it & 1) * ISLOT + k * S_PATCH_F);
                 f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-                const bool empty = TR && a.empty_step != 0;
+                const bool empty = TR && a.empty_step != 0 && a.empty_step < 6;  // (6, 7: full arithmetic, doctored I/O)
                 const bool mm = t < T - 1 && !empty;
                 const unsigned char* Ar = At + (lane & 15) * (LDA * 2) + kq * 16;
                 constexpr int PKD = 4, NF = G * KSTEPS;
@@ -794,16 +800,18 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_bwd_kernel(R2Args a) {
             constexpr bool EDGY = decltype(EDGYC)::value != 0;
             // saved tensors of a step, one 16-byte access each: [0..NS) gates, NS = h_{t-1}, NS+1 = dY
             f32x4 in0[4][NIN], in1[4][NIN];  // the saved tensors of even / odd iterations, loaded two iterations ahead
+            const bool nt_ld = (a.flush_late & 4) != 0;
             auto load_step = [&](f32x4 (&in)[4][NIN], int t) {
+                if (TR && a.empty_step >= 5) t = 1 + (t & 3);  // diagnostics: the same few rows again and again (cache hits)
                 const unsigned ts = (unsigned)(adir ? (T - 1 - t) : t);
                 const unsigned tp = t > 0 ? (adir ? ts + 1 : ts - 1) : ts;  // storage time of step t-1 (any valid row when t == 0)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const int nvp = t > 0 ? anv[w] : 0;
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) in[w][k] = s_ld4<EDGY>(a.S, vS0 + ts * vSs + k * H + w * 16, anv[w], edge[w]);
-                    in[w][NS] = s_ld4<EDGY>(a.Y, vY0 + tp * vYs + w * 16, nvp, edge[w]);
-                    in[w][NS + 1] = s_ld4<EDGY>(a.dY, vY0 + ts * vYs + w * 16, anv[w], edge[w]);
+                    for (int k = 0; k < NS; ++k) in[w][k] = s_ld4<EDGY>(a.S, vS0 + ts * vSs + k * H + w * 16, anv[w], edge[w], nt_ld);
+                    in[w][NS] = s_ld4<EDGY>(a.Y, vY0 + tp * vYs + w * 16, nvp, edge[w], nt_ld);
+                    in[w][NS + 1] = s_ld4<EDGY>(a.dY, vY0 + ts * vYs + w * 16, anv[w], edge[w], nt_ld);
                     if (t == 0) in[w][NS] = f32x4{0.f, 0.f, 0.f, 0.f};  // h_{-1} = 0
                 }
             };
@@ -830,7 +838,7 @@ __global__ __launch_bounds__((5 + NP) * 64) void recs_bwd_kernel(R2Args a) {
             if (T > 1) load_step(in1, T - 2);
             if (T > 2) load_step(in0, T - 3);
             PK_BARRIER_LDS();  // B(0)
-            const bool no_io = TR && a.empty_step == 2;  // diagnostics (EMPTY=2): no HBM traffic at all from this CU
+            const bool no_io = TR && (a.empty_step == 2 || a.empty_step == 4);  // diagnostics (EMPTY=2 / 4): no HBM loads from this CU
             auto iter = [&](int it, f32x4 (&in)[4][NIN]) {  // while the compute waves work on iteration it; in: the set of iteration it + 1
                 if (it + 1 < T) {
                     stage_step(in, (it + 1) & 1);

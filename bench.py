@@ -86,6 +86,7 @@ class Trainer:
     def __init__(self, args, rank, world):
         self.U = importlib.import_module("pytorch-kaldi_amd.utils")
         self.R = importlib.import_module("pytorch-kaldi_amd.recipes")
+        self.F = importlib.import_module("pytorch-kaldi_amd.functional")
         self.DP = importlib.import_module("pytorch-kaldi_amd.dp")
         self.OPT = importlib.import_module("pytorch-kaldi_amd.optim")
         F_ = importlib.import_module("pytorch-kaldi_amd.functional")
@@ -134,7 +135,8 @@ class Trainer:
                                     self.costs, inp, self.inp_out_dict, self.T, self.B, "train", [])
         for o in self.opts.values():
             o.zero_grad()
-        outs["loss_final"].backward()
+        with self.F.accumulating_backward():  # (a training step: small-batch kernels may add to the flat .grad themselves)
+            outs["loss_final"].backward()
         self.reducer.finish()
         for o in self.opts.values():
             o.step()

@@ -294,7 +294,8 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
                              inp_.shape[0], local, to_do, forward_outs)
         for opt in optimizers.keys():
             optimizers[opt].zero_grad()
-        outs["loss_final"].backward()
+        with F_.accumulating_backward():  # (a training step: kernels may add to the flat .grad themselves)
+            outs["loss_final"].backward()
         if reducer is not None:
             reducer.finish()
         for opt in optimizers.keys():

@@ -7,6 +7,7 @@ torch-op fallback: a CPU tensor or a missing library raises.
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -397,13 +398,30 @@ def side_targets_ok(params):
             and all(getattr(q, "_pk_flat", False) and q.grad is not None and q.requires_grad for q in params))
 
 
+class accumulating_backward:
+    """`with accumulating_backward(): loss.backward()` - the caller states that this backward pass ACCUMULATES into the
+    parameters' .grad (an ordinary training step), which is what lets small-batch kernels add their gradients to the
+    flat .grad themselves (direct_grads_ok).  Without it every gradient is returned to autograd, so torch.autograd.grad()
+    and other gradient-only callers get what they ask for.  core.run_nn's step and bench.py use it."""
+    depth = 0
+
+    def __enter__(self):
+        accumulating_backward.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        accumulating_backward.depth -= 1
+        return False
+
+
 def direct_grads_ok(params):
     """Small-batch layers (an MLP step of 128 frames is launch-bound): a gradient may be ACCUMULATED into the parameter's
     pre-allocated flat .grad by the kernel that produces it, on the current stream, instead of being returned to autograd
-    (whose AccumulateGrad node is one more add launch per parameter).  Same conditions as the side-stream weight
+    (whose AccumulateGrad node is one more add launch per parameter).  Only inside `with accumulating_backward():` (the
+    engine's own step: a backward pass that is known to accumulate), under the conditions of the side-stream weight
     gradients, and only while no data-parallel reducer listens for gradient hooks.  PK_DIRECT_GRADS=0 turns it off."""
-    return (_Side.listener is None and os.environ.get("PK_DIRECT_GRADS", "1") != "0" and torch.is_grad_enabled() is False
-            and side_targets_ok(params))
+    return (accumulating_backward.depth > 0 and _Side.listener is None and os.environ.get("PK_DIRECT_GRADS", "1") != "0"
+            and torch.is_grad_enabled() is False and side_targets_ok(params))
 
 
 _DEBUG_SKIP_SIDE = os.environ.get("PK_DEBUG_SKIP_SIDE", "0") == "1"  # timing experiments only: drops the weight-gradient work
@@ -544,10 +562,41 @@ class _DxShare:
     autograd adds them with an element-wise kernel (0.2 ms, 846 MB of traffic).  Instead the first head to run backward
     allocates dX and every later head's dX GEMM accumulates into it (beta = 1) and returns no gradient of its own.
     Keyed by the input's identity at forward time; the table is cleared whenever a new forward pass builds heads, i.e.
-    after the backward pass that used it.  PK_HEAD_DX_SHARE=0 switches it off."""
+    after the backward pass that used it.  PK_HEAD_DX_SHARE=0 switches it off.
+
+    Accumulating in place into a tensor autograd already holds is only sound while nobody else adds to that buffer, so
+    the heads do not consume x itself: they consume ONE private alias of it (_ShareIn, made by the first head built on x
+    and handed to every later one).  The alias has no other consumers, its gradient buffer therefore only ever sees
+    the heads' contributions - the first as the shared tensor, the rest as None - and whatever else reads x adds to x's
+    own buffer, behind _ShareIn.backward, which also lets go of the shared dX."""
     on = os.environ.get("PK_HEAD_DX_SHARE", "1") != "0"
     epoch = 0
-    table = {}  # key -> (epoch, dx tensor)
+    table = {}  # key -> (epoch, dx tensor, contributors)
+    alias = None  # (weakref to x, its private alias) of the head input seen last
+
+
+class _ShareIn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        _DxShare.table.clear()  # every head in this backward pass has contributed: nothing keeps dX alive from here
+        _DxShare.alias = None
+        return g
+
+
+def _head_input(x):
+    """The tensor the fused heads on x consume (see _DxShare)."""
+    if not (_DxShare.on and x.requires_grad and torch.is_grad_enabled() and x.is_contiguous()):
+        return x
+    a = _DxShare.alias
+    if a is not None and a[0]() is x and a[1]._version == x._version:
+        return a[1]
+    xs = _ShareIn.apply(x)
+    _DxShare.alias = (weakref.ref(x), xs)
+    return xs
 
 
 def _dx_share_key(x):
@@ -697,8 +746,9 @@ def linear_log_softmax(x, weight, bias=None):
             assert wb.shape[1] == xb.shape[1]
     _DxShare.epoch += 1   # (a new forward pass: whatever the previous backward pass shared is history)
     _DxShare.table.clear()
-    y = LinearLogSoftmaxFn.apply(x, weight if weight.is_contiguous() else w, bias, xb, wb, wb_plain, xseg)
-    y._pk_head = (x, weight, bias, xb, wb_plain, xseg, y._version)
+    xs = _head_input(x)
+    y = LinearLogSoftmaxFn.apply(xs, weight if weight.is_contiguous() else w, bias, xb, wb, wb_plain, xseg)
+    y._pk_head = (xs, weight, bias, xb, wb_plain, xseg, y._version)
     return y
 
 

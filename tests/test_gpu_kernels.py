@@ -788,6 +788,44 @@ def test_output_layers_on_one_input_share_their_input_gradient():
 
 
 @pytest.mark.gpu
+def test_shared_input_gradient_with_another_consumer_in_between():
+    """The shared dX must survive a third consumer of the same activation whose gradient reaches autograd's buffer
+    BETWEEN the two heads' backward nodes (node order = reverse creation order: head 2's cost, the extra term, head 1's
+    cost): the heads consume a private alias of the input (functional._ShareIn), so the in-place accumulation never
+    races autograd's own out-of-place add.  Also: a head left out of the loss simply does not contribute."""
+    g = torch.Generator().manual_seed(6)
+    rows, K = 1300, 96
+    x0 = torch.randn(rows, K, generator=g)
+    w1, w2 = torch.randn(21, K, generator=g) / 10, torch.randn(9, K, generator=g) / 10
+    l1, l2 = torch.randint(0, 21, (rows,), generator=g).cuda(), torch.randint(0, 9, (rows,), generator=g).cuda()
+    F_.set_precision("bf16")
+    res = {}
+    try:
+        for share in (True, False):
+            F_._DxShare.on = share
+            for both in (True, False):
+                x = x0.clone().cuda().requires_grad_(True)
+                h = x * 1.0
+                a, b = w1.clone().cuda().requires_grad_(True), w2.clone().cuda().requires_grad_(True)
+                y1, y2 = F_.linear_log_softmax(h, a, None), F_.linear_log_softmax(h, b, None)
+                c1 = F_.head_nll(y1, l1)[0]
+                extra = (h * h).mean()
+                c2 = F_.head_nll(y2, l2)[0]
+                loss = c1 + 3.0 * extra + (0.5 * c2 if both else 0.0)
+                loss.backward()
+                torch.cuda.synchronize()
+                res[share, both] = (x.grad.clone(), a.grad.clone())
+                assert (b.grad is not None) == both
+                assert F_._DxShare.alias is None and not F_._DxShare.table  # (the shared dX is let go once x has its gradient)
+    finally:
+        F_._DxShare.on = True
+        F_.set_precision("fp32")
+    for both in (True, False):
+        for got, ref in zip(res[True, both], res[False, both]):
+            assert rel_err(got, ref) < 1e-6, both
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K,act,masked", [(128, 1024, 1024, "relu", True), (128, 1024, 440, "relu", True), (37, 200, 520, "tanh", False),
                                              (2, 8, 128, "relu", False), (128, 1024, 3300, "relu", True)])
 def test_small_batch_layer_two_launch_form_matches_the_one_launch_form(M, N, K, act, masked):

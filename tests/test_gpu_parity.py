@@ -758,7 +758,8 @@ def test_small_batch_mlp_step_direct_gradients(monkeypatch):
             try:
                 flat.zero_grad()
                 loss = torch.nn.functional.nll_loss(net(x), lab)
-                loss.backward()
+                with F_amd.accumulating_backward():  # (the engine's step says so; without it nothing bypasses autograd)
+                    loss.backward()
                 torch.cuda.synchronize()
             finally:
                 F_amd.set_forced_dropout(None)

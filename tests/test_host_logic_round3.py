@@ -144,8 +144,9 @@ def test_oracle_bf16_convolution_model():
 
 def test_direct_gradients_only_without_a_reducer_and_inside_backward(monkeypatch):
     """functional.direct_grads_ok: kernels may accumulate into the flat .grad themselves only when the parameters are
-    flat-bucket views with a pre-allocated gradient, autograd is not recording (a plain backward pass), no data-parallel
-    reducer listens for gradient hooks, and PK_DIRECT_GRADS is not 0."""
+    flat-bucket views with a pre-allocated gradient, the caller has declared an accumulating backward pass
+    (functional.accumulating_backward: run_nn's step does; torch.autograd.grad() callers do not), autograd is not
+    recording, no data-parallel reducer listens for gradient hooks, and PK_DIRECT_GRADS is not 0."""
     monkeypatch.delenv("PK_DIRECT_GRADS", raising=False)
     old = F_.settings.precision
     q = torch.nn.Parameter(torch.zeros(4, 3))
@@ -158,7 +159,12 @@ def test_direct_gradients_only_without_a_reducer_and_inside_backward(monkeypatch
         monkeypatch.setattr(F_._Side, "listener", None)
         assert not F_.direct_grads_ok([q])            # autograd is recording: not inside a backward pass
         with torch.no_grad():
+            assert not F_.direct_grads_ok([q])        # nobody said this backward pass accumulates into .grad
+        with torch.no_grad(), F_.accumulating_backward():
             assert F_.direct_grads_ok([q])
+            with F_.accumulating_backward():
+                assert F_.direct_grads_ok([q])
+            assert F_.direct_grads_ok([q])            # (nests)
             assert not F_.direct_grads_ok([plain])    # not a flat-bucket parameter
             assert not F_.direct_grads_ok([q, plain])
             monkeypatch.setattr(F_._Side, "listener", lambda params: None)

@@ -131,11 +131,11 @@ class Trainer:
 
     def step_on(self, inp):
         rcp = self.rcp
-        outs = self.U.forward_model(rcp["fea_dict"], rcp["lab_dict"], rcp["arch_dict"], rcp["model"], self.nns,
-                                    self.costs, inp, self.inp_out_dict, self.T, self.B, "train", [])
-        for o in self.opts.values():
-            o.zero_grad()
-        with self.F.accumulating_backward():  # (a training step: small-batch kernels may add to the flat .grad themselves)
+        with self.F.accumulating_backward():  # (a training step, as in core.run_nn: kernels may add to the flat .grad themselves)
+            outs = self.U.forward_model(rcp["fea_dict"], rcp["lab_dict"], rcp["arch_dict"], rcp["model"], self.nns,
+                                        self.costs, inp, self.inp_out_dict, self.T, self.B, "train", [])
+            for o in self.opts.values():
+                o.zero_grad()
             outs["loss_final"].backward()
         self.reducer.finish()
         for o in self.opts.values():

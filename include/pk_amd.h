@@ -122,6 +122,11 @@ int pk_bn_finalize(void* stream, int64_t N, const float* mean, const float* var,
 int pk_bn_finalize_gates(void* stream, int G, int H, const float* mean, const float* var, const float* gamma,
                          const float* beta, float eps, float* scale, float* shift, float* const* running_mean,
                          float* const* running_var, int64_t* const* num_batches, float momentum, double count);
+/* pk_bn_stats_merge followed by pk_bn_finalize_gates, as one launch (the [rb][G*H][3] partials pk_gemm_bf16_stats wrote). */
+int pk_bn_stats_merge_finalize_gates(void* stream, const float* partial, int rb, int G, int H, float* mean, float* var,
+                                     const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                     float* const* running_mean, float* const* running_var, int64_t* const* num_batches,
+                                     float momentum, double count);
 /* y = dropmask * act(x*scale[n] + shift[n]); scale/shift NULL = identity;
  * mask NULL = no dropout (mask holds 0 or 1/(1-p)).  In-place allowed. */
 int pk_affine_act_fwd(void* stream, const float* x, int64_t ldx, int64_t M, int64_t N, const float* scale,
@@ -144,10 +149,14 @@ int pk_bn_bwd_apply(void* stream, const float* g, const float* g2, int64_t ldg, 
  * column g*Hp; g1 may be NULL).  Writes sum_g / sum_gx [G*H] (= dbeta / dgamma; sum_g = the bias
  * gradient when mean == NULL, i.e. no BatchNorm: then dx = g0 + g1) and the projection gradient as
  * bf16 in the plain layout out[M][out_pitch] (column g*H + j, pad columns zeroed) that the dX / dW
- * GEMMs (pk_gemm_bf16) read.  partial: >= pk_bn_partial_floats(M, G*H) floats. */
+ * GEMMs (pk_gemm_bf16) read.  partial: >= pk_bn_partial_floats(M, G*H) floats.
+ * acc_beta / acc_gamma (NULL or [G*H]): sum_g / sum_gx are also ADDED to these in place (the flat gradient of the
+ * BatchNorm shifts / scales of the layer's gates - or of its biases without BatchNorm: acc_beta - when they lie
+ * back to back). */
 int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* g1, int64_t g_pitch, int G, int H, const float* x,
                    int64_t ldx, int64_t M, const float* mean, const float* var, float eps, const float* gamma,
-                   double count, float* partial, float* sum_g, float* sum_gx, uint16_t* out, int64_t out_pitch);
+                   double count, float* partial, float* sum_g, float* sum_gx, uint16_t* out, int64_t out_pitch,
+                   float* acc_beta, float* acc_gamma);
 /* Backward of drop(act(bn(z))) for a batch of up to 128 rows in ONE launch (an MLP layer at the recipes' batch size;
  * neural_networks.py:139-148 backwards): g = dy * mask * act'(a), sum_g / sum_gx [N] = the BatchNorm reductions
  * (d beta, d gamma), dz = gamma * invstd * (g - sum_g / M - xhat * sum_gx / M) as bf16 [M][ldb] (pad columns zero) and,

@@ -40,13 +40,15 @@ SIGNATURES = {
     "pk_bn_stats": (c_int, [P, P, c_int64, c_int64, c_int64, P, P, P]),
     "pk_bn_finalize": (c_int, [P, c_int64, P, P, P, P, c_float, P, P, P, P, c_float, c_double]),
     "pk_bn_finalize_gates": (c_int, [P, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, c_float, c_double]),
+    "pk_bn_stats_merge_finalize_gates": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, c_float,
+                                                 c_double]),
     "pk_affine_act_fwd": (c_int, [P, P, c_int64, c_int64, c_int64, P, P, c_int, P, P, c_int64]),
     "pk_act_bwd": (c_int, [P, P, P, P, c_int, c_int64, P]),
     "pk_bn_bwd_reduce": (c_int, [P, P, P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_float, P, P, P]),
     "pk_bn_bwd_apply": (c_int, [P, P, P, c_int64, P, c_int64, c_int64, c_int64, P, P, c_float, P, P, P, c_double, P,
                                 c_int64]),
     "pk_bn_bwd_bf16": (c_int, [P, P, P, c_int64, c_int, c_int, P, c_int64, c_int64, P, P, c_float, P, c_double, P, P, P, P,
-                               c_int64]),
+                               c_int64, P, P]),
     "pk_colsum": (c_int, [P, P, P, c_int64, c_int64, c_int64, P, P]),
     "pk_add": (c_int, [P, P, P, c_int64, P]),
     "pk_layernorm_fwd": (c_int, [P, P, c_int64, c_int64, P, P, c_float, P, P, P]),

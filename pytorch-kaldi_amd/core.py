@@ -290,11 +290,13 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
               if to_do == "forward" and forward_normalize_post[i]}
 
     def train_step(inp_):
-        outs = forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp_, inp_out_dict, 0 if not seq_model else
-                             inp_.shape[0], local, to_do, forward_outs)
-        for opt in optimizers.keys():
-            optimizers[opt].zero_grad()
-        with F_.accumulating_backward():  # (a training step: kernels may add to the flat .grad themselves)
+        # (a training step - forward and the backward pass that accumulates into .grad: kernels may add to the flat
+        # .grad themselves, and recurrent layers take their BatchNorm affine as views of the flat buffer)
+        with F_.accumulating_backward():
+            outs = forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp_, inp_out_dict, 0 if not seq_model
+                                 else inp_.shape[0], local, to_do, forward_outs)
+            for opt in optimizers.keys():
+                optimizers[opt].zero_grad()
             outs["loss_final"].backward()
         if reducer is not None:
             reducer.finish()

@@ -221,6 +221,58 @@ __global__ void bn_finalize_gates_kernel(int G, int H, const float* __restrict__
     if (j == 0 && bufs.batches[g] != nullptr) bufs.batches[g][0] += 1;  // num_batches_tracked
 }
 
+// bn_stats_final_kernel + bn_finalize_gates_kernel in one launch (a recurrent layer's projection in training mode: the
+// statistics partials of the GEMM epilogue -> mean / var, scale / shift, running statistics of every gate's module)
+__global__ __launch_bounds__(FIN_COLS* FIN_GROUPS) void bn_stats_final_gates_kernel(const float* __restrict__ partial, int rb, int G,
+                                                                                   int H, float* __restrict__ mean,
+                                                                                   float* __restrict__ var,
+                                                                                   const float* __restrict__ gamma,
+                                                                                   const float* __restrict__ beta, float eps,
+                                                                                   float* __restrict__ scale,
+                                                                                   float* __restrict__ shift, BnGateBufs bufs,
+                                                                                   float momentum, float unbias) {
+    __shared__ float sh[FIN_GROUPS][FIN_COLS][3];
+    const long N = (long)G * H;
+    const int cx = threadIdx.x & (FIN_COLS - 1), q = threadIdx.x / FIN_COLS;
+    const long c = (long)blockIdx.x * FIN_COLS + cx;
+    float na = 0.f, ma = 0.f, qa = 0.f;
+    if (c < N) {
+        int k = q;
+        for (; k + 3 * FIN_GROUPS < rb; k += 4 * FIN_GROUPS) {
+            float v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* o = partial + ((long)(k + u * FIN_GROUPS) * N + c) * 3;
+                v[u][0] = o[0], v[u][1] = o[1], v[u][2] = o[2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) chan_merge(na, ma, qa, v[u][0], v[u][1], v[u][2]);
+        }
+        for (; k < rb; k += FIN_GROUPS) {
+            const float* o = partial + ((long)k * N + c) * 3;
+            chan_merge(na, ma, qa, o[0], o[1], o[2]);
+        }
+    }
+    sh[q][cx][0] = na, sh[q][cx][1] = ma, sh[q][cx][2] = qa;
+    __syncthreads();
+    if (q == 0 && c < N) {
+        for (int g = 1; g < FIN_GROUPS; ++g) chan_merge(na, ma, qa, sh[g][cx][0], sh[g][cx][1], sh[g][cx][2]);
+        const float m = ma, v = na > 0.f ? qa / na : 0.f;  // biased, as BatchNorm normalises with
+        mean[c] = m;
+        var[c] = v;
+        const int g = (int)(c / H), j = (int)(c - (long)g * H);
+        const float inv = 1.0f / sqrtf(v + eps);
+        const float sc = (gamma ? gamma[c] : 1.f) * inv;
+        scale[c] = sc;
+        shift[c] = (beta ? beta[c] : 0.f) - m * sc;
+        float* rm = bufs.rmean[g];
+        float* rv = bufs.rvar[g];
+        rm[j] = (1.f - momentum) * rm[j] + momentum * m;
+        rv[j] = (1.f - momentum) * rv[j] + momentum * (v * unbias);
+        if (j == 0 && bufs.batches[g] != nullptr) bufs.batches[g][0] += 1;  // num_batches_tracked
+    }
+}
+
 // ---- y = mask * act(x*scale + shift) ----------------------------------------
 __global__ void affine_act_fwd_kernel(const float* __restrict__ x, long ldx, long M, long N,
                                       const float* __restrict__ scale, const float* __restrict__ shift, int act,
@@ -295,9 +347,16 @@ __global__ __launch_bounds__(256) void col_reduce_partial_kernel(const float* __
 // columns per block the 35 blocks of the first version took 40 us per call, seven calls per training step); a thread
 // keeps eight partial rows in flight; fixed reduction order, deterministic run to run.
 constexpr int CF_COLS = 16, CF_GROUPS = 16;
+// acc0 / acc1 (optional): the sums are also ADDED there (the flat .grad of BatchNorm shift / scale: no add launch behind it).
+// pad (optional): the pad columns [pad_n0, pad_pitch) of a bf16 matrix of pad_rows rows are zeroed on the way (the matrix
+// the caller's next kernel fills; its own zero-fill launch is gone).
 __global__ __launch_bounds__(CF_COLS* CF_GROUPS) void col_reduce_final_kernel(const float* __restrict__ partial, int rb, long N,
                                                                              float* __restrict__ out0,
-                                                                             float* __restrict__ out1) {
+                                                                             float* __restrict__ out1,
+                                                                             float* __restrict__ acc0,
+                                                                             float* __restrict__ acc1,
+                                                                             unsigned short* __restrict__ pad, long pad_pitch,
+                                                                             long pad_rows, int pad_n0) {
     __shared__ float sh[CF_GROUPS][CF_COLS][2];
     const int cx = threadIdx.x & (CF_COLS - 1), q = threadIdx.x / CF_COLS;
     const long c = (long)blockIdx.x * CF_COLS + cx;
@@ -322,6 +381,26 @@ __global__ __launch_bounds__(CF_COLS* CF_GROUPS) void col_reduce_final_kernel(co
         for (int g = 1; g < CF_GROUPS; ++g) a0 += sh[g][cx][0], a1 += sh[g][cx][1];
         out0[c] = a0;
         if (out1) out1[c] = a1;
+        if (acc0) acc0[c] += a0;
+        if (acc1) acc1[c] += a1;
+    }
+    if (pad != nullptr) {
+        const int w = (int)pad_pitch - pad_n0;
+        const long nt = (long)gridDim.x * blockDim.x, t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        if ((w & 3) == 0 && (pad_n0 & 3) == 0 && (pad_pitch & 3) == 0 && ((uintptr_t)pad & 7) == 0) {  // 8-byte stores
+            const int wq = w >> 2;
+            const long total = pad_rows * wq;
+            for (long i = t0; i < total; i += nt) {
+                const long r = i / wq;
+                *reinterpret_cast<uint2*>(pad + r * pad_pitch + pad_n0 + 4 * (i - r * wq)) = make_uint2(0u, 0u);
+            }
+        } else {
+            const long total = pad_rows * w;
+            for (long i = t0; i < total; i += nt) {
+                const long r = i / w;
+                pad[r * pad_pitch + pad_n0 + (i - r * w)] = 0;
+            }
+        }
     }
 }
 
@@ -744,7 +823,7 @@ extern "C" int pk_bn_bwd_reduce(void* stream, const float* g, const float* g2, i
                        (long)N, mean, var, eps, partial);
     PK_LAUNCH_CHECK();
     hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_GROUPS), 0, st, partial, rb, (long)N,
-                       sum_g, sum_gx);
+                       sum_g, sum_gx, (float*)nullptr, (float*)nullptr, (unsigned short*)nullptr, 0L, 0L, 0);
     PK_LAUNCH_CHECK();
     return 0;
 }
@@ -936,7 +1015,7 @@ extern "C" int pk_colsum(void* stream, const float* g, const float* g2, int64_t 
                        (long)M, (long)N, (const float*)nullptr, (const float*)nullptr, 0.f, partial);
     PK_LAUNCH_CHECK();
     hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_GROUPS), 0, st, partial, rb, (long)N,
-                       out, (float*)nullptr);
+                       out, (float*)nullptr, (float*)nullptr, (float*)nullptr, (unsigned short*)nullptr, 0L, 0L, 0);
     PK_LAUNCH_CHECK();
     return 0;
 }
@@ -975,6 +1054,29 @@ extern "C" int pk_bn_stats_merge(void* stream, const float* partial, int rb, int
     PK_REQUIRE(rb > 0 && N > 0 && partial && mean && var, "pk_bn_stats_merge: bad arguments");
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0,
                        pk_stream(stream), partial, rb, (long)N, mean, var);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+// pk_bn_stats_merge + pk_bn_finalize_gates as one launch
+extern "C" int pk_bn_stats_merge_finalize_gates(void* stream, const float* partial, int rb, int G, int H, float* mean, float* var,
+                                                const float* gamma, const float* beta, float eps, float* scale, float* shift,
+                                                float* const* running_mean, float* const* running_var,
+                                                int64_t* const* num_batches, float momentum, double count) {
+    PK_REQUIRE(rb > 0 && partial && mean && var && scale && shift, "pk_bn_stats_merge_finalize_gates: bad arguments");
+    PK_REQUIRE(G >= 1 && G <= 4 && H >= 1, "pk_bn_stats_merge_finalize_gates: 1..4 gates");
+    PK_REQUIRE(running_mean != nullptr && running_var != nullptr, "pk_bn_stats_merge_finalize_gates: null running-statistics tables");
+    BnGateBufs bufs;
+    for (int g = 0; g < 4; ++g) {
+        bufs.rmean[g] = g < G ? running_mean[g] : nullptr;
+        bufs.rvar[g] = g < G ? running_var[g] : nullptr;
+        bufs.batches[g] = (g < G && num_batches != nullptr) ? (long long*)num_batches[g] : nullptr;
+        PK_REQUIRE(g >= G || (bufs.rmean[g] && bufs.rvar[g]), "pk_bn_stats_merge_finalize_gates: null running statistics of a gate");
+    }
+    const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.0f;
+    const long N = (long)G * H;
+    hipLaunchKernelGGL(bn_stats_final_gates_kernel, dim3((unsigned)((N + FIN_COLS - 1) / FIN_COLS)), dim3(FIN_COLS * FIN_GROUPS), 0,
+                       pk_stream(stream), partial, rb, G, H, mean, var, gamma, beta, eps, scale, shift, bufs, momentum, unbias);
     PK_LAUNCH_CHECK();
     return 0;
 }
@@ -1044,7 +1146,7 @@ static int lsm_bwd_bf16_launch(hipStream_t st, bool onehot, const float* dy, con
 #undef PK_LSMB
     PK_LAUNCH_CHECK();
     hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_GROUPS), 0, st,
-                       partial, (int)blocks, (long)N, colsum, (float*)nullptr);
+                       partial, (int)blocks, (long)N, colsum, (float*)nullptr, (float*)nullptr, (float*)nullptr, (unsigned short*)nullptr, 0L, 0L, 0);
     PK_LAUNCH_CHECK();
     return 0;
 }
@@ -1347,22 +1449,12 @@ __global__ __launch_bounds__(256) void bnb_apply_kernel(const unsigned short* __
     }
 }
 
-// zero the pad columns [n0, pitch) of every row of a bf16 matrix
-__global__ void bf16_zero_pad_kernel(unsigned short* __restrict__ out, long pitch, long M, int n0) {
-    const int w = (int)pitch - n0;
-    const long total = M * w;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / w;
-        out[r * pitch + n0 + (i - r * w)] = 0;
-    }
-}
-
 }  // namespace
 
 extern "C" int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* g1, int64_t g_pitch, int G, int H,
                               const float* x, int64_t ldx, int64_t M, const float* mean, const float* var, float eps,
                               const float* gamma, double count, float* partial, float* sum_g, float* sum_gx,
-                              uint16_t* out, int64_t out_pitch) {
+                              uint16_t* out, int64_t out_pitch, float* acc_beta, float* acc_gamma) {
     PK_REQUIRE(M > 0 && G > 0 && H > 0, "pk_bn_bwd_bf16: empty input");
     PK_REQUIRE((g_pitch % 8) == 0 && ((uintptr_t)g0 & 15) == 0 && (g1 == nullptr || ((uintptr_t)g1 & 15) == 0),
                "pk_bn_bwd_bf16: gate gradients must be 16-byte aligned with a pitch that is a multiple of 8");
@@ -1400,7 +1492,8 @@ extern "C" int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* 
                   (long)ldx, (long)M, mean, var, eps, partial);
     PK_LAUNCH_CHECK();
     hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_GROUPS), 0, st, partial, rb, N, sum_g,
-                       use_bn ? sum_gx : (float*)nullptr);
+                       use_bn ? sum_gx : (float*)nullptr, acc_beta, use_bn ? acc_gamma : (float*)nullptr,
+                       out_pitch > N ? (unsigned short*)out : (unsigned short*)nullptr, (long)out_pitch, (long)M, (int)N);
     PK_LAUNCH_CHECK();
     PK_BNB_LAUNCH(bnb_apply_kernel, grid_a, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x,
                   (long)ldx, (long)M, mean, var, eps, gamma, sum_g, sum_gx, use_bn ? (float)(1.0 / count) : 0.f,
@@ -1408,12 +1501,5 @@ extern "C" int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* 
     PK_LAUNCH_CHECK();
 #undef PK_BNB_LAUNCH
 #undef PK_BNB_LAUNCH2
-    if (out_pitch > N) {
-        const long total = M * (out_pitch - N);
-        long blocks = (total + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(bf16_zero_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned short*)out, (long)out_pitch, (long)M, (int)N);
-        PK_LAUNCH_CHECK();
-    }
     return 0;
 }

@@ -34,7 +34,8 @@ struct R2Args {
     float* trash;               // >= 64 bytes per lane-group of write-only scratch for masked-off stores
     int poll_delay;             // s_sleep units (64 clocks) between the publish and the first poll of the next step
     int force_safe;             // 1 = always use the placement-independent write-through exchange
-    unsigned* xcd_tab;          // [C][16] placement handshake words (0xFFFFFFFF before the launch)
+    unsigned* xcd_tab;          // [C][16] placement handshake words: (hs_gen << 4) | XCD of the member that wrote it
+    unsigned hs_gen;            // this launch's handshake generation (words of earlier launches are simply not current)
     unsigned long long* trace;  // optional [T][8] phase time stamps of (cluster 0, member 0, wave 0); null = off
     int helper_delay;           // eight-wave LSTM kernels: extra s_sleep units before the second wave of a pair polls
     int self_fill;              // 1 = the kernel writes the "not written yet" pattern itself, PK_R2_FILL_AHEAD steps ahead of its publishes
@@ -265,20 +266,23 @@ __device__ __forceinline__ LnSlots ln_slots(const R2Args& a, int c, int p, int w
 
 // One-time placement handshake: every member publishes the XCD it runs on (write-through) and
 // reads all members' words (agent scope); all members see the same words, hence take the same
-// decision.  Returns true when the whole cluster shares one XCD.
+// decision.  Returns true when the whole cluster shares one XCD.  A word carries the launch's generation number, so the
+// table needs no reset between launches (that was one hipMemsetAsync on the critical path in front of every recurrence).
 __device__ __forceinline__ bool cluster_on_one_xcd(const R2Args& a, int c, int p, int tid, bool& dead) {
-    const unsigned my = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;  // HW_REG_XCC_ID
+    const unsigned my = (a.hs_gen << 4) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu);  // HW_REG_XCC_ID
     unsigned* tab = a.xcd_tab + c * 16;
     if (tid == 0) __hip_atomic_store(tab + p, my, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int same = 1;
     if (tid < a.Pn) {
         unsigned v = 0xFFFFFFFFu;
+        bool current = false;
         for (int spins = 0; spins < a.spin_limit; ++spins) {
             v = __hip_atomic_load(tab + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (v != 0xFFFFFFFFu) break;
+            current = (v >> 4) == a.hs_gen;
+            if (current) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        if (v == 0xFFFFFFFFu) {
+        if (!current) {
             atomicAdd_system(a.err, 1u);
             same = 0;
             dead = true;
@@ -399,7 +403,7 @@ int pk_rec2_ln_setup(hipStream_t st, R2Args& a, const Plan2& pl, const PkLnHost*
 int pk_rec2_ln_finish(hipStream_t st, const R2Args& a, const PkLnHost* ln);  // backward: per-cluster partial sums -> d gamma, d beta
 int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidir, int H);
 int pk_rec2_host_setup(R2Args& a, bool backward, int cell);                 // error word, trash page, handshake table, tuning knobs
-int pk_rec2_reset_handshake(hipStream_t st);       // before every launch
+int pk_rec2_reset_handshake(hipStream_t st, R2Args& a);  // before every launch: a fresh handshake generation
 // The clusters of a persistent launch exchange h_t with each other every step: every workgroup of the grid has to be
 // resident at the same time.  Checks the grid against what the device can hold (occupancy query for this kernel, block
 // size and dynamic LDS x CU count, cached per kernel) - a grid that cannot be co-resident is refused here instead of

@@ -707,6 +707,8 @@ constexpr size_t XCD_TAB_BYTES = 256 * 16 * sizeof(unsigned);
 int ensure_err2() {
     if (g2_err_host) return 0;
     PK_CHECK_HIP(hipMalloc((void**)&g2_xcd_tab, XCD_TAB_BYTES));
+    PK_CHECK_HIP(hipMemset(g2_xcd_tab, 0xFF, XCD_TAB_BYTES));  // no generation is current yet (pk_rec2_reset_handshake)
+    PK_CHECK_HIP(hipDeviceSynchronize());
     PK_CHECK_HIP(hipMalloc((void**)&g2_trash, 4096));
     PK_CHECK_HIP(hipHostMalloc((void**)&g2_err_host, 64, hipHostMallocMapped | hipHostMallocCoherent));
     *g2_err_host = 0;
@@ -866,8 +868,21 @@ int pk_rec2_check_residency(const void* kernel, int threads, size_t lds, int gri
     return 0;
 }
 
-int pk_rec2_reset_handshake(hipStream_t st) {
-    PK_CHECK_HIP(hipMemsetAsync(g2_xcd_tab, 0xFF, XCD_TAB_BYTES, st));
+int pk_rec2_reset_handshake(hipStream_t st, R2Args& a) {
+    // generations 1 .. 2^28 - 17 (the table starts out as 0xFF bytes: generation 2^28 - 1, never handed out).  Inside a
+    // stream capture the number is baked into the graph, so every replay would find its own words from the replay
+    // before: there the table is reset by a memset node in front of the kernel, as it used to be everywhere.
+    static unsigned gen = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
+    if (gen >= 0x0FFFFFEFu) {  // wrap: nothing of the old numbering may survive
+        PK_CHECK_HIP(hipDeviceSynchronize());
+        PK_CHECK_HIP(hipMemset(g2_xcd_tab, 0xFF, XCD_TAB_BYTES));
+        PK_CHECK_HIP(hipDeviceSynchronize());
+        gen = 0;
+    }
+    if (cs != hipStreamCaptureStatusNone) PK_CHECK_HIP(hipMemsetAsync(g2_xcd_tab, 0xFF, XCD_TAB_BYTES, st));
+    a.hs_gen = ++gen;
     return 0;
 }
 
@@ -974,7 +989,7 @@ static int rec_fwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
         a.ln_cg0 = l * pl.C;
-        rc = pk_rec2_reset_handshake(st);
+        rc = pk_rec2_reset_handshake(st, a);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_fwd_bf16");
@@ -1047,7 +1062,7 @@ static int rec_bwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
         a.ln_cg0 = l * pl.C;
-        rc = pk_rec2_reset_handshake(st);
+        rc = pk_rec2_reset_handshake(st, a);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_bwd_bf16");

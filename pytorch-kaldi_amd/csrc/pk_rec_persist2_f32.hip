@@ -638,7 +638,7 @@ int pk_rec2f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
         a.ln_cg0 = l * pl.C;
-        rc = pk_rec2_reset_handshake(st);
+        rc = pk_rec2_reset_handshake(st, a);
         if (rc) return rc;
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_fwd (fp32, persistent)");
         if (rc) return rc;
@@ -679,7 +679,7 @@ int pk_rec2f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
         a.ln_cg0 = l * pl.C;
-        rc = pk_rec2_reset_handshake(st);
+        rc = pk_rec2_reset_handshake(st, a);
         if (rc) return rc;
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_bwd (fp32, persistent)");
         if (rc) return rc;

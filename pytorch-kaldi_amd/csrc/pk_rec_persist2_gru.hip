@@ -1005,7 +1005,7 @@ int rec2p_fwd_impl(void* stream, int cell, int act, int T, int B, int bidir, int
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
         a.ln_cg0 = l * pl.C;
-        rc = pk_rec2_reset_handshake(st);
+        rc = pk_rec2_reset_handshake(st, a);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
         rc = pk_rec2_check_residency((const void*)fn, 256, lds, pl.C * pl.Pn, "pk_rec2p_*_bf16");
@@ -1056,7 +1056,7 @@ int rec2p_bwd_impl(void* stream, int cell, int act, int T, int B, int bidir, int
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
         a.ln_cg0 = l * pl.C;
-        rc = pk_rec2_reset_handshake(st);
+        rc = pk_rec2_reset_handshake(st, a);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(256);
         rc = pk_rec2_check_residency((const void*)fn, 256, lds, pl.C * pl.Pn, "pk_rec2p_*_bf16");

@@ -983,7 +983,7 @@ int pk_rec2l_launch(hipStream_t st, R2Args& a, const Plan2& pl, int act, bool ba
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
-        int rc = pk_rec2_reset_handshake(st);
+        int rc = pk_rec2_reset_handshake(st, a);
         if (rc) return rc;
         dim3 grid(pl.C * pl.Pn), block(512);
         rc = pk_rec2_check_residency((const void*)k, 512, lds, pl.C * pl.Pn, "pk_rec_*_bf16 (LSTM, eight waves)");

@@ -932,7 +932,7 @@ int pk_recs_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
-        int rc = pk_rec2_reset_handshake(st);
+        int rc = pk_rec2_reset_handshake(st, a);
         if (rc) return rc;
         rc = pk_rec2_check_residency((const void*)k, threads, lds, pl.C * pl.Pn, backward ? "pk_rec_bwd_bf16" : "pk_rec_fwd_bf16");
         if (rc) return rc;

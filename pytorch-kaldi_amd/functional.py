@@ -327,22 +327,37 @@ def gemm_bf16(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, alpha=1.0, beta=0.0, 
     return C
 
 
-def gemm_bf16_bn_stats(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, bias=None):
+def gemm_bf16_bn_stats(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, bias=None, gates=None):
     """C = A.B (+ bias) on bf16 operands together with the BatchNorm statistics of C's columns (biased variance):
     taken in the GEMM epilogue where the shape runs on the 256-tile (pk_gemm_bf16_stats), by pk_bn_stats otherwise.
-    -> (mean, var)"""
+    -> (mean, var), or (mean, var, scale, shift) with gates = the arguments of bn_finalize_gates behind (mean, var):
+    (gamma, beta, eps, H, running_means, running_vars, batches, momentum, count) - the merge of the statistics partials
+    and the finalize step are then one launch."""
     lib = _lib.load()
+
+    def done(mean, var):
+        return (mean, var) if gates is None else (mean, var) + tuple(bn_finalize_gates(mean, var, *gates))
+
     if os.environ.get("PK_GEMM_STATS", "1") == "0":  # A/B switch: statistics by a second pass over C
         gemm_bf16(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, bias=bias)
-        return bn_stats(C if ldc == N else C.as_strided((M, N), (ldc, 1)))
+        return done(*bn_stats(C if ldc == N else C.as_strided((M, N), (ldc, 1))))
     stats = torch.empty(int(lib.pk_gemm_bf16_stats_floats(M, N)), device=C.device, dtype=torch.float32)
     rb = ctypes.c_int(0)
     rc = lib.pk_gemm_bf16_stats(_stream(), M, N, K, 1.0, _p(A), lda, int(a_kc), _p(B), ldb, int(b_kc), _p(C), ldc, _p(bias),
                                 _p(stats), ctypes.byref(rb))
     _lib.check(rc, "pk_gemm_bf16_stats")
     if rb.value == 0:
-        return bn_stats(C if ldc == N else C.as_strided((M, N), (ldc, 1)))
+        return done(*bn_stats(C if ldc == N else C.as_strided((M, N), (ldc, 1))))
     mean, var = torch.empty(N, device=C.device), torch.empty(N, device=C.device)
+    if gates is not None:
+        gamma, beta, eps, H, rms, rvs, nbs, momentum, count = gates
+        G = len(rms)
+        scale, shift = torch.empty_like(mean), torch.empty_like(mean)
+        arr = lambda ts: (ctypes.c_void_p * G)(*[t.data_ptr() for t in ts])
+        _lib.check(lib.pk_bn_stats_merge_finalize_gates(_stream(), _p(stats), rb.value, G, H, _p(mean), _p(var), _p(gamma),
+                                                        _p(beta), eps, _p(scale), _p(shift), arr(rms), arr(rvs), arr(nbs),
+                                                        momentum, float(count)), "pk_bn_stats_merge_finalize_gates")
+        return mean, var, scale, shift
     _lib.check(lib.pk_bn_stats_merge(_stream(), _p(stats), rb.value, N, _p(mean), _p(var)), "pk_bn_stats_merge")
     return mean, var
 
@@ -399,10 +414,12 @@ def side_targets_ok(params):
 
 
 class accumulating_backward:
-    """`with accumulating_backward(): loss.backward()` - the caller states that this backward pass ACCUMULATES into the
-    parameters' .grad (an ordinary training step), which is what lets small-batch kernels add their gradients to the
-    flat .grad themselves (direct_grads_ok).  Without it every gradient is returned to autograd, so torch.autograd.grad()
-    and other gradient-only callers get what they ask for.  core.run_nn's step and bench.py use it."""
+    """`with accumulating_backward(): out = net(x); ...; loss.backward()` - the caller states that this is an ordinary
+    training step whose backward pass ACCUMULATES into the parameters' .grad, which is what lets kernels add their
+    gradients to the flat .grad themselves (direct_grads_ok, decided in backward: small-batch weight / BatchNorm / bias
+    gradients; direct_affine_ok, decided in forward: the BatchNorm affine of recurrent layers).  Without it every such
+    gradient is returned to autograd, so torch.autograd.grad() and other gradient-only callers get what they ask for.
+    core.run_nn's step and bench.py wrap forward and backward in it."""
     depth = 0
 
     def __enter__(self):
@@ -422,6 +439,14 @@ def direct_grads_ok(params):
     gradients, and only while no data-parallel reducer listens for gradient hooks.  PK_DIRECT_GRADS=0 turns it off."""
     return (accumulating_backward.depth > 0 and _Side.listener is None and os.environ.get("PK_DIRECT_GRADS", "1") != "0"
             and torch.is_grad_enabled() is False and side_targets_ok(params))
+
+
+def direct_affine_ok(params):
+    """direct_grads_ok for a decision that has to be taken in FORWARD (a recurrent layer's BatchNorm scales / shifts are
+    handed to its node as detached views of the flat buffer - no torch.cat per layer and step, no AccumulateGrad adds
+    behind the node - only when the whole step runs inside `with accumulating_backward():`)."""
+    return (accumulating_backward.depth > 0 and _Side.listener is None and os.environ.get("PK_DIRECT_GRADS", "1") != "0"
+            and torch.is_grad_enabled() and side_targets_ok(params))
 
 
 _DEBUG_SKIP_SIDE = os.environ.get("PK_DEBUG_SKIP_SIDE", "0") == "1"  # timing experiments only: drops the weight-gradient work
@@ -1505,13 +1530,16 @@ class RecLayerPerfFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, xb_in, Wcat, bcat, Ucat, gamma, beta, running_mean, running_var, mask, cfg):
+    def forward(ctx, x, xb_in, Wcat, bcat, Ucat, gamma, beta, running_mean, running_var, mask, cfg, edge=None):
         ctx.set_materialize_grads(False)  # no 147 MB zero tensor for the (non-differentiable) bf16 twin in backward
         _need_gpu(x, Wcat, bcat, Ucat, gamma, beta, mask)
         lib = _lib.load()
         cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar, xseg = cfg[:10]
         ctx.wparams, ctx.uparams = (cfg[10], cfg[11]) if len(cfg) > 10 else (None, None)
         ctx.side_w, ctx.side_u = (bool(cfg[12]), bool(cfg[13])) if len(cfg) > 13 else (False, False)
+        # (gamma parameters, beta parameters) when the BatchNorm affine was handed over DETACHED (views of the flat
+        # buffer): backward adds d gamma / d beta to their flat .grad inside pk_bn_bwd_bf16 (`edge` keeps the node alive)
+        ctx.affine = cfg[15] if len(cfg) > 15 else None
         T, B, D = x.shape
         G = lib.pk_rec_num_gates(CELL[cell])
         NS = lib.pk_rec_num_saved(CELL[cell])
@@ -1544,15 +1572,20 @@ class RecLayerPerfFn(torch.autograd.Function):
             fill.start(Yb, Xb, dGb)
         P = _new(TB, GH, like=Wcat)
         mean = var = None
-        if use_bn and training:  # the statistics come out of the projection GEMM's epilogue
+        bn_bufs = cfg[14] if len(cfg) > 14 else None  # per-gate (running_mean, running_var, num_batches_tracked) lists
+        pscale = pshift = None
+        if use_bn and training and bn_bufs is not None:
+            # the statistics come out of the projection GEMM's epilogue; their merge, scale / shift and the running
+            # statistics of every gate's module are one launch behind it
+            mean, var, pscale, pshift = gemm_bf16_bn_stats(TB, GH, K, xb, xb.shape[1], 1, Wb, Wb.shape[1], 1, P, GH, gates=(
+                gamma, beta, eps, H, bn_bufs[0], bn_bufs[1], bn_bufs[2], momentum, ndir * TB))
+        elif use_bn and training:
             mean, var = gemm_bf16_bn_stats(TB, GH, K, xb, xb.shape[1], 1, Wb, Wb.shape[1], 1, P, GH)
         else:
             gemm_bf16(TB, GH, K, xb, xb.shape[1], 1, Wb, Wb.shape[1], 1, P, GH)
-        bn_bufs = cfg[14] if len(cfg) > 14 else None  # per-gate (running_mean, running_var, num_batches_tracked) lists
         if use_bn:
-            if training and bn_bufs is not None:
-                pscale, pshift = bn_finalize_gates(mean, var, gamma, beta, eps, H, bn_bufs[0], bn_bufs[1], bn_bufs[2],
-                                                   momentum, ndir * TB)
+            if pscale is not None:
+                pass
             elif training:
                 pscale, pshift = bn_finalize(mean, var, gamma, beta, eps, running_mean, running_var, momentum, ndir * TB)
             else:
@@ -1592,7 +1625,7 @@ class RecLayerPerfFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY, _dm, _dv, _dyb):
         if dY is None:  # the layer output did not reach the loss
-            return (None,) * 11
+            return (None,) * 12
         lib = _lib.load()
         xb, Wb, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, Yb = ctx.saved_tensors
         cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar, xseg = ctx.cfg
@@ -1643,14 +1676,21 @@ class RecLayerPerfFn(torch.autograd.Function):
         sum_g = _new(GH, like=dY)
         sum_gx = _new(GH, like=dY) if use_bn else None
         g1 = ctypes.c_void_p(dGb.data_ptr() + 2 * TB * Gp) if bidir else None
+        acc_g = acc_b = None
+        if use_bn and ctx.affine is not None:  # decided in forward: d gamma / d beta go straight into the flat .grad
+            acc_g = adjacent_view([q.grad for q in ctx.affine[0]])
+            acc_b = adjacent_view([q.grad for q in ctx.affine[1]])
+            if acc_g is None or acc_b is None:
+                raise _lib.PkError("perf-mode recurrent layer: the BatchNorm gradients left the flat buffer between forward "
+                                   "and backward (optim.FlatParams.zero_grad() re-aliases them)")
         rc = lib.pk_bn_bwd_bf16(_stream(), _p(dGb), g1, Gp, G, H, _p(P), GH, TB, _p(mean) if use_bn else None,
                                 _p(var) if use_bn else None, eps, _p(gamma) if use_bn else None, float(TB), _p(part),
-                                _p(sum_g), _p(sum_gx), _p(dPb), dPb.shape[1])
+                                _p(sum_g), _p(sum_gx), _p(dPb), dPb.shape[1], _p(acc_b), _p(acc_g))
         _lib.check(rc, "pk_bn_bwd_bf16")
         dgamma = dbeta = dbias = None
-        if use_bn:
+        if use_bn and acc_g is None:
             dgamma, dbeta = sum_gx, sum_g
-        elif ctx.has_bias:
+        elif not use_bn and ctx.has_bias:
             dbias = sum_g
         # dW[n,d] = sum_m dP[m,n] x[m,d]: both operands k-major; with a re-pitched input the columns come out re-pitched
         Kx = D if xseg is None else xseg[0] * xseg[2]
@@ -1698,7 +1738,7 @@ class RecLayerPerfFn(torch.autograd.Function):
                 side_launch(_sized_for(free, do_dW), (dPb, xb, dWp), ctx.wparams)
         if not side_w:
             do_dW()
-        return dx, None, (None if side_w else dW), dbias, (None if side_u else dU), dgamma, dbeta, None, None, None, None
+        return dx, None, (None if side_w else dW), dbias, (None if side_u else dU), dgamma, dbeta, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------

@@ -26,6 +26,7 @@ only: ``forward`` never calls them, it hands their tensors to the HIP kernels
 through ``functional``.  There is no CPU path: ``use_cuda`` must be True.
 """
 import math
+import os
 import weakref
 
 import numpy as np
@@ -434,7 +435,19 @@ class _Recurrent(nn.Module):
             return None, 1.0 - p
         rows = 2 * batch if self.bidir else batch
         if F_.settings.mask_rng == "device":
-            return torch.empty(rows, self._lay[i], device=device).bernoulli_(1 - p), 1.0
+            # layers of one width and one dropout rate (every shipped recipe): the masks of all layers are ONE draw at
+            # layer 0 (a launch per layer and step otherwise); 16-byte aligned slices
+            H = self._lay[i]
+            if (self._n_lay > 1 and len(set(self._lay)) == 1 and len(set(self._drop)) == 1 and (rows * H) % 4 == 0
+                    and os.environ.get("PK_MASK_ONE_DRAW", "1") != "0"):
+                if i == 0:
+                    self._mask_all = torch.empty(self._n_lay, rows, H, device=device).bernoulli_(1 - p)
+                m_all = getattr(self, "_mask_all", None)
+                if m_all is not None and m_all.shape[1] == rows and m_all.device == device:
+                    if i == self._n_lay - 1:
+                        self._mask_all = None
+                    return m_all[i], 1.0
+            return torch.empty(rows, H, device=device).bernoulli_(1 - p), 1.0
         if getattr(self, "_prefetch", None) is None or self._prefetch not in _MaskPrefetcher.live:
             self._prefetch = _MaskPrefetcher()
         m = self._prefetch.get(i, self._n_lay, rows, self._lay[i], p)  # the reference's own call, a forward call ahead
@@ -512,9 +525,20 @@ class _Recurrent(nn.Module):
             gamma = beta = rmean = rvar = None
             use_bn = bool(self._use_bn[i])
             bns = [getattr(self, b)[i] for (_, _, b) in self._gates]
+            affine = edge_t = None
             if use_bn:
-                gamma = torch.cat([b.weight for b in bns], 0)
-                beta = torch.cat([b.bias for b in bns], 0)
+                gps, bps = [b.weight for b in bns], [b.bias for b in bns]
+                if (self.training and F_.direct_affine_ok(gps + bps)
+                        and F_.perf_path_ok(self.KIND, H, bool(self._use_ln[i]), use_bn, self.training)):
+                    # the engine's own training step: scales / shifts as views of the flat buffer (no concatenation
+                    # launches), their gradients added to the flat .grad by the BatchNorm backward itself
+                    gamma, beta = F_.adjacent_view([q.detach() for q in gps]), F_.adjacent_view([q.detach() for q in bps])
+                    if (gamma is not None and beta is not None and F_.adjacent_view([q.grad for q in gps]) is not None
+                            and F_.adjacent_view([q.grad for q in bps]) is not None):
+                        affine, edge_t = (gps, bps), gps[0]  # (the first scale carries the autograd edge, gradient None)
+                if affine is None:
+                    gamma = torch.cat(gps, 0)
+                    beta = torch.cat(bps, 0)
                 if not self.training:
                     rmean = torch.cat([b.running_mean for b in bns], 0)
                     rvar = torch.cat([b.running_var for b in bns], 0)
@@ -550,7 +574,8 @@ class _Recurrent(nn.Module):
                            [b.num_batches_tracked for b in bns]) if stats_in_kernel else None
                 y, bmean, bvar, xb = F_.RecLayerPerfFn.apply(x, xb, Wcat.detach() if side_w else Wcat, bcat,
                                                            Ucat.detach() if side_u else Ucat, gamma, beta, rmean, rvar,
-                                                           mask_i, cfg + (xseg, wps, ups, side_w, side_u, bn_bufs))
+                                                           mask_i, cfg + (xseg, wps, ups, side_w, side_u, bn_bufs, affine),
+                                                           edge_t)
                 xseg = (2 if self.bidir else 1, H, (H + 7) // 8 * 8)
                 if stats_in_kernel:
                     x = y

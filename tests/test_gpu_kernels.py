@@ -912,6 +912,100 @@ def test_bn_act_bwd_small_against_the_arithmetic(M, N, act, masked):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,B,G,H,bidir,use_bn", [(7, 6, 2, 550, True, True), (5, 4, 2, 24, False, True), (4, 8, 4, 36, True, True),
+                                                 (6, 4, 1, 50, True, False)])
+def test_bn_bwd_bf16_sums_into_the_flat_gradient_and_zeroes_the_pad_itself(T, B, G, H, bidir, use_bn):
+    """pk_bn_bwd_bf16 (BatchNorm backward of a recurrent layer's projections from the bf16 gate gradients; round 4: the sums
+    are also ADDED to acc_beta / acc_gamma - the flat .grad of the gates' BatchNorm shifts / scales - and the pad columns of
+    the bf16 output are zeroed by the launch that finishes the sums) against an fp64 evaluation on the same bf16 inputs.
+    The output buffer starts out as NaN patterns: whatever the launch leaves beyond G*H columns must be zero."""
+    lib = _lib.load()
+    TB, GH = T * B, G * H
+    Hp = (H + 7) // 8 * 8
+    Gp = (G * Hp + 63) // 64 * 64
+    ndir = 2 if bidir else 1
+    g = torch.Generator().manual_seed(T * 100 + H)
+    dG = torch.randn(ndir * TB, Gp, generator=g).to(torch.bfloat16)
+    P = torch.randn(TB, GH, generator=g) * 1.5 + 0.2
+    gamma = 1 + 0.1 * torch.randn(GH, generator=g)
+    mean, var = P.double().mean(0), P.double().var(0, unbiased=False)
+    # plain-layout fp64 view of the gate gradients (gate g at column g*Hp; both directions add up)
+    gsum = torch.zeros(TB, GH, dtype=torch.float64)
+    for d in range(ndir):
+        for k in range(G):
+            gsum[:, k * H:(k + 1) * H] += dG[d * TB:(d + 1) * TB, k * Hp:k * Hp + H].double()
+    if use_bn:
+        xh = (P.double() - mean) / (var + 1e-5).sqrt()
+        sg, sgx = gsum.sum(0), (gsum * xh).sum(0)
+        dP = gamma.double() / (var + 1e-5).sqrt() * (gsum - sg / TB - xh * sgx / TB)
+    else:
+        sg, sgx, dP = gsum.sum(0), None, gsum
+    opitch = (GH + 63) // 64 * 64
+    dGc, Pc = dG.cuda(), P.cuda()
+    out = torch.full((TB, opitch), float("nan"), dtype=torch.bfloat16).cuda()
+    part = torch.empty(int(lib.pk_bn_partial_floats(TB, GH))).cuda()
+    s_g, s_gx = torch.empty(GH).cuda(), torch.empty(GH).cuda()
+    accb, accg = torch.full((GH,), 2.0).cuda(), torch.full((GH,), -1.0).cuda()
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g1 = ctypes.c_void_p(dGc.data_ptr() + 2 * TB * Gp) if bidir else None
+    dev = lambda t: t.float().cuda()
+    mc, vc, gc = dev(mean), dev(var), dev(gamma)
+    _lib.check(lib.pk_bn_bwd_bf16(st, p(dGc), g1, Gp, G, H, p(Pc), GH, TB, p(mc) if use_bn else None, p(vc) if use_bn else None,
+                                  1e-5, p(gc) if use_bn else None, float(TB), p(part), p(s_g), p(s_gx) if use_bn else None, p(out),
+                                  opitch, p(accb), p(accg) if use_bn else None), "pk_bn_bwd_bf16")
+    torch.cuda.synchronize()
+    assert rel_err(out[:, :GH].float(), dP) < 8e-3
+    if opitch > GH:
+        assert float(out[:, GH:].float().abs().max()) == 0.0  # (NaN would fail the comparison too)
+    assert rel_err(s_g, sg) < 2e-5 and rel_err(accb - 2.0, sg) < 2e-5
+    if use_bn:
+        assert rel_err(s_gx, sgx) < 2e-5 and rel_err(accg + 1.0, sgx) < 2e-5
+    else:
+        assert float((accg + 1.0).abs().max()) == 0.0  # untouched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,G,H", [(64000, 2, 550), (1500, 3, 40), (512, 4, 36)])
+def test_statistics_merge_and_finalize_in_one_launch(M, G, H):
+    """pk_bn_stats_merge_finalize_gates against pk_bn_stats_merge followed by pk_bn_finalize_gates on the partials of one
+    pk_gemm_bf16_stats call: same mean / var / scale / shift and the same running statistics and batch counters, bit for bit
+    (the merge order is the same; only the launch boundary is gone)."""
+    lib = _lib.load()
+    N, K = G * H, 96
+    g = torch.Generator().manual_seed(M + H)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    Bm = (torch.randn(N, K, generator=g) / 8).to(torch.bfloat16).cuda()
+    C = torch.empty(M, N).cuda()
+    stats = torch.empty(int(lib.pk_gemm_bf16_stats_floats(M, N))).cuda()
+    rb = ctypes.c_int(0)
+    p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.pk_gemm_bf16_stats(st, M, N, K, 1.0, p(A), K, 1, p(Bm), K, 1, p(C), N, None, p(stats), ctypes.byref(rb)), "gemm")
+    if rb.value == 0:
+        pytest.skip("this shape does not take the statistics epilogue")
+    gamma, beta = (1 + 0.1 * torch.randn(N, generator=g)).cuda(), (0.1 * torch.randn(N, generator=g)).cuda()
+    res = []
+    for merged in (False, True):
+        mean, var, scale, shift = (torch.empty(N).cuda() for _ in range(4))
+        rms, rvs = [torch.full((H,), 0.5).cuda() for _ in range(G)], [torch.full((H,), 2.0).cuda() for _ in range(G)]
+        nbs = [torch.tensor(3, dtype=torch.int64).cuda() for _ in range(G)]
+        arr = lambda ts: (ctypes.c_void_p * G)(*[t.data_ptr() for t in ts])
+        if merged:
+            _lib.check(lib.pk_bn_stats_merge_finalize_gates(st, p(stats), rb.value, G, H, p(mean), p(var), p(gamma), p(beta), 1e-5,
+                                                            p(scale), p(shift), arr(rms), arr(rvs), arr(nbs), 0.05, float(2 * M)), "merged")
+        else:
+            _lib.check(lib.pk_bn_stats_merge(st, p(stats), rb.value, N, p(mean), p(var)), "merge")
+            _lib.check(lib.pk_bn_finalize_gates(st, G, H, p(mean), p(var), p(gamma), p(beta), 1e-5, p(scale), p(shift), arr(rms),
+                                                arr(rvs), arr(nbs), 0.05, float(2 * M)), "finalize")
+        torch.cuda.synchronize()
+        res.append([mean, var, scale, shift] + rms + rvs + nbs)
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+    assert rel_err(res[1][0], C.double().mean(0)) < 1e-5 and int(res[1][-1]) == 4
+
+
+@pytest.mark.gpu
 def test_fused_step_matches_torch_zeroes_the_gradient_and_refreshes_the_bf16_copies():
     """pk_fused_step (round 4) against torch.optim for the three optimizers, with its two side jobs: the gradient is zero
     afterwards, and the bf16 copies of the 2-D weights named in the segment table equal bf16(new weights) at their pitch

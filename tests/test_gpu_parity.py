@@ -454,6 +454,51 @@ def test_side_stream_weight_gradients_equal_the_autograd_path():
         F_.settings.wgrad_side = old_side
 
 
+@pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("GRU", "gru", "tanh"), ("LSTM", "lstm", "tanh")])
+def test_training_step_context_leaves_the_gradients_of_the_autograd_path(kind, pre, act):
+    """Inside functional.accumulating_backward (what run_nn's step wraps forward and backward in) a recurrent layer takes
+    its BatchNorm scales / shifts as views of the flat buffer - no concatenation, one draw for all layers' masks - and the
+    BatchNorm backward adds d gamma / d beta to the flat .grad itself (pk_bn_bwd_bf16's acc arguments).  Same gradients
+    and running statistics as the step outside the context, where they travel through torch.cat and AccumulateGrad; two
+    steps (the second accumulates on a zeroed buffer again), two layers, dropout masks injected."""
+    optim_ = importlib.import_module("pytorch-kaldi_amd.optim")
+    F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+    nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
+    opts = _rec_opts(pre, [72, 72], act, drop=0.2)
+    T, B, D = 40, 16, 24
+    old_prec = F_.settings.precision
+    F_.set_precision("bf16")
+    try:
+        res = {}
+        x = torch.randn(T, B, D, generator=torch.Generator().manual_seed(6)).cuda()
+        masks = [(torch.rand(2 * B, 72, generator=torch.Generator().manual_seed(70 + i)) > 0.2).float() for i in range(2)]
+        for inside in (False, True):
+            torch.manual_seed(5)
+            net = getattr(nn_amd, kind)(dict(opts), D).cuda().train()
+            flat = optim_.FlatParams(net)
+            snaps = []
+            for _ in range(2):
+                if inside:
+                    with F_.accumulating_backward():
+                        y = net(x, drop_masks=masks)
+                        flat.zero_grad()
+                        y.square().mean().backward()
+                else:
+                    y = net(x, drop_masks=masks)
+                    flat.zero_grad()
+                    y.square().mean().backward()
+                F_.join_side()
+                torch.cuda.synchronize()
+                snaps.append(flat.grad.clone())
+            res[inside] = (snaps, {k: v.clone() for k, v in net.state_dict().items() if "running" in k or "tracked" in k})
+        for a, b in zip(res[True][0], res[False][0]):
+            assert float(a.abs().max()) > 0 and rel_err(a, b) < 1e-6
+        for k, v in res[False][1].items():
+            assert torch.equal(v, res[True][1][k]), k
+    finally:
+        F_.set_precision(old_prec)
+
+
 def test_hip_graph_replay_trains_like_eager_steps():
     """graphs.GraphedStep: an MLP training step (forward, NLL, backward, fused RMSprop) captured once and replayed on
     new batches ends with the same parameters, optimizer state and step count as the eager loop."""

@@ -31,7 +31,7 @@ g1 = ctypes.c_void_p(dGb.data_ptr() + 2 * TB * Gp)
 
 def run():
     _lib.check(lib.pk_bn_bwd_bf16(st, p(dGb), g1, Gp, G, H, p(P), GH, TB, p(mean), p(var), 1e-5, p(gamma), float(TB), p(part),
-                                  p(sum_g), p(sum_gx), p(dPb), dPb.shape[1]), "pk_bn_bwd_bf16")
+                                  p(sum_g), p(sum_gx), p(dPb), dPb.shape[1], None, None), "pk_bn_bwd_bf16")
 
 
 big = torch.empty(256 << 20, device="cuda", dtype=torch.float32)  # 1 GB: flushes the Infinity Cache between launches

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/<round>_rec_step_floor.json from the two traces of tools/gpu_call_floor.sh (full step / EMPTY=1):
+"""profiles/<round>_rec_step_floor.json from the two traces tools/gpu_evidence.sh takes with tools/trace_rec2.py (full step / EMPTY=1):
     python tools/make_step_floor.py gpurun_out/floor3 profiles/r03_rec_step_floor.json "<note>"
 bench.py reads hop_us.{fwd,bwd} and floor_us_{fwd,bwd} from it (latency record of the roofline object)."""
 import json

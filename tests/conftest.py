@@ -40,3 +40,23 @@ def _built_library():
     if not os.path.exists(lib):
         importlib.import_module("pytorch-kaldi_amd.build").build()
     yield
+
+
+@pytest.fixture(autouse=True)
+def _engine_settings_do_not_leak():
+    """A test that switches the engine's process-wide settings (precision, recurrence algorithm, side-stream policy) and
+    fails - or forgets - to switch them back must not change what the tests behind it measure (round 4: a bf16 test
+    without a finally turned an fp32 test three files later red)."""
+    import importlib
+
+    F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+    keep = {k: getattr(F_.settings, k) for k in ("precision", "rec_algo", "wgrad_side", "mask_rng") if hasattr(F_.settings, k)}
+    yield
+    for k, v in keep.items():
+        if getattr(F_.settings, k) != v:
+            if k == "precision":
+                F_.set_precision(v)
+            elif k == "rec_algo":
+                F_.set_rec_algo(v)
+            else:
+                setattr(F_.settings, k, v)

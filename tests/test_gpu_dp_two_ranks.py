@@ -153,40 +153,45 @@ def test_persistent_recurrences_next_to_a_long_running_foreign_kernel(hog_cus):
     opts = {"ligru_lay": str(H), "ligru_drop": "0.2", "ligru_use_laynorm_inp": "False", "ligru_use_batchnorm_inp": "False",
             "ligru_use_laynorm": "False", "ligru_use_batchnorm": "True", "ligru_bidir": "True", "ligru_act": "relu",
             "ligru_orthinit": "True", "use_cuda": "True", "to_do": "train"}
+    old_prec, old_algo = F_amd.settings.precision, F_amd.settings.rec_algo
     F_amd.set_precision("bf16")
     F_amd.set_rec_algo("persistent")
-    torch.manual_seed(5)
-    net = nn_amd.liGRU(opts, D).cuda().train()
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(T, B, D, generator=g).cuda()
-    cot = torch.randn(T, B, 2 * H, generator=g).cuda()
-    masks = [(torch.rand(2 * B, H, generator=g) > 0.2).float().cuda() / 0.8]
-    side = torch.cuda.Stream()
-    buf = torch.zeros(hog_cus * 16384, device="cuda")
-    lib.pk_persist2_error_reset()
+    try:
+        torch.manual_seed(5)
+        net = nn_amd.liGRU(opts, D).cuda().train()
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(T, B, D, generator=g).cuda()
+        cot = torch.randn(T, B, 2 * H, generator=g).cuda()
+        masks = [(torch.rand(2 * B, H, generator=g) > 0.2).float().cuda() / 0.8]
+        side = torch.cuda.Stream()
+        buf = torch.zeros(hog_cus * 16384, device="cuda")
+        lib.pk_persist2_error_reset()
 
-    def run(hog):
-        net.zero_grad(set_to_none=True)
-        xe = x.clone().requires_grad_(True)
-        torch.cuda.synchronize()
-        if hog:
-            _lib.check(lib.pk_selftest_cu_hog(ctypes.c_void_p(side.cuda_stream), hog_cus, 60000, ctypes.c_void_p(buf.data_ptr())), "hog")
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = net(xe, drop_masks=masks)
-        (y * cot).sum().backward()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1), y.detach().clone(), xe.grad.clone(), {k: q.grad.clone() for k, q in net.named_parameters() if q.grad is not None}
+        def run(hog):
+            net.zero_grad(set_to_none=True)
+            xe = x.clone().requires_grad_(True)
+            torch.cuda.synchronize()
+            if hog:
+                _lib.check(lib.pk_selftest_cu_hog(ctypes.c_void_p(side.cuda_stream), hog_cus, 60000, ctypes.c_void_p(buf.data_ptr())), "hog")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = net(xe, drop_masks=masks)
+            (y * cot).sum().backward()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1), y.detach().clone(), xe.grad.clone(), {k: q.grad.clone() for k, q in net.named_parameters() if q.grad is not None}
 
-    run(False)  # warm-up (allocator, first-use attributes)
-    t_plain, y0, dx0, g0 = run(False)
-    t_hog, y1, dx1, g1 = run(True)
-    assert float(buf[0]) > 10, "the stand-in kernel did not run"
-    assert lib.pk_persist2_error_count() == 0, "a bounded spin of a persistent kernel timed out next to the foreign kernel"
-    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
-    for k in g0:
-        assert torch.equal(g0[k], g1[k]), k
-    print("\nLi-GRU layer fwd+bwd (T=%d, B=%d): %.2f ms alone, %.2f ms next to a %d-CU foreign kernel (x%.2f)"
-          % (T, B, t_plain, t_hog, hog_cus, t_hog / t_plain))
-    assert t_hog < 2.0 * t_plain
+        run(False)  # warm-up (allocator, first-use attributes)
+        t_plain, y0, dx0, g0 = run(False)
+        t_hog, y1, dx1, g1 = run(True)
+        assert float(buf[0]) > 10, "the stand-in kernel did not run"
+        assert lib.pk_persist2_error_count() == 0, "a bounded spin of a persistent kernel timed out next to the foreign kernel"
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+        print("\nLi-GRU layer fwd+bwd (T=%d, B=%d): %.2f ms alone, %.2f ms next to a %d-CU foreign kernel (x%.2f)"
+              % (T, B, t_plain, t_hog, hog_cus, t_hog / t_plain))
+        assert t_hog < 2.0 * t_plain
+    finally:
+        F_amd.set_precision(old_prec)
+        F_amd.set_rec_algo(old_algo)

@@ -194,6 +194,7 @@ class GradReducer:
         side = None
         if buf.is_cuda:
             from . import functional as _F
+            _F.flush_deferred_side()  # (postponed weight-gradient launches of this bucket's parameters: enqueue them first)
             side = _F._Side.stream if _F._Side.pending else None
         if side is not None:
             # behind the weight-gradient GEMMs of this bucket (side stream) AND behind the gradients autograd has

@@ -399,6 +399,7 @@ class _Side:
     stream = None
     pending = False
     listener = None  # dp.GradReducer (overlap mode): told which parameters' gradients were just enqueued on the side stream
+    deferred = []    # side_launch(defer=True) calls waiting for the next recurrence launch (flush_deferred_side)
 
 
 def set_side_listener(fn):
@@ -458,10 +459,21 @@ def _make_side_stream():
     return torch.cuda.Stream()
 
 
-def side_launch(fn, keep, params=None):
+def side_launch(fn, keep, params=None, defer=False):
     """Run fn() on the side stream after everything enqueued so far on the current stream; `keep` are the tensors
     fn reads or writes that autograd may free before the side stream is done; `params`: the parameters whose .grad fn
-    accumulates into (the data-parallel reducer launches a bucket's all-reduce behind them, on this stream)."""
+    accumulates into (the data-parallel reducer launches a bucket's all-reduce behind them, on this stream).
+
+    defer = True (PK_SIDE_LATE and PK_SIDE_DEFER_HEADS, default on): the whole call - the stream dependency included - is postponed until the
+    next recurrent layer's backward is about to launch its recurrence (flush_deferred_side), or until join_side().  For
+    the output layers on top of a recurrent stack: their weight-gradient GEMMs fill the whole chip for 0.3 ms, and the
+    short kernels of the NEXT head's backward on the main stream queued behind their workgroups (0.29 ms per step in the
+    round-4 timeline); next to the recurrence, which leaves 112 CUs idle, the same work is free."""
+    if defer and settings.side_late and os.environ.get("PK_SIDE_DEFER_HEADS", "1") != "0":
+        _Side.deferred.append((fn, keep, params))
+        _Side.pending = True
+        return
+    flush_deferred_side()
     main = torch.cuda.current_stream()
     if _Side.stream is None:
         _Side.stream = _make_side_stream()
@@ -478,10 +490,20 @@ def side_launch(fn, keep, params=None):
         _Side.listener(params)
 
 
+def flush_deferred_side():
+    """Launch what side_launch(defer=True) postponed, in order, behind everything enqueued so far on the current stream."""
+    if _Side.deferred:
+        items, _Side.deferred = _Side.deferred, []
+        for fn, keep, params in items:
+            side_launch(fn, keep, params)
+
+
 def join_side():
     """Make the current stream wait for the side stream (before anything reads or rewrites .grad)."""
+    flush_deferred_side()
     if _Side.pending:
-        torch.cuda.current_stream().wait_stream(_Side.stream)
+        if _Side.stream is not None:
+            torch.cuda.current_stream().wait_stream(_Side.stream)
         _Side.pending = False
 
 
@@ -675,8 +697,8 @@ def _linear_bwd_bf16(ctx, dyb, xb, wb, like):
                         for s_ in range(nseg):
                             wp.grad[:, s_ * seglen:(s_ + 1) * seglen].add_(dwp[:, s_ * segpad:s_ * segpad + seglen])
 
-            if side:
-                side_launch(run, (dyb, xb, dwp), [wp])
+            if side:  # (the input is a recurrent layer's output: next to that layer's backward recurrence)
+                side_launch(run, (dyb, xb, dwp), [wp], defer=True)
             else:
                 run()
                 dw = torch.cat([dwp[:, s_ * segpad:s_ * segpad + seglen] for s_ in range(nseg)], 1)
@@ -1643,6 +1665,7 @@ class RecLayerPerfFn(torch.autograd.Function):
             dGb = torch.empty(ndir * TB, _up(G * Hp, 64), device=dY.device, dtype=torch.bfloat16)
             prefilled = 2 if ctx.self_fill else 0
         Gp = dGb.shape[1]
+        flush_deferred_side()  # the output layers' weight gradients: ready when this recurrence is, next to it on the idle CUs
         if ctx.Xb is not None:
             rc = lib.pk_rec2p_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
                                        float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dGb), Gp, prefilled)

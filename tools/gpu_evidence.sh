@@ -39,6 +39,7 @@ S="python $R/bench.py --steps 2 --warmup 1 --prewarm-s 0 --no-cpu-baseline --no-
 timeout 400 rocprofv3 --kernel-trace --stats -d $out/kt -- $B > $out/kt.log 2>&1
 python $R/tools/rocpd_stats.py $(find $out/kt -name "*.db" | head -1) $out/${tag}_bench_bf16_kernel_stats.csv > /dev/null 2>&1
 python $R/tools/rocpd_dump.py $(find $out/kt -name "*.db" | head -1) $out/${tag}_timeline_tail.csv 1200 > /dev/null 2>&1
+python $R/tools/timeline_step.py $out/${tag}_timeline_tail.csv 3 > $out/${tag}_timeline_step.txt 2>/dev/null
 rm -rf $out/kt
 head -6 $out/${tag}_bench_bf16_kernel_stats.csv
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -- $S > $out/pmc_fetch.log 2>&1

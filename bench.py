@@ -395,7 +395,7 @@ def roofline_of(tr, args, summ, prec):
         # its MFMA block and gate math removed (EMPTY=1: poll + barrier + flush / prefetch issue + patches + publish).
         lat = {"bound": "latency", "dependent_steps_per_launch": tr.T, "us_per_step": round(d["avg_ms"] * 1e3 / tr.T, 3)}
         hop, floor, src_ = 0.9, None, None
-        for cand in ("r03_rec_step_floor.json", "r02_rec_step_floor.json"):
+        for cand in ("r04_rec_step_floor.json", "r03_rec_step_floor.json", "r02_rec_step_floor.json"):
             try:
                 fl_ = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 side_ = "bwd" if "bwd" in dom else "fwd"
@@ -415,7 +415,7 @@ def roofline_of(tr, args, summ, prec):
         roof["hop_floor_us"], roof["latency_frac"] = hop, lat["frac"]
         if "structure_frac" in lat:
             roof["step_floor_us"], roof["structure_frac"] = lat["step_floor_us"], lat["structure_frac"]
-    for src in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for src in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", src)))
             if dom in pm and args.recipe == "timit_ligru" and (tr.T, tr.B) == (500, 128) and args.layers is None:

@@ -204,6 +204,12 @@ int pk_logsoftmax_bwd_bf16(void* stream, const float* dy, const float* y, int64_
 int64_t pk_nll_err_partial_floats(int64_t rows);
 int pk_nll_err_fwd(void* stream, const float* y, const int64_t* lab, int64_t ignore_index, int64_t rows, int64_t N,
                    float* partial, float* out4, float* loss_out, float* bad_acc);
+/* The same output together with the arg-max position of every row (first index on ties; a NaN row: column 0), and the
+ * cost of such an output: cost_nll / cost_err (utils.py:2361-2367) as ONE gathered load and one compare per row instead of
+ * a second pass over the [rows][N] log-posteriors.  amax: [rows] int32.  N <= 2048. */
+int pk_logsoftmax_fwd_ld_argmax(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t N, float* y, int32_t* amax);
+int pk_nll_err_fwd_argmax(void* stream, const float* y, const int64_t* lab, const int32_t* amax, int64_t ignore_index,
+                          int64_t rows, int64_t N, float* partial, float* out4, float* loss_out, float* bad_acc);
 /* ... and its backward joined with the LogSoftmax backward: the one-hot gradient of the mean NLL is never written;
  * dz = (dloss / count) * (exp(y) - onehot(lab)) as bf16 plus its column sums.  dloss, count: device scalars. */
 int pk_nll_logsoftmax_bwd_bf16(void* stream, const float* y, const int64_t* lab, const float* dloss, const float* count,

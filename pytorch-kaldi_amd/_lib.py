@@ -56,10 +56,12 @@ SIGNATURES = {
     "pk_logsoftmax_fwd": (c_int, [P, P, c_int64, c_int64, P]),
     "pk_logsoftmax_bwd": (c_int, [P, P, P, c_int64, c_int64, P]),
     "pk_logsoftmax_fwd_ld": (c_int, [P, P, c_int64, c_int64, c_int64, P]),
+    "pk_logsoftmax_fwd_ld_argmax": (c_int, [P, P, c_int64, c_int64, c_int64, P, P]),
     "pk_logsoftmax_bwd_bf16_partial_floats": (c_int64, [c_int64, c_int64]),
     "pk_logsoftmax_bwd_bf16": (c_int, [P, P, P, c_int64, c_int64, P, c_int64, P, P]),
     "pk_nll_err_partial_floats": (c_int64, [c_int64]),
     "pk_nll_err_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, P, P, P, P]),
+    "pk_nll_err_fwd_argmax": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P, P, P, P]),
     "pk_nll_logsoftmax_bwd_bf16": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64, P, P]),
     "pk_rec_num_saved": (c_int, [c_int]),
     "pk_rec_num_gates": (c_int, [c_int]),

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_kernel(const float* __rest
 // HBM once, all loads of a lane in flight together) and the reductions are wave shuffles - no LDS, no barriers.
 template <int NPL>
 __global__ __launch_bounds__(256) void logsoftmax_fwd_wave_kernel(const float* __restrict__ x, long ldx, long rows, long N,
-                                                                   float* __restrict__ y) {
+                                                                   float* __restrict__ y, int* __restrict__ amax) {
     const int lane = threadIdx.x & 63;
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
     for (long r = wid; r < rows; r += nw) {
@@ -562,7 +562,28 @@ __global__ __launch_bounds__(256) void logsoftmax_fwd_wave_kernel(const float* _
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             const long c = lane + 64 * i;
-            if (c < N) y[r * N + c] = v[i] - lse;
+            v[i] -= lse;
+            if (c < N) y[r * N + c] = v[i];
+        }
+        if (amax != nullptr) {
+            // the row's arg-max over the values just stored, by the rule of nll_err_partial_kernel (first index on ties; a
+            // NaN row: the first column), so that the cost kernel behind this output need not read the row again: the
+            // frame-error count of cost_err (utils.py:2363-2367) becomes one compare per row
+            float best = -INFINITY;
+            long besti = N;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const long c = lane + 64 * i;
+                const float u = c < N ? v[i] : -INFINITY;
+                if (c < N && (u > best || (u == best && c < besti) || besti == N)) best = u, besti = c;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ob = __shfl_xor(best, off);
+                const long oi = __shfl_xor(besti, off);
+                if (ob > best || (ob == best && oi < besti)) best = ob, besti = oi;
+            }
+            if (lane == 0) amax[r] = (int)besti;
         }
     }
 }
@@ -695,6 +716,34 @@ __global__ __launch_bounds__(256) void nll_err_partial_kernel(const float* __res
         if (!ignored && in_range) loss -= at_lab, cnt += 1.f;
         if (!ignored && !in_range) bad += 1.f;
     }
+    if (lane == 0) {
+        float* o = partial + wid * 4;
+        o[0] = loss, o[1] = err, o[2] = cnt, o[3] = bad;
+    }
+}
+
+// The cost of an output whose rows' arg-max positions are already known (logsoftmax_fwd_wave_kernel's amax): a lane per row,
+// one gathered load (the entry at the label) and one compare - 64 000 x 1938 log-posteriors are NOT read again (0.12 ms
+// of the step).  Same partial format and the same decisions as nll_err_partial_kernel.
+__global__ __launch_bounds__(256) void nll_err_gather_kernel(const float* __restrict__ y, const long* __restrict__ lab,
+                                                              const int* __restrict__ amax, long ignore_index, long rows,
+                                                              long N, float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+    float loss = 0.f, err = 0.f, cnt = 0.f, bad = 0.f;
+    for (long r0 = wid * 64; r0 < rows; r0 += nw * 64) {
+        const long r = r0 + lane;
+        if (r < rows) {
+            const long lr = lab[r];
+            const bool ignored = lr == ignore_index;
+            const bool in_range = lr >= 0 && lr < N;
+            const float at_lab = in_range ? y[r * N + lr] : 0.f;
+            err += (long)amax[r] != lr ? 1.f : 0.f;
+            if (!ignored && in_range) loss -= at_lab, cnt += 1.f;
+            if (!ignored && !in_range) bad += 1.f;
+        }
+    }
+    loss = pk_wave_sum(loss), err = pk_wave_sum(err), cnt = pk_wave_sum(cnt), bad = pk_wave_sum(bad);
     if (lane == 0) {
         float* o = partial + wid * 4;
         o[0] = loss, o[1] = err, o[2] = cnt, o[3] = bad;
@@ -1096,11 +1145,23 @@ extern "C" int pk_logsoftmax_fwd_ld(void* stream, const float* x, int64_t ldx, i
     PK_REQUIRE(ldx >= N, "pk_logsoftmax_fwd_ld: input pitch shorter than a row");
     hipStream_t st = pk_stream(stream);
     if (N <= 2048) {
-        PK_LSM_DISPATCH(logsoftmax_fwd_wave_kernel, x, (long)ldx, (long)rows, (long)N, y);
+        PK_LSM_DISPATCH(logsoftmax_fwd_wave_kernel, x, (long)ldx, (long)rows, (long)N, y, (int*)nullptr);
     } else {
         int blocks = (int)(rows < 8192 ? rows : 8192);
         hipLaunchKernelGGL(logsoftmax_fwd_kernel, dim3(blocks), dim3(256), 0, st, x, (long)ldx, (long)rows, (long)N, y);
     }
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+// ... and the arg-max position of every output row (first index on ties), for pk_nll_err_fwd_argmax
+extern "C" int pk_logsoftmax_fwd_ld_argmax(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t N, float* y,
+                                           int32_t* amax) {
+    if (rows == 0) return 0;
+    PK_REQUIRE(ldx >= N && N >= 1 && N <= 2048, "pk_logsoftmax_fwd_ld_argmax: rows of 1..2048 columns, pitch >= row length");
+    PK_REQUIRE(x && y && amax, "pk_logsoftmax_fwd_ld_argmax: null argument");
+    hipStream_t st = pk_stream(stream);
+    PK_LSM_DISPATCH(logsoftmax_fwd_wave_kernel, x, (long)ldx, (long)rows, (long)N, y, (int*)amax);
     PK_LAUNCH_CHECK();
     return 0;
 }
@@ -1193,6 +1254,24 @@ extern "C" int pk_nll_err_fwd(void* stream, const float* y, const int64_t* lab, 
     else if (N <= 256) hipLaunchKernelGGL((nll_err_partial_kernel<4>), grid, dim3(256), 0, st, y, l, (long)ignore_index, (long)rows, (long)N, partial);
     else if (N <= 1024) hipLaunchKernelGGL((nll_err_partial_kernel<16>), grid, dim3(256), 0, st, y, l, (long)ignore_index, (long)rows, (long)N, partial);
     else hipLaunchKernelGGL((nll_err_partial_kernel<32>), grid, dim3(256), 0, st, y, l, (long)ignore_index, (long)rows, (long)N, partial);
+    PK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nll_err_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks * 4, (long)rows, out4, loss_out, bad_acc);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+// pk_nll_err_fwd for an output that came with its rows' arg-max positions (pk_logsoftmax_fwd_ld_argmax): same four numbers
+// without reading the rows again
+extern "C" int pk_nll_err_fwd_argmax(void* stream, const float* y, const int64_t* lab, const int32_t* amax, int64_t ignore_index,
+                                     int64_t rows, int64_t N, float* partial, float* out4, float* loss_out, float* bad_acc) {
+    PK_REQUIRE(rows > 0 && N >= 1, "pk_nll_err_fwd_argmax: empty input");
+    PK_REQUIRE(y && lab && amax && partial && out4, "pk_nll_err_fwd_argmax: null argument");
+    hipStream_t st = pk_stream(stream);
+    long blocks = (rows + 255) / 256;  // a lane per row
+    const long cap = nll_err_blocks(rows);  // (the workspace is sized by pk_nll_err_partial_floats)
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(nll_err_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, st, y, (const long*)lab, (const int*)amax,
+                       (long)ignore_index, (long)rows, (long)N, partial);
     PK_LAUNCH_CHECK();
     hipLaunchKernelGGL(nll_err_final_kernel, dim3(1), dim3(256), 0, st, partial, blocks * 4, (long)rows, out4, loss_out, bad_acc);
     PK_LAUNCH_CHECK();

@@ -741,17 +741,21 @@ class LinearLogSoftmaxFn(torch.autograd.Function):
         Kx = K if xseg is None else xseg[0] * xseg[2]
         gemm_bf16(M, N, Kx, xb, xb.shape[1], 1, wb, wb.shape[1], 1, z, ldz, bias=bias)
         y = _new(M, N, like=x2)
-        _lib.check(lib.pk_logsoftmax_fwd_ld(_stream(), _p(z), ldz, M, N, _p(y)), "pk_logsoftmax_fwd_ld")
+        # (with the arg-max position of every row: the cost behind this output - head_nll - then needs one gathered load
+        # and one compare per row instead of a second pass over y)
+        amax = torch.empty(M, device=x2.device, dtype=torch.int32)
+        _lib.check(lib.pk_logsoftmax_fwd_ld_argmax(_stream(), _p(z), ldz, M, N, _p(y), _p(amax)), "pk_logsoftmax_fwd_ld_argmax")
         ctx.save_for_backward(xb, wb_plain, y)
         ctx.xseg = xseg
         ctx.dims = (M, N, K)
         ctx.has_bias = bias is not None
         ctx.in_shape = x.shape
         ctx.wparam = weight if isinstance(weight, torch.nn.Parameter) else None
-        return y
+        ctx.mark_non_differentiable(amax)
+        return y, amax
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _damax=None):
         lib = _lib.load()
         xb, wb, y = ctx.saved_tensors
         M, N, K = ctx.dims
@@ -794,8 +798,8 @@ def linear_log_softmax(x, weight, bias=None):
     _DxShare.epoch += 1   # (a new forward pass: whatever the previous backward pass shared is history)
     _DxShare.table.clear()
     xs = _head_input(x)
-    y = LinearLogSoftmaxFn.apply(xs, weight if weight.is_contiguous() else w, bias, xb, wb, wb_plain, xseg)
-    y._pk_head = (xs, weight, bias, xb, wb_plain, xseg, y._version)
+    y, amax = LinearLogSoftmaxFn.apply(xs, weight if weight.is_contiguous() else w, bias, xb, wb, wb_plain, xseg)
+    y._pk_head = (xs, weight, bias, xb, wb_plain, xseg, y._version, amax)
     return y
 
 
@@ -808,7 +812,7 @@ class HeadNllFn(torch.autograd.Function):
     up in (x, weight, bias) as they should.  The same forward pass counts the frame errors of the cost_err line."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, y, lab, xb, wb, xseg, ignore_index):
+    def forward(ctx, x, weight, bias, y, lab, xb, wb, xseg, ignore_index, amax=None):
         lib = _lib.load()
         ctx.set_materialize_grads(False)  # (no zero tensor for the statistics output in backward)
         ctx.xseg = xseg
@@ -819,8 +823,13 @@ class HeadNllFn(torch.autograd.Function):
         part = _new(int(lib.pk_nll_err_partial_floats(M)), like=y)
         # bad labels are counted IN PLACE into the device's persistent counter by the same launch (HIP-graph safe; the loss
         # of such a batch is NaN; the count is reported at the next point where the host waits for the GPU anyway)
-        _lib.check(lib.pk_nll_err_fwd(_stream(), _p(y), _p(lab), int(ignore_index), M, N, _p(part), _p(out4), _p(loss),
-                                      _p(label_check_counter(y.device))), "pk_nll_err_fwd")
+        if amax is not None and os.environ.get("PK_HEAD_ARGMAX", "1") != "0":
+            # the rows' arg-max positions came with y (pk_logsoftmax_fwd_ld_argmax): y is not read a second time
+            _lib.check(lib.pk_nll_err_fwd_argmax(_stream(), _p(y), _p(lab), _p(amax), int(ignore_index), M, N, _p(part), _p(out4),
+                                                 _p(loss), _p(label_check_counter(y.device))), "pk_nll_err_fwd_argmax")
+        else:
+            _lib.check(lib.pk_nll_err_fwd(_stream(), _p(y), _p(lab), int(ignore_index), M, N, _p(part), _p(out4), _p(loss),
+                                          _p(label_check_counter(y.device))), "pk_nll_err_fwd")
         ctx.save_for_backward(xb, wb, y, lab, out4)
         ctx.dx_share = _dx_share_key(x) if (_DxShare.on and x.is_contiguous()) else None
         ctx.dims = (M, N, x.shape[-1])
@@ -835,7 +844,7 @@ class HeadNllFn(torch.autograd.Function):
     def backward(ctx, dloss, _d4):
         lib = _lib.load()
         if dloss is None:
-            return (None,) * 9
+            return (None,) * 10
         xb, wb, y, lab, out4 = ctx.saved_tensors
         M, N, K = ctx.dims
         dl = dloss.contiguous().float()
@@ -847,7 +856,7 @@ class HeadNllFn(torch.autograd.Function):
         _lib.check(lib.pk_nll_logsoftmax_bwd_bf16(_stream(), _p(y), _p(lab), _p(dl), cnt, ctx.ignore_index, M, N, _p(dzb),
                                                   ldb, _p(part), _p(db)), "pk_nll_logsoftmax_bwd_bf16")
         dx, dw = _linear_bwd_bf16(ctx, dzb, xb, wb, y)
-        return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None, None, None, None, None
+        return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None, None, None, None, None, None
 
 
 def linear(x, weight, bias=None):
@@ -899,10 +908,10 @@ def head_nll(y, lab, ignore_index=-100):
     head = getattr(y, "_pk_head", None)
     if head is None or y.dim() != 2 or lab.dim() != 1 or lab.shape[0] != y.shape[0] or lab.dtype != torch.int64:
         return None
-    x, weight, bias, xb, wb, xseg, version = head
+    x, weight, bias, xb, wb, xseg, version, amax = head
     if y._version != version or not lab.is_cuda:
         return None
-    loss, out4 = HeadNllFn.apply(x, weight, bias, y.detach(), lab, xb, wb, xseg, ignore_index)
+    loss, out4 = HeadNllFn.apply(x, weight, bias, y.detach(), lab, xb, wb, xseg, ignore_index, amax)
     return loss, out4
 
 

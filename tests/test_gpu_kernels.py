@@ -611,6 +611,51 @@ def test_head_nll_matches_nll_loss_behind_the_head(rows, K, N, ignored):
     assert rel_err(db1, db2) < 1e-5
 
 
+@pytest.mark.parametrize("rows,K,N", [(300, 32, 48), (1000, 64, 1938), (257, 16, 200), (64, 40, 1024), (5000, 24, 64)])
+def test_cost_from_the_arg_max_positions_equals_the_second_pass(rows, K, N, monkeypatch):
+    """Round 4: the fused output layer writes every row's arg-max position next to the log-posteriors and the cost takes
+    one gathered load + one compare per row (pk_logsoftmax_fwd_ld_argmax / pk_nll_err_fwd_argmax) instead of reading the
+    rows again (pk_nll_err_fwd).  Same four numbers: error rate, counted rows and bad labels EXACTLY - on logits built to
+    tie constantly (small integers: the first index must win), with NaN rows (column 0 by convention), ignored and
+    out-of-range labels - the loss to summation order; and the positions themselves against torch on tie-free rows."""
+    g = torch.Generator().manual_seed(rows + N)
+    x = torch.randint(-1, 2, (rows, K), generator=g).float()
+    w = torch.randint(-1, 2, (N, K), generator=g).float() * 0.5
+    b = torch.randint(-2, 3, (N,), generator=g).float() * 0.25
+    x[3] = float("nan")
+    x[rows - 2] = float("nan")
+    lab = torch.randint(0, N, (rows,), generator=g)
+    lab[3] = lab[rows - 2] = -100          # (their log-posteriors are NaN: keep the loss finite)
+    lab[7:17] = -100
+    F_.set_precision("bf16")
+    try:
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("PK_HEAD_ARGMAX", mode)
+            y = F_.linear_log_softmax(x.cuda(), w.cuda(), b.cuda())
+            assert y._pk_head[-1] is not None and y._pk_head[-1].dtype == torch.int32
+            loss, stats = F_.head_nll(y, lab.cuda())
+            bad = lab.clone()
+            bad[20] = N + 3
+            _, stats_bad = F_.head_nll(y, bad.cuda())
+            torch.cuda.synchronize()
+            out[mode] = (float(loss), stats.clone(), stats_bad.clone(), y.detach().clone(), y._pk_head[-1].clone())
+        F_.label_check_counter("cuda").zero_()
+    finally:
+        F_.set_precision("fp32")
+    (l1, s1, sb1, y1, a1), (l0, s0, sb0, y0, _) = out["1"], out["0"]
+    assert torch.equal(y1, y0, ) or torch.equal(torch.nan_to_num(y1), torch.nan_to_num(y0))
+    assert torch.equal(s1[1:], s0[1:]) and torch.equal(sb1[1:], sb0[1:]) and float(sb1[3]) == 1.0
+    assert abs(l1 - l0) <= 2e-6 * abs(l0) and abs(float(s1[0]) - float(s0[0])) <= 2e-6 * abs(l0)
+    # the positions: first index of the row maximum; NaN rows -> 0
+    yc = y1.cpu()
+    first = torch.full((rows,), -1, dtype=torch.int64)
+    for r in range(rows):
+        row = yc[r]
+        first[r] = 0 if bool(torch.isnan(row).any()) else int((row == row.max()).nonzero()[0])
+    assert torch.equal(a1.cpu().long(), first)
+
+
 def test_head_nll_declines_what_it_does_not_cover():
     F_.set_precision("bf16")
     try:

@@ -6,9 +6,10 @@
 #   1. the driver's exact command as the FIRST process on the fresh box (what BENCH_rNN.json will hold), with the step trace
 #   2. the whole GPU suite, smoke()
 #   3. the default bench line (headline + parity_mode + other_configs + cpu_baseline)
-#   4. rocprofv3 kernel trace of the headline; PMC passes (FETCH_SIZE / WRITE_SIZE separately; SQ busy shares)
+#   1b. the hand-off / step-floor traces of the recurrence (tools/trace_rec2.py, full and EMPTY) and the PMC passes of the
+#       headline (FETCH_SIZE / WRITE_SIZE separately; SQ busy shares): what the bench line's roofline record reads
+#   4. rocprofv3 kernel trace of the headline
 #   5. kernel traces of the other recipes and of the fp32 mode
-#   6. the hand-off / step-floor traces of the recurrence (tools/trace_rec2.py, full and EMPTY)
 #   7. one full-shape bf16 step against the oracle's bf16-operand model (minutes of host time)
 set -u
 tag=${1:-rXX}
@@ -23,6 +24,23 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --
 echo "driver command, first process: $(python3 tools/jget.py "$out/driver_cmd_first.json" ms_per_step value step_ms.first step_ms.median config.prewarm_steps)"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline --step-trace > "$out/driver_cmd_second.json" 2> "$out/driver_cmd_second.err"
 echo "driver command, second process: $(python3 tools/jget.py "$out/driver_cmd_second.json" ms_per_step value step_ms.first step_ms.median)"
+# ---- 1b: what the bench line's roofline record reads (written into profiles/ of THIS copy before bench.py runs)
+JSON_OUT=$out/trace_full.json timeout 150 python tools/trace_rec2.py > $out/trace_full.log 2>&1; grep -E "cycles/step|launch ms" $out/trace_full.log | head -4
+EMPTY=1 JSON_OUT=$out/trace_empty.json timeout 150 python tools/trace_rec2.py > $out/trace_empty.log 2>&1; grep -E "cycles/step|launch ms" $out/trace_empty.log | head -4
+python tools/make_step_floor.py $out $out/${tag}_rec_step_floor.json "round ${tag#r}: tools/trace_rec2.py on the closing tree, full step and EMPTY=1 (no arithmetic)" 2>&1 | tail -1
+cp $out/${tag}_rec_step_floor.json profiles/ 2>/dev/null
+( cd /tmp && export TMPDIR=/tmp
+S="python $R/bench.py --steps 2 --warmup 1 --prewarm-s 0 --no-cpu-baseline --no-extras"
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -- $S > $out/pmc_fetch.log 2>&1
+python $R/tools/rocpd_pmc.py $(find $out/pmc_fetch -name "*.db" | head -1) $out/${tag}_pmc_fetch_size.csv
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write -- $S > $out/pmc_write.log 2>&1
+python $R/tools/rocpd_pmc.py $(find $out/pmc_write -name "*.db" | head -1) $out/${tag}_pmc_write_size.csv
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $out/pmc_sq -- $S > $out/pmc_sq.log 2>&1
+python $R/tools/rocpd_pmc.py $(find $out/pmc_sq -name "*.db" | head -1) $out/${tag}_pmc_sq.csv
+rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_sq
+python $R/tools/pmc_summaries.py $out $tag > $out/pmc_summaries.log 2>&1; head -12 $out/pmc_summaries.log
+)
+cp $out/${tag}_pmc_traffic.json $out/${tag}_pmc_mfma_busy.json profiles/ 2>/dev/null
 # ---- 2
 timeout 1500 python -m pytest tests -q -m gpu > "$out/pytest_gpu.log" 2>&1
 echo "pytest rc=$? $(tail -1 "$out/pytest_gpu.log")"
@@ -42,14 +60,6 @@ python $R/tools/rocpd_dump.py $(find $out/kt -name "*.db" | head -1) $out/${tag}
 python $R/tools/timeline_step.py $out/${tag}_timeline_tail.csv 3 > $out/${tag}_timeline_step.txt 2>/dev/null
 rm -rf $out/kt
 head -6 $out/${tag}_bench_bf16_kernel_stats.csv
-timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -- $S > $out/pmc_fetch.log 2>&1
-python $R/tools/rocpd_pmc.py $(find $out/pmc_fetch -name "*.db" | head -1) $out/${tag}_pmc_fetch_size.csv
-timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write -- $S > $out/pmc_write.log 2>&1
-python $R/tools/rocpd_pmc.py $(find $out/pmc_write -name "*.db" | head -1) $out/${tag}_pmc_write_size.csv
-timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $out/pmc_sq -- $S > $out/pmc_sq.log 2>&1
-python $R/tools/rocpd_pmc.py $(find $out/pmc_sq -name "*.db" | head -1) $out/${tag}_pmc_sq.csv
-rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_sq
-python $R/tools/pmc_summaries.py $out $tag > $out/pmc_summaries.log 2>&1; head -12 $out/pmc_summaries.log
 for r in timit_lstm libri_gru timit_mlp timit_sincnet; do
   timeout 200 rocprofv3 --kernel-trace --stats -d $out/kt_$r -- $B --recipe $r > $out/kt_$r.log 2>&1
   python $R/tools/rocpd_stats.py $(find $out/kt_$r -name "*.db" | head -1) $out/${tag}_${r}_kernel_stats.csv > /dev/null 2>&1
@@ -59,10 +69,6 @@ timeout 200 rocprofv3 --kernel-trace --stats -d $out/kt_fp32 -- python $R/bench.
 python $R/tools/rocpd_stats.py $(find $out/kt_fp32 -name "*.db" | head -1) $out/${tag}_bench_fp32_kernel_stats.csv > /dev/null 2>&1
 rm -rf $out/kt_fp32
 cd $R
-# ---- 6
-JSON_OUT=$out/trace_full.json timeout 150 python tools/trace_rec2.py > $out/trace_full.log 2>&1; grep -E "cycles/step|launch ms" $out/trace_full.log | head -4
-EMPTY=1 JSON_OUT=$out/trace_empty.json timeout 150 python tools/trace_rec2.py > $out/trace_empty.log 2>&1; grep -E "cycles/step|launch ms" $out/trace_empty.log | head -4
-python tools/make_step_floor.py $out $out/${tag}_rec_step_floor.json "round ${tag#r}: tools/trace_rec2.py on the closing tree, full step and EMPTY=1 (no arithmetic)" 2>&1 | tail -1
 # ---- 7
 timeout 120 python tools/full_shape_parity.py --T 20 --B 8 --out $out/parity_small.json > $out/parity_small.log 2>&1
 echo "small-shape parity tool rc=$? $(python3 tools/jget.py $out/parity_small.json pass loss_rel_diff grad_rel_err_worst)"

@@ -50,7 +50,9 @@ opts1 = m["options"]["architecture1"]
 masks = O.make_drop_masks("liGRU", opts1, B, "train", generator=gen)
 
 # ---- the bf16-operand model on the host (the slow part)
-cores = len(os.sched_getaffinity(0))
+# (16 threads: with one thread per logical core of a 256-thread host the step's many small ops spend their time in the
+# thread pool - the first attempt of round 4 did not finish in 15 minutes; 8 cores of the build container take 73 s)
+cores = min(len(os.sched_getaffinity(0)), 16)
 torch.set_num_threads(cores)
 osd = {n: {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in init[n].items()} for n in init}
 t0 = time.time()

@@ -578,12 +578,13 @@ def release(tr):
 OTHER_CONFIGS = [("timit_mlp", 400, 5), ("timit_lstm", 50, 5), ("libri_gru", 50, 5), ("timit_sincnet", 100, 5)]
 
 
-def through_run_nn(args, n_batches=12):
+def through_run_nn(args, n_batches=12, reps=3):
     """The same workload THROUGH the chunk loop (`elapsed_time_chunk`, core.py:567-701): a synthetic
     chunk of n_batches x B sentences of T frames resident in HBM, handed to pytorch-kaldi_amd.core.run_nn_dp with a
     chunk cfg on disk - batch assembly (the zero-padding gather), forward_model, backward, fused optimizers, ONE host
-    sync per chunk, checkpoint + .info written afterwards.  Two chunks: the first warms up, the second is reported from
-    its own .info file (`elapsed_time_chunk`, which brackets the batch loop exactly as the reference's does)."""
+    sync per chunk, checkpoint + .info written afterwards.  `reps` chunks: the first warms up, the MEDIAN of the others is
+    reported, each from its own .info file (`elapsed_time_chunk`, which brackets the batch loop exactly as the reference's
+    does; every chunk builds its networks, flat buffers and optimizers anew, as the reference's chunk function does)."""
     import configparser
     import tempfile
 
@@ -624,15 +625,16 @@ def through_run_nn(args, n_batches=12):
 
         fea_dict = {k: list(v) for k, v in rcp["fea_dict"].items()}
         times = []
-        for rep in range(2):
+        for rep in range(max(2, reps)):
             core.run_nn_dp(names, data.cuda(), end, {k: list(v) for k, v in fea_dict.items()}, rcp["lab_dict"],
                            rcp["arch_dict"], path, False, path, reader=reader)
             info = configparser.ConfigParser()
             info.read(os.path.join(tmp, "chunk.info"))
             times.append(float(info["results"]["elapsed_time_chunk"]))
-        dt = times[-1]
+        dt = sorted(times[1:])[(len(times) - 1) // 2]
         out = {"value": round(n_batches * T * B / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_batches, 3),
                "batches": n_batches, "elapsed_time_chunk_s": round(dt, 4), "warmup_chunk_s": round(times[0], 4),
+               "chunks_s": [round(t, 4) for t in times],
                "note": "pytorch-kaldi_amd.core.run_nn_dp on a resident synthetic chunk (%d sentences of %d frames): batch "
                        "assembly + forward_model + backward + fused optimizers, one host sync per chunk; the time is the "
                        ".info file's elapsed_time_chunk (core.py:567, 701)" % (n_snt, T)}

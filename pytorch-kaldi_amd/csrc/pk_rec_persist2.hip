@@ -24,6 +24,7 @@
 //    barrier per step); projections / saved gates of step t+1 are prefetched
 //    right after the poll of step t returns, so HBM latency is off the
 //    dependency chain; every spin is bounded (host-visible error word).
+#include <atomic>
 #include <stdlib.h>
 
 #include "pk_rec2_common.h"
@@ -872,17 +873,19 @@ int pk_rec2_reset_handshake(hipStream_t st, R2Args& a) {
     // generations 1 .. 2^28 - 17 (the table starts out as 0xFF bytes: generation 2^28 - 1, never handed out).  Inside a
     // stream capture the number is baked into the graph, so every replay would find its own words from the replay
     // before: there the table is reset by a memset node in front of the kernel, as it used to be everywhere.
-    static unsigned gen = 0;
+    static std::atomic<unsigned> gen{0};  // (atomic: two host threads must never hand out the same number)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
-    if (gen >= 0x0FFFFFEFu) {  // wrap: nothing of the old numbering may survive
+    unsigned g = gen.fetch_add(1u) + 1u;
+    if (g >= 0x0FFFFFEFu) {  // wrap: nothing of the old numbering may survive
         PK_CHECK_HIP(hipDeviceSynchronize());
         PK_CHECK_HIP(hipMemset(g2_xcd_tab, 0xFF, XCD_TAB_BYTES));
         PK_CHECK_HIP(hipDeviceSynchronize());
-        gen = 0;
+        gen.store(1u);
+        g = 1u;
     }
     if (cs != hipStreamCaptureStatusNone) PK_CHECK_HIP(hipMemsetAsync(g2_xcd_tab, 0xFF, XCD_TAB_BYTES, st));
-    a.hs_gen = ++gen;
+    a.hs_gen = g;
     return 0;
 }
 

@@ -1,9 +1,13 @@
-"""Print dotted fields of the last JSON line of a file:  jget.py file a.b c ..."""
+"""Print dotted fields of the last JSON line of a file (or of an indented JSON file):  jget.py file a.b c ..."""
 import json
 import sys
 
 try:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    text = open(sys.argv[1]).read().strip()
+    try:
+        d = json.loads(text.splitlines()[-1])  # a bench line: one JSON object on the last line
+    except ValueError:
+        d = json.loads(text)                   # an indented JSON file
 except Exception as e:  # noqa: BLE001
     print("no JSON (%s)" % e)
     sys.exit(0)

@@ -8,7 +8,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BASE = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-LINES = ["profiles/r03_bench_bf16.json", "profiles/r02_bench_bf16.json", "profiles/r01_bench_bf16.json", "profiles/r01_bench_fp32_with_cpu_baseline.json",
+LINES = ["profiles/r04_bench_bf16.json", "profiles/r04_bench_bf16_evidence_pass.json", "profiles/r04_driver_exact_cmd_line.json",
+         "profiles/r03_bench_bf16.json", "profiles/r02_bench_bf16.json", "profiles/r01_bench_bf16.json", "profiles/r01_bench_fp32_with_cpu_baseline.json",
          "profiles/r01_timit_lstm_8wave_bench.json", "profiles/r01_timit_lstm_4wave_bench.json"]
 
 
@@ -102,3 +103,23 @@ def test_round3_line_carries_the_chunk_loop_and_the_reference_caller():
         assert got[name]["parity_mode"]["dtype"] == "fp32"
     full = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_full_shape.json")))
     assert (full["T"], full["B"]) == (500, 128) and full["kind"] == "port" and full["value"] > 0
+
+
+def test_round4_line_carries_the_step_trace_the_prewarm_and_the_chunk_median():
+    """Round 4: per-step GPU times of the timed region (where a slow phase would show), the untimed pre-warm the line was
+    taken behind, the chunk-loop record as a median over chunks, and a full-shape CPU record that says it was not measured
+    in this run."""
+    d = _line("profiles/r04_bench_bf16.json")
+    sm = d["step_ms"]
+    assert sm["min"] <= sm["median"] <= sm["max"] and abs(sm["median"] - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
+    assert d["config"]["prewarm_s"] > 0 and d["config"]["prewarm_steps"] >= 4
+    rn = d["through_run_nn"]
+    assert len(rn["chunks_s"]) >= 3 and rn["elapsed_time_chunk_s"] == sorted(rn["chunks_s"][1:])[(len(rn["chunks_s"]) - 1) // 2]
+    fs = d["cpu_baseline"]["full_shape"]
+    assert fs["measured_in_run"] is False and "source" in fs
+    r = d["roofline"]
+    assert r["latency"]["floor_source"] == "profiles/r04_rec_step_floor.json" and "r04_pmc_traffic" in r["traffic_source"]
+    assert 0.9 < r["structure_frac"] < 1.1  # the step IS its hand-off structure (DESIGN.md 11.2)
+    # the driver's command exactly as typed, first process on a fresh box
+    e = _line("profiles/r04_driver_exact_cmd_line.json")
+    assert e["steps"] == 20 and e["warmup"] == 5 and e["n_gpus"] == 1 and e["ms_per_step"] < 17.5

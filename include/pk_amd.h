@@ -314,6 +314,13 @@ void pk_persist2_set_poll_delay(int units);
  * units, each holding half of the recurrent-matrix fragments (pk_rec_persist2_lstm.hip).  Default: PK_LSTM_WAVES. */
 void pk_persist2_set_lstm_waves(int waves);
 int pk_persist2_get_lstm_waves(void);
+/* L2 run-ahead helpers of the persistent bf16 recurrences (pk_rec_helper.hip; default: PK_REC_HELPER): workgroups on the
+ * CUs a recurrence leaves idle touch the lines its time loop (neural_networks.py:457-469, :629-641, :1130-1141) is about to
+ * use a few steps ahead of it, paced by the exchange buffer itself.  bit 0: the projections of the forward pass, bit 1:
+ * the Y / S lines the forward pass is about to write, bit 2: the saved tensors the backward pass reads.  The helpers only
+ * load: results never depend on the mode. */
+void pk_rec_helper_set_mode(int mode);
+int pk_rec_helper_get_mode(void);
 /* two-phase cells (GRU :629-641, minimalGRU :1291-1302): the candidate GEMM consumes a gate of the same
  * step, so every step is two cluster-wide exchanges.  Xb [T*B][y_pitch] (bf16 r*h / z*h, laid out like Yb)
  * is the second exchange buffer and the k-major operand of the dU_h GEMM; of S only the z(,r),a slots are

@@ -99,6 +99,8 @@ SIGNATURES = {
     "pk_persist2_set_mode": (None, [c_int]),
     "pk_persist2_set_poll_delay": (None, [c_int]),
     "pk_persist2_set_lstm_waves": (None, [c_int]),
+    "pk_rec_helper_set_mode": (None, [c_int]),
+    "pk_rec_helper_get_mode": (c_int, []),
     "pk_persist2_get_lstm_waves": (c_int, []),
     "pk_persist2_error_count": (ctypes.c_uint, []),
     "pk_persist2_error_reset": (None, []),

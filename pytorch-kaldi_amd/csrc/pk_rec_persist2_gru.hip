@@ -1010,8 +1010,12 @@ int rec2p_fwd_impl(void* stream, int cell, int act, int T, int B, int bidir, int
         dim3 grid(pl.C * pl.Pn), block(256);
         rc = pk_rec2_check_residency((const void*)fn, 256, lds, pl.C * pl.Pn, "pk_rec2p_*_bf16");
         if (rc) return rc;
+        // (forward: the projections only - this cell's S has its own layout)
+        const bool help = !ln && (pk_rec_helper_wanted(false, pl.launches) & 1) != 0;
+        if (help && (rc = pk_rec_helper_fork(st)) != 0) return rc;
         hipLaunchKernelGGL(fn, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
+        if (help && (rc = pk_rec_helper_launch(st, a, pl, G, 0, false, false)) != 0) return rc;
     }
     return 0;
 }

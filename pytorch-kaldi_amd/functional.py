@@ -1776,6 +1776,15 @@ class RecLayerPerfFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------
 # conv1d + max_pool1d (neural_networks.py:1546-1552, 1655-1661, 1805-1813)
 # ----------------------------------------------------------------------------
+CONV_BF16_DEFAULT = "0"
+
+
+def conv_bf16_mode():
+    """PK_CONV_BF16: "0" exact-fp32 convolutions, "1" bf16 MFMA operands for layers with >= 8 input channels, "2" for every
+    covered layer (perf mode only).  One place for the default: the tests' bf16-operand model follows it."""
+    return os.environ.get("PK_CONV_BF16", CONV_BF16_DEFAULT)
+
+
 class ConvPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, pool):
@@ -1794,7 +1803,7 @@ class ConvPoolFn(torch.autograd.Function):
         # to bf16 the recipe-scale fixture's worst parameter gradient sits 30 % from the reference's (bf16-operand model
         # vs reference), and the network's own noise floor exceeds the fixed grading limits: not a
         # default until the first layer's treatment is settled
-        mode = os.environ.get("PK_CONV_BF16", "0")
+        mode = conv_bf16_mode()
         ctx.conv_bf = (bf16_mode() and mode in ("1", "2") and (Cin >= 8 or mode == "2")
                        and lib.pk_conv_bf16_covers(Cin, Cout, K, pool) == 1)
         if ctx.conv_bf:

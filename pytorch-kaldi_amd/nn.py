@@ -668,8 +668,8 @@ class SincConv(nn.Module):
         self.window_ = self.window_.to(dev)
         low = self.min_low_hz / self.sample_rate + torch.abs(self.low_hz_)
         high = low + self.min_band_hz / self.sample_rate + torch.abs(self.band_hz_)
-        lp1 = 2 * low * self._sinc(2 * math.pi * torch.matmul(low, self.n_) * self.sample_rate)
-        lp2 = 2 * high * self._sinc(2 * math.pi * torch.matmul(high, self.n_) * self.sample_rate)
+        lp1 = 2 * low * self._sinc(2 * math.pi * (low * self.n_) * self.sample_rate)  # (N,1) x (1,K) outer product: a broadcast, no BLAS launch
+        lp2 = 2 * high * self._sinc(2 * math.pi * (high * self.n_) * self.sample_rate)
         bp = lp2 - lp1
         mx, _ = torch.max(bp, dim=1, keepdim=True)
         bp = bp / mx

@@ -97,7 +97,7 @@ def conv_bf16_on():
     """Which of the engine's perf-mode convolutions take bf16 operands (pk_conv_bf16.hip): False = none (default),
     True = layers with at least 8 input channels (PK_CONV_BF16=1), "all" (PK_CONV_BF16=2).  The bf16-operand model of the oracle is
     switched the same way: O.bf16_operands(conv=conv_bf16_on())."""
-    import os
+    import importlib
 
-    mode = os.environ.get("PK_CONV_BF16", "0")
+    mode = importlib.import_module("pytorch-kaldi_amd.functional").conv_bf16_mode()
     return True if mode == "1" else ("all" if mode == "2" else False)

@@ -86,7 +86,7 @@ def oracle_params(nns):
                 for k, v in net.state_dict().items()} for n, net in nns.items()}
 
 
-def oracle_run(O, g, sds, emulate=False, forced=False, force_pool=True, conv_bf16=False, inp_noise=0.0):
+def oracle_run(O, g, sds, emulate=False, forced=False, force_pool=True, conv_bf16=False, inp_noise=0.0, noise_seed=99):
     """The oracle on the fixture's batch (CPU): outs dict, gradients left in sds.  forced: differentiate on the
     reference run's discrete decisions (ReLU patterns, pooling arg-max when force_pool) instead of this run's own."""
     import contextlib
@@ -103,7 +103,7 @@ def oracle_run(O, g, sds, emulate=False, forced=False, force_pool=True, conv_bf1
     if inp_noise:  # the features (not the label columns) perturbed at fp32-rounding level: the model's own noise floor
         nfea = inp.shape[-1] - len(m["lab_dict"])
         inp = inp.clone()
-        gen = torch.Generator().manual_seed(99)
+        gen = torch.Generator().manual_seed(noise_seed)
         inp[..., :nfea] *= 1.0 + inp_noise * torch.randn(inp[..., :nfea].shape, generator=gen)
     with (O.bf16_operands(conv=conv_bf16) if emulate else contextlib.nullcontext()):
         outs = O.recipe_forward(m["model"], m["options"], m["arch_dict"], sds, inp, m["fea_dict"], m["lab_dict"],

@@ -532,7 +532,15 @@ def test_recipe_scale_golden(case, prec):
         frac = float(ref_rows.double().norm()) / ref_ck[0]
         tight = TIGHT_GRAD
         if conv_bf16:
-            tight = max(tight, 2.0 * grad_err(SU.rows(noisy[name][k].grad, s_), SU.rows(init[name][k].grad, s_), gtot * frac))
+            # (A) on WHOLE tensors.  Round 5 (tools/diag_conv_bf16_floor.py, profiles/r05_conv_bf16_floor.json): the miss of
+            # rounds 3 / 4 ("MLP_layers wx.4.weight 3.2e-2 against 2e-2") was the limit - the floor was estimated on the
+            # fixture's handful of sampled rows (0.8e-2 for that tensor) while the model's distance from itself over the
+            # whole tensor is 8e-2, seed after seed (the flips of a run concentrate in few rows of a weight gradient)
+            whole = float(init[name][k].grad.double().norm())
+            tight = max(tight, 2.0 * grad_err(noisy[name][k].grad, init[name][k].grad, whole))
+            e_whole = grad_err(gr, init[name][k].grad, whole)
+            assert e_whole < tight, ((name, k), "engine vs bf16-operand model, whole tensor", e_whole, "limit", tight)
+            tight = float("inf")  # (the row sample below keeps step (B): engine vs reference within the model's deviation)
         worst = max(worst, _two_step((name, k), SU.rows(gr, s_), SU.rows(init[name][k].grad, s_), ref_rows, tight,
                                      gtot * frac), key=lambda t: t[2])
     print("\n%s [bf16]: outputs (engine-vs-model, model-vs-ref, engine-vs-ref) %s; worst gradient %s; decisions that bf16 "

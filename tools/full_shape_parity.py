@@ -5,7 +5,7 @@ bf16-operand model (oracle/pk_oracle.py: the reference algorithm with the operan
 pinned to the reference at 2e-6 / 5e-5 by tests/test_oracle_golden.py) run on the GPU box's host cores from the same
 seed-derived parameters, batch and drop masks; the engine differentiates the model run's own ReLU kink pattern
 (functional.set_forced_kinks - DESIGN.md section 2).  Minutes of CPU time: run once per round
-(tools/gpu_evidence_r04.sh), result in profiles/r04_full_shape_parity.json.
+(tools/gpu_evidence.sh; since round 5 also tests/test_gpu_full_shape.py, i.e. the driver's `pytest -m gpu`).
 
     python tools/full_shape_parity.py [--T 500 --B 128] --out gpurun_out/x/r04_full_shape_parity.json
 
@@ -105,11 +105,15 @@ for name, net in nns.items():
         if e > worst[1]:
             worst = ("%s/%s" % (name, k), e)
 res["grad_rel_err_worst"] = {"tensor": worst[0], "err": worst[1]}
+# error growth over the stack: the input weights of the update gate, layer by layer (the worst family in round 4)
+res["grad_rel_err_by_layer"] = {fam: [round(gerr.get("liGRU_layers/%s.%d.weight" % (fam, i), float("nan")), 6) for i in range(L)]
+                                for fam in ("wz", "wh", "uz", "uh")}
 res["grad_rel_err"] = {k: round(v, 6) for k, v in sorted(gerr.items(), key=lambda kv: -kv[1])[:12]}
 res["kink_report_flipped_total_worst_a"] = [[int(a), int(b), float(c)] for a, b, c in report]
 res["limits"] = {"outputs": 5e-3, "gradients": 2e-2, "note": "the limits of tests/test_gpu_reference_pins.py step (A): engine vs the bf16-operand model"}
 res["pass"] = bool(res["loss_rel_diff"] < 5e-3 and all(res["out_rel_err/" + k] < 5e-3 for k in ("out_dnn1", "out_dnn2", "out_dnn3"))
                    and worst[1] < 2e-2)
+res["worst_gradient_under_1p5e-2"] = bool(worst[1] < 1.5e-2)
 print(json.dumps(res, indent=1))
 if args.out:
     with open(args.out, "w") as f:

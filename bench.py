@@ -552,7 +552,7 @@ def measure(args, rank, world, steps, warmup):
         out["config"]["cost"] = "nn.NLLLoss on the log-posteriors" if args.unfused_cost else "fused"
         out["config"]["host_sync"] = "every step" if args.sync_every_step else "end of region"
     if tr.rcp["cfg"]["architecture1"]["arch_class"] == "LSTM":
-        out["config"]["lstm_waves"] = int(_lib.load().pk_persist2_get_lstm_waves())  # DESIGN.md 6.1 (PK_LSTM_WAVES)
+        out["config"]["lstm_waves"] = int(_lib.load().pk_persist2_get_lstm_waves())  # DESIGN.md 6.1 (PK_EXPERIMENT lstm_waves)
     # roofline of the dominant kernel class, measured live with HIP events (every rank runs the two extra steps:
     # they contain the gradient all-reduce)
     summ = profile_entry_points(tr)

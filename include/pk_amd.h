@@ -76,7 +76,7 @@ int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha, const floa
 int pk_gemm_bf16_tile_m(int M);
 /* the split-K factor the library recommends for a k-major x k-major product of this shape (1 for short reductions) */
 int pk_gemm_bf16_auto_splitk(int M, int N, int K);
-/* tests / tools: 128 or 256 forces that block tile for every shape, 0 = automatic (also PK_GEMM_TILE) */
+/* tests / tools: 128 or 256 forces that block tile for every shape, 0 = automatic (also PK_EXPERIMENT gemm_tile) */
 /* split-K factor for a k-major x k-major product that will only get `cus` CUs (0 = the whole device) */
 int pk_gemm_bf16_auto_splitk_cus(int M, int N, int K, int cus);
 void pk_gemm_bf16_set_tile(int tile);
@@ -311,7 +311,7 @@ void pk_persist2_set_mode(int force_safe);
 /* tuning: idle time (units of 64 clocks) between a workgroup's publish and its first poll of the next step */
 void pk_persist2_set_poll_delay(int units);
 /* LSTM only: 4 = four waves per workgroup (the kernels every cell uses), 8 = eight waves, two per group of 16 hidden
- * units, each holding half of the recurrent-matrix fragments (pk_rec_persist2_lstm.hip).  Default: PK_LSTM_WAVES. */
+ * units, each holding half of the recurrent-matrix fragments (pk_rec_persist2_lstm.hip).  Default: PK_EXPERIMENT lstm_waves. */
 void pk_persist2_set_lstm_waves(int waves);
 int pk_persist2_get_lstm_waves(void);
 /* L2 run-ahead helpers of the persistent bf16 recurrences (pk_rec_helper.hip; default: PK_REC_HELPER): workgroups on the

@@ -224,6 +224,17 @@ class _TimedLib:
         return timed
 
 
+def experiment(key, default=None):
+    """Value of one A/B lever of past experiments.  They live behind ONE environment variable,
+    PK_EXPERIMENT="key=value,key=value" (the library reads its own keys from the same string: pk_lib.hip;
+    INTEGRATION.md lists them); a recipe author only ever needs the switches of INTEGRATION.md's first table."""
+    for item in os.environ.get("PK_EXPERIMENT", "").split(","):
+        k, _, v = item.partition("=")
+        if k.strip() == key:
+            return v.strip()
+    return default
+
+
 class Profiler:
     def __init__(self):
         self.events = []

@@ -8,6 +8,9 @@
 
 // ---- error plumbing -------------------------------------------------------
 void pk_set_error(const char* fmt, ...);
+// A/B levers of past experiments live behind ONE environment variable, PK_EXPERIMENT="key=value,key=value" (pk_lib.hip;
+// the keys are listed in INTEGRATION.md): value of `key`, or nullptr.  Callers cache what they read.
+const char* pk_experiment(const char* key);
 
 #define PK_CHECK_HIP(expr)                                                                  \
     do {                                                                                    \

@@ -1285,22 +1285,22 @@ extern "C" int pk_cvt_bf16(void* stream, const float* src, int64_t ld_src, int64
 // and the senone head's dW (1938 x 1100 x 64000: 670 -> 830) - while the row-streaming shapes (M = 64000, K ~ 1100:
 // 18 k-tiles per output tile, 282 MB of fp32 output) gain nothing from it (prologue / epilogue are not overlapped with
 // one workgroup per CU) and the 550 x 550 dU shape loses (3 x 3 tiles of which 28 % is padding).
-// PK_GEMM_TILE=128|256 / pk_gemm_bf16_set_tile() force one of them.
+// PK_EXPERIMENT gemm_tile=128|256 / pk_gemm_bf16_set_tile() force one of them.
 static int g_gemm_tile_forced = -1;
 extern "C" void pk_gemm_bf16_set_tile(int tile) { g_gemm_tile_forced = (tile == 128 || tile == 256) ? tile : 0; }
 static int gemm_tile_for(int M, int N, int a_kc, int b_kc, int K = 1 << 30) {
     int& forced = g_gemm_tile_forced;
     if (forced < 0) {
-        const char* e = getenv("PK_GEMM_TILE");
+        const char* e = pk_experiment("gemm_tile");
         forced = (e && atoi(e) == 128) ? 128 : (e && atoi(e) == 256) ? 256 : 0;
     }
     if (forced) return forced;
     // row-streaming shapes (projection, dX, output layers: M = T*B rows, k-contiguous A, N >= 1024): the 256-tile is worth
     // 3-10 % on the current kernel (652 vs 603, 775 vs 695 TFLOP/s: profiles/r02_gemm_tiles.txt) and 0.22 ms of the
-    // 21.1 ms training step (A/B on one box, tools/gpu_ab3.sh); PK_GEMM_TILE_ROWS=0 keeps them on the 128-tile
+    // 21.1 ms training step (A/B on one box, tools/gpu_ab3.sh); PK_EXPERIMENT gemm_tile_rows=0 keeps them on the 128-tile
     static int rows256 = -1;
     if (rows256 < 0) {
-        const char* e = getenv("PK_GEMM_TILE_ROWS");
+        const char* e = pk_experiment("gemm_tile_rows");
         rows256 = (e && atoi(e) == 0) ? 0 : 1;
     }
     if (rows256 && a_kc && M >= 16384 && N >= 1024) return 256;
@@ -1382,10 +1382,10 @@ static int gemm_bf16_impl(void* stream, int M, int N, int K, float alpha, const 
     p.ws = splitk > 1 ? workspace : nullptr;
     p.items = splitk * p.tiles_m * p.tiles_n;
     p.per_xcd = (p.items + 7) / 8;
-    {   // small-batch products: all rows of 32 columns per workgroup (gemm_bf16s_kernel); PK_GEMM_SKINNY=0 keeps the 128-tile
+    {   // small-batch products: all rows of 32 columns per workgroup (gemm_bf16s_kernel); PK_EXPERIMENT gemm_skinny=0 keeps the 128-tile
         static int skinny_on = -1;
         if (skinny_on < 0) {
-            const char* e = getenv("PK_GEMM_SKINNY");
+            const char* e = pk_experiment("gemm_skinny");
             skinny_on = (e && e[0] == '0') ? 0 : 1;
         }
         if (skinny_on && !g_gemm_tile_forced && a_kc && M <= TM && splitk > 1 && p.k_per_split <= SK_TILES * TK && stats == nullptr) {
@@ -1454,10 +1454,10 @@ static int gemm_bf16_impl(void* stream, int M, int N, int K, float alpha, const 
     dim3 grid((unsigned)(p.per_xcd * 8)), block(256);
     // measured on MI355X (tools/bench_gemm.py): the single-buffer variant with four workgroups per CU wins on the
     // row-streaming shapes (A k-contiguous: 640-680 vs 530-540 TFLOP/s at M = 64000), the double-buffered one on
-    // the split-K k-major shapes (687 vs 661).  PK_GEMM_STAGES=1|2 forces one of them.
+    // the split-K k-major shapes (687 vs 661).  PK_EXPERIMENT gemm_stages=1|2 forces one of them.
     static int forced = -1;
     if (forced < 0) {
-        const char* e = getenv("PK_GEMM_STAGES");
+        const char* e = pk_experiment("gemm_stages");
         forced = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 0;
         PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         PK_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16x_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));

@@ -1,5 +1,6 @@
 // pk_lib.hip - library plumbing: version, thread-local error string, device info.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "pk_common.h"
@@ -11,6 +12,23 @@ void pk_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+const char* pk_experiment(const char* key) {
+    // (returns a pointer INTO the environment string: the value ends at the next ',' or at the end - atoi / sscanf / a
+    // first-character test, which is all the callers do, stop there by themselves)
+    const char* e = getenv("PK_EXPERIMENT");
+    if (e == nullptr) return nullptr;
+    const size_t kl = strlen(key);
+    for (const char* p = e; *p;) {
+        const char* end = strchr(p, ',');
+        if (end == nullptr) end = p + strlen(p);
+        if ((size_t)(end - p) > kl && strncmp(p, key, kl) == 0 && p[kl] == '=') {
+            return p + kl + 1;
+        }
+        p = *end ? end + 1 : end;
+    }
+    return nullptr;
 }
 
 extern "C" int pk_version(void) { return 100; }

@@ -1544,9 +1544,9 @@ extern "C" int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* 
     int rb = row_blocks(M);
     static int k_rbr = -1, k_rba = -1, k_cw = 0;  // development knobs (tools/bench_bnb.py): row blocks of the two passes, block width
     if (k_rbr < 0) {
-        const char* e = getenv("PK_BNB_RBR"); k_rbr = e ? atoi(e) : 0;
-        e = getenv("PK_BNB_RBA"); k_rba = e ? atoi(e) : 0;
-        e = getenv("PK_BNB_CW"); k_cw = e ? atoi(e) : 0;
+        const char* e = pk_experiment("bnb_rbr"); k_rbr = e ? atoi(e) : 0;
+        e = pk_experiment("bnb_rba"); k_rba = e ? atoi(e) : 0;
+        e = pk_experiment("bnb_cw"); k_cw = e ? atoi(e) : 0;
     }
     if (k_rbr > 0) rb = k_rbr;
     PK_REQUIRE(((M + rb - 1) / rb) * ldx * 4 < 0x7fffffffL, "pk_bn_bwd_bf16: a row strip of the projection exceeds 2 GB");

@@ -410,17 +410,14 @@ int pk_rec2_reset_handshake(hipStream_t st, R2Args& a);  // before every launch:
 // ending in bounded-spin time-outs.  (Kernels of OTHER streams or processes can still delay a workgroup's start; that
 // only costs time: every spin is bounded at ~10 ms and reported.)
 int pk_rec2_check_residency(const void* kernel, int threads, size_t lds, int grid, const char* who);
-// third generation (pk_rec_persist3.hip: swapped MFMA operands): the backward pass of liGRU / RNN by default (PK_REC_GEN*)
+// third generation (pk_rec_persist3.hip: swapped MFMA operands): the backward pass of liGRU / RNN by default (PK_EXPERIMENT rec_gen*)
 int pk_rec3_covers(int cell, int backward);
 int pk_rec3_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act, bool backward, bool traced);
-// fifth generation (pk_rec_split.hip: role-split workgroups - compute / poll / I/O waves): PK_REC_GEN* = 5
-int pk_recs_covers(int cell, int backward);
-int pk_recs_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act, bool backward, bool traced, bool delay_forced);
 // L2 run-ahead helpers on the idle CUs (pk_rec_helper.hip; PK_REC_HELPER): fork before the recurrence is launched,
 // launch behind it.  They only load - results never depend on them.
 int pk_rec_helper_wanted(bool backward, int launches);
 int pk_rec_helper_fork(hipStream_t st);
 int pk_rec_helper_launch(hipStream_t st, const R2Args& a, const Plan2& pl, int G, int NS, bool backward, bool s_layout_ok);
-// eight-wave LSTM kernels (pk_rec_persist2_lstm.hip): on unless PK_LSTM_WAVES=4; the launch loop over pl.launches
+// eight-wave LSTM kernels (pk_rec_persist2_lstm.hip): on unless PK_EXPERIMENT lstm_waves=4; the launch loop over pl.launches
 int pk_rec2l_enabled();
 int pk_rec2l_launch(hipStream_t st, R2Args& a, const Plan2& pl, int act, bool backward);

@@ -16,7 +16,7 @@
 // still hold valid-looking data of an earlier launch; behind it the first PK_R2_FILL_AHEAD slabs carry the pattern and
 // every later slab is patterned four steps before it is published).  A helper workgroup serves a cluster that sits on
 // ITS OWN XCD (HW_REG_XCC_ID against the handshake word), because L2s are per XCD; one CU sustains ~25 GB/s of misses,
-// a cluster's step is ~190 KB per 2.3 us, hence several helper workgroups per cluster (PK_REC_HELPER_WGS).  A helper
+// a cluster's step is ~190 KB per 2.3 us, hence several helper workgroups per cluster (PK_EXPERIMENT helper_wgs).  A helper
 // asks for 96 KB of LDS it never uses, so that it cannot be placed on a CU that holds a recurrent workgroup.
 // Every wait is bounded in time.
 #include <stdlib.h>
@@ -48,16 +48,30 @@ struct HelpArgs {
     unsigned limit_clocks;   // bound of every wait, shader clocks
 };
 
-constexpr int MAXJOBS = 6;      // 128-byte lines per thread and step
+constexpr int MAXJOBS = 8;      // 128-byte lines per toucher thread and step
 constexpr int HELPER_LDS = 96 * 1024;
+constexpr int TOUCHERS = 192;   // threads of a helper workgroup that touch lines (waves 1-3); wave 0 paces
 
 __device__ __forceinline__ bool timed_out(unsigned long long t0, unsigned limit) {
     return (unsigned long long)__builtin_readcyclecounter() - t0 > (unsigned long long)limit;
 }
+// a load that is never waited for (the wave keeps no count of it: inline asm is invisible to the wait-count pass);
+// `sink` stays allocated for the whole kernel ("+v" here, consumed behind the final s_waitcnt), so a late return can
+// only ever overwrite itself
+__device__ __forceinline__ void touch_line(const char* p, unsigned& sink) {
+    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
+}
 
+// First round-5 version: every wave polled the exchange, issued its loads and consumed them in the same iteration - one
+// L2 round trip + one HBM round trip per step, serial: ~3 us against the 2.3 us step of a Li-GRU recurrence, so the
+// helpers fell behind and the launch (which joins them) went 1.09 -> 1.45 ms, while the LSTM forward pass (3.6 us per
+// step) gained 15 %.  Now the roles are split by WAVE, because loads return in order within a wave: wave 0 only polls
+// (its vmcnt never holds an HBM load) and posts the newest published step in LDS; waves 1-3 read that word (lgkmcnt)
+// and issue their touches without ever waiting for one.
 __global__ __launch_bounds__(256) void rec_helper_kernel(HelpArgs a) {
     extern __shared__ unsigned char unused_lds[];  // placement only (see the header)
     __shared__ int s_cluster, s_part;
+    __shared__ volatile int s_progress;            // newest published step seen by wave 0 (-1: none; T: stop)
     const int tid = threadIdx.x;
     const unsigned my_xcd = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;  // HW_REG_XCC_ID
     if (tid == 0) {
@@ -93,6 +107,7 @@ __global__ __launch_bounds__(256) void rec_helper_kernel(HelpArgs a) {
         }
         s_cluster = mine;
         s_part = part;
+        s_progress = -1;
     }
     __syncthreads();
     const int c = s_cluster, part = s_part;
@@ -102,15 +117,42 @@ __global__ __launch_bounds__(256) void rec_helper_kernel(HelpArgs a) {
     int nrows = a.R - n_base;
     nrows = nrows < a.rpc ? nrows : a.rpc;
     if (nrows <= 0) return;
+    const int rev = a.backward;
 
-    // ---- my line jobs: (range, row, line) -> byte offset at storage time 0 + per-time stride; the same every step
+    if (tid < 64) {
+        // ---- wave 0: the pace.  The chunk (row n_base, units 0..7) of the exchange buffer is published by (member 0,
+        // wave 0, lane 0) each step; a chunk is ONE 16-byte store and a published dword is never all ones.
+        const int dir0 = n_base >= B ? 1 : 0, b0 = n_base - dir0 * B;
+        const char* xrow = a.xbase + (long long)dir0 * a.x_dir_bytes + (long long)b0 * a.x_row_bytes;
+        unsigned long long tlast = __builtin_readcyclecounter();
+        for (int q = 0; q < T; ++q) {
+            const long long ts = (dir0 ^ rev) ? (T - 1 - q) : q;
+            const unsigned* px = reinterpret_cast<const unsigned*>(xrow + ts * a.x_ts);
+            while (__hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xFFFFFFFFu) {
+                if (timed_out(tlast, a.limit_clocks)) {
+                    if (tid == 0) s_progress = T;  // give up: the touchers stop too
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            tlast = __builtin_readcyclecounter();
+            if (tid == 0) s_progress = q;
+        }
+        if (tid == 0) s_progress = T;
+        return;
+    }
+
+    // ---- waves 1-3: my line jobs: (range, row, line) -> byte offset at storage time 0 + per-time stride
     const char* jb[MAXJOBS];
     long long jstride[MAXJOBS], joff[MAXJOBS];
     int jdir[MAXJOBS], jlead[MAXJOBS];
+    unsigned sink[MAXJOBS];
     int njobs = 0;
+#pragma unroll
+    for (int i = 0; i < MAXJOBS; ++i) sink[i] = 0u;
     {
-        const int stride = 256 * a.hpc;
-        int j = tid + 256 * part, acc = 0;  // global job index walks ranges x rows x lines
+        const int stride = TOUCHERS * a.hpc;
+        int j = (tid - 64) + TOUCHERS * part, acc = 0;  // global job index walks ranges x rows x lines
         for (int k = 0; k < a.nranges; ++k) {
             const HelpRange& r = a.r[k];
             const int lines = (r.len + 127) / 128 + 1;  // (+1: a range that does not start on a line boundary)
@@ -132,25 +174,20 @@ __global__ __launch_bounds__(256) void rec_helper_kernel(HelpArgs a) {
             acc += total;
         }
     }
-    // ---- the chunk (row n_base, units 0..7) of the exchange buffer: published by (member 0, wave 0, lane 0) each step
-    const int dir0 = n_base >= B ? 1 : 0, b0 = n_base - dir0 * B;
-    const char* xrow = a.xbase + (long long)dir0 * a.x_dir_bytes + (long long)b0 * a.x_row_bytes;
-    const int rev = a.backward;
-
-    unsigned acc = 0;
-    unsigned long long tlast = __builtin_readcyclecounter();
-    // published step q -> touch step q + lead of every range (q == -1: the first steps at once)
-    for (int q = -1; q < T; ++q) {
-        if (q >= 0) {
-            const long long ts = (dir0 ^ rev) ? (T - 1 - q) : q;
-            const unsigned* px = reinterpret_cast<const unsigned*>(xrow + ts * a.x_ts);
-            // (a chunk is ONE 16-byte store and a published dword is never all ones: its first dword tells)
-            while (__hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0xFFFFFFFFu) {
-                if (timed_out(tlast, a.limit_clocks)) return;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            tlast = __builtin_readcyclecounter();
+    // published step q -> touch step q + lead of every range; before anything is published: the steps 0 .. lead - 1
+    int done = -2;  // last q handled (-1 = the head start)
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (true) {
+        int p = s_progress;
+        if (done == -2) p = -1;
+        else if (p <= done) {
+            if (p >= T || timed_out(t0, 4u * a.limit_clocks)) break;
+            __builtin_amdgcn_s_sleep(1);
+            continue;
         }
+        if (p >= T) break;
+        // (a toucher that fell behind skips to the newest published step: old steps are history)
+        const int q = p;
 #pragma unroll
         for (int i = 0; i < MAXJOBS; ++i) {
             if (i < njobs) {
@@ -158,12 +195,18 @@ __global__ __launch_bounds__(256) void rec_helper_kernel(HelpArgs a) {
                 const int last = q < 0 ? jlead[i] - 1 : q + jlead[i];
                 for (int s = first; s <= last && s < T; ++s) {
                     const long long ts = (jdir[i] ^ rev) ? (T - 1 - s) : s;
-                    acc ^= *reinterpret_cast<const unsigned*>(jb[i] + joff[i] + ts * jstride[i]);
+                    touch_line(jb[i] + joff[i] + ts * jstride[i], sink[i]);
                 }
             }
         }
+        done = q;
+        if (q >= T - 1) break;
     }
-    if (acc == 0x9E3779B9u && a.sink != nullptr) a.sink[0] = acc + unused_lds[0];  // (keeps the loads alive)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < MAXJOBS; ++i) acc ^= sink[i];
+    if (acc == 0x9E3779B9u && a.sink != nullptr) a.sink[0] = acc + unused_lds[0];  // (keeps the sinks alive)
 }
 
 hipStream_t g_hstream = nullptr;
@@ -176,15 +219,15 @@ int helper_mode() {
     if (g_mode < 0) {
         const char* e = getenv("PK_REC_HELPER");
         g_mode = e ? atoi(e) : 0;
-        const char* l = getenv("PK_REC_HELPER_LEAD");  // "p,o,b": steps ahead for P / the output lines / the backward loads
+        const char* l = pk_experiment("helper_lead");  // "p:o:b": steps ahead for P / the output lines / the backward loads
         if (l) {
             int p = 0, o = 0, b = 0;
-            const int n = sscanf(l, "%d,%d,%d", &p, &o, &b);
+            const int n = sscanf(l, "%d:%d:%d", &p, &o, &b);
             if (n >= 1 && p > 0) g_lead_p = p;
             if (n >= 2 && o > 0) g_lead_o = o;
             if (n >= 3 && b > 0) g_lead_b = b;
         }
-        const char* w = getenv("PK_REC_HELPER_WGS");  // helper workgroups per cluster
+        const char* w = pk_experiment("helper_wgs");  // helper workgroups per cluster
         if (w && atoi(w) > 0) g_hpc = atoi(w) > 6 ? 6 : atoi(w);
     }
     return g_mode;
@@ -269,7 +312,7 @@ int pk_rec_helper_launch(hipStream_t st, const R2Args& a, const Plan2& pl, int G
     {   // the job lists of a cluster's helpers must hold the lines of one step (speed only: no helper otherwise)
         long long lines = 0;
         for (int k = 0; k < n; ++k) lines += (long long)pl.rpc * ((h.r[k].len + 127) / 128 + 1);
-        if (lines > 256ll * MAXJOBS * h.hpc) return 0;
+        if (lines > (long long)TOUCHERS * MAXJOBS * h.hpc) return 0;
     }
     g_ticket_row = (g_ticket_row + 1) & 63;
     h.tickets = g_tickets + g_ticket_row * 8;

@@ -632,7 +632,7 @@ int pk_rec2f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
 static bool use_gen2_f32(int prec, int cell, int H) {
     static int off = -1;
     if (off < 0) {
-        const char* e = getenv("PK_REC_F32_GEN");  // 1 = keep the first-generation kernels (A/B measurements)
+        const char* e = pk_experiment("rec_f32_gen");  // 1 = keep the first-generation kernels (A/B measurements)
         off = (e && e[0] == '1') ? 1 : 0;
     }
     return !off && prec == PK_PREC_F32 && pk_rec2f_covers(cell, H);

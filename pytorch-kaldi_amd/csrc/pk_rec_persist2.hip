@@ -729,10 +729,10 @@ int pk_rec2_make_plan(int R, int H, Plan2& pl) {
     {   // no more clusters than full 16-row MFMA tiles need (rounded up to the XCD count): a step costs the same for 11
         // rows as for 16, and the CUs left over go to the weight-gradient GEMMs of the side stream (256 rows: 16 clusters
         // instead of 24, 19.09 -> 18.99 ms per step; a count that is not a multiple of 8 straddles XCDs: 23.6 ms).
-        // PK_REC_CLUSTERS overrides the cap.
+        // PK_EXPERIMENT rec_clusters overrides the cap.
         static int cap = -1;
         if (cap < 0) {
-            const char* e = getenv("PK_REC_CLUSTERS");
+            const char* e = pk_experiment("rec_clusters");
             cap = e ? atoi(e) : 0;
         }
         const int full = (((R + RMAX - 1) / RMAX) + 7) & ~7;
@@ -802,7 +802,7 @@ int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidi
 }
 
 // Idle time between a workgroup's publish and its first poll of the next step, in s_sleep units of 64 clocks
-// (PK_POLL_DELAY_FWD / PK_POLL_DELAY_BWD override).  A poll that arrives before the other members' stores is repeated;
+// (PK_EXPERIMENT poll_delay_fwd / PK_EXPERIMENT poll_delay_bwd override).  A poll that arrives before the other members' stores is repeated;
 // while the sentinel test was expensive that cost ~2300 clocks and 6 units were best (re-polls 0.4 -> 0.04 per step);
 // with the dword-level test a re-poll is cheap and the DELAY sweep of tools/trace_rec2.py (Li-GRU, BASELINE geometry) is
 // flat between 0 and 2 units (forward 5160-5200, backward 5750-5870 clocks per step) and rises beyond.
@@ -810,13 +810,13 @@ static int default_poll_delay(bool backward, int cell) {
     static int env[2] = {-2, -2};
     int& e = env[backward ? 1 : 0];
     if (e == -2) {
-        const char* v = getenv(backward ? "PK_POLL_DELAY_BWD" : "PK_POLL_DELAY_FWD");
+        const char* v = pk_experiment(backward ? "poll_delay_bwd" : "poll_delay_fwd");
         e = v ? atoi(v) : -1;
     }
     if (e >= 0) return e;
     // Per cell and pass.  Li-GRU (end of round 2, 16 clusters + self-filling exchange, whole training step on one box):
     // backward 1 -> 18.47 ms, 0 -> 18.36, 2 -> 18.24; forward 1 vs 2: 18.45 vs 18.47.  The eight-wave LSTM backward polls
-    // from TWO waves per SIMD whose helper wave is delayed separately (PK_LSTM_HELPER_DELAY): any idle time in front of
+    // from TWO waves per SIMD whose helper wave is delayed separately (PK_EXPERIMENT lstm_helper_delay): any idle time in front of
     // its first poll only delays the hand-over - round 3, timit_lstm step on one box, two rounds each: 0 -> 26.5 / 26.5 ms,
     // 1 -> 40.8 / 36.6, 2 -> 33.9 / 36.0, 3 -> 35.2 / 39.7 (the round-2 default of 2 for every cell is what made the
     // driver's LSTM line 33.2 ms against the 26.7 ms measured before that commit).
@@ -830,21 +830,13 @@ int pk_rec2_host_setup(R2Args& a, bool backward, int cell) {
     a.err = g2_err_dev; a.spin_limit = 400000; a.trace = g2_trace; a.xcd_tab = g2_xcd_tab; a.force_safe = g2_force_safe;
     a.trash = g2_trash; a.poll_delay = g2_poll_delay >= 0 ? g2_poll_delay : default_poll_delay(backward, cell);
     a.helper_delay = 0;
-    {   // role-split kernels (pk_rec_split.hip): which compute wave writes the phase trace (diagnostics)
-        static int tw = -1;
-        if (tw < 0) {
-            const char* e = getenv("PK_TRACE_WAVE");
-            tw = e ? (atoi(e) & 3) : 0;
-        }
-        if (g2_trace != nullptr) a.helper_delay = tw;
-    }
     a.empty_step = g2_empty_step;
     a.self_fill = 0;
-    {   // PK_REC_FLUSH_LATE=1: the third-generation kernels issue a step's output stores / next-step loads behind its MFMA
+    {   // PK_EXPERIMENT rec_flush_late=1: the third-generation kernels issue a step's output stores / next-step loads behind its MFMA
         // block instead of right behind the barrier (A/B switch)
         static int fl = -1;
         if (fl < 0) {
-            const char* e = getenv("PK_REC_FLUSH_LATE");
+            const char* e = pk_experiment("rec_flush_late");
             fl = e ? atoi(e) : 0;  // (third generation: 1 = late; role-split kernels: bit 0 no priorities, bit 1 nt stores, bit 2 nt loads)
         }
         a.flush_late = fl;
@@ -975,7 +967,6 @@ static int rec_fwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
     if (rc) return rc;
     // (per-step LayerNorm lives in the four-wave second-generation kernels of this file, for every cell)
     if (lstm8 && !ln) return pk_rec2l_launch(st, a, pl, act, false);
-    if (!ln && pk_recs_covers(cell, 0)) return pk_recs_launch(st, a, pl, cell, act, false, traced(cell, act), g2_poll_delay >= 0);
     if (!ln && pk_rec3_covers(cell, 0)) return pk_rec3_launch(st, a, pl, cell, act, false, traced(cell, act));
     const int G = pk_cell_gates(cell);
     const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell) + (ln ? 1 : 0)) * 1024 + 512) + 16;
@@ -1050,7 +1041,6 @@ static int rec_bwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
     rc = pk_rec2_ln_setup(st, a, pl, ln, true);
     if (rc) return rc;
     if (lstm8 && !ln) return pk_rec2l_launch(st, a, pl, act, true);
-    if (!ln && pk_recs_covers(cell, 1)) return pk_recs_launch(st, a, pl, cell, act, true, traced(cell, act), g2_poll_delay >= 0);
     if (!ln && pk_rec3_covers(cell, 1)) return pk_rec3_launch(st, a, pl, cell, act, true, traced(cell, act));
     const size_t atile = (size_t)RMAX * pk_r2_lda_bf16(G * KPAD) * 2;
     const int nin = pk_cell_saved(cell) + 2 + (cell == PK_CELL_LSTM ? 1 : 0) + (ln ? 1 : 0);

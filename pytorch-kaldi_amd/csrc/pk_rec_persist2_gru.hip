@@ -951,14 +951,14 @@ Rec2gKernel pick_bwd3(int act) {
     return act == PK_ACT_RELU ? rec3g_bwd_kernel<CELL, PK_ACT_RELU> : act == PK_ACT_TANH ? rec3g_bwd_kernel<CELL, PK_ACT_TANH>
                                                                                         : rec3g_bwd_kernel<CELL, -1>;
 }
-// PK_GRU_BWD_GEN=3 selects the third-generation backward kernel.  NOT the default: on the two-phase step it measured
+// PK_EXPERIMENT gru_bwd_gen=3 selects the third-generation backward kernel.  NOT the default: on the two-phase step it measured
 // slower (libri_gru 35.7 vs 34.7 ms per step, two rounds on one box) - the loads and fill stores issued behind barrier 1
 // sit in front of the vmcnt(0) of the phase-2 poll half a step later, and without the patch traffic in between the fill
 // stores' HBM acknowledge is still outstanding there.  (The one-hop kernels gain: liGRU -12 %, LSTM -5 % of the step.)
 inline bool bwd_gen3() {
     static int g = -1;
     if (g < 0) {
-        const char* e = getenv("PK_GRU_BWD_GEN");
+        const char* e = pk_experiment("gru_bwd_gen");
         g = (e && e[0] == '3') ? 3 : 2;
     }
     return g == 3;

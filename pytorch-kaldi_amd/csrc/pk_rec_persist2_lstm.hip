@@ -921,11 +921,11 @@ Rec2Kernel pick_bwd(int act) {
 Rec2Kernel pick_bwd3(int act) {
     return act == PK_ACT_RELU ? rec3l_bwd_kernel<PK_ACT_RELU> : act == PK_ACT_TANH ? rec3l_bwd_kernel<PK_ACT_TANH> : rec3l_bwd_kernel<-1>;
 }
-// PK_LSTM_BWD_GEN=2 keeps the second-generation backward kernel (A/B measurements)
+// PK_EXPERIMENT lstm_bwd_gen=2 keeps the second-generation backward kernel (A/B measurements)
 inline bool bwd_gen3() {
     static int g = -1;
     if (g < 0) {
-        const char* e = getenv("PK_LSTM_BWD_GEN");
+        const char* e = pk_experiment("lstm_bwd_gen");
         g = (e && e[0] == '2') ? 2 : 3;
     }
     return g == 3;
@@ -935,14 +935,14 @@ inline int act_slot(int act) { return act == PK_ACT_RELU ? 0 : act == PK_ACT_TAN
 }  // namespace
 
 // Which LSTM kernels pk_rec_{fwd,bwd}_bf16 launch: 8 = the ones in this file (default), 4 = the four-wave kernels of
-// pk_rec_persist2.hip (what every other cell uses).  PK_LSTM_WAVES=4 changes the default; pk_persist2_set_lstm_waves
+// pk_rec_persist2.hip (what every other cell uses).  PK_EXPERIMENT lstm_waves=4 changes the default; pk_persist2_set_lstm_waves
 // overrides it at run time (tests/test_gpu_lstm_waves.py compares the two).
 namespace {
 int g_lstm_waves = 0;  // 0: not decided yet
 }
 int pk_rec2l_enabled() {
     if (g_lstm_waves == 0) {
-        const char* v = getenv("PK_LSTM_WAVES");
+        const char* v = pk_experiment("lstm_waves");
         g_lstm_waves = (v && atoi(v) == 4) ? 4 : 8;
     }
     return g_lstm_waves == 8;
@@ -952,7 +952,7 @@ extern "C" int pk_persist2_get_lstm_waves(void) { return pk_rec2l_enabled() ? 8 
 int pk_rec2l_helper_delay() {
     static int d = -1;
     if (d < 0) {
-        const char* v = getenv("PK_LSTM_HELPER_DELAY");
+        const char* v = pk_experiment("lstm_helper_delay");
         d = v ? atoi(v) : 4;
         if (d < 0) d = 0;
     }

@@ -675,13 +675,13 @@ int g3_gen[2] = {-1, -1};  // per pass (forward, backward): 2 = second generatio
 // (-12 %).  The forward pass also STORES three fp32 tensors per step (Y, S); in the third-generation loop those stores
 // end up in front of a counted vmcnt wait inside the MFMA block and their ~1 us HBM acknowledge lands on the dependency
 // chain (MFMA phase 1 450 -> 3 300 clocks; issued behind the MFMA block instead they delay the next poll by as much),
-// so forward stays on the second generation.  PK_REC_GEN = 2 / 3 / 4 forces one generation for both passes,
-// PK_REC_GEN_FWD / PK_REC_GEN_BWD for one pass (A/B measurements).
+// so forward stays on the second generation.  PK_EXPERIMENT rec_gen=2 / 3 / 4 forces one generation for both passes,
+// PK_EXPERIMENT rec_gen_fwd / PK_EXPERIMENT rec_gen_bwd for one pass (A/B measurements).
 int pk_rec3_covers(int cell, int backward) {
     if (g3_gen[0] < 0) {
-        const char* both = getenv("PK_REC_GEN");
-        const char* ef = getenv("PK_REC_GEN_FWD");
-        const char* eb = getenv("PK_REC_GEN_BWD");
+        const char* both = pk_experiment("rec_gen");
+        const char* ef = pk_experiment("rec_gen_fwd");
+        const char* eb = pk_experiment("rec_gen_bwd");
         auto parse = [](const char* e, int dflt) { return (e && e[0] >= '2' && e[0] <= '4') ? e[0] - '0' : dflt; };
         g3_gen[0] = parse(ef, parse(both, 2));
         g3_gen[1] = parse(eb, parse(both, 4));

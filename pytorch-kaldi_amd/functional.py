@@ -39,19 +39,19 @@ class _Settings:
         # perf mode: weight-gradient GEMMs (dW, dU) of a recurrent layer / a Linear run on a second HIP stream, next to
         # the following layer's recurrent backward, and accumulate straight into the parameters' flat .grad buffer
         # (only for parameters owned by optim.FlatParams; see side_launch / join_side)
-        self.wgrad_side = os.environ.get("PK_WGRAD_SIDE", "1") != "0"
+        self.wgrad_side = _lib.experiment("wgrad_side", "1") != "0"
         # the liGRU / RNN persistent kernels keep their exchange buffers filled themselves (0 = whole-buffer fill on a third stream)
-        self.self_fill = os.environ.get("PK_REC_SELF_FILL", "1") != "0"
+        self.self_fill = _lib.experiment("rec_self_fill", "1") != "0"
         # weight-gradient GEMMs of a recurrent layer go to the side stream behind the layer's LAST main-stream kernel
         # (its dX GEMM), so that they run next to the layer below's latency-bound recurrence and not next to this
         # layer's bandwidth-bound BatchNorm backward / dX GEMM (0 = as soon as their operands exist)
-        self.side_late = os.environ.get("PK_SIDE_LATE", "1") != "0"
+        self.side_late = _lib.experiment("side_late", "1") != "0"
         # ... and size their split-K grids for the CUs that recurrence leaves free (0 = for the whole device)
-        self.side_cus = os.environ.get("PK_SIDE_CUS", "0") != "0"
+        self.side_cus = _lib.experiment("side_cus", "0") != "0"
         # perf mode: a cost_nll line directly behind a fused output layer is computed by head_nll (one pass, no dense
         # one-hot gradient); 0 = through the caller's nn.NLLLoss on the log-posteriors, which is what the reference's
         # own forward_model does with this package's classes (utils.py:2361)
-        self.fused_cost = os.environ.get("PK_FUSED_COST", "1") != "0"
+        self.fused_cost = _lib.experiment("fused_cost", "1") != "0"
         assert self.precision in PREC, self.precision
         assert self.rec_algo in ("auto", "stepwise", "persistent"), self.rec_algo
 
@@ -301,7 +301,7 @@ def cvt_bf16(x2, nseg=1, seglen=None, segpad=None, out=None):
     return out
 
 
-_SMALL_SPLITK = os.environ.get("PK_SMALL_SPLITK", "1") != "0"
+_SMALL_SPLITK = _lib.experiment("small_splitk", "1") != "0"
 
 
 def gemm_bf16(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, alpha=1.0, beta=0.0, bias=None, splitk=1):
@@ -338,7 +338,7 @@ def gemm_bf16_bn_stats(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, bias=None, g
     def done(mean, var):
         return (mean, var) if gates is None else (mean, var) + tuple(bn_finalize_gates(mean, var, *gates))
 
-    if os.environ.get("PK_GEMM_STATS", "1") == "0":  # A/B switch: statistics by a second pass over C
+    if _lib.experiment("gemm_stats", "1") == "0":  # A/B switch: statistics by a second pass over C
         gemm_bf16(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, bias=bias)
         return done(*bn_stats(C if ldc == N else C.as_strided((M, N), (ldc, 1))))
     stats = torch.empty(int(lib.pk_gemm_bf16_stats_floats(M, N)), device=C.device, dtype=torch.float32)
@@ -437,8 +437,8 @@ def direct_grads_ok(params):
     pre-allocated flat .grad by the kernel that produces it, on the current stream, instead of being returned to autograd
     (whose AccumulateGrad node is one more add launch per parameter).  Only inside `with accumulating_backward():` (the
     engine's own step: a backward pass that is known to accumulate), under the conditions of the side-stream weight
-    gradients, and only while no data-parallel reducer listens for gradient hooks.  PK_DIRECT_GRADS=0 turns it off."""
-    return (accumulating_backward.depth > 0 and _Side.listener is None and os.environ.get("PK_DIRECT_GRADS", "1") != "0"
+    gradients, and only while no data-parallel reducer listens for gradient hooks.  PK_EXPERIMENT direct_grads=0 turns it off."""
+    return (accumulating_backward.depth > 0 and _Side.listener is None and _lib.experiment("direct_grads", "1") != "0"
             and torch.is_grad_enabled() is False and side_targets_ok(params))
 
 
@@ -446,11 +446,11 @@ def direct_affine_ok(params):
     """direct_grads_ok for a decision that has to be taken in FORWARD (a recurrent layer's BatchNorm scales / shifts are
     handed to its node as detached views of the flat buffer - no torch.cat per layer and step, no AccumulateGrad adds
     behind the node - only when the whole step runs inside `with accumulating_backward():`)."""
-    return (accumulating_backward.depth > 0 and _Side.listener is None and os.environ.get("PK_DIRECT_GRADS", "1") != "0"
+    return (accumulating_backward.depth > 0 and _Side.listener is None and _lib.experiment("direct_grads", "1") != "0"
             and torch.is_grad_enabled() and side_targets_ok(params))
 
 
-_DEBUG_SKIP_SIDE = os.environ.get("PK_DEBUG_SKIP_SIDE", "0") == "1"  # timing experiments only: drops the weight-gradient work
+_DEBUG_SKIP_SIDE = _lib.experiment("debug_skip_side", "0") == "1"  # timing experiments only: drops the weight-gradient work
 
 
 def _make_side_stream():
@@ -464,12 +464,12 @@ def side_launch(fn, keep, params=None, defer=False):
     fn reads or writes that autograd may free before the side stream is done; `params`: the parameters whose .grad fn
     accumulates into (the data-parallel reducer launches a bucket's all-reduce behind them, on this stream).
 
-    defer = True (PK_SIDE_LATE and PK_SIDE_DEFER_HEADS, default on): the whole call - the stream dependency included - is postponed until the
+    defer = True (PK_EXPERIMENT side_late and PK_EXPERIMENT side_defer_heads, default on): the whole call - the stream dependency included - is postponed until the
     next recurrent layer's backward is about to launch its recurrence (flush_deferred_side), or until join_side().  For
     the output layers on top of a recurrent stack: their weight-gradient GEMMs fill the whole chip for 0.3 ms, and the
     short kernels of the NEXT head's backward on the main stream queued behind their workgroups (0.29 ms per step in the
     round-4 timeline); next to the recurrence, which leaves 112 CUs idle, the same work is free."""
-    if defer and settings.side_late and os.environ.get("PK_SIDE_DEFER_HEADS", "1") != "0":
+    if defer and settings.side_late and _lib.experiment("side_defer_heads", "1") != "0":
         _Side.deferred.append((fn, keep, params))
         _Side.pending = True
         return
@@ -609,14 +609,14 @@ class _DxShare:
     autograd adds them with an element-wise kernel (0.2 ms, 846 MB of traffic).  Instead the first head to run backward
     allocates dX and every later head's dX GEMM accumulates into it (beta = 1) and returns no gradient of its own.
     Keyed by the input's identity at forward time; the table is cleared whenever a new forward pass builds heads, i.e.
-    after the backward pass that used it.  PK_HEAD_DX_SHARE=0 switches it off.
+    after the backward pass that used it.  PK_EXPERIMENT head_dx_share=0 switches it off.
 
     Accumulating in place into a tensor autograd already holds is only sound while nobody else adds to that buffer, so
     the heads do not consume x itself: they consume ONE private alias of it (_ShareIn, made by the first head built on x
     and handed to every later one).  The alias has no other consumers, its gradient buffer therefore only ever sees
     the heads' contributions - the first as the shared tensor, the rest as None - and whatever else reads x adds to x's
     own buffer, behind _ShareIn.backward, which also lets go of the shared dX."""
-    on = os.environ.get("PK_HEAD_DX_SHARE", "1") != "0"
+    on = _lib.experiment("head_dx_share", "1") != "0"
     epoch = 0
     table = {}  # key -> (epoch, dx tensor, contributors)
     alias = None  # (weakref to x, its private alias) of the head input seen last
@@ -823,7 +823,7 @@ class HeadNllFn(torch.autograd.Function):
         part = _new(int(lib.pk_nll_err_partial_floats(M)), like=y)
         # bad labels are counted IN PLACE into the device's persistent counter by the same launch (HIP-graph safe; the loss
         # of such a batch is NaN; the count is reported at the next point where the host waits for the GPU anyway)
-        if amax is not None and os.environ.get("PK_HEAD_ARGMAX", "1") != "0":
+        if amax is not None and _lib.experiment("head_argmax", "1") != "0":
             # the rows' arg-max positions came with y (pk_logsoftmax_fwd_ld_argmax): y is not read a second time
             _lib.check(lib.pk_nll_err_fwd_argmax(_stream(), _p(y), _p(lab), _p(amax), int(ignore_index), M, N, _p(part), _p(out4),
                                                  _p(loss), _p(label_check_counter(y.device))), "pk_nll_err_fwd_argmax")
@@ -1074,7 +1074,7 @@ class LinearBnActFn(torch.autograd.Function):
         dy2 = _rows2d(dy.contiguous())
         sum_g, sum_gx = _new(N, like=z), _new(N, like=z)
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
-        if lib.pk_bn_act_bwd_small_covers(M, N) == 1 and os.environ.get("PK_MLP_FUSED_BWD", "1") != "0":
+        if lib.pk_bn_act_bwd_small_covers(M, N) == 1 and _lib.experiment("mlp_fused_bwd", "1") != "0":
             # one launch: activation / mask backward, both BatchNorm reductions, BatchNorm backward, the bf16 operand
             direct = ctx.bnparams is not None and direct_grads_ok(ctx.bnparams)
             dzb = torch.empty(M, _up(N, 64), device=z.device, dtype=torch.bfloat16)
@@ -1107,7 +1107,7 @@ class LinearBnActFn(torch.autograd.Function):
 def linear_bn_act_ok(x, weight, training, use_bn, act):
     """The one-launch MLP layer covers perf mode, training-mode BatchNorm, 2-D batches of up to 128 rows."""
     return (bf16_mode() and training and use_bn and x.dim() == 2 and act in ACT and x.is_cuda
-            and os.environ.get("PK_MLP_FUSED", "1") != "0"
+            and _lib.experiment("mlp_fused", "1") != "0"
             and _lib.load().pk_linear_bn_act_bf16_covers(x.shape[0], weight.shape[0], x.shape[1]) == 1)
 
 
@@ -1226,13 +1226,13 @@ def log_softmax(x):
 # ----------------------------------------------------------------------------
 def ln_persistent_ok(cell, H):
     """Per-step LayerNorm of h_t inside the persistent time loop: the second-generation kernels - liGRU / RNN / LSTM in
-    perf mode, liGRU / RNN in fp32 (LSTM's first-generation fp32 kernels do not have it).  PK_REC_LN_PERSIST=0 sends such
+    perf mode, liGRU / RNN in fp32 (LSTM's first-generation fp32 kernels do not have it).  PK_EXPERIMENT rec_ln_persist=0 sends such
     layers back to the step-wise algorithm."""
-    if os.environ.get("PK_REC_LN_PERSIST", "1") == "0" or H < 2:
+    if _lib.experiment("rec_ln_persist", "1") == "0" or H < 2:
         return False
     if bf16_mode():
         return cell in ("liGRU", "RNN", "LSTM", "GRU", "minimalGRU")
-    return cell in ("liGRU", "RNN") and os.environ.get("PK_REC_F32_GEN", "")[:1] != "1"
+    return cell in ("liGRU", "RNN") and _lib.experiment("rec_f32_gen", "")[:1] != "1"
 
 
 def choose_rec_algo(cell, H, use_ln):
@@ -1241,8 +1241,8 @@ def choose_rec_algo(cell, H, use_ln):
     if cell in ("GRU", "minimalGRU"):  # the two-phase persistent kernels are perf-mode only; on this (general) path they
         ok = H <= 576 and use_ln and ln_persistent_ok(cell, H)  # serve the layers that normalise h_t
     # the first-generation exact-fp32 kernels exchange pairs of fp32 values: LSTM always, liGRU / RNN when
-    # PK_REC_F32_GEN=1 keeps them (the library reads the same switch, pk_rec_persist.hip::use_gen2_f32)
-    if not bf16_mode() and (cell == "LSTM" or os.environ.get("PK_REC_F32_GEN", "")[:1] == "1"):
+    # PK_EXPERIMENT rec_f32_gen=1 keeps them (the library reads the same switch, pk_rec_persist.hip::use_gen2_f32)
+    if not bf16_mode() and (cell == "LSTM" or _lib.experiment("rec_f32_gen", "")[:1] == "1"):
         ok = ok and H % 2 == 0
     if want == "persistent":
         if not ok:
@@ -1525,7 +1525,7 @@ class _Prefill:
         self.done = 0
 
     def start(self, *bufs):
-        if not settings.wgrad_side:  # PK_WGRAD_SIDE=0 keeps the whole step on one stream
+        if not settings.wgrad_side:  # PK_EXPERIMENT wgrad_side=0 keeps the whole step on one stream
             return
         main = torch.cuda.current_stream()
         if _Prefill.stream is None:

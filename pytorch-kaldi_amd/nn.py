@@ -439,7 +439,7 @@ class _Recurrent(nn.Module):
             # layer 0 (a launch per layer and step otherwise); 16-byte aligned slices
             H = self._lay[i]
             if (self._n_lay > 1 and len(set(self._lay)) == 1 and len(set(self._drop)) == 1 and (rows * H) % 4 == 0
-                    and os.environ.get("PK_MASK_ONE_DRAW", "1") != "0"):
+                    and F_._lib.experiment("mask_one_draw", "1") != "0"):
                 if i == 0:
                     self._mask_all = torch.empty(self._n_lay, rows, H, device=device).bernoulli_(1 - p)
                 m_all = getattr(self, "_mask_all", None)

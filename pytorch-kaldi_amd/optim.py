@@ -45,7 +45,7 @@ class FlatParams:
         self.unused = [id(p) in unused for p in self.params]
         index = {id(p): i for i, p in enumerate(self.params)}
         units, placed = [], set()
-        if hasattr(module, "pk_flat_groups") and os.environ.get("PK_FLAT_GROUPS", "1") != "0":
+        if hasattr(module, "pk_flat_groups") and _lib.experiment("flat_groups", "1") != "0":
             for grp in module.pk_flat_groups():
                 ids = [index[id(q)] for q in grp if id(q) in index and id(q) not in unused and index[id(q)] not in placed]
                 if ids:
@@ -161,7 +161,7 @@ class FusedOptimizer:
         self.param_groups = [{"lr": lr}]  # run_nn overrides the LR through param_groups (core.py:533-535)
         # True: step() leaves the flat gradient zeroed (and the following zero_grad() skips its fill launch).  For loops
         # that call zero_grad() in front of every backward pass anyway - core.run_nn_dp, bench.py - and never read .grad
-        # behind step(); off by default (torch.optim leaves .grad alone).  PK_OPT_ZERO_IN_STEP=0 turns it off everywhere.
+        # behind step(); off by default (torch.optim leaves .grad alone).  PK_EXPERIMENT opt_zero_in_step=0 turns it off everywhere.
         self.zero_in_step = False
 
     @property
@@ -180,12 +180,12 @@ class FusedOptimizer:
         lr = float(self.param_groups[0]["lr"])
         f = self.flat
         ptr = lambda k: self.bufs[k].data_ptr() if k in self.bufs else None
-        if f.n_active % 4 == 0 and os.environ.get("PK_FUSED_STEP", "1") != "0":
+        if f.n_active % 4 == 0 and _lib.experiment("fused_step", "1") != "0":
             # one launch that also zeroes the gradient (zero_in_step) and refreshes the bf16 copies of the weights
             if f._shadow_req and not torch.cuda.is_current_stream_capturing():
                 f.build_shadows()
             nseg = len(f._shadow_have)
-            zero = bool(self.zero_in_step) and os.environ.get("PK_OPT_ZERO_IN_STEP", "1") != "0"
+            zero = bool(self.zero_in_step) and _lib.experiment("opt_zero_in_step", "1") != "0"
             kind = {"rmsprop": 0, "sgd": 1, "adam": 2}[self.kind]
             h = {"rmsprop": (self.alpha, self.eps, 0.0), "sgd": (self.momentum, 0.0, 0.0),
                  "adam": (self.betas[0], self.betas[1], self.eps)}[self.kind]

@@ -631,7 +631,7 @@ def test_cost_from_the_arg_max_positions_equals_the_second_pass(rows, K, N, monk
     try:
         out = {}
         for mode in ("1", "0"):
-            monkeypatch.setenv("PK_HEAD_ARGMAX", mode)
+            monkeypatch.setenv("PK_EXPERIMENT", "head_argmax=" + mode)
             y = F_.linear_log_softmax(x.cuda(), w.cuda(), b.cuda())
             assert y._pk_head[-1] is not None and y._pk_head[-1].dtype == torch.int32
             loss, stats = F_.head_nll(y, lab.cuda())

@@ -1,5 +1,5 @@
 """The eight-wave LSTM time loops (pk_rec_persist2_lstm.hip, the default) against the four-wave ones
-(pk_rec_persist2.hip, PK_LSTM_WAVES=4 / pk_persist2_set_lstm_waves(4)) on identical inputs.
+(pk_rec_persist2.hip, PK_EXPERIMENT lstm_waves=4 / pk_persist2_set_lstm_waves(4)) on identical inputs.
 
 Forward: the gate split keeps the per-gate MFMA accumulation order, so the two kernels differ only where an fp32
 expression contracts differently and a bf16 rounding of h_t flips (measured 1e-7 .. 2e-4 norm-relative).  Backward: the
@@ -13,6 +13,8 @@ import pytest
 import torch
 
 from golden_util import rel_err
+
+_lib_mod = importlib.import_module("pytorch-kaldi_amd._lib")
 
 pytestmark = pytest.mark.gpu
 
@@ -58,10 +60,8 @@ def engine():
 
 
 def test_default_is_eight_waves(engine):
-    import os
-
     _, _, lib = engine
-    assert lib.pk_persist2_get_lstm_waves() == (4 if os.environ.get("PK_LSTM_WAVES") == "4" else 8)
+    assert lib.pk_persist2_get_lstm_waves() == (4 if _lib_mod.experiment("lstm_waves") == "4" else 8)
 
 
 @pytest.mark.parametrize("H,T,B,bidir,act,safe", [

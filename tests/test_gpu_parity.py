@@ -292,7 +292,7 @@ def test_self_filled_exchange_on_a_dirty_buffer(kind, pre, act, H, T, B, bidir, 
     """The bf16 persistent kernels write the "not written yet" pattern of their exchange buffers themselves, a few
     steps ahead of their own publishes (prefilled = 2).  Run twice in a row on different inputs, so that the second
     run's buffers are the allocator's recycled blocks holding the FIRST run's perfectly valid-looking data: outputs and
-    gradients must equal, bit for bit, what the whole-buffer fill (PK_REC_SELF_FILL=0 path) gives on the second input -
+    gradients must equal, bit for bit, what the whole-buffer fill (PK_EXPERIMENT rec_self_fill=0 path) gives on the second input -
     a poll that accepted a stale chunk would show up here."""
     from engine_util import F_amd, nn_amd
 
@@ -773,8 +773,8 @@ def test_per_step_layernorm_first_step_with_a_large_common_offset(kind, pre, pre
 # --------------------------------------------------------------------------------
 def test_small_batch_mlp_step_direct_gradients(monkeypatch):
     """TIMIT_MLP at its batch size (128 frames, 440 -> 1024 x 4 -> softmax head) in perf mode with flat parameters: the
-    backward pass with its small-batch shortcuts on (one launch for activation / BatchNorm backward, PK_MLP_FUSED_BWD;
-    weight and BatchNorm gradients accumulated into the flat .grad by the kernels that produce them, PK_DIRECT_GRADS)
+    backward pass with its small-batch shortcuts on (one launch for activation / BatchNorm backward, PK_EXPERIMENT mlp_fused_bwd;
+    weight and BatchNorm gradients accumulated into the flat .grad by the kernels that produce them, PK_EXPERIMENT direct_grads)
     must leave the gradients of the node-by-node backward through autograd's AccumulateGrad - same forward, same saved
     tensors; the fp32 operation order inside the BatchNorm backward differs, which flips the bf16 rounding of a few
     entries of dz per layer (measured 7e-4 at the bottom layer; two different forward kernels are 2e-2 apart, the bf16
@@ -791,8 +791,7 @@ def test_small_batch_mlp_step_direct_gradients(monkeypatch):
     F_amd.set_precision("bf16")
     results = {}
     for mode in ("plain", "direct"):
-        for k in ("PK_MLP_FUSED_BWD", "PK_DIRECT_GRADS"):
-            monkeypatch.setenv(k, "0" if mode == "plain" else "1")
+        monkeypatch.setenv("PK_EXPERIMENT", "mlp_fused_bwd=0,direct_grads=0" if mode == "plain" else "mlp_fused_bwd=1,direct_grads=1")
         torch.manual_seed(3)
         net = nn_amd.MLP(opts, 440).cuda().train()
         flat = optim_.FlatParams(net)

@@ -52,9 +52,8 @@ def test_small_batch_and_conv_coverage_predicates(lib):
 
 def test_algorithm_choice_for_layers_that_normalise_h(monkeypatch):
     """functional.choose_rec_algo: per-step LayerNorm inside the persistent loop where the kernels have it, step-wise
-    elsewhere; PK_REC_LN_PERSIST=0 and the forced algorithms are honoured."""
-    monkeypatch.delenv("PK_REC_LN_PERSIST", raising=False)
-    monkeypatch.delenv("PK_REC_F32_GEN", raising=False)
+    elsewhere; PK_EXPERIMENT rec_ln_persist=0 and the forced algorithms are honoured."""
+    monkeypatch.delenv("PK_EXPERIMENT", raising=False)
     old_prec, old_algo = F_.settings.precision, F_.settings.rec_algo
     try:
         F_.set_rec_algo("auto")
@@ -73,10 +72,9 @@ def test_algorithm_choice_for_layers_that_normalise_h(monkeypatch):
         with pytest.raises(_lib.PkError):
             F_.choose_rec_algo("LSTM", 550, True)
         F_.set_rec_algo("auto")
-        monkeypatch.setenv("PK_REC_LN_PERSIST", "0")
+        monkeypatch.setenv("PK_EXPERIMENT", "rec_ln_persist=0")
         assert F_.choose_rec_algo("liGRU", 550, True) == F_.REC_STEPWISE
-        monkeypatch.setenv("PK_REC_LN_PERSIST", "1")
-        monkeypatch.setenv("PK_REC_F32_GEN", "1")
+        monkeypatch.setenv("PK_EXPERIMENT", "rec_ln_persist=1,rec_f32_gen=1")
         assert F_.choose_rec_algo("liGRU", 550, True) == F_.REC_STEPWISE  # the first-generation fp32 kernels do not normalise
     finally:
         F_.set_precision(old_prec)
@@ -146,8 +144,8 @@ def test_direct_gradients_only_without_a_reducer_and_inside_backward(monkeypatch
     """functional.direct_grads_ok: kernels may accumulate into the flat .grad themselves only when the parameters are
     flat-bucket views with a pre-allocated gradient, the caller has declared an accumulating backward pass
     (functional.accumulating_backward: run_nn's step does; torch.autograd.grad() callers do not), autograd is not
-    recording, no data-parallel reducer listens for gradient hooks, and PK_DIRECT_GRADS is not 0."""
-    monkeypatch.delenv("PK_DIRECT_GRADS", raising=False)
+    recording, no data-parallel reducer listens for gradient hooks, and PK_EXPERIMENT direct_grads is not 0."""
+    monkeypatch.delenv("PK_EXPERIMENT", raising=False)
     old = F_.settings.precision
     q = torch.nn.Parameter(torch.zeros(4, 3))
     q.grad = torch.zeros(4, 3)
@@ -170,9 +168,9 @@ def test_direct_gradients_only_without_a_reducer_and_inside_backward(monkeypatch
             monkeypatch.setattr(F_._Side, "listener", lambda params: None)
             assert not F_.direct_grads_ok([q])        # a reducer counts gradient hooks: everything goes through autograd
             monkeypatch.setattr(F_._Side, "listener", None)
-            monkeypatch.setenv("PK_DIRECT_GRADS", "0")
+            monkeypatch.setenv("PK_EXPERIMENT", "direct_grads=0")
             assert not F_.direct_grads_ok([q])
-            monkeypatch.delenv("PK_DIRECT_GRADS")
+            monkeypatch.delenv("PK_EXPERIMENT")
             F_.set_precision("fp32")
             assert not F_.direct_grads_ok([q])        # parity mode: node by node
     finally:

@@ -17,8 +17,8 @@ def _flat_param(shape):
 def test_affine_views_only_inside_the_training_step_context(monkeypatch):
     """functional.direct_affine_ok (decided in FORWARD: a recurrent layer takes its BatchNorm scales / shifts as detached
     views of the flat buffer): only inside accumulating_backward, with autograd recording, flat-bucket parameters with a
-    pre-allocated gradient, perf mode, no data-parallel listener, PK_DIRECT_GRADS not 0."""
-    monkeypatch.delenv("PK_DIRECT_GRADS", raising=False)
+    pre-allocated gradient, perf mode, no data-parallel listener, PK_EXPERIMENT direct_grads not 0."""
+    monkeypatch.delenv("PK_EXPERIMENT", raising=False)
     old = F_.settings.precision
     q, plain = _flat_param((6,)), torch.nn.Parameter(torch.zeros(6))
     plain.grad = torch.zeros(6)
@@ -34,9 +34,9 @@ def test_affine_views_only_inside_the_training_step_context(monkeypatch):
             monkeypatch.setattr(F_._Side, "listener", lambda params: None)
             assert not F_.direct_affine_ok([q])
             monkeypatch.setattr(F_._Side, "listener", None)
-            monkeypatch.setenv("PK_DIRECT_GRADS", "0")
+            monkeypatch.setenv("PK_EXPERIMENT", "direct_grads=0")
             assert not F_.direct_affine_ok([q])
-            monkeypatch.delenv("PK_DIRECT_GRADS")
+            monkeypatch.delenv("PK_EXPERIMENT")
             F_.set_precision("fp32")
             assert not F_.direct_affine_ok([q])             # parity mode: node by node
         assert F_.accumulating_backward.depth == 0
@@ -86,11 +86,11 @@ def test_heads_share_one_private_alias_of_their_input():
 
 
 def test_deferred_side_launches_are_kept_in_order_and_flushed_by_join(monkeypatch):
-    """functional.side_launch(defer=True) only queues (PK_SIDE_LATE / PK_SIDE_DEFER_HEADS on); flush_deferred_side hands
+    """functional.side_launch(defer=True) only queues (PK_EXPERIMENT side_late / side_defer_heads on); flush_deferred_side hands
     the queue to side_launch in order; join_side flushes first.  (The streams themselves need a GPU: the launch is
     replaced by a recorder here.)"""
     calls = []
-    monkeypatch.delenv("PK_SIDE_DEFER_HEADS", raising=False)
+    monkeypatch.delenv("PK_EXPERIMENT", raising=False)
     monkeypatch.setattr(F_.settings, "side_late", True)
     monkeypatch.setattr(F_._Side, "deferred", [])
     monkeypatch.setattr(F_._Side, "pending", False)
@@ -111,7 +111,7 @@ def test_deferred_side_launches_are_kept_in_order_and_flushed_by_join(monkeypatc
     F_.side_launch(lambda: "c", (), None, defer=True)
     F_.join_side()                                          # (no stream was ever made: nothing to wait for)
     assert calls == ["a", "b", "c"] and not F_._Side.pending
-    monkeypatch.setenv("PK_SIDE_DEFER_HEADS", "0")
+    monkeypatch.setenv("PK_EXPERIMENT", "side_defer_heads=0")
     monkeypatch.setattr(F_, "side_launch", real)
     ran = []
     monkeypatch.setattr(F_.torch.cuda, "current_stream", lambda: (_ for _ in ()).throw(AssertionError("launched at once")))

@@ -56,6 +56,11 @@ def parse():
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--cpu-T", type=int, default=100, help="sequence length of the CPU baseline sample")
     ap.add_argument("--cpu-B", type=int, default=128, help="batch of the CPU baseline sample (the metric's: 128)")
+    ap.add_argument("--cpu-full-in-run", action="store_true", default=os.environ.get("PK_BENCH_CPU_FULL", "0") == "1",
+                    help="additionally time ONE step of the CPU port at the metric's FULL shape inside this run (~4 minutes of "
+                         "host time on the GPU box's 16 usable cores): cpu_baseline.full_shape is then measured_in_run = true. "
+                         "Off by default - the default run's CPU leg stays a bounded sample of the workload; the round's "
+                         "evidence pass (tools/gpu_evidence.sh) runs it and commits the line under profiles/")
     ap.add_argument("--cpu-full", action="store_true",
                     help="CPU baseline only: ONE step at the metric's full shape (T, B of --T / --B; minutes of CPU time), "
                          "printed as JSON - the source of profiles/r03_cpu_full_shape.json")
@@ -108,9 +113,11 @@ class Trainer:
             for o in self.opts.values():
                 o.zero_in_step = True  # (as core.run_nn_dp sets it: zero_grad() runs in front of every backward pass)
             flats = {k: o.flat for k, o in self.opts.items()}
-        # 8 MB buckets: the recurrent stack's 31.7 MB of gradients leave in 4 pieces while BPTT of the lower layers runs
-        self.reducer = self.DP.GradReducer(self.nns, flats=flats, bucket_bytes=8 << 20, overlap=args.overlap,
-                                           force=bool(getattr(args, "force_reducer", False)))
+        # 8 MB buckets: the recurrent stack's 31.7 MB of gradients leave in 4 pieces while BPTT of the lower layers runs;
+        # the launch-bound recipes (a step shorter than its own exchange): 4 MB buckets and the bf16 wire, as core.make_reducer
+        self.reducer = self.DP.GradReducer(self.nns, flats=flats, bucket_bytes=(8 << 20) if rcp["seq"] else (4 << 20),
+                                           overlap=args.overlap, force=bool(getattr(args, "force_reducer", False)),
+                                           wire=os.environ.get("PK_DP_WIRE") or ("fp32" if rcp["seq"] else "bf16"))
         # one resident synthetic batch per rank (different seeds per rank = different shards)
         self.T, self.B = (args.T, args.B) if rcp["seq"] else (1, args.B)
         self.batches = [self.R.synthetic_batch(rcp, self.T, self.B, 4234 + 17 * rank + i, "cuda") for i in range(2)]
@@ -335,7 +342,11 @@ def cpu_baseline(args, rcp_name, full=False):
                      "projections indexed in the time loop like the reference; the reference's own classes run 1.04x "
                      "(T=500) / 1.11x (T=50) slower than this port on the build host (profiles/r02_cpu_port_vs_reference.json)"
                      % (n, T, B, model or "host CPU"), "T": T, "B": B, "seconds": round(dt, 2)}
-    if not full:
+    if not full and getattr(args, "cpu_full_in_run", False) and rcp["seq"]:
+        fsr = cpu_baseline(args, rcp_name, full=True)  # the same port, ONE step at the metric's full (T, B): minutes
+        rec["full_shape"] = {k: fsr[k] for k in ("value", "unit", "cores", "T", "B", "seconds", "sample") if k in fsr}
+        rec["full_shape"]["measured_in_run"] = True
+    elif not full:
         try:  # the same port at the metric's FULL shape, measured once on the GPU box's host (bench.py --cpu-full)
             fs = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_full_shape.json")))
             if fs.get("recipe", "timit_ligru") == rcp_name:
@@ -450,7 +461,12 @@ def measure(args, rank, world, steps, warmup):
     for i in range(warmup):
         tr.step(i)
         torch.cuda.synchronize()
-    use_graph = args.graph == "on" or (args.graph == "auto" and not tr.rcp["seq"] and world == 1 and not args.torch_optim)
+    # (several ranks: the bucketed all-reduces are captured with the step - the reducer has placed them during the eager
+    # warm-up steps; RCCL kernels are capturable)
+    use_graph = args.graph == "on" or (args.graph == "auto" and not tr.rcp["seq"] and not args.torch_optim)
+    if use_graph and tr.reducer.active and warmup < 2:
+        for i in range(2 - warmup):  # the reducer learns which gradients arrive per step in its first step
+            tr.step(i)
     if use_graph:
         if warmup == 0:
             tr.step(0)  # lazy one-time initialisation must not land inside the capture
@@ -542,7 +558,9 @@ def measure(args, rank, world, steps, warmup):
         with open(args.dump_losses, "w") as f:
             json.dump([float(v) for v in losses], f)
     if tr.reducer.active:
-        out["config"]["reducer"] = "%d buckets, %s" % (len(tr.reducer.buckets), "forced on one rank" if world == 1 else "RCCL")
+        out["config"]["reducer"] = "%d buckets, %s wire, %s%s" % (len(tr.reducer.buckets), tr.reducer.wire,
+                                                                 "forced on one rank" if world == 1 else "RCCL",
+                                                                 ", inside the step's HIP graph" if tr.graphed is not None else "")
         if tr.reducer.trace and rank == 0:
             out["allreduce_timeline"] = tr.reducer.timeline()[-3:]
     if len(regions) > 1:

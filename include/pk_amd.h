@@ -174,6 +174,18 @@ int pk_colsum(void* stream, const float* g, const float* g2, int64_t ldg, int64_
 /* out = a + b (element-wise, n floats) */
 int pk_add(void* stream, const float* a, const float* b, int64_t n, float* out);
 
+/* ---- the tail of a conv layer in one launch: drop(act(LayerNorm(z))) with the CNN / SincNet flavour of the reference's
+ * LayerNorm (features [C, L], statistics over the last dim: neural_networks.py:1510-1512, 1546-1552, 1639-1641,
+ * 1655-1661).  z, a, y, mask: [B, C, L]; gamma, beta: [C, L]; mean, rinv: [B * C] (saved for backward).
+ * a = act(LN(z)) is always written (backward takes the activation's derivative from it); y = a * mask only with a mask
+ * (both NULL otherwise).  Backward: dz, and pg [B][2][C][L] = (g * xhat, g) with g = dy * mask * act'(a): pk_colsum over the
+ * B rows of pg gives (d gamma, d beta). */
+int pk_ln_last_act_drop_fwd(void* stream, const float* z, int64_t B, int C, int L, const float* gamma, const float* beta,
+                            float eps, int act, const float* mask, float* a, float* y, float* mean, float* rinv);
+int pk_ln_last_act_drop_bwd(void* stream, const float* dy, const float* z, const float* a, const float* mask, int64_t B, int C,
+                            int L, const float* gamma, const float* mean, const float* rinv, float eps, int act, float* dz,
+                            float* pg);
+
 /* ---- LayerNorm: neural_networks.py:23-33 (unbiased std, eps added to std).
  * Rows of length F; saves mean and 1/(std+eps) per row for backward. */
 int pk_layernorm_fwd(void* stream, const float* x, int64_t rows, int64_t F, const float* gamma, const float* beta,

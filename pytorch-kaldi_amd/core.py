@@ -162,13 +162,20 @@ def rank_columns(batch_size, rank, world):
     return local, np.arange(rank * local, (rank + 1) * local)
 
 
-def make_reducer(nns, optimizers, world):
-    """Gradient all-reduce over the flat buckets of the fused optimizers (None on one rank)."""
-    if world <= 1:
+def make_reducer(nns, optimizers, world, launch_bound=False, force=False):
+    """Gradient all-reduce over the flat buckets of the fused optimizers (None on one rank).
+    launch_bound: a recipe whose step is shorter than its own gradient exchange (MLP / SincNet on 128 frames: 0.3-4 ms
+    per step, 27-40 MB of gradients): 4 MB buckets, so that the upper layers' gradients are on the wire while the lower
+    layers still run backward, and the bf16 wire unless PK_DP_WIRE says otherwise (half the ring's payload; graded
+    against the fp32 wire in tests/test_dp_gloo.py).  The collectives are part of the step's HIP graph there
+    (round 5: RCCL kernels are capturable; the reference's only data-parallel hook is core.py:103-104, 537-538)."""
+    if world <= 1 and not force:
         return None
     # bucket by bucket, behind the layer that produced it (PK_DP_OVERLAP=0: everything after backward)
-    return _dp.GradReducer({k: nns[k] for k in nns}, flats={k: optimizers[k].flat for k in nns}, bucket_bytes=8 << 20,
-                           overlap=os.environ.get("PK_DP_OVERLAP", "1") != "0")
+    return _dp.GradReducer({k: nns[k] for k in nns}, flats={k: optimizers[k].flat for k in nns},
+                           bucket_bytes=(4 << 20) if launch_bound else (8 << 20),
+                           overlap=os.environ.get("PK_DP_OVERLAP", "1") != "0", force=force,
+                           wire=os.environ.get("PK_DP_WIRE") or ("bf16" if launch_bound else "fp32"))
 
 
 def mean_over_ranks(loss_sum, err_sum, world):
@@ -270,7 +277,8 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
             nns[net].load_state_dict(checkpoint_load["model_par"])
             optimizers[net].load_state_dict(checkpoint_load["optimizer_par"])
             optimizers[net].param_groups[0]["lr"] = float(config[arch_dict[net][0]]["arch_lr"])
-    reducer = make_reducer(nns, optimizers, world) if to_do == "train" else None
+    seq_model = is_sequential_dict(config, arch_dict)
+    reducer = make_reducer(nns, optimizers, world, launch_bound=not seq_model) if to_do == "train" else None
 
     post_file = {}
     if to_do == "forward" and rank == 0:
@@ -278,7 +286,6 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
             suffix = "_to_decode.ark" if require_decodings[out_id] else ".ark"
             post_file[name] = open(info_file.replace(".info", "_" + name + suffix), "wb")
 
-    seq_model = is_sequential_dict(config, arch_dict)
     if seq_model or to_do == "forward":
         N_batches = int(len(data_name) / batch_size)
     else:
@@ -305,10 +312,11 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
                 optimizers[opt].step()
         return {"loss_final": outs["loss_final"].detach(), "err_final": outs["err_final"].detach()}
 
-    # fixed-shape (non-sequence) training batches on one GPU are launch-bound: after a few eager batches the whole
-    # step is replayed as one HIP graph (graphs.py); PK_HIPGRAPH=0 keeps it eager
+    # fixed-shape (non-sequence) training batches are launch-bound: after a few eager batches the whole step - on
+    # several ranks with its bucketed RCCL all-reduces, which the first eager batches have taught the reducer to place -
+    # is replayed as one HIP graph (graphs.py); PK_HIPGRAPH=0 keeps it eager
     GRAPH_WARMUP = 3
-    graph_ok = (to_do == "train" and not seq_model and world == 1 and os.environ.get("PK_HIPGRAPH", "1") != "0"
+    graph_ok = (to_do == "train" and not seq_model and os.environ.get("PK_HIPGRAPH", "1") != "0"
                 and N_batches > GRAPH_WARMUP + 1)
     graphed = None
 

@@ -508,6 +508,84 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// ---- a conv layer's tail in one launch: drop(act(LayerNorm(z))) with the CNN / SincNet flavour of the reference's
+// LayerNorm (neural_networks.py:1510-1512, 1639-1641 - features [C, L], statistics over the last dim only; then
+// :1546-1552, :1655-1661).  z: [B, C, L] as rows r = b * C + c of length L; gamma / beta: [C, L].  One WAVE per row
+// (rows are 36 .. 1024 samples long in the shipped recipes): shuffles only, no LDS, no barrier.  The same arithmetic as
+// layernorm_fwd_kernel + the broadcast affine + affine_act: two-pass statistics, unbiased std + eps.
+//   a = act(gamma[c] * ((z - mean) * rinv) + beta[c]),  y = a * mask  (y == nullptr without a mask)
+__global__ __launch_bounds__(256) void ln_last_act_drop_fwd_kernel(const float* __restrict__ z, long rows, int C, int L,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float eps, int act,
+                                                                    const float* __restrict__ mask, float* __restrict__ a,
+                                                                    float* __restrict__ y, float* __restrict__ mean_o,
+                                                                    float* __restrict__ rinv_o) {
+    const int lane = threadIdx.x & 63;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+        const float* zr = z + r * L;
+        const long po = (long)(r % C) * L;
+        float s = 0.f;
+        for (int f = lane; f < L; f += 64) s += zr[f];
+        const float mu = pk_wave_sum(s) / (float)L;
+        float q = 0.f;
+        for (int f = lane; f < L; f += 64) {
+            const float d = zr[f] - mu;
+            q += d * d;
+        }
+        const float var = pk_wave_sum(q) / (float)(L - 1);
+        const float rinv = 1.0f / (sqrtf(var) + eps);
+        for (int f = lane; f < L; f += 64) {
+            const float u = gamma[po + f] * ((zr[f] - mu) * rinv) + beta[po + f];
+            const float av = pk_act(act, u);
+            a[r * L + f] = av;
+            if (y) y[r * L + f] = av * mask[r * L + f];
+        }
+        if (lane == 0) {
+            mean_o[r] = mu;
+            rinv_o[r] = rinv;
+        }
+    }
+}
+// backward of the same: g = dy * mask * act'(a) (from the OUTPUT, like pk_act_bwd); LayerNorm backward with the row's
+// gamma; the parameter-gradient terms leave as pg[b][0][c][f] = g * xhat, pg[b][1][c][f] = g (one column sum over the
+// batch then gives d gamma and d beta: pk_colsum on [B, 2 * C * L]).
+__global__ __launch_bounds__(256) void ln_last_act_drop_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                    const float* __restrict__ a,
+                                                                    const float* __restrict__ mask, long rows, int C, int L,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ rinv_i, float eps, int act,
+                                                                    float* __restrict__ dz, float* __restrict__ pg) {
+    const int lane = threadIdx.x & 63;
+    const long CL = (long)C * L;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+        const long c = r % C, b = r / C, po = c * L;
+        const float mu = mean[r], rinv = rinv_i[r];
+        const float stdv = 1.0f / rinv - eps;
+        float sg = 0.f, sgd = 0.f;
+        for (int f = lane; f < L; f += 64) {
+            float g = dy[r * L + f] * pk_act_grad_from_out(act, a[r * L + f]);
+            if (mask) g *= mask[r * L + f];
+            const float gg = g * gamma[po + f];
+            sg += gg;
+            sgd += gg * (z[r * L + f] - mu);
+        }
+        sg = pk_wave_sum(sg);
+        sgd = pk_wave_sum(sgd);
+        const float mg = sg / (float)L;
+        const float k2 = rinv * rinv * sgd / ((float)(L - 1) * stdv);
+        float* pgx = pg + b * 2 * CL + po;
+        for (int f = lane; f < L; f += 64) {
+            float g = dy[r * L + f] * pk_act_grad_from_out(act, a[r * L + f]);
+            if (mask) g *= mask[r * L + f];
+            const float d = z[r * L + f] - mu;
+            dz[r * L + f] = rinv * (g * gamma[po + f] - mg) - k2 * d;
+            pgx[f] = g * (d * rinv);
+            pgx[CL + f] = g;
+        }
+    }
+}
+
 // ---- LogSoftmax(dim=1) -------------------------------------------------------------
 __global__ __launch_bounds__(256) void logsoftmax_fwd_kernel(const float* __restrict__ x, long ldx, long rows, long N,
                                                               float* __restrict__ y) {
@@ -1083,6 +1161,32 @@ extern "C" int pk_layernorm_fwd(void* stream, const float* x, int64_t rows, int6
     int blocks = (int)(rows < 4096 ? rows : 4096);
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, pk_stream(stream), x, (long)rows, (long)F, gamma,
                        beta, eps, y, mean, rinv);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pk_ln_last_act_drop_fwd(void* stream, const float* z, int64_t B, int C, int L, const float* gamma,
+                                       const float* beta, float eps, int act, const float* mask, float* a, float* y,
+                                       float* mean, float* rinv) {
+    const int64_t rows = B * C;
+    if (rows == 0) return 0;
+    PK_REQUIRE(L > 1, "pk_ln_last_act_drop_fwd: needs at least 2 samples per row (unbiased std)");
+    PK_REQUIRE(act >= PK_ACT_LINEAR && act <= PK_ACT_ELU, "pk_ln_last_act_drop_fwd: element-wise activations only (got %d)", act);
+    PK_REQUIRE((mask == nullptr) == (y == nullptr), "pk_ln_last_act_drop_fwd: y is the masked output - give both or neither");
+    const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
+    hipLaunchKernelGGL(ln_last_act_drop_fwd_kernel, dim3(blocks), dim3(256), 0, pk_stream(stream), z, (long)rows, C, L, gamma,
+                       beta, eps, act, mask, a, y, mean, rinv);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int pk_ln_last_act_drop_bwd(void* stream, const float* dy, const float* z, const float* a, const float* mask,
+                                       int64_t B, int C, int L, const float* gamma, const float* mean, const float* rinv,
+                                       float eps, int act, float* dz, float* pg) {
+    const int64_t rows = B * C;
+    if (rows == 0) return 0;
+    const int blocks = (int)((rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192);
+    hipLaunchKernelGGL(ln_last_act_drop_bwd_kernel, dim3(blocks), dim3(256), 0, pk_stream(stream), dy, z, a, mask, (long)rows, C,
+                       L, gamma, mean, rinv, eps, act, dz, pg);
     PK_LAUNCH_CHECK();
     return 0;
 }

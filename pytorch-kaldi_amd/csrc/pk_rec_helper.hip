@@ -35,6 +35,8 @@ struct HelpRange {           // one contiguous byte range per (row, step): a row
 };
 struct HelpArgs {
     int T, B, R, C, rpc, row0, backward, hpc;
+    int delay;               // s_sleep units (64 clocks) between seeing a step published and touching
+
     int nranges;
     HelpRange r[4];
     const char* xbase;       // exchange buffer (Yb forward, dGb backward)
@@ -188,6 +190,11 @@ __global__ __launch_bounds__(256) void rec_helper_kernel(HelpArgs a) {
         if (p >= T) break;
         // (a toucher that fell behind skips to the newest published step: old steps are history)
         const int q = p;
+        // The publish of step q is the START of the cluster's hand-off (every member now polls the exchange through the
+        // same L2): a burst of misses issued right then queues in front of those polls.  The recurrent kernels issue
+        // their own traffic behind the poll for the same reason; the touchers wait out the hand-off too.
+        if (q >= 0)
+            for (int d = 0; d < a.delay; ++d) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int i = 0; i < MAXJOBS; ++i) {
             if (i < njobs) {
@@ -213,7 +220,7 @@ hipStream_t g_hstream = nullptr;
 hipEvent_t g_fork = nullptr, g_join = nullptr;
 unsigned* g_tickets = nullptr;  // [64][8]: one row of tickets per launch, recycled
 unsigned g_ticket_row = 0;
-int g_mode = -1, g_lead_p = 3, g_lead_o = 1, g_lead_b = 2, g_hpc = 4;
+int g_mode = -1, g_lead_p = 3, g_lead_o = 1, g_lead_b = 2, g_hpc = 4, g_delay = 0;
 
 int helper_mode() {
     if (g_mode < 0) {
@@ -229,6 +236,8 @@ int helper_mode() {
         }
         const char* w = pk_experiment("helper_wgs");  // helper workgroups per cluster
         if (w && atoi(w) > 0) g_hpc = atoi(w) > 6 ? 6 : atoi(w);
+        const char* d = pk_experiment("helper_delay");  // units of 64 clocks
+        if (d && atoi(d) >= 0) g_delay = atoi(d);
     }
     return g_mode;
 }
@@ -245,7 +254,7 @@ int ensure_helper() {
 }  // namespace
 
 // mode: bits 0-2 as PK_REC_HELPER; optional tuning fields (0 = keep): bits 8-11 lead of P, 12-15 lead of the output lines,
-// 16-19 lead of the backward loads, 20-23 helper workgroups per cluster
+// 16-19 lead of the backward loads, 20-23 helper workgroups per cluster, 24-29 delay behind a publish (units of 256 clocks)
 extern "C" void pk_rec_helper_set_mode(int mode) {
     helper_mode();  // (reads the environment once)
     g_mode = mode & 7;
@@ -253,6 +262,7 @@ extern "C" void pk_rec_helper_set_mode(int mode) {
     if ((mode >> 12) & 15) g_lead_o = (mode >> 12) & 15;
     if ((mode >> 16) & 15) g_lead_b = (mode >> 16) & 15;
     if ((mode >> 20) & 15) g_hpc = ((mode >> 20) & 15) > 6 ? 6 : ((mode >> 20) & 15);
+    g_delay = ((mode >> 24) & 63) * 4;  // bits 24-29: units of 256 clocks
 }
 extern "C" int pk_rec_helper_get_mode(void) { return helper_mode(); }
 
@@ -278,6 +288,7 @@ int pk_rec_helper_launch(hipStream_t st, const R2Args& a, const Plan2& pl, int G
     HelpArgs h;
     h.T = a.T; h.B = a.B; h.R = a.R; h.C = pl.C; h.rpc = pl.rpc; h.row0 = a.row0; h.backward = backward ? 1 : 0;
     h.hpc = g_hpc;
+    h.delay = g_delay;
     const long long TB = (long long)a.T * a.B, H4 = (long long)a.H * 4;
     int n = 0;
     auto add = [&](const void* base, long long row_bytes, long long dir_rows, int dir_bytes, int len, int lead) {

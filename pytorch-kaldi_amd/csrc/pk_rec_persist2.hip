@@ -870,6 +870,10 @@ int pk_rec2_reset_handshake(hipStream_t st, R2Args& a) {
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) cs = hipStreamCaptureStatusNone;
     unsigned g = gen.fetch_add(1u) + 1u;
     if (g >= 0x0FFFFFEFu) {  // wrap: nothing of the old numbering may survive
+        // (one handshake table per process, used by ONE persistent launch at a time: every caller launches on the stream
+        // torch made current; the wrap needs a device-wide sync, which a stream capture does not allow)
+        PK_REQUIRE(cs == hipStreamCaptureStatusNone, "persistent recurrence: the handshake generation wrapped inside a stream "
+                   "capture (2^28 launches): end the capture, launch once eagerly, capture again");
         PK_CHECK_HIP(hipDeviceSynchronize());
         PK_CHECK_HIP(hipMemset(g2_xcd_tab, 0xFF, XCD_TAB_BYTES));
         PK_CHECK_HIP(hipDeviceSynchronize());

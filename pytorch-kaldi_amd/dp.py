@@ -213,8 +213,6 @@ class GradReducer:
         if self.wire == "bf16":
             w = buf.to(torch.bfloat16)
             b["wire"] = (w, buf)
-            if w.is_cuda:
-                w.record_stream(torch.cuda.current_stream())
             return dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -232,6 +230,10 @@ class GradReducer:
             h.wait()
             if "wire" in b:  # the widened sum back into the fp32 bucket
                 w, buf = b.pop("wire")
+                # w was allocated on the stream the bucket was launched from (the side stream under overlap); its real
+                # cross-stream consumer is this copy on the main stream: tell the allocator before w is dropped
+                if w.is_cuda and not torch.cuda.is_current_stream_capturing():
+                    w.record_stream(torch.cuda.current_stream())
                 buf.copy_(w)
             if b["flat"] is None:
                 buf, grads = b.pop("packed")

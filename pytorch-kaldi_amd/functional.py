@@ -267,12 +267,18 @@ def weight_bf16(w):
     move it; load_state_dict / any torch in-place op does, and the copy is then redone)."""
     sh = getattr(w, "_pk_shadow", None)
     if sh is not None:
-        view, version, alive = sh
+        view, version, alive, flat_version = sh
         if alive() is not None:
-            if w._version == version:
+            owner = getattr(w, "_pk_owner", None)
+            owner = owner() if owner is not None else None
+            fv = owner.flat._version if owner is not None else flat_version
+            # (the Parameter's own counter AND the flat buffer's: an in-place op or a collective on FlatParams.flat
+            # rewrites the weight without touching the Parameter's counter; raw-pointer writers other than the fused
+            # step must call FlatParams.invalidate_shadows())
+            if w._version == version and fv == flat_version:
                 return view
             cvt_bf16(w.detach(), out=view)  # somebody rewrote the weight through torch: resynchronise
-            w._pk_shadow = (view, w._version, alive)
+            w._pk_shadow = (view, w._version, alive, fv)
             return view
     owner = getattr(w, "_pk_owner", None)
     owner = owner() if owner is not None else None
@@ -881,7 +887,8 @@ def label_check_counter(device):
     accumulates on every replay)."""
     dev = torch.empty(0, device=device).device
     if dev not in _LabelCheck.bad:
-        _LabelCheck.bad[dev] = torch.zeros((), device=dev)
+        _LabelCheck.bad[dev] = torch.zeros((), device=dev, dtype=torch.float32)
+    assert _LabelCheck.bad[dev].dtype == torch.float32  # pk_nll_err_fwd* add into it in place through a `float*`
     return _LabelCheck.bad[dev]
 
 
@@ -1174,6 +1181,56 @@ class LayerNormFn(torch.autograd.Function):
 
 def layer_norm(x, gamma, beta, eps=1e-6):
     return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class LnLastActDropFn(torch.autograd.Function):
+    """drop(act(LayerNorm(z))) behind a conv layer's max-pool as ONE launch each way (pk_ln_last_act_drop_*), the CNN /
+    SincNet flavour of the reference's LayerNorm (features [C, L], statistics over the last dim:
+    neural_networks.py:1510-1512 + :1546-1552, :1639-1641 + :1655-1661).  Replaces layer_norm_last (two fills, the
+    normalisation, two broadcast launches) + NormActDropFn (activation, mask) - six launches forward, about ten backward -
+    with the same arithmetic in the same order."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, eps, act, mask):
+        _need_gpu(z, gamma, beta, mask)
+        lib = _lib.load()
+        z = z.contiguous()
+        B, C, L = z.shape
+        g, b = gamma.contiguous(), beta.contiguous()
+        assert tuple(g.shape) == (C, L) and tuple(b.shape) == (C, L), (tuple(g.shape), (C, L))
+        a = torch.empty_like(z)
+        y = torch.empty_like(z) if mask is not None else None
+        if mask is not None:
+            mask = mask.contiguous()
+        mean, rinv = _new(B * C, like=z), _new(B * C, like=z)
+        _lib.check(lib.pk_ln_last_act_drop_fwd(_stream(), _p(z), B, C, L, _p(g), _p(b), float(eps), ACT[act], _p(mask), _p(a),
+                                               _p(y), _p(mean), _p(rinv)), "pk_ln_last_act_drop_fwd")
+        out = y if mask is not None else a
+        if _Decisions.relu is not None and act == "relu":  # test mode (see NormActDropFn)
+            pat = _Decisions.relu.pop(0).to(a.device).reshape(B, C, L)
+            _Decisions.report.append(("relu", int(((a > 0) != pat).sum()), a.numel()))
+            a = torch.where(pat, a.clamp_min(1e-30), torch.zeros_like(a))
+        ctx.save_for_backward(z, g, mean, rinv, a, mask)
+        ctx.cfg = (float(eps), act)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        z, g, mean, rinv, a, mask = ctx.saved_tensors
+        eps, act = ctx.cfg
+        B, C, L = z.shape
+        dy = dy.contiguous()
+        dz = torch.empty_like(z)
+        pg = _new(B, 2 * C * L, like=z)
+        _lib.check(lib.pk_ln_last_act_drop_bwd(_stream(), _p(dy), _p(z), _p(a), _p(mask), B, C, L, _p(g), _p(mean), _p(rinv), eps,
+                                               ACT[act], _p(dz), _p(pg)), "pk_ln_last_act_drop_bwd")
+        both = colsum(pg)
+        return dz, both[:C * L].view(C, L), both[C * L:].view(C, L), None, None, None
+
+
+def ln_last_act_drop(z, gamma, beta, eps, act, mask=None):
+    return LnLastActDropFn.apply(z, gamma, beta, eps, act, mask)
 
 
 def layer_norm_last(x, gamma, beta, eps=1e-6):

@@ -772,7 +772,14 @@ class _ConvStack(nn.Module):
         for i in range(self._n_lay):
             x_in = x
             if self._use_ln[i]:
-                x = self._post(i, self.ln[i](self._conv_pool(i, x_in)), False)
+                ln = self.ln[i]
+                z = self._conv_pool(i, x_in)
+                if ln.gamma.dim() == 2 and self._act[i] != "softmax" and tuple(ln.gamma.shape) == tuple(z.shape[1:]):
+                    # the layer's tail - LayerNorm, activation, dropout - as one launch each way
+                    mask = F_.dropout_mask(z, self._drop[i]) if (self.training and self._drop[i] > 0.0) else None
+                    x = F_.ln_last_act_drop(z, ln.gamma, ln.beta, ln.eps, self._act[i], mask)
+                else:
+                    x = self._post(i, ln(z), False)
             if self._use_bn[i]:
                 x = self._post(i, self._conv_pool(i, x), True)
             if not self._use_bn[i] and not self._use_ln[i]:

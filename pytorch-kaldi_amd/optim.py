@@ -87,8 +87,21 @@ class FlatParams:
     # ---- bf16 copies of 2-D weights, refreshed by the fused optimizer step itself (pk_fused_step) -------------------
     def want_shadow(self, p):
         i = self._index.get(id(p))
-        if i is not None and not self.unused[i] and p.dim() == 2 and p.shape[1] % 4 == 0 and p.is_cuda:
+        # (pk_fused_step's threads own four consecutive elements of the flat buffer: a weight's rows AND its offset in
+        # the buffer must be multiples of 4, or a quad would straddle the segment start / two rows)
+        if (i is not None and not self.unused[i] and p.dim() == 2 and p.shape[1] % 4 == 0 and self.offsets[i] % 4 == 0
+                and p.is_cuda):
             self._shadow_req.add(i)
+
+    def invalidate_shadows(self):
+        """Call after writing the flat buffer through anything but torch in-place ops on the Parameters or the fused
+        step (a broadcast into ``flat``, ``p.data.copy_``, a raw-pointer kernel): those do not move the Parameters'
+        version counters, which is what functional.weight_bf16 trusts a bf16 copy by.  The copies are redone at their
+        next use."""
+        for p in self.params:
+            sh = getattr(p, "_pk_shadow", None)
+            if sh is not None:
+                p._pk_shadow = (sh[0], -1, sh[2], -1)
 
     def build_shadows(self):
         """(Re)build the copies for everything asked for so far: one bf16 buffer, a weight's rows at a pitch of its
@@ -112,11 +125,13 @@ class FlatParams:
             p = self.params[i]
             view = self.shadow[so:so + r * pitch].view(r, pitch)
             F_.cvt_bf16(p.detach(), out=view)
-            p._pk_shadow = (view, p._version, weakref.ref(self.shadow))
+            p._pk_shadow = (view, p._version, weakref.ref(self.shadow), self.flat._version)
 
     def zero_grad(self):
         from .functional import join_side
         join_side()
+        # (contract of zero_in_step: between step() and this call nothing writes .grad - one backward pass per step; a
+        # loop that accumulates gradients over several backward passes must call mark_dirty() or leave zero_in_step off)
         if self._clean:
             self._clean = False  # (whatever comes next may write gradients)
         else:
@@ -124,6 +139,15 @@ class FlatParams:
         for p, o in zip(self.params, self.offsets):  # keep .grad aliased to the flat buffer
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+def _flat_mark_dirty(self):
+    """Somebody wrote (or is about to write) .grad outside the zero_grad() -> backward -> step() cycle: the next
+    zero_grad() must really fill."""
+    self._clean = False
+
+
+FlatParams.mark_dirty = _flat_mark_dirty
 
 
 class FusedOptimizer:

@@ -179,6 +179,38 @@ def test_layernorm(rows, F):
         assert rel_err(a.grad, r.grad) < 1e-5
 
 
+@pytest.mark.parametrize("B,C,L,act,drop", [(3, 5, 36, "relu", True), (4, 60, 340, "relu", True), (2, 128, 1024, "leaky_relu", False),
+                                           (5, 7, 112, "tanh", True), (2, 3, 1027, "relu", False), (1, 1, 2, "linear", True)])
+def test_conv_layer_tail_in_one_launch(B, C, L, act, drop):
+    """pk_ln_last_act_drop_fwd / _bwd: drop(act(LayerNorm(z))) of a conv layer (features [C, L], statistics over the last
+    dim: neural_networks.py:1510-1512, 1546-1552) against an fp64 evaluation of the oracle's LayerNorm + activation + mask,
+    and against the launches it replaces (layer_norm_last + norm_act_drop)."""
+    import pk_oracle as O
+
+    g = torch.Generator().manual_seed(B * 1000 + C * 10 + L)
+    z = torch.randn(B, C, L, generator=g) * 2 + 0.3
+    gamma = torch.rand(C, L, generator=g) + 0.5
+    beta = torch.randn(C, L, generator=g) * 0.3
+    cot = torch.randn(B, C, L, generator=g)
+    mask = ((torch.rand(B, C, L, generator=g) > 0.2).float() / 0.8) if drop else None
+    zr, gr, br = (t.double().requires_grad_(True) for t in (z, gamma, beta))
+    yr = O.activation(act, O.layer_norm(zr, gr, br))
+    if mask is not None:
+        yr = yr * mask.double()
+    (yr * cot.double()).sum().backward()
+    ze, ge, be = (t.clone().cuda().requires_grad_(True) for t in (z, gamma, beta))
+    y = F_.ln_last_act_drop(ze, ge, be, 1e-6, act, None if mask is None else mask.cuda())
+    (y * cot.cuda()).sum().backward()
+    assert rel_err(y, yr) < 1e-5
+    for a, r in ((ze, zr), (ge, gr), (be, br)):
+        assert rel_err(a.grad, r.grad) < 2e-5, (rel_err(a.grad, r.grad), tuple(r.shape))
+    with torch.no_grad():  # the launches it replaces: the same values
+        m2 = None if mask is None else mask.cuda().reshape(B * C, L)
+        old = F_.norm_act_drop(F_.layer_norm_last(z.cuda(), gamma.cuda(), beta.cuda(), 1e-6).reshape(B * C, L), None, False, True,
+                               act, m2).view(B, C, L)
+    assert rel_err(y.detach(), old) < 2e-6  # (another summation order in the row statistics, one fused multiply-add)
+
+
 @pytest.mark.parametrize("rows,N", [(1, 1), (5, 48), (7, 64), (9, 200), (33, 1000), (300, 1938), (3, 2048), (6, 3400)])
 def test_logsoftmax(rows, N):
     g = torch.Generator().manual_seed(rows + N)

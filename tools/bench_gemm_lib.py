@@ -45,6 +45,8 @@ for name, M, N, K, akc, bkc in SHAPES:
     # product-side operands (pitched), library-side operands (dense) over the same values
     A = torch.randn((M, up(K, 64)) if akc else (K, up(M, 64)), device="cuda").to(torch.bfloat16)
     B = torch.randn((N, up(K, 64)) if bkc else (K, up(N, 64)), device="cuda").to(torch.bfloat16)
+    (A[:, K:] if akc else A[:, M:]).zero_()  # the product's operands are zero-padded up to their pitch
+    (B[:, K:] if bkc else B[:, N:]).zero_()
     a_lib = (A[:, :K] if akc else A[:, :M].t()).contiguous()          # [M, K]
     b_lib = (B[:, :K].t() if bkc else B[:, :N]).contiguous()          # [K, N]
     ldc = up(N, 32)  # 128-byte row pitch of the fp32 output

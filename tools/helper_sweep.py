@@ -31,14 +31,17 @@ masks = [(torch.rand(2 * B, H, device="cuda") > 0.2).float() / 0.8]
 lib = _lib.load()
 
 
-def pack(mode, lp=0, lo=0, lb=0, wgs=0):
-    return mode | (lp << 8) | (lo << 12) | (lb << 16) | (wgs << 20)
+def pack(mode, lp=0, lo=0, lb=0, wgs=0, delay=0):
+    """delay: units of 256 clocks between seeing a publish and touching"""
+    return mode | (lp << 8) | (lo << 12) | (lb << 16) | (wgs << 20) | (delay << 24)
 
 
-CONFIGS = [("off", pack(0)), ("P lead3 x4", pack(1, 3, 1, 2, 4)), ("P+out lead3/1 x4", pack(3, 3, 1, 2, 4)), ("P+out lead4/2 x4", pack(3, 4, 2, 2, 4)),
-           ("P+out lead3/1 x2", pack(3, 3, 1, 2, 2)), ("P+out lead3/1 x6", pack(3, 3, 1, 2, 6)), ("P lead2 x4", pack(1, 2, 1, 2, 4)),
-           ("P lead6 x4", pack(1, 6, 1, 2, 4)), ("bwd lead2 x4", pack(4, 3, 1, 2, 4)), ("bwd lead4 x4", pack(4, 3, 1, 4, 4)),
-           ("all lead3/1/2 x4", pack(7, 3, 1, 2, 4))]
+CONFIGS = [("off", pack(0)),
+           ("P lead3 x4 d0", pack(1, 3, 1, 2, 4, 0)), ("P lead3 x4 d4", pack(1, 3, 1, 2, 4, 4)), ("P lead3 x4 d8", pack(1, 3, 1, 2, 4, 8)),
+           ("P lead3 x4 d12", pack(1, 3, 1, 2, 4, 12)), ("P lead4 x2 d8", pack(1, 4, 1, 2, 2, 8)), ("P lead4 x6 d8", pack(1, 4, 1, 2, 6, 8)),
+           ("P+out lead3/1 x4 d8", pack(3, 3, 1, 2, 4, 8)), ("P+out lead4/2 x4 d12", pack(3, 4, 2, 2, 4, 12)),
+           ("bwd lead4 x4 d0", pack(4, 3, 1, 4, 4, 0)), ("bwd lead4 x4 d8", pack(4, 3, 1, 4, 4, 8)), ("bwd lead6 x6 d8", pack(4, 3, 1, 6, 6, 8)),
+           ("all lead3/1/4 x4 d8", pack(7, 3, 1, 4, 4, 8))]
 if os.environ.get("CONFIGS"):
     keep = set(os.environ["CONFIGS"].split(";"))
     CONFIGS = [c for c in CONFIGS if c[0] in keep or c[0] == "off"]

@@ -329,8 +329,10 @@ int pk_persist2_get_lstm_waves(void);
 /* L2 run-ahead helpers of the persistent bf16 recurrences (pk_rec_helper.hip; default: PK_REC_HELPER): workgroups on the
  * CUs a recurrence leaves idle touch the lines its time loop (neural_networks.py:457-469, :629-641, :1130-1141) is about to
  * use a few steps ahead of it, paced by the exchange buffer itself.  bit 0: the projections of the forward pass, bit 1:
- * the Y / S lines the forward pass is about to write, bit 2: the saved tensors the backward pass reads.  The helpers only
- * load: results never depend on the mode. */
+ * the Y / S lines the forward pass is about to write, bit 2: the saved tensors the backward pass reads; bits 8-29: tuning
+ * fields (pk_rec_helper.hip).  -1 = the per-cell default (what an unset PK_REC_HELPER means: the LSTM forward pass takes
+ * bits 0 and 1, everything else none - profiles/r05_rec_helper.json).  The helpers only load: results never depend on the
+ * mode. */
 void pk_rec_helper_set_mode(int mode);
 int pk_rec_helper_get_mode(void);
 /* two-phase cells (GRU :629-641, minimalGRU :1291-1302): the candidate GEMM consumes a gate of the same

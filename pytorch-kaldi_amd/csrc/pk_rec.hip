@@ -374,6 +374,18 @@ inline Work carve(float* w, long R, long H, long G) {
     return k;
 }
 
+// The per-step products of the step-wise algorithm are [R x G*H] over K = H (256 x 1650 x 550 at the GRU recipe): 18-26
+// tiles of 128 x 128 - a tenth of the chip, ~30 us per product in exact fp32 (the step-wise GRU in parity mode ran
+// 1.29 s per training step).  The reduction is split over the grid (partials in the scratch the deferred dU
+// products use after the loop) so that a product reaches ~150 workgroups.
+inline int step_splitk(long M, long N, long K, long G, long H) {
+    const long tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    long sk = 160 / (tiles > 0 ? tiles : 1);
+    sk = sk > 8 ? 8 : sk;
+    while (sk > 1 && (K / sk < 64 || sk * M * N > (long)DU_SPLITK * G * H * H)) --sk;
+    return (int)(sk < 1 ? 1 : sk);
+}
+
 #define PK_TRY(expr)          \
     do {                      \
         int _rc = (expr);     \
@@ -394,20 +406,20 @@ int fwd_stepwise(hipStream_t st, int prec, int act, StepGeom g, const float* P, 
         const bool first = (t == 0);
         if constexpr (!TWO) {
             if (!first)  // urec[R, G*H] = hcur[R,H] . U[G*H,H]^T
-                PK_TRY(pk_gemm(st, prec, g.R, G * H, H, 1.f, hcur, H, 1, U, 1, H, 0.f, w.urec, G * H, nullptr, 1, nullptr));
+                PK_TRY(pk_gemm(st, prec, g.R, G * H, H, 1.f, hcur, H, 1, U, 1, H, 0.f, w.urec, G * H, nullptr, step_splitk(g.R, G * H, H, G, H), w.ws));
             hipLaunchKernelGGL((step_fwd_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, act, P, pscale, pshift,
                                first ? (const float*)nullptr : w.urec, hcur, ccur, mask, mask_scalar, hnext, cnext, Y, S);
             PK_LAUNCH_CHECK();
         } else {
             constexpr int G1 = G - 1;
             if (!first)
-                PK_TRY(pk_gemm(st, prec, g.R, G1 * H, H, 1.f, hcur, H, 1, U, 1, H, 0.f, w.urec, G1 * H, nullptr, 1, nullptr));
+                PK_TRY(pk_gemm(st, prec, g.R, G1 * H, H, 1.f, hcur, H, 1, U, 1, H, 0.f, w.urec, G1 * H, nullptr, step_splitk(g.R, G1 * H, H, G, H), w.ws));
             hipLaunchKernelGGL((step_fwd_p1_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, P, pscale, pshift,
                                first ? (const float*)nullptr : w.urec, hcur, w.gh, S);
             PK_LAUNCH_CHECK();
             if (!first)  // ua[R,H] = gh[R,H] . U_h[H,H]^T   (gh = r*h or z*h; zero at t = 0)
-                PK_TRY(pk_gemm(st, prec, g.R, H, H, 1.f, w.gh, H, 1, U + (long)G1 * H * H, 1, H, 0.f, w.ua, H, nullptr, 1,
-                               nullptr));
+                PK_TRY(pk_gemm(st, prec, g.R, H, H, 1.f, w.gh, H, 1, U + (long)G1 * H * H, 1, H, 0.f, w.ua, H, nullptr,
+                               step_splitk(g.R, H, H, G, H), w.ws));
             hipLaunchKernelGGL((step_fwd_p2_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, act, P, pscale, pshift,
                                first ? (const float*)nullptr : w.ua, hcur, mask, mask_scalar, hnext, Y, S);
             PK_LAUNCH_CHECK();
@@ -447,20 +459,20 @@ int bwd_stepwise(hipStream_t st, int prec, int act, StepGeom g, const float* U, 
                                mask_scalar, last ? (const float*)nullptr : ch, cc, dh_in, w.dg, dP2, nh, nc);
             PK_LAUNCH_CHECK();
             if (t > 0)  // nh[R,H] += dG[R,G*H] . U[G*H,H]
-                PK_TRY(pk_gemm(st, prec, g.R, H, G * H, 1.f, w.dg, G * H, 1, U, H, 1, 1.f, nh, H, nullptr, 1, nullptr));
+                PK_TRY(pk_gemm(st, prec, g.R, H, G * H, 1.f, w.dg, G * H, 1, U, H, 1, 1.f, nh, H, nullptr, step_splitk(g.R, H, G * H, G, H), w.ws));
         } else {
             constexpr int G1 = G - 1;
             hipLaunchKernelGGL((step_bwd_pa_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, act, Y, S, dY, mask,
                                mask_scalar, last ? (const float*)nullptr : ch, dh_in, w.gh, w.ua, nh);
             PK_LAUNCH_CHECK();
             // q[R,H] = dA[R,H] . U_h[H,H]
-            PK_TRY(pk_gemm(st, prec, g.R, H, H, 1.f, w.gh, H, 1, U + (long)G1 * H * H, H, 1, 0.f, w.urec, H, nullptr, 1,
-                           nullptr));
+            PK_TRY(pk_gemm(st, prec, g.R, H, H, 1.f, w.gh, H, 1, U + (long)G1 * H * H, H, 1, 0.f, w.urec, H, nullptr,
+                           step_splitk(g.R, H, H, G, H), w.ws));
             hipLaunchKernelGGL((step_bwd_pb_kernel<CELL>), dim3(blocks), dim3(256), 0, st, g, t, Y, S, w.urec, w.gh, w.ua,
                                w.dg, dP2, nh);
             PK_LAUNCH_CHECK();
             if (t > 0)
-                PK_TRY(pk_gemm(st, prec, g.R, H, G1 * H, 1.f, w.dg, G1 * H, 1, U, H, 1, 1.f, nh, H, nullptr, 1, nullptr));
+                PK_TRY(pk_gemm(st, prec, g.R, H, G1 * H, 1.f, w.dg, G1 * H, 1, U, H, 1, 1.f, nh, H, nullptr, step_splitk(g.R, H, G1 * H, G, H), w.ws));
         }
         float* tmp = ch; ch = nh; nh = tmp;
         tmp = cc; cc = nc; nc = tmp;

@@ -415,9 +415,10 @@ int pk_rec3_covers(int cell, int backward);
 int pk_rec3_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act, bool backward, bool traced);
 // L2 run-ahead helpers on the idle CUs (pk_rec_helper.hip; PK_REC_HELPER): fork before the recurrence is launched,
 // launch behind it.  They only load - results never depend on them.
-int pk_rec_helper_wanted(bool backward, int launches);
+int pk_rec_helper_wanted(bool backward, int launches, int cell);  // -> the mode bits this pass takes (0: none)
 int pk_rec_helper_fork(hipStream_t st);
-int pk_rec_helper_launch(hipStream_t st, const R2Args& a, const Plan2& pl, int G, int NS, bool backward, bool s_layout_ok);
+int pk_rec_helper_launch(hipStream_t st, const R2Args& a, const Plan2& pl, int G, int NS, bool backward, bool s_layout_ok,
+                         int mode);
 // eight-wave LSTM kernels (pk_rec_persist2_lstm.hip): on unless PK_EXPERIMENT lstm_waves=4; the launch loop over pl.launches
 int pk_rec2l_enabled();
 int pk_rec2l_launch(hipStream_t st, R2Args& a, const Plan2& pl, int act, bool backward);

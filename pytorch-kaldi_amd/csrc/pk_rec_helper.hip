@@ -222,10 +222,13 @@ unsigned* g_tickets = nullptr;  // [64][8]: one row of tickets per launch, recyc
 unsigned g_ticket_row = 0;
 int g_mode = -1, g_lead_p = 3, g_lead_o = 1, g_lead_b = 2, g_hpc = 4, g_delay = 0;
 
+// -1 = PK_REC_HELPER unset: the per-cell default (pk_rec_helper_wanted)
 int helper_mode() {
-    if (g_mode < 0) {
+    static bool read = false;
+    if (!read) {
+        read = true;
         const char* e = getenv("PK_REC_HELPER");
-        g_mode = e ? atoi(e) : 0;
+        g_mode = e ? (atoi(e) & 7) : -1;
         const char* l = pk_experiment("helper_lead");  // "p:o:b": steps ahead for P / the output lines / the backward loads
         if (l) {
             int p = 0, o = 0, b = 0;
@@ -257,6 +260,10 @@ int ensure_helper() {
 // 16-19 lead of the backward loads, 20-23 helper workgroups per cluster, 24-29 delay behind a publish (units of 256 clocks)
 extern "C" void pk_rec_helper_set_mode(int mode) {
     helper_mode();  // (reads the environment once)
+    if (mode < 0) {  // back to the per-cell default
+        g_mode = -1;
+        return;
+    }
     g_mode = mode & 7;
     if ((mode >> 8) & 15) g_lead_p = (mode >> 8) & 15;
     if ((mode >> 12) & 15) g_lead_o = (mode >> 12) & 15;
@@ -264,11 +271,18 @@ extern "C" void pk_rec_helper_set_mode(int mode) {
     if ((mode >> 20) & 15) g_hpc = ((mode >> 20) & 15) > 6 ? 6 : ((mode >> 20) & 15);
     g_delay = ((mode >> 24) & 63) * 4;  // bits 24-29: units of 256 clocks
 }
-extern "C" int pk_rec_helper_get_mode(void) { return helper_mode(); }
+extern "C" int pk_rec_helper_get_mode(void) { return helper_mode(); }  // -1: the per-cell default
 
-// Is a helper wanted for this pass?  (bit 0: forward P, bit 1: forward output lines, bit 2: backward loads)
-int pk_rec_helper_wanted(bool backward, int launches) {
-    const int m = helper_mode();
+// Which helpers does this pass take?  (bit 0: forward P, bit 1: forward output lines, bit 2: backward loads)
+// Default (PK_REC_HELPER unset), from the round-5 sweeps on one layer at the BASELINE geometry and the recipes' steps
+// (profiles/r05_rec_helper.json): the eight-wave LSTM forward pass gains 15-18 % per launch with P and the output lines
+// run ahead (timit_lstm 24.98 -> 23.76 ms per step); its backward pass gains 7 % alone but nothing in the training step
+// (the helpers then compete with the side-stream weight-gradient GEMMs for the idle CUs); the Li-GRU forward pass - the
+// shortest step, 2.2 us - LOSES 20-40 % whatever the lead, helper count or delay behind the publish, its backward pass
+// gains 1-3 % alone and nothing in the step; GRU does not move.  So: LSTM forward only.
+int pk_rec_helper_wanted(bool backward, int launches, int cell) {
+    int m = helper_mode();
+    if (m < 0) m = (cell == PK_CELL_LSTM && !backward) ? 3 : 0;
     if (launches != 1) return 0;
     return backward ? (m & 4) : (m & 3);
 }
@@ -283,8 +297,8 @@ int pk_rec_helper_fork(hipStream_t st) {
 // Behind the launch of the recurrence (a carries its arguments, handshake generation included): launch the helpers on
 // their own stream and make st wait for their exit (they end a few steps before the recurrence does).
 // s_layout_ok: S is [ndir][T * B][NS * H] fp32 (liGRU / RNN / LSTM).
-int pk_rec_helper_launch(hipStream_t st, const R2Args& a, const Plan2& pl, int G, int NS, bool backward, bool s_layout_ok) {
-    const int m = helper_mode();
+int pk_rec_helper_launch(hipStream_t st, const R2Args& a, const Plan2& pl, int G, int NS, bool backward, bool s_layout_ok,
+                         int m) {
     HelpArgs h;
     h.T = a.T; h.B = a.B; h.R = a.R; h.C = pl.C; h.rpc = pl.rpc; h.row0 = a.row0; h.backward = backward ? 1 : 0;
     h.hpc = g_hpc;

@@ -992,11 +992,11 @@ static int rec_fwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
         dim3 grid(pl.C * pl.Pn), block(256);
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_fwd_bf16");
         if (rc) return rc;
-        const bool help = !ln && pk_rec_helper_wanted(false, pl.launches) != 0;
+        const int help = ln ? 0 : pk_rec_helper_wanted(false, pl.launches, cell);
         if (help && (rc = pk_rec_helper_fork(st)) != 0) return rc;
         hipLaunchKernelGGL(k, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
-        if (help && (rc = pk_rec_helper_launch(st, a, pl, G, pk_cell_saved(cell), false, true)) != 0) return rc;
+        if (help && (rc = pk_rec_helper_launch(st, a, pl, G, pk_cell_saved(cell), false, true, help)) != 0) return rc;
     }
     return 0;
 }
@@ -1067,11 +1067,11 @@ static int rec_bwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
         dim3 grid(pl.C * pl.Pn), block(256);
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_bwd_bf16");
         if (rc) return rc;
-        const bool help = !ln && pk_rec_helper_wanted(true, pl.launches) != 0;
+        const int help = ln ? 0 : pk_rec_helper_wanted(true, pl.launches, cell);
         if (help && (rc = pk_rec_helper_fork(st)) != 0) return rc;
         hipLaunchKernelGGL(k, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
-        if (help && (rc = pk_rec_helper_launch(st, a, pl, G, pk_cell_saved(cell), true, true)) != 0) return rc;
+        if (help && (rc = pk_rec_helper_launch(st, a, pl, G, pk_cell_saved(cell), true, true, help)) != 0) return rc;
     }
     return pk_rec2_ln_finish(st, a, ln);
 }

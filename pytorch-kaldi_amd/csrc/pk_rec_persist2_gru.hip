@@ -1011,11 +1011,11 @@ int rec2p_fwd_impl(void* stream, int cell, int act, int T, int B, int bidir, int
         rc = pk_rec2_check_residency((const void*)fn, 256, lds, pl.C * pl.Pn, "pk_rec2p_*_bf16");
         if (rc) return rc;
         // (forward: the projections only - this cell's S has its own layout)
-        const bool help = !ln && (pk_rec_helper_wanted(false, pl.launches) & 1) != 0;
+        const int help = ln ? 0 : (pk_rec_helper_wanted(false, pl.launches, cell) & 1);
         if (help && (rc = pk_rec_helper_fork(st)) != 0) return rc;
         hipLaunchKernelGGL(fn, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
-        if (help && (rc = pk_rec_helper_launch(st, a, pl, G, 0, false, false)) != 0) return rc;
+        if (help && (rc = pk_rec_helper_launch(st, a, pl, G, 0, false, false, help)) != 0) return rc;
     }
     return 0;
 }

@@ -988,11 +988,11 @@ int pk_rec2l_launch(hipStream_t st, R2Args& a, const Plan2& pl, int act, bool ba
         dim3 grid(pl.C * pl.Pn), block(512);
         rc = pk_rec2_check_residency((const void*)k, 512, lds, pl.C * pl.Pn, "pk_rec_*_bf16 (LSTM, eight waves)");
         if (rc) return rc;
-        const bool help = pk_rec_helper_wanted(backward, pl.launches) != 0;
+        const int help = pk_rec_helper_wanted(backward, pl.launches, PK_CELL_LSTM);
         if (help && (rc = pk_rec_helper_fork(st)) != 0) return rc;
         hipLaunchKernelGGL(k, grid, block, lds, st, a);
         PK_LAUNCH_CHECK();
-        if (help && (rc = pk_rec_helper_launch(st, a, pl, 4, pk_cell_saved(PK_CELL_LSTM), backward, true)) != 0) return rc;
+        if (help && (rc = pk_rec_helper_launch(st, a, pl, 4, pk_cell_saved(PK_CELL_LSTM), backward, true, help)) != 0) return rc;
     }
     return 0;
 }

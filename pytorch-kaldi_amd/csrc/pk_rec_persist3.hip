@@ -721,11 +721,11 @@ int pk_rec3_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act
         if (rc) return rc;
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, backward ? "pk_rec_bwd_bf16" : "pk_rec_fwd_bf16");
         if (rc) return rc;
-        const bool help = pk_rec_helper_wanted(backward, pl.launches) != 0;
+        const int help = pk_rec_helper_wanted(backward, pl.launches, cell);
         if (help && (rc = pk_rec_helper_fork(st)) != 0) return rc;
         hipLaunchKernelGGL(k, dim3(pl.C * pl.Pn), dim3(256), lds, st, a);
         PK_LAUNCH_CHECK();
-        if (help && (rc = pk_rec_helper_launch(st, a, pl, G, NS, backward, true)) != 0) return rc;
+        if (help && (rc = pk_rec_helper_launch(st, a, pl, G, NS, backward, true, help)) != 0) return rc;
     }
     return 0;
 }

@@ -180,7 +180,7 @@ def test_layernorm(rows, F):
 
 
 @pytest.mark.parametrize("B,C,L,act,drop", [(3, 5, 36, "relu", True), (4, 60, 340, "relu", True), (2, 128, 1024, "leaky_relu", False),
-                                           (5, 7, 112, "tanh", True), (2, 3, 1027, "relu", False), (1, 1, 2, "linear", True)])
+                                           (5, 7, 112, "tanh", True), (2, 3, 1027, "relu", False), (3, 2, 3, "linear", True)])
 def test_conv_layer_tail_in_one_launch(B, C, L, act, drop):
     """pk_ln_last_act_drop_fwd / _bwd: drop(act(LayerNorm(z))) of a conv layer (features [C, L], statistics over the last
     dim: neural_networks.py:1510-1512, 1546-1552) against an fp64 evaluation of the oracle's LayerNorm + activation + mask,

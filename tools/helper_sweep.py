@@ -85,7 +85,7 @@ for rnd in range(ROUNDS):
             if "bwd" in k and k.startswith("pk_rec"):
                 r["bwd_ms"].append(round(v["avg_ms"], 4))
         r["bit_identical_to_off"] = r["bit_identical_to_off"] and same
-lib.pk_rec_helper_set_mode(0)
+lib.pk_rec_helper_set_mode(-1)
 _lib.raise_if_persist_failed()
 for name, r in res.items():
     print("%-22s fwd %s  bwd %s  identical %s" % (name, r["fwd_ms"], r["bwd_ms"], r["bit_identical_to_off"]), flush=True)

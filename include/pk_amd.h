@@ -297,17 +297,6 @@ int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, in
 int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
                     float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, uint16_t* dGb,
                     int64_t g_pitch, int prefilled);
-/* Gated dY (round 5): the gradient a backward recurrence consumes may still be in production - the layer above's dX, cut
- * along time into chunks of (1 << shift) steps that GEMM launches on ANOTHER stream write from both ends of the sequence
- * inwards, each followed by pk_flag_set(stream, flags + k, gen).  pk_rec_set_dy_gate arms the NEXT pk_rec_bwd_bf16 call of
- * this thread: its workgroups wait (bounded) for flags[k] == gen before they load rows of chunk k, so the recurrence starts
- * as soon as the two outermost chunks exist instead of behind the whole product (neural_networks.py:1130-1141 run backward
- * by autograd after the layer above's Linear backward, :1114-1115).  Ask pk_rec_dy_gate_ok first: only the
- * third-generation liGRU / RNN kernels take a gate; anything else refuses the call.  flags: device memory, >= T >> shift
- * + 1 words, never holding `gen` from an earlier use. */
-int pk_rec_dy_gate_ok(int cell, int T, int B, int bidir, int H);
-void pk_rec_set_dy_gate(const void* flags, unsigned gen, int shift);
-int pk_flag_set(void* stream, void* flag, unsigned value);
 /* ... with per-step LayerNorm of h_t inside the persistent time loop (liGRU / RNN / LSTM; the reference's
  * `if self.*_use_laynorm[i]: ht = self.ln[i](ht)`, neural_networks.py:466-467, :1138-1139, :1444-1445): every step
  * exchanges the rows' partial sums between the workgroups of a cluster a second time (fp32, 32 bytes per wave and row

@@ -101,9 +101,6 @@ SIGNATURES = {
     "pk_persist2_set_mode": (None, [c_int]),
     "pk_persist2_set_poll_delay": (None, [c_int]),
     "pk_persist2_set_lstm_waves": (None, [c_int]),
-    "pk_rec_dy_gate_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "pk_rec_set_dy_gate": (None, [P, ctypes.c_uint, c_int]),
-    "pk_flag_set": (c_int, [P, P, ctypes.c_uint]),
     "pk_rec_helper_set_mode": (None, [c_int]),
     "pk_rec_helper_get_mode": (c_int, []),
     "pk_persist2_get_lstm_waves": (c_int, []),

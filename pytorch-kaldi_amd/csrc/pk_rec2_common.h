@@ -51,12 +51,6 @@ struct R2Args {
     float* lnpart;   // backward: [2][ln_ncg][KPAD] per-cluster partial sums of d gamma, d beta
     int ln_cg0;      // global index of this launch's first cluster
     int ln_ncg;      // clusters over all launches
-    // ---- gated dY (third-generation backward kernels only; null = off): the incoming gradient is still being produced,
-    // chunk by chunk along time, by GEMM launches on another stream (the layer above's dX).  dy_flags[k] == dy_gen once
-    // the rows of storage times [k << dy_shift, (k + 1) << dy_shift) are complete (pk_flag_set behind that chunk's launch).
-    const unsigned* dy_flags;
-    unsigned dy_gen;
-    int dy_shift;
 };
 
 struct Plan2 {
@@ -299,18 +293,6 @@ __device__ __forceinline__ bool cluster_on_one_xcd(const R2Args& a, int c, int p
     return __syncthreads_and(same) != 0;
 }
 
-// Gated dY: wait until the chunk that holds storage time ts has been produced (bounded like every spin here).  The
-// producer is a whole kernel on another stream followed by a one-word store (pk_flag_set): its results have left its
-// XCDs' L2 when the flag appears, and this launch has not touched those lines before - they are fetched fresh.
-__device__ __forceinline__ bool dy_gate_wait(const R2Args& a, int ts, int lane, bool dead) {
-    const unsigned* f = a.dy_flags + (ts >> a.dy_shift);
-    int spins = 0;
-    while (!dead && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.dy_gen) {
-        if (spin_check2(spins, a.spin_limit, a.err, lane)) dead = true;
-    }
-    return dead;
-}
-
 // workgroup barrier that orders LDS only: __syncthreads() also drains vmcnt, i.e. it would wait for
 // the prefetch loads issued just before it (HBM latency on the dependency chain)
 #define PK_BARRIER_LDS()                               \
@@ -422,8 +404,6 @@ int pk_rec2_ln_finish(hipStream_t st, const R2Args& a, const PkLnHost* ln);  // 
 int pk_rec2_check(const char* who, int cell_ok, int cell, int T, int B, int bidir, int H);
 int pk_rec2_host_setup(R2Args& a, bool backward, int cell);                 // error word, trash page, handshake table, tuning knobs
 int pk_rec2_reset_handshake(hipStream_t st, R2Args& a);  // before every launch: a fresh handshake generation
-// gated dY (pk_rec_set_dy_gate): consumed by the next pk_rec_bwd_bf16 of this thread; false = none pending
-bool pk_rec_take_dy_gate(R2Args& a);
 // The clusters of a persistent launch exchange h_t with each other every step: every workgroup of the grid has to be
 // resident at the same time.  Checks the grid against what the device can hold (occupancy query for this kernel, block
 // size and dynamic LDS x CU count, cached per kernel) - a grid that cannot be co-resident is refused here instead of

@@ -832,7 +832,6 @@ int pk_rec2_host_setup(R2Args& a, bool backward, int cell) {
     a.helper_delay = 0;
     a.empty_step = g2_empty_step;
     a.self_fill = 0;
-    a.dy_flags = nullptr; a.dy_gen = 0; a.dy_shift = 0;
     {   // PK_EXPERIMENT rec_flush_late=1: the third-generation kernels issue a step's output stores / next-step loads behind its MFMA
         // block instead of right behind the barrier (A/B switch)
         static int fl = -1;
@@ -898,40 +897,6 @@ extern "C" int pk_rec_plan_cus(int R, int H) {
     Plan2 pl;
     if (R <= 0 || H <= 0 || H > KPAD || pk_rec2_make_plan(R, H, pl) != 0) return 0;
     return pl.C * pl.Pn;
-}
-
-// ---- gated dY: the next pk_rec_bwd_bf16 call of this thread consumes a gradient that other launches are still producing
-namespace {
-thread_local const unsigned* tl_gate_flags = nullptr;
-thread_local unsigned tl_gate_gen = 0;
-thread_local int tl_gate_shift = 0;
-__global__ void flag_set_kernel(unsigned* flag, unsigned value) {
-    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-}  // namespace
-extern "C" void pk_rec_set_dy_gate(const void* flags, unsigned gen, int shift) {
-    tl_gate_flags = (const unsigned*)flags;
-    tl_gate_gen = gen;
-    tl_gate_shift = shift;
-}
-bool pk_rec_take_dy_gate(R2Args& a) {
-    if (tl_gate_flags == nullptr) return false;
-    a.dy_flags = tl_gate_flags; a.dy_gen = tl_gate_gen; a.dy_shift = tl_gate_shift;
-    tl_gate_flags = nullptr;
-    return true;
-}
-// one word, stored behind everything enqueued on `stream` so far (a kernel boundary: what those launches wrote has left
-// their L2s when the word appears)
-extern "C" int pk_flag_set(void* stream, void* flag, unsigned value) {
-    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(64), 0, pk_stream(stream), (unsigned*)flag, value);
-    PK_LAUNCH_CHECK();
-    return 0;
-}
-// Does pk_rec_bwd_bf16 take a gated dY for this layer?  (the third-generation kernels of liGRU / RNN, one launch)
-extern "C" int pk_rec_dy_gate_ok(int cell, int T, int B, int bidir, int H) {
-    Plan2 pl;
-    if (T <= 0 || B <= 0 || H <= 0 || H > KPAD || pk_rec2_make_plan(B * (1 + bidir), H, pl) != 0) return 0;
-    return (pk_rec3_covers(cell, 1) && pl.launches == 1) ? 1 : 0;
 }
 
 extern "C" void pk_persist2_set_mode(int force_safe) { g2_force_safe = force_safe ? 1 : 0; }
@@ -1079,9 +1044,6 @@ static int rec_bwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
     if (prefilled != 1 && !a.self_fill) PK_CHECK_HIP(hipMemsetAsync(dGb, 0xFF, (size_t)ndir * T * B * g_pitch * 2, st));
     rc = pk_rec2_ln_setup(st, a, pl, ln, true);
     if (rc) return rc;
-    if (pk_rec_take_dy_gate(a))  // (the caller asked pk_rec_dy_gate_ok first; anything else would read dY too early)
-        PK_REQUIRE(!ln && !lstm8 && pk_rec3_covers(cell, 1) && pl.launches == 1,
-                   "pk_rec_bwd_bf16: a gated dY is only taken by the third-generation liGRU / RNN kernels (one launch)");
     if (lstm8 && !ln) return pk_rec2l_launch(st, a, pl, act, true);
     if (!ln && pk_rec3_covers(cell, 1)) return pk_rec3_launch(st, a, pl, cell, act, true, traced(cell, act));
     const size_t atile = (size_t)RMAX * pk_r2_lda_bf16(G * KPAD) * 2;

@@ -489,23 +489,6 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
 #pragma unroll
         for (int g = 0; g < G; ++g) st4<decltype(E)::value>(a.dP2, vG0 + ts * vGs + g * H, anv, trash, gout[g]);
     };
-    // gated dY (a.dy_flags): which directions do this wave's rows belong to, which chunk has been waited for
-    const bool gate = a.dy_flags != nullptr;
-    const bool has0 = gate && __any(anv > 0 && adir == 0) != 0, has1 = gate && __any(anv > 0 && adir == 1) != 0;
-    int gk0 = -1, gk1 = -1;
-    bool gdead = false;
-    auto gate_for = [&](int t) {  // before the loads of step t: direction 0 reads storage time t, direction 1 T - 1 - t
-        const int k0 = t >> a.dy_shift, k1 = (T - 1 - t) >> a.dy_shift;
-        if (has0 && k0 != gk0) {
-            gdead = dy_gate_wait(a, t, lane, gdead);
-            gk0 = k0;
-        }
-        if (has1 && k1 != gk1) {
-            gdead = dy_gate_wait(a, T - 1 - t, lane, gdead);
-            gk1 = k1;
-        }
-    };
-    if (gate) gate_for(T - 1);
 #define PK3_LS0(E) load_step_e(inext, T - 1, E)
     PK_EDGE_DISPATCH(PK3_LS0);
 #pragma unroll
@@ -578,7 +561,6 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
         // one, the fill pattern ahead - in front of the MFMA block, or (flush_late) behind it
         auto side_traffic = [&]() {
             if (t > 0) {  // (loads first: see the forward kernel)
-                if (gate) gate_for(t - 1);
 #define PK3_LS1(E) load_step_e(inext, t - 1, E)
                 PK_EDGE_DISPATCH_S(PK3_LS1);
             }

@@ -507,7 +507,6 @@ def flush_deferred_side():
 def join_side():
     """Make the current stream wait for the side stream (before anything reads or rewrites .grad)."""
     flush_deferred_side()
-    _DyGate.settle()
     if _Side.pending:
         if _Side.stream is not None:
             torch.cuda.current_stream().wait_stream(_Side.stream)
@@ -1604,78 +1603,6 @@ class _Prefill:
             torch.cuda.current_stream().wait_stream(_Prefill.stream)
 
 
-class _DyGate:
-    """Gated dY (round 5; include/pk_amd.h: pk_rec_set_dy_gate).  In BPTT of a stack the recurrence of layer L-1 used to wait
-    for the whole dX GEMM of layer L (0.21 ms of 64 000 rows at the BASELINE shape, four times per step).  A layer whose
-    input comes straight from a gate-capable recurrent layer below now cuts its dX along time into chunks of 2^shift
-    steps and launches them on a stream of their own from both ends of the sequence inwards - the order in which the two
-    directions of the layer below consume them - each followed by a one-word ready flag; the recurrence below is armed
-    with those flags and starts at once.  Results are those of the one-launch GEMM bit for bit (same tiles, same
-    reduction order per output element)."""
-    flags = None      # int32 device words: flags[k] == gen <=> chunk k of the pending product is complete
-    gen = 0
-    stream = None
-    pending = None    # (data_ptr of dx, gen, shift)
-
-    @staticmethod
-    def enabled():
-        return (_lib.experiment("dy_gate", "1") != "0" and settings.wgrad_side and accumulating_backward.depth > 0
-                and not torch.cuda.is_current_stream_capturing())
-
-    @staticmethod
-    def produce(lib, dx, dPb, Wb2, T, B, D, GH, shift):
-        G_ = _DyGate
-        if G_.flags is None or G_.flags.device != dx.device:
-            G_.flags = torch.zeros(4096, dtype=torch.int32, device=dx.device)
-            G_.stream = torch.cuda.Stream(device=dx.device, priority=-1)  # (high priority: its chunks are what the chain waits for)
-        S, K = 1 << shift, (T + (1 << shift) - 1) >> shift
-        if K > G_.flags.numel():
-            return False
-        G_.gen = G_.gen + 1 if G_.gen < 0x7FFFFFF0 else 1
-        if G_.gen == 1:
-            G_.flags.zero_()
-        st = G_.stream
-        st.wait_stream(torch.cuda.current_stream())  # dPb is complete on the main stream at this point
-        order, lo, hi = [], 0, K - 1
-        while lo <= hi:  # ends inwards: direction 0 of the consumer walks down from T - 1, direction 1 up from 0
-            order.append(hi)
-            if lo != hi:
-                order.append(lo)
-            lo, hi = lo + 1, hi - 1
-        fbase = G_.flags.data_ptr()
-        with torch.cuda.stream(st):
-            for k in order:
-                t0, t1 = k * S, min((k + 1) * S, T)
-                gemm_bf16((t1 - t0) * B, D, GH, (dPb, t0 * B * dPb.shape[1]), dPb.shape[1], 1, Wb2, Wb2.shape[1], 0,
-                          dx[t0 * B:t1 * B], D)
-                _lib.check(lib.pk_flag_set(_stream(), ctypes.c_void_p(fbase + 4 * k), G_.gen), "pk_flag_set")
-        for t_ in (dPb, Wb2, dx):
-            t_.record_stream(st)
-        G_.pending = (dx.data_ptr(), G_.gen, shift)
-        return True
-
-    @staticmethod
-    def take(dY):
-        """-> (flags pointer, gen, shift) when dY is the product pending on the gate stream; anything else pending is
-        waited for on the main stream (its consumer is not the one that was announced)."""
-        G_ = _DyGate
-        if G_.pending is None:
-            return None
-        ptr, gen, shift = G_.pending
-        G_.pending = None
-        if dY.data_ptr() == ptr and dY.is_contiguous():
-            return (ctypes.c_void_p(G_.flags.data_ptr()), gen, shift)
-        torch.cuda.current_stream().wait_stream(G_.stream)
-        return None
-
-    @staticmethod
-    def settle():
-        """Nothing may stay pending behind a backward pass (join_side calls this)."""
-        if _DyGate.pending is not None:
-            _DyGate.pending = None
-            torch.cuda.current_stream().wait_stream(_DyGate.stream)
-
-
 class RecLayerPerfFn(torch.autograd.Function):
     """Perf-mode (bf16 MFMA operands) recurrent layer: same math as RecLayerFn, but every GEMM operand
     lives in HBM as bf16 and nothing is converted twice:
@@ -1701,8 +1628,6 @@ class RecLayerPerfFn(torch.autograd.Function):
         # (gamma parameters, beta parameters) when the BatchNorm affine was handed over DETACHED (views of the flat
         # buffer): backward adds d gamma / d beta to their flat .grad inside pk_bn_bwd_bf16 (`edge` keeps the node alive)
         ctx.affine = cfg[15] if len(cfg) > 15 else None
-        # (cell, H) of the recurrent layer directly below when ITS backward can take this layer's dX chunk by chunk
-        ctx.gate_below = cfg[16] if len(cfg) > 16 else None
         T, B, D = x.shape
         G = lib.pk_rec_num_gates(CELL[cell])
         NS = lib.pk_rec_num_saved(CELL[cell])
@@ -1800,10 +1725,6 @@ class RecLayerPerfFn(torch.autograd.Function):
         TB, GH = T * B, G * H
         Hp = _up(H, 8)
         dY = dY.contiguous()
-        gate = _DyGate.take(dY)  # dY may still be in production on the gate stream (the layer above's chunked dX)
-        if gate is not None and (ctx.Xb is not None or lib.pk_rec_dy_gate_ok(CELL[cell], T, B, int(bidir), H) != 1):
-            torch.cuda.current_stream().wait_stream(_DyGate.stream)  # (not what the producer was told: wait for all of it)
-            gate = None
         dGb, prefilled = ctx.dGb, 1  # filled with the "not written" pattern during forward (third stream)
         ctx.dGb = None
         if dGb is None:
@@ -1816,8 +1737,6 @@ class RecLayerPerfFn(torch.autograd.Function):
                                        float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dGb), Gp, prefilled)
             _lib.check(rc, "pk_rec2p_bwd_bf16")
         else:
-            if gate is not None:
-                lib.pk_rec_set_dy_gate(gate[0], gate[1], gate[2])
             rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
                                      float(mask_scalar), _p(Y), _p(S), _p(dY), None, _p(dGb), Gp, prefilled)
             _lib.check(rc, "pk_rec_bwd_bf16")
@@ -1895,14 +1814,7 @@ class RecLayerPerfFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:  # dx[m,d] = sum_n dP[m,n] W[n,d]: A k-contiguous, B = W (plain pitch) k-major
             Wb2 = Wb if xseg is None else cvt_bf16(Wcat)
             dx = _new(TB, D, like=dY)
-            chunked = False
-            if ctx.gate_below is not None and _DyGate.enabled():
-                cell_b, H_b = ctx.gate_below
-                shift = int(_lib.experiment("dy_gate_shift", "6"))
-                if T > (2 << shift) and D == (2 if bidir else 1) * H_b and lib.pk_rec_dy_gate_ok(CELL[cell_b], T, B, int(bidir), H_b) == 1:
-                    chunked = _DyGate.produce(lib, dx, dPb, Wb2, T, B, D, GH, shift)
-            if not chunked:
-                gemm_bf16(TB, D, GH, dPb, dPb.shape[1], 1, Wb2, Wb2.shape[1], 0, dx, D)
+            gemm_bf16(TB, D, GH, dPb, dPb.shape[1], 1, Wb2, Wb2.shape[1], 0, dx, D)
             dx = dx.view(T, B, D)
         if late:  # behind the dX GEMM: next on the main stream is the recurrence of the layer below
             free = 0

@@ -513,7 +513,6 @@ class _Recurrent(nn.Module):
             masks = [m.to(x.device).float().contiguous() if m is not None else None for m in masks]
         batch = x.shape[1]
         xb = xseg = None  # perf mode: bf16 copy of the running activation, handed from layer to layer
-        below = None      # (cell, H) of the perf-mode layer whose output is this layer's input, nothing in between
         for i in range(self._n_lay):
             mask_i, scalar_i = (masks[i], scalars[i]) if masks is not None else self._drop_mask(i, batch, x.device)
             H = self._lay[i]
@@ -575,11 +574,9 @@ class _Recurrent(nn.Module):
                            [b.num_batches_tracked for b in bns]) if stats_in_kernel else None
                 y, bmean, bvar, xb = F_.RecLayerPerfFn.apply(x, xb, Wcat.detach() if side_w else Wcat, bcat,
                                                            Ucat.detach() if side_u else Ucat, gamma, beta, rmean, rvar,
-                                                           mask_i, cfg + (xseg, wps, ups, side_w, side_u, bn_bufs, affine, below),
+                                                           mask_i, cfg + (xseg, wps, ups, side_w, side_u, bn_bufs, affine),
                                                            edge_t)
                 xseg = (2 if self.bidir else 1, H, (H + 7) // 8 * 8)
-                # (this layer's backward consumes the next layer's dX directly: functional._DyGate)
-                below = (self.KIND, H) if (self.training and self.KIND in ("liGRU", "RNN") and not self._use_ln[i]) else None
                 if stats_in_kernel:
                     x = y
                     continue
@@ -590,7 +587,6 @@ class _Recurrent(nn.Module):
                 lnb = self.ln[i].beta if self._use_ln[i] else None
                 y, bmean, bvar = F_.RecLayerFn.apply(x, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, mask_i, lng, lnb, cfg)
                 xb = xseg = None
-                below = None
             if use_bn and self.training:
                 n = x.shape[0] * x.shape[1] * (2 if self.bidir else 1)
                 with torch.no_grad():  # BatchNorm1d(momentum=0.05) running statistics, per gate: four multi-tensor launches

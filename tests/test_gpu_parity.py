@@ -815,59 +815,3 @@ def test_small_batch_mlp_step_direct_gradients(monkeypatch):
                 continue
             got = results["direct"][step][k]
             assert rel_err(got, ref) < 4e-3, (step, k, rel_err(got, ref))
-
-
-# --------------------------------------------------------------------------------
-# gated dY (round 5): the recurrence of layer L-1 starts on the two outermost time chunks of layer L's dX while the rest
-# of that product is still being written on another stream
-# --------------------------------------------------------------------------------
-@pytest.mark.gpu
-@pytest.mark.parametrize("T,B,H,shift", [(100, 16, 64, 4), (300, 128, 550, 6), (77, 5, 40, 3)])
-def test_gated_dy_equals_the_whole_dx_product(monkeypatch, T, B, H, shift):
-    """A three-layer bidirectional Li-GRU stack, one training step in perf mode with flat parameters, twice: the dX of
-    layers 2 and 1 as ONE GEMM each on the main stream (PK_EXPERIMENT dy_gate=0), and cut into 2^shift-step chunks
-    produced from both ends of the sequence inwards on the gate stream while the recurrence below already runs, armed
-    with the chunks' ready flags (functional._DyGate, pk_rec_set_dy_gate).  Same tiles, same reduction order per output
-    element: every gradient must be bit-identical, no bounded spin may time out (neural_networks.py:1114-1141 run
-    backward)."""
-    from engine_util import F_amd, nn_amd
-
-    _lib = importlib.import_module("pytorch-kaldi_amd._lib")
-    optim_ = importlib.import_module("pytorch-kaldi_amd.optim")
-    lib = _lib.load()
-    D = 40
-    opts = {"ligru_lay": ",".join([str(H)] * 3), "ligru_drop": "0.2,0.2,0.2", "ligru_use_laynorm_inp": "False",
-            "ligru_use_batchnorm_inp": "False", "ligru_use_laynorm": "False,False,False", "ligru_use_batchnorm": "True,True,True",
-            "ligru_bidir": "True", "ligru_act": "relu,relu,relu", "ligru_orthinit": "True", "use_cuda": "True", "to_do": "train"}
-    gen = torch.Generator().manual_seed(T + H)
-    x = torch.randn(T, B, D, generator=gen).cuda()
-    cot = torch.randn(T, B, 2 * H, generator=gen).cuda()
-    masks = [((torch.rand(2 * B, H, generator=gen) > 0.2).float() / 0.8) for _ in range(3)]
-    old_prec, old_algo = F_amd.settings.precision, F_amd.settings.rec_algo
-    F_amd.set_precision("bf16")
-    F_amd.set_rec_algo("persistent")
-    lib.pk_gemm_bf16_set_tile(128)  # (chunk and whole product on the same block tile: the comparison is bit for bit)
-    res = {}
-    try:
-        for mode in ("0", "1"):
-            monkeypatch.setenv("PK_EXPERIMENT", "dy_gate=%s,dy_gate_shift=%d" % (mode, shift))
-            torch.manual_seed(3)
-            net = nn_amd.liGRU(opts, D).cuda().train()
-            flat = optim_.FlatParams(net)
-            flat.zero_grad()
-            with F_amd.accumulating_backward():
-                y = net(x, drop_masks=masks)
-                (y * cot).sum().backward()
-            F_amd.join_side()
-            torch.cuda.synchronize()
-            _lib.raise_if_persist_failed()
-            res[mode] = ({k: q.grad.detach().clone() for k, q in net.named_parameters()}, y.detach().clone(),
-                         F_amd._DyGate.gen)
-    finally:
-        lib.pk_gemm_bf16_set_tile(0)
-        F_amd.set_precision(old_prec)
-        F_amd.set_rec_algo(old_algo)
-    assert res["1"][2] >= res["0"][2] + 2, "the gate was not used (two chunked products expected)"
-    assert torch.equal(res["0"][1], res["1"][1])
-    for k, ref in res["0"][0].items():
-        assert torch.equal(ref, res["1"][0][k]), (k, rel_err(res["1"][0][k], ref))

@@ -227,6 +227,17 @@ int pk_nll_err_fwd_argmax(void* stream, const float* y, const int64_t* lab, cons
 int pk_nll_logsoftmax_bwd_bf16(void* stream, const float* y, const int64_t* lab, const float* dloss, const float* count,
                                int64_t ignore_index, int64_t rows, int64_t N, uint16_t* dxb, int64_t ldb, float* partial,
                                float* colsum);
+/* The two bf16 backward passes above writing into a COLUMN SLICE of a wider buffer (ldb columns per row: values + zero
+ * padding; rows `pitch` elements apart).  Several output layers on one input (the senone and the monophone head of every
+ * shipped recipe: cfg/TIMIT_baselines/TIMIT_liGRU_fmllr.cfg, [model] out_dnn2 / out_dnn3 on out_dnn1) then share ONE
+ * concatenated operand and their input gradients are ONE GEMM over the concatenated reduction instead of one GEMM per
+ * head accumulating into the same 282 MB (neural_networks.py:139-148 run backward by autograd, which adds the heads'
+ * input gradients element-wise). */
+int pk_logsoftmax_bwd_bf16_p(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, uint16_t* dxb,
+                             int64_t ldb, int64_t pitch, float* partial, float* colsum);
+int pk_nll_logsoftmax_bwd_bf16_p(void* stream, const float* y, const int64_t* lab, const float* dloss, const float* count,
+                                 int64_t ignore_index, int64_t rows, int64_t N, uint16_t* dxb, int64_t ldb, int64_t pitch,
+                                 float* partial, float* colsum);
 
 /* ---- recurrent layers (LSTM / GRU / liGRU / minimalGRU / RNN time loops):
  * neural_networks.py:457-469, 629-641, 1130-1141, 1291-1302, 1438-1447, with

@@ -65,6 +65,8 @@ SIGNATURES = {
     "pk_nll_err_fwd": (c_int, [P, P, P, c_int64, c_int64, c_int64, P, P, P, P]),
     "pk_nll_err_fwd_argmax": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P, P, P, P]),
     "pk_nll_logsoftmax_bwd_bf16": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64, P, P]),
+    "pk_logsoftmax_bwd_bf16_p": (c_int, [P, P, P, c_int64, c_int64, P, c_int64, c_int64, P, P]),
+    "pk_nll_logsoftmax_bwd_bf16_p": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, P, c_int64, c_int64, P, P]),
     "pk_rec_num_saved": (c_int, [c_int]),
     "pk_rec_num_gates": (c_int, [c_int]),
     "pk_conv1d_pool_dgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),

@@ -702,7 +702,9 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_bf16_kernel(const float* _
                                                                    const float* __restrict__ dloss,
                                                                    const float* __restrict__ count, long ignore_index,
                                                                    long rows, long N, unsigned short* __restrict__ dxb,
-                                                                   long ldb, float* __restrict__ partial) {
+                                                                   long ldb, long pitch, float* __restrict__ partial) {
+    // ldb: columns written per row (N values + zero padding); pitch >= ldb: elements between rows (dxb may be a column
+    // slice of a wider buffer: several output layers on one input write ONE concatenated operand for a single dX GEMM)
     __shared__ float sh[3][64 * NPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long wid = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_bf16_kernel(const float* _
             const long c = lane + 64 * i;
             const float d = c < N ? g[i] - expf(e[i]) * sum : 0.f;
             acc[i] += d;
-            if (c < ldb) dxb[r * ldb + c] = pk_f2bf(d);
+            if (c < ldb) dxb[r * pitch + c] = pk_f2bf(d);
         }
     }
     // the four waves' column sums -> one partial row per block (the layout col_reduce_final_kernel reads)
@@ -1293,16 +1295,17 @@ extern "C" int64_t pk_logsoftmax_bwd_bf16_partial_floats(int64_t rows, int64_t N
 
 static int lsm_bwd_bf16_launch(hipStream_t st, bool onehot, const float* dy, const float* y, const long* lab,
                                const float* dloss, const float* count, long ignore_index, int64_t rows, int64_t N,
-                               uint16_t* dxb, int64_t ldb, float* partial, float* colsum) {
+                               uint16_t* dxb, int64_t ldb, float* partial, float* colsum, int64_t pitch = 0) {
+    if (pitch <= 0) pitch = ldb;
     const long blocks = lsm_bf16_blocks(rows, N);
     const dim3 grid((unsigned)blocks);
     unsigned short* o = (unsigned short*)dxb;
 #define PK_LSMB(NPL)                                                                                                      \
     do {                                                                                                                  \
         if (onehot) hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<NPL, true>), grid, dim3(256), 0, st, dy, y, lab, dloss, \
-                                       count, ignore_index, (long)rows, (long)N, o, (long)ldb, partial);                  \
+                                       count, ignore_index, (long)rows, (long)N, o, (long)ldb, (long)pitch, partial);     \
         else hipLaunchKernelGGL((logsoftmax_bwd_bf16_kernel<NPL, false>), grid, dim3(256), 0, st, dy, y, lab, dloss,       \
-                                count, ignore_index, (long)rows, (long)N, o, (long)ldb, partial);                         \
+                                count, ignore_index, (long)rows, (long)N, o, (long)ldb, (long)pitch, partial);            \
     } while (0)
     if (ldb <= 64) PK_LSMB(1);
     else if (ldb <= 256) PK_LSMB(4);
@@ -1334,6 +1337,27 @@ extern "C" int pk_nll_logsoftmax_bwd_bf16(void* stream, const float* y, const in
     PK_REQUIRE(y && lab && dloss && count && partial && colsum, "pk_nll_logsoftmax_bwd_bf16: null argument");
     return lsm_bwd_bf16_launch(pk_stream(stream), true, nullptr, y, (const long*)lab, dloss, count, (long)ignore_index, rows, N,
                                dxb, ldb, partial, colsum);
+}
+
+// ... into a column slice of a wider bf16 buffer: `ldb` columns are written per row (values + zero padding), rows are
+// `pitch` elements apart
+extern "C" int pk_logsoftmax_bwd_bf16_p(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, uint16_t* dxb,
+                                        int64_t ldb, int64_t pitch, float* partial, float* colsum) {
+    if (rows == 0) return 0;
+    PK_REQUIRE(N >= 1 && N <= 2048, "pk_logsoftmax_bwd_bf16_p: rows of 1..2048 columns");
+    PK_REQUIRE(ldb >= N && ldb <= 2048 && (ldb % 8) == 0 && pitch >= ldb && (pitch % 8) == 0, "pk_logsoftmax_bwd_bf16_p: bad bf16 pitch");
+    PK_REQUIRE(partial && colsum, "pk_logsoftmax_bwd_bf16_p: null workspace");
+    return lsm_bwd_bf16_launch(pk_stream(stream), false, dy, y, nullptr, nullptr, nullptr, 0, rows, N, dxb, ldb, partial, colsum, pitch);
+}
+extern "C" int pk_nll_logsoftmax_bwd_bf16_p(void* stream, const float* y, const int64_t* lab, const float* dloss,
+                                            const float* count, int64_t ignore_index, int64_t rows, int64_t N, uint16_t* dxb,
+                                            int64_t ldb, int64_t pitch, float* partial, float* colsum) {
+    if (rows == 0) return 0;
+    PK_REQUIRE(N >= 1 && N <= 2048, "pk_nll_logsoftmax_bwd_bf16_p: rows of 1..2048 columns");
+    PK_REQUIRE(ldb >= N && ldb <= 2048 && (ldb % 8) == 0 && pitch >= ldb && (pitch % 8) == 0, "pk_nll_logsoftmax_bwd_bf16_p: bad bf16 pitch");
+    PK_REQUIRE(y && lab && dloss && count && partial && colsum, "pk_nll_logsoftmax_bwd_bf16_p: null argument");
+    return lsm_bwd_bf16_launch(pk_stream(stream), true, nullptr, y, (const long*)lab, dloss, count, (long)ignore_index, rows, N,
+                               dxb, ldb, partial, colsum, pitch);
 }
 
 static inline long nll_err_blocks(int64_t rows) {

@@ -624,8 +624,69 @@ class _DxShare:
     own buffer, behind _ShareIn.backward, which also lets go of the shared dX."""
     on = _lib.experiment("head_dx_share", "1") != "0"
     epoch = 0
+    epoch_fwd = 0
     table = {}  # key -> (epoch, dx tensor, contributors)
     alias = None  # (weakref to x, its private alias) of the head input seen last
+    # Round 5: ONE input-gradient GEMM for all heads on one input.  The heads' dz (bf16) are column slices of one
+    # buffer [M, sum of the heads' padded widths], the heads' weights rows of one [same sum, pitch] bf16 copy, and
+    # dX = dz_cat . W_cat is launched once, by _ShareIn.backward - which autograd runs behind every head that takes part
+    # in this backward pass (a head that does not: its slice is zeroed there).  At the BASELINE shape the monophone
+    # head's own dX GEMM cost 0.21 ms for 7 GFLOP: it read and rewrote the 282 MB the senone head had just written.
+    cat = {}       # key -> dict(epoch, heads=[dict(id, N, off, wb)], width, dz, dx, done)
+    wcat = {}      # (ids of the weight copies) -> persistent zero-padded bf16 buffer [width, pitch]
+
+
+def _cat_register(key, ctx_id, N, wb, M):
+    """Forward of a fused-cost head on the shared input `key`: reserve its columns of the concatenated operand."""
+    if not (_DxShare.on and _lib.experiment("head_dx_cat", "1") != "0" and M >= 4096):
+        return
+    c = _DxShare.cat.get(key)
+    if c is None or c["epoch"] != _DxShare.epoch_fwd:
+        c = _DxShare.cat[key] = {"epoch": _DxShare.epoch_fwd, "heads": [], "width": 0, "dz": None, "dx": None, "done": set()}
+        for k in [k for k, v in _DxShare.cat.items() if v["epoch"] != _DxShare.epoch_fwd]:
+            del _DxShare.cat[k]
+    c["heads"].append({"id": ctx_id, "N": N, "off": c["width"], "wb": wb})
+    c["width"] += _up(N, 64)
+
+
+def _cat_slot(ctx, M):
+    """Backward of a head: (cat, head entry) when its dz belongs into a shared operand of at least two heads."""
+    key = getattr(ctx, "dx_share", None)
+    c = _DxShare.cat.get(key) if key is not None else None
+    if c is None or len(c["heads"]) < 2:
+        return None
+    pitches = {h["wb"].shape[1] for h in c["heads"]}
+    mine = [h for h in c["heads"] if h["id"] == id(ctx)]
+    if len(pitches) != 1 or len(mine) != 1 or id(ctx) in c["done"]:
+        return None
+    if c["dz"] is None:
+        c["dz"] = torch.empty(M, c["width"], device=c["heads"][0]["wb"].device, dtype=torch.bfloat16)
+    return c, mine[0]
+
+
+def _cat_finish(g):
+    """_ShareIn.backward: every head that takes part has written its slice of dz_cat - launch the one dX GEMM into g."""
+    for key, c in list(_DxShare.cat.items()):
+        if c["dx"] is None or c["dx"].data_ptr() != g.data_ptr():
+            continue
+        heads, dz = c["heads"], c["dz"]
+        for h in heads:  # a head whose cost did not reach the loss contributes nothing
+            if h["id"] not in c["done"]:
+                dz[:, h["off"]:h["off"] + _up(h["N"], 64)].zero_()
+        wkey = tuple((h["wb"].data_ptr(), h["N"], h["off"]) for h in heads)
+        wc = _DxShare.wcat.get(wkey)
+        pitch = heads[0]["wb"].shape[1]
+        if wc is None:
+            _DxShare.wcat.clear()  # (one set of heads at a time: the copies are 4-9 MB)
+            wc = _DxShare.wcat[wkey] = torch.zeros(c["width"], pitch, device=dz.device, dtype=torch.bfloat16)
+        for h in heads:  # the weights moved this step: refresh their rows (pad rows stay zero)
+            wc[h["off"]:h["off"] + h["N"]].copy_(h["wb"])
+        M, K = c["dx"].shape[0], c["dx"].shape[-1]
+        dx2 = c["dx"].view(-1, K)
+        gemm_bf16(dx2.shape[0], K, c["width"], dz, dz.shape[1], 1, wc, pitch, 0, dx2, K)
+        del _DxShare.cat[key]
+        return True
+    return False
 
 
 class _ShareIn(torch.autograd.Function):
@@ -635,6 +696,8 @@ class _ShareIn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is not None and _DxShare.cat:
+            _cat_finish(g)
         _DxShare.table.clear()  # every head in this backward pass has contributed: nothing keeps dX alive from here
         _DxShare.alias = None
         return g
@@ -656,25 +719,34 @@ def _dx_share_key(x):
     return (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()))
 
 
-def _linear_bwd_bf16(ctx, dyb, xb, wb, like):
+def _linear_bwd_bf16(ctx, dyb, xb, wb, like, cat=None):
     """dX and dW of a perf-mode Linear from the bf16 copy of the output gradient (ctx: dims, in_shape, wparam, and
-    xseg = (nseg, seglen, segpad) when xb is a re-pitched twin of the input: wb is then the plain-pitch weight copy)."""
+    xseg = (nseg, seglen, segpad) when xb is a re-pitched twin of the input: wb is then the plain-pitch weight copy).
+    dyb may be a column slice of a wider buffer (its row pitch is its stride).  cat: the shared operand of several heads
+    on one input (_cat_slot) - dX is then ONE GEMM over all of them, launched by _ShareIn.backward."""
     M, N, K = ctx.dims
     xseg = getattr(ctx, "xseg", None)
     Kx = K if xseg is None else xseg[0] * xseg[2]  # columns of xb that carry data (pad columns are zero)
     dx = dw = None
-    if ctx.needs_input_grad[0]:  # dx[m,k] = sum_n dy[m,n] W[n,k]: A k-contiguous, B = W is k-major
+    ldy = dyb.stride(0)
+    if ctx.needs_input_grad[0] and cat is not None:
+        c = cat[0]
+        c["done"].add(id(ctx))
+        if c["dx"] is None:  # the first head to run hands autograd the buffer the GEMM will fill
+            c["dx"] = _new(M, K, like=like)
+            dx = c["dx"].view(ctx.in_shape)
+    elif ctx.needs_input_grad[0]:  # dx[m,k] = sum_n dy[m,n] W[n,k]: A k-contiguous, B = W is k-major
         key = getattr(ctx, "dx_share", None)
         shared = _DxShare.table.get(key) if key is not None else None
         if shared is not None and shared[0] == _DxShare.epoch and id(ctx) not in shared[2]:
             # another head on the same input already produced dX in this backward pass: accumulate into it
             # (a head that finds ITSELF among the contributors is in a second backward pass over a retained graph)
-            gemm_bf16(M, K, N, dyb, dyb.shape[1], 1, wb, wb.shape[1], 0, shared[1], K, beta=1.0)
+            gemm_bf16(M, K, N, dyb, ldy, 1, wb, wb.shape[1], 0, shared[1], K, beta=1.0)
             shared[2].add(id(ctx))
             dx = None
         else:
             dx = _new(M, K, like=like)
-            gemm_bf16(M, K, N, dyb, dyb.shape[1], 1, wb, wb.shape[1], 0, dx, K)
+            gemm_bf16(M, K, N, dyb, ldy, 1, wb, wb.shape[1], 0, dx, K)
             if key is not None:
                 _DxShare.table[key] = (_DxShare.epoch, dx, {id(ctx)})
             dx = dx.view(ctx.in_shape)
@@ -684,20 +756,20 @@ def _linear_bwd_bf16(ctx, dyb, xb, wb, like):
         sk = _splitk_bf(_tiles_bf(N, Kx), M)
         if xseg is None:
             if side:  # off the dependency chain: accumulate into the flat .grad on the side stream (beta = 1)
-                side_launch(lambda: gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0,
+                side_launch(lambda: gemm_bf16(N, K, M, dyb, ldy, 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0,
                                               splitk=sk), (dyb, xb), [wp])
             elif M <= 512 and wp is not None and wp.is_contiguous() and direct_grads_ok([wp]):
                 # small batch: straight into the flat .grad on this stream (no AccumulateGrad add behind it)
-                gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0, splitk=sk)
+                gemm_bf16(N, K, M, dyb, ldy, 0, xb, xb.shape[1], 0, wp.grad, K, beta=1.0, splitk=sk)
             else:
                 dw = _new(N, K, like=like)
-                gemm_bf16(N, K, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dw, K, splitk=sk)
+                gemm_bf16(N, K, M, dyb, ldy, 0, xb, xb.shape[1], 0, dw, K, splitk=sk)
         else:  # the product comes out with the input's segment pitch: its segments are copied / added back
             nseg, seglen, segpad = xseg
             dwp = _new(N, Kx, like=like)
 
             def run():
-                gemm_bf16(N, Kx, M, dyb, dyb.shape[1], 0, xb, xb.shape[1], 0, dwp, Kx, splitk=sk)
+                gemm_bf16(N, Kx, M, dyb, ldy, 0, xb, xb.shape[1], 0, dwp, Kx, splitk=sk)
                 if side:
                     with torch.no_grad():
                         for s_ in range(nseg):
@@ -803,6 +875,7 @@ def linear_log_softmax(x, weight, bias=None):
             assert wb.shape[1] == xb.shape[1]
     _DxShare.epoch += 1   # (a new forward pass: whatever the previous backward pass shared is history)
     _DxShare.table.clear()
+    _DxShare.epoch_fwd = _DxShare.epoch  # heads registered behind this point belong to this forward pass (_cat_register)
     xs = _head_input(x)
     y, amax = LinearLogSoftmaxFn.apply(xs, weight if weight.is_contiguous() else w, bias, xb, wb, wb_plain, xseg)
     y._pk_head = (xs, weight, bias, xb, wb_plain, xseg, y._version, amax)
@@ -838,6 +911,8 @@ class HeadNllFn(torch.autograd.Function):
                                           _p(label_check_counter(y.device))), "pk_nll_err_fwd")
         ctx.save_for_backward(xb, wb, y, lab, out4)
         ctx.dx_share = _dx_share_key(x) if (_DxShare.on and x.is_contiguous()) else None
+        if ctx.dx_share is not None and x.requires_grad:
+            _cat_register(ctx.dx_share, id(ctx), N, wb, M)  # (wb: the plain-pitch copy of the weight)
         ctx.dims = (M, N, x.shape[-1])
         ctx.has_bias = bias is not None
         ctx.in_shape = x.shape
@@ -855,13 +930,21 @@ class HeadNllFn(torch.autograd.Function):
         M, N, K = ctx.dims
         dl = dloss.contiguous().float()
         ldb = _up(N, 64)
-        dzb = torch.empty(M, ldb, device=y.device, dtype=torch.bfloat16)
         part = _new(int(lib.pk_logsoftmax_bwd_bf16_partial_floats(M, N)), like=y)
         db = _new(N, like=y)
         cnt = ctypes.c_void_p(out4.data_ptr() + 8)
-        _lib.check(lib.pk_nll_logsoftmax_bwd_bf16(_stream(), _p(y), _p(lab), _p(dl), cnt, ctx.ignore_index, M, N, _p(dzb),
-                                                  ldb, _p(part), _p(db)), "pk_nll_logsoftmax_bwd_bf16")
-        dx, dw = _linear_bwd_bf16(ctx, dzb, xb, wb, y)
+        cat = _cat_slot(ctx, M) if ctx.needs_input_grad[0] else None
+        if cat is not None:  # my columns of the operand all heads on this input share
+            dz, off = cat[0]["dz"], cat[1]["off"]
+            dzb = dz[:, off:off + ldb]
+            _lib.check(lib.pk_nll_logsoftmax_bwd_bf16_p(_stream(), _p(y), _p(lab), _p(dl), cnt, ctx.ignore_index, M, N,
+                                                        ctypes.c_void_p(dzb.data_ptr()), ldb, dz.shape[1], _p(part), _p(db)),
+                       "pk_nll_logsoftmax_bwd_bf16_p")
+        else:
+            dzb = torch.empty(M, ldb, device=y.device, dtype=torch.bfloat16)
+            _lib.check(lib.pk_nll_logsoftmax_bwd_bf16(_stream(), _p(y), _p(lab), _p(dl), cnt, ctx.ignore_index, M, N, _p(dzb),
+                                                      ldb, _p(part), _p(db)), "pk_nll_logsoftmax_bwd_bf16")
+        dx, dw = _linear_bwd_bf16(ctx, dzb, xb, wb, y, cat)
         return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None, None, None, None, None, None
 
 

@@ -174,6 +174,17 @@ int pk_colsum(void* stream, const float* g, const float* g2, int64_t ldg, int64_
 /* out = a + b (element-wise, n floats) */
 int pk_add(void* stream, const float* a, const float* b, int64_t n, float* out);
 
+/* ---- SincNet's band-pass bank (neural_networks.py:1789-1800: SincConv.forward up to `self.filters`): N filters of K (odd)
+ * taps from 2 x N parameters, forward and backward as one launch each.  n_ [K] and window [K] are the module's buffers
+ * (n_ = (k - (K-1)/2) / sample_rate; Hamming window), min_low = min_low_hz / sample_rate, min_band likewise.  Forward
+ * follows the reference operation by operation in fp32 (the right half of a filter repeats the left values, the maximum
+ * takes the first index on ties); it saves the maxima mx [N] and their taps kstar [N] for backward, which is analytic. */
+int pk_sinc_bank_fwd(void* stream, const float* low_hz, const float* band_hz, const float* n_, const float* window, int N, int K,
+                     float sample_rate, float min_low, float min_band, float* filt, float* mx, int32_t* kstar);
+int pk_sinc_bank_bwd(void* stream, const float* g, const float* low_hz, const float* band_hz, const float* n_, const float* window,
+                     const float* mx, const int32_t* kstar, int N, int K, float sample_rate, float min_low, float min_band,
+                     float* dlow, float* dband);
+
 /* ---- the tail of a conv layer in one launch: drop(act(LayerNorm(z))) with the CNN / SincNet flavour of the reference's
  * LayerNorm (features [C, L], statistics over the last dim: neural_networks.py:1510-1512, 1546-1552, 1639-1641,
  * 1655-1661).  z, a, y, mask: [B, C, L]; gamma, beta: [C, L]; mean, rinv: [B * C] (saved for backward).

@@ -666,6 +666,10 @@ class SincConv(nn.Module):
         dev = self.low_hz_.device
         self.n_ = self.n_.to(dev)
         self.window_ = self.window_.to(dev)
+        if self.low_hz_.is_cuda:  # the synthesis and its gradient as one launch each (pk_sinc.hip)
+            return F_.sinc_bank(self.low_hz_, self.band_hz_, self.n_, self.window_, self.sample_rate,
+                                self.min_low_hz / self.sample_rate, self.min_band_hz / self.sample_rate)
+        # (CPU: only the parameter-free inspection of a module that has not been moved to the GPU; forward raises there)
         low = self.min_low_hz / self.sample_rate + torch.abs(self.low_hz_)
         high = low + self.min_band_hz / self.sample_rate + torch.abs(self.band_hz_)
         lp1 = 2 * low * self._sinc(2 * math.pi * (low * self.n_) * self.sample_rate)  # (N,1) x (1,K) outer product: a broadcast, no BLAS launch

@@ -179,6 +179,34 @@ def test_layernorm(rows, F):
         assert rel_err(a.grad, r.grad) < 1e-5
 
 
+@pytest.mark.parametrize("N,K", [(128, 129), (80, 251), (7, 3), (16, 33)])
+def test_sinc_bank_in_one_launch(N, K):
+    """pk_sinc_bank_fwd / _bwd (SincConv.forward up to self.filters, neural_networks.py:1789-1800): the module's bank
+    against the oracle's synthesis - filters against its fp32 evaluation (what the reference computes) and against fp64,
+    the ANALYTIC parameter gradients against autograd through the fp64 evaluation."""
+    import pk_oracle as O
+
+    nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
+    torch.manual_seed(N + K)
+    conv = nn_amd.SincConv(1, N, K, sample_rate=16000, min_low_hz=50, min_band_hz=50)
+    with torch.no_grad():  # move the mel initialisation around a little, both signs (abs() in the synthesis)
+        conv.low_hz_.mul_(1.0 + 0.1 * torch.randn(N, 1)).mul_(torch.where(torch.rand(N, 1) > 0.8, -1.0, 1.0))
+        conv.band_hz_.mul_(1.0 + 0.1 * torch.randn(N, 1)).mul_(torch.where(torch.rand(N, 1) > 0.8, -1.0, 1.0))
+    lo, ba = conv.low_hz_.detach().clone(), conv.band_hz_.detach().clone()
+    cot = torch.randn(N, 1, conv.kernel_size)
+    ref32 = O.sinc_filters(lo, ba, K, 16000, 50, 50)
+    lo64, ba64 = lo.double().requires_grad_(True), ba.double().requires_grad_(True)
+    ref64 = O.sinc_filters(lo64, ba64, K, 16000, 50, 50)
+    (ref64 * cot.double()).sum().backward()
+    conv = conv.cuda()
+    f = conv.filters()
+    (f * cot.cuda()).sum().backward()
+    assert tuple(f.shape) == tuple(ref32.shape)
+    assert rel_err(f, ref32) < 2e-6 and rel_err(f, ref64) < 2e-5   # (fp32 sin / division of arguments up to ~200 rad)
+    assert rel_err(conv.low_hz_.grad, lo64.grad) < 1e-4, rel_err(conv.low_hz_.grad, lo64.grad)
+    assert rel_err(conv.band_hz_.grad, ba64.grad) < 1e-4, rel_err(conv.band_hz_.grad, ba64.grad)
+
+
 @pytest.mark.parametrize("B,C,L,act,drop", [(3, 5, 36, "relu", True), (4, 60, 340, "relu", True), (2, 128, 1024, "leaky_relu", False),
                                            (5, 7, 112, "tanh", True), (2, 3, 1027, "relu", False), (3, 2, 3, "linear", True)])
 def test_conv_layer_tail_in_one_launch(B, C, L, act, drop):

@@ -348,11 +348,12 @@ def cpu_baseline(args, rcp_name, full=False):
         rec["full_shape"]["measured_in_run"] = True
     elif not full:
         try:  # the same port at the metric's FULL shape, measured once on the GPU box's host (bench.py --cpu-full)
-            fs = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_full_shape.json")))
+            fsrc = "r05_cpu_full_shape.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_cpu_full_shape.json")) else "r03_cpu_full_shape.json"
+            fs = json.load(open(os.path.join(ROOT, "profiles", fsrc)))
             if fs.get("recipe", "timit_ligru") == rcp_name:
                 rec["full_shape"] = {k: fs[k] for k in ("value", "unit", "cores", "T", "B", "seconds", "sample") if k in fs}
                 rec["full_shape"]["measured_in_run"] = False  # a constant quoted from the file below, NOT timed by this run
-                rec["full_shape"]["source"] = "profiles/r03_cpu_full_shape.json (bench.py --cpu-full on a GPU box's host, round 3)"
+                rec["full_shape"]["source"] = "profiles/%s (the same port, one step at the full shape on a GPU box's host)" % fsrc
         except (OSError, ValueError):
             pass
     return rec
@@ -406,7 +407,7 @@ def roofline_of(tr, args, summ, prec):
         # its MFMA block and gate math removed (EMPTY=1: poll + barrier + flush / prefetch issue + patches + publish).
         lat = {"bound": "latency", "dependent_steps_per_launch": tr.T, "us_per_step": round(d["avg_ms"] * 1e3 / tr.T, 3)}
         hop, floor, src_ = 0.9, None, None
-        for cand in ("r04_rec_step_floor.json", "r03_rec_step_floor.json", "r02_rec_step_floor.json"):
+        for cand in ("r05_rec_step_floor.json", "r04_rec_step_floor.json", "r03_rec_step_floor.json", "r02_rec_step_floor.json"):
             try:
                 fl_ = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 side_ = "bwd" if "bwd" in dom else "fwd"
@@ -426,7 +427,7 @@ def roofline_of(tr, args, summ, prec):
         roof["hop_floor_us"], roof["latency_frac"] = hop, lat["frac"]
         if "structure_frac" in lat:
             roof["step_floor_us"], roof["structure_frac"] = lat["step_floor_us"], lat["structure_frac"]
-    for src in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for src in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", src)))
             if dom in pm and args.recipe == "timit_ligru" and (tr.T, tr.B) == (500, 128) and args.layers is None:

@@ -49,6 +49,8 @@ struct BArgs {
     int items, per_xcd;  // work items = splits x tiles_m x tiles_n, and ceil(items / 8)
     const unsigned short* zeros;  // >= 16 bytes of zeros
     float* stats;  // 256-tile, no split-K: per (m-tile, column) (rows, mean, M2) of the output, [tiles_m][N][3], or null
+    int stagger;   // 256-tile: the first wave of workgroups starts in four phases, this many units of 1024 clocks apart
+    int nostore;   // diagnostics (PK_EXPERIMENT gemm_nostore=1): skip the epilogue stores - what the stores cost
 };
 
 __device__ unsigned short g_zero_page[64];
@@ -1030,6 +1032,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(BArgs p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);  // XCD-aware mapping, as above
     if (item >= p.items) return;
+    // The row-streaming shapes write 256 KB of fp32 per tile.  The first wave of workgroups - one per CU - starts together,
+    // computes for the same time and reaches its epilogue together: 256 CUs x 256 KB against ~6 TB/s is an 11 us store
+    // burst during which nothing computes, and since every later workgroup starts when one of these ends, the rounds stay
+    // in lock step.  Four start phases spread the bursts: while one quarter of the chip stores, three quarters compute.
+    if (p.stagger > 0 && blockIdx.x < 256) {
+        const int ph = (blockIdx.x >> 3) & 3;
+        for (int d = 0; d < ph * p.stagger; ++d) __builtin_amdgcn_s_sleep(16);
+    }
     const int tn = item % p.tiles_n;
     const int tm = (item / p.tiles_n) % p.tiles_m;
     const int split = item / (p.tiles_n * p.tiles_m);
@@ -1146,6 +1156,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(BArgs p) {
     if constexpr (A_KC && B_KC) {  // (projections: both operands k-contiguous; the other instantiations stay as they were)
         if (p.stats != nullptr) tile_colstats(p, acc, m0, n0, tm, wm, wn, lane, reinterpret_cast<float*>(smem));
     }
+    if (p.nostore) return;
     const bool vec_ok = (((uintptr_t)(p.ws ? p.ws : p.C) & 15) == 0) && (((p.ws ? (long)p.N : p.ldc) & 3) == 0);
     const bool interior = m0 + 256 <= p.M && n0 + 256 <= p.N;
     if (vec_ok && interior && (p.ws != nullptr || p.beta == 0.f)) {
@@ -1359,6 +1370,19 @@ static int gemm_bf16_impl(void* stream, int M, int N, int K, float alpha, const 
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.bias = bias;
     p.stats = stats;
+    p.stagger = 0; p.nostore = 0;
+    {
+        static int stg = -2, nst = -1;
+        if (stg == -2) {
+            const char* e = pk_experiment("gemm_stagger");
+            stg = e ? atoi(e) : -1;  // -1: the default below
+            const char* n = pk_experiment("gemm_nostore");
+            nst = n ? atoi(n) : 0;
+        }
+        // row-streaming shapes (every tile stores 256 KB, several rounds of tiles): four start phases
+        if (a_kc && M >= 16384 && splitk <= 1) p.stagger = stg >= 0 ? stg : 0;
+        p.nostore = nst;
+    }
     const int tile = gemm_tile_for(M, N, a_kc, b_kc, K);
     PK_REQUIRE(stats == nullptr || (tile == 256 && a_kc && b_kc && splitk <= 1 && beta == 0.f), "pk_gemm_bf16_stats: internal: shape not covered");
     p.tiles_m = (M + tile - 1) / tile;

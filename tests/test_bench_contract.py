@@ -8,7 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BASE = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-LINES = ["profiles/r04_bench_bf16.json", "profiles/r04_bench_bf16_evidence_pass.json", "profiles/r04_driver_exact_cmd_line.json",
+LINES = ["profiles/r05_bench_bf16.json", "profiles/r04_bench_bf16.json", "profiles/r04_bench_bf16_evidence_pass.json", "profiles/r04_driver_exact_cmd_line.json",
          "profiles/r03_bench_bf16.json", "profiles/r02_bench_bf16.json", "profiles/r01_bench_bf16.json", "profiles/r01_bench_fp32_with_cpu_baseline.json",
          "profiles/r01_timit_lstm_8wave_bench.json", "profiles/r01_timit_lstm_4wave_bench.json"]
 
@@ -123,3 +123,21 @@ def test_round4_line_carries_the_step_trace_the_prewarm_and_the_chunk_median():
     # the driver's command exactly as typed, first process on a fresh box
     e = _line("profiles/r04_driver_exact_cmd_line.json")
     assert e["steps"] == 20 and e["warmup"] == 5 and e["n_gpus"] == 1 and e["ms_per_step"] < 17.5
+
+
+def test_round5_line_measures_the_cpu_full_shape_in_the_run_and_carries_the_round5_sources():
+    """Round 5: the CPU port at the metric's FULL shape timed inside the bench run of the closing pass (--cpu-full-in-run),
+    the roofline's latency floor / counter traffic from this round's profiles, the other configurations with the LSTM
+    helpers and the bf16 convolutions on."""
+    d = _line("profiles/r05_bench_bf16.json")
+    fs = d["cpu_baseline"]["full_shape"]
+    assert fs["measured_in_run"] is True and (fs["T"], fs["B"]) == (500, 128) and 100 < fs["value"] < 1000 and fs["seconds"] > 60
+    r = d["roofline"]
+    assert r["latency"]["floor_source"] == "profiles/r05_rec_step_floor.json" and "r05_pmc_traffic" in r["traffic_source"]
+    assert d["ms_per_step"] < 17.5
+    got = {o["recipe"]: o for o in d["other_configs"]}
+    assert got["timit_lstm"]["ms_per_step"] < 24.5 and got["timit_sincnet"]["ms_per_step"] < 3.3
+    assert got["libri_gru"]["parity_mode"]["ms_per_step"] < 600   # the step-wise fp32 products split over the grid (was 1 293)
+    dc = json.load(open(os.path.join(ROOT, "profiles", "r05_driver_cmd.json")))
+    first = dc["first_process"]
+    assert first["steps"] == 20 and first["warmup"] == 5 and first["n_gpus"] == 1 and first["ms_per_step"] < 17.5

@@ -49,9 +49,6 @@ struct BArgs {
     int items, per_xcd;  // work items = splits x tiles_m x tiles_n, and ceil(items / 8)
     const unsigned short* zeros;  // >= 16 bytes of zeros
     float* stats;  // 256-tile, no split-K: per (m-tile, column) (rows, mean, M2) of the output, [tiles_m][N][3], or null
-    int stagger;   // 256-tile: the first wave of workgroups starts in four phases, this many units of 1024 clocks apart
-    int nostore;   // diagnostics (PK_EXPERIMENT gemm_nostore=1): skip the epilogue stores - what the stores cost
-    int epi_plain; // 256-tile: 1 = store from the accumulator layout (PK_EXPERIMENT gemm_epi=0), 0 = transposed across lanes
 };
 
 __device__ unsigned short g_zero_page[64];
@@ -1033,14 +1030,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(BArgs p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int item = (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3);  // XCD-aware mapping, as above
     if (item >= p.items) return;
-    // The row-streaming shapes write 256 KB of fp32 per tile.  The first wave of workgroups - one per CU - starts together,
-    // computes for the same time and reaches its epilogue together: 256 CUs x 256 KB against ~6 TB/s is an 11 us store
-    // burst during which nothing computes, and since every later workgroup starts when one of these ends, the rounds stay
-    // in lock step.  Four start phases spread the bursts: while one quarter of the chip stores, three quarters compute.
-    if (p.stagger > 0 && blockIdx.x < 256) {
-        const int ph = (blockIdx.x >> 3) & 3;
-        for (int d = 0; d < ph * p.stagger; ++d) __builtin_amdgcn_s_sleep(16);
-    }
     const int tn = item % p.tiles_n;
     const int tm = (item / p.tiles_n) % p.tiles_m;
     const int split = item / (p.tiles_n * p.tiles_m);
@@ -1157,77 +1146,38 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256_kernel(BArgs p) {
     if constexpr (A_KC && B_KC) {  // (projections: both operands k-contiguous; the other instantiations stay as they were)
         if (p.stats != nullptr) tile_colstats(p, acc, m0, n0, tm, wm, wn, lane, reinterpret_cast<float*>(smem));
     }
-    if (p.nostore) return;
     const bool vec_ok = (((uintptr_t)(p.ws ? p.ws : p.C) & 15) == 0) && (((p.ws ? (long)p.N : p.ldc) & 3) == 0);
     const bool interior = m0 + 256 <= p.M && n0 + 256 <= p.N;
-    // Epilogue.  In the accumulator layout lane L (rr = L & 15, q = L >> 4) holds 16 bytes of ROW rr: consecutive lanes are
-    // consecutive rows, a row pitch apart, and the four lanes of one row sit 16 lanes apart - a store instruction is 64
-    // separate 16-byte requests (round 5: the epilogue was 29-31 % of the row-streaming GEMMs, 7.6 bytes / clock / CU:
-    // profiles/r05_gemm_epilogue.json).  The two column blocks (j = 0, 1) of a 16-row fragment are therefore transposed
-    // across lanes (ds_bpermute: the LDS crossbar, no LDS memory) so that EIGHT CONSECUTIVE lanes hold 128 contiguous bytes
-    // of one row: lane l -> row l >> 3 of the first (then the second) eight rows, columns (l & 7) * 4 .. + 3 of the 32.
-    const int r8 = lane >> 3, cq = lane & 7;
-    const int srcA = (r8 + 16 * (cq & 3)) * 4, srcB = (8 + r8 + 16 * (cq & 3)) * 4;  // byte addresses of the source lanes
-    const bool hi = cq >= 4;                                                           // columns 16..31: from the j = 1 block
-    auto transposed = [&](const f32x4 v0, const f32x4 v1, f32x4& oa, f32x4& ob) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int x0 = __float_as_int(v0[e]), x1 = __float_as_int(v1[e]);
-            const int a0 = __builtin_amdgcn_ds_bpermute(srcA, x0), a1 = __builtin_amdgcn_ds_bpermute(srcA, x1);
-            const int b0 = __builtin_amdgcn_ds_bpermute(srcB, x0), b1 = __builtin_amdgcn_ds_bpermute(srcB, x1);
-            oa[e] = __int_as_float(hi ? a1 : a0);
-            ob[e] = __int_as_float(hi ? b1 : b0);
-        }
-    };
-    if (vec_ok && interior && (p.ws != nullptr || p.beta == 0.f) && p.epi_plain == 0) {
+    if (vec_ok && interior && (p.ws != nullptr || p.beta == 0.f)) {
         // the common case, straight-line: no bounds, no read-modify-write; 16 bytes per lane and store
         const bool direct = p.ws == nullptr;
         float* base = direct ? p.C : p.ws + (long)split * p.M * p.N;
         const long ld = direct ? p.ldc : (long)p.N;
         const float alpha = direct ? p.alpha : 1.f;
 #pragma unroll
-        for (int bh = 0; bh < 2; ++bh) {
-            const int col = n0 + bh * 128 + wn * 32 + cq * 4;
-            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (direct && p.bias != nullptr) {
+        for (int bh = 0; bh < 2; ++bh)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bv[r] = p.bias[col + r];
-            }
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + bh * 128 + wn * 32 + j * 16 + (lane >> 4) * 4;
+                f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (direct && p.bias != nullptr) {
 #pragma unroll
-            for (int ah = 0; ah < 2; ++ah)
+                    for (int r = 0; r < 4; ++r) bv[r] = p.bias[col + r];
+                }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = m0 + ah * 128 + wm * 64 + i * 16 + r8;
-                    f32x4 oa, ob;
-                    transposed(acc[ah][bh][i][0], acc[ah][bh][i][1], oa, ob);
+                for (int ah = 0; ah < 2; ++ah)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        oa[r] = alpha * oa[r] + bv[r];
-                        ob[r] = alpha * ob[r] + bv[r];
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = m0 + ah * 128 + wm * 64 + i * 16 + (lane & 15);
+                        const f32x4 v = acc[ah][bh][i][j];
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = alpha * v[r] + bv[r];
+                        *reinterpret_cast<f32x4*>(base + (long)row * ld + col) = o;
                     }
-                    *reinterpret_cast<f32x4*>(base + (long)row * ld + col) = oa;
-                    *reinterpret_cast<f32x4*>(base + (long)(row + 8) * ld + col) = ob;
-                }
-        }
+            }
         return;
     }
-    if (p.epi_plain == 0) {
-        // edges, read-modify-write, unaligned outputs: the same lane layout through the checked store
-#pragma unroll
-        for (int ah = 0; ah < 2; ++ah)
-#pragma unroll
-            for (int bh = 0; bh < 2; ++bh)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x4 oa, ob;
-                    transposed(acc[ah][bh][i][0], acc[ah][bh][i][1], oa, ob);
-                    const int row = m0 + ah * 128 + wm * 64 + i * 16 + r8, col = n0 + bh * 128 + wn * 32 + cq * 4;
-                    store_frag(p, oa, row, col, split, vec_ok);
-                    store_frag(p, ob, row + 8, col, split, vec_ok);
-                }
-        return;
-    }
-    // PK_EXPERIMENT gemm_epi=0: the accumulator layout as it is (A/B of the transposed epilogue)
     // (fully unrolled: a run-time index into the accumulator array would move the whole array to scratch memory)
 #pragma unroll
     for (int ah = 0; ah < 2; ++ah)
@@ -1409,22 +1359,6 @@ static int gemm_bf16_impl(void* stream, int M, int N, int K, float alpha, const 
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.bias = bias;
     p.stats = stats;
-    p.stagger = 0; p.nostore = 0; p.epi_plain = 0;
-    {
-        static int stg = -2, nst = -1, epi = 1;
-        if (stg == -2) {
-            const char* e = pk_experiment("gemm_stagger");
-            stg = e ? atoi(e) : -1;  // -1: the default below
-            const char* n = pk_experiment("gemm_nostore");
-            nst = n ? atoi(n) : 0;
-            const char* t = pk_experiment("gemm_epi");
-            epi = t ? atoi(t) : 1;
-        }
-        p.epi_plain = epi == 0 ? 1 : 0;
-        // row-streaming shapes (every tile stores 256 KB, several rounds of tiles): four start phases
-        if (a_kc && M >= 16384 && splitk <= 1) p.stagger = stg >= 0 ? stg : 0;
-        p.nostore = nst;
-    }
     const int tile = gemm_tile_for(M, N, a_kc, b_kc, K);
     PK_REQUIRE(stats == nullptr || (tile == 256 && a_kc && b_kc && splitk <= 1 && beta == 0.f), "pk_gemm_bf16_stats: internal: shape not covered");
     p.tiles_m = (M + tile - 1) / tile;

@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--prec", default=os.environ.get("PK_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "persistent"])
     ap.add_argument("--layers", type=int, default=None)
-    ap.add_argument("--mask-rng", default="device", choices=["device", "reference"],
+    ap.add_argument("--mask-rng", default="device", choices=["device", "reference", "reference_host"],
                     help="recurrent drop masks: GPU RNG (default) or the reference's CPU torch.bernoulli stream")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="N > 1: reduce every gradient bucket after backward instead of behind the layer that produced it")

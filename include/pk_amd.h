@@ -174,6 +174,13 @@ int pk_colsum(void* stream, const float* g, const float* g2, int64_t ldg, int64_
 /* out = a + b (element-wise, n floats) */
 int pk_add(void* stream, const float* a, const float* b, int64_t n, float* out);
 
+/* ---- the reference's drop-mask stream on the device.  neural_networks.py:1102-1107 (and :430-441, :604-615, :1266-1277,
+ * :1411-1422) draw a layer's mask with torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p)) on the global CPU generator: one
+ * 32-bit mt19937 output per element, u = (y & 0xFFFFFF) * 2^-24, mask = u < 1 - p.  state [626] (device) = the engine's 624
+ * words, `left`, `next` (the fields of the engine behind the CPU generator: bytes 24.., 8 and 16 of its saved state); the call draws n elements from it
+ * exactly as that loop would and leaves the advanced state behind.  out: 1.0 / 0.0. */
+int pk_mt19937_bernoulli(void* stream, uint32_t* state, int64_t n, float keep, float* out);
+
 /* ---- SincNet's band-pass bank (neural_networks.py:1789-1800: SincConv.forward up to `self.filters`): N filters of K (odd)
  * taps from 2 x N parameters, forward and backward as one launch each.  n_ [K] and window [K] are the module's buffers
  * (n_ = (k - (K-1)/2) / sample_rate; Hamming window), min_low = min_low_hz / sample_rate, min_band likewise.  Forward

@@ -51,6 +51,7 @@ SIGNATURES = {
                                c_int64, P, P]),
     "pk_colsum": (c_int, [P, P, P, c_int64, c_int64, c_int64, P, P]),
     "pk_add": (c_int, [P, P, P, c_int64, P]),
+    "pk_mt19937_bernoulli": (c_int, [P, P, c_int64, c_float, P]),
     "pk_sinc_bank_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, P, P, P]),
     "pk_sinc_bank_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, P, P]),
     "pk_ln_last_act_drop_fwd": (c_int, [P, P, c_int64, c_int, c_int, P, P, c_float, c_int, P, P, P, P, P]),

@@ -31,11 +31,12 @@ class _Settings:
         self.precision = os.environ.get("PK_PRECISION", "fp32")
         self.rec_algo = os.environ.get("PK_REC_ALGO", "auto")
         # recurrent drop masks: "device" (default) = Bernoulli(1-p) drawn on the GPU RNG, no host work in the step;
-        # "reference" = the reference's own torch.bernoulli(torch.Tensor(rows,H).fill_(1-p)) call on the CPU RNG
-        # (same seed -> bit-identical masks to the reference; costs ~5.6 ms of host time per layer at 256x550 and
-        # makes the step host-bound: 109 vs 32 ms at BASELINE config 2)
+        # "reference" = the reference's stream - the masks torch.bernoulli(torch.Tensor(rows,H).fill_(1-p)) gives on the
+        # CPU generator, same seed -> bit-identical masks - drawn ON THE DEVICE from a mirror of that generator (round 5:
+        # _RefRng, csrc/pk_rng.hip); "reference_host" = the same stream by making the reference's own call on the host (a
+        # forward call ahead on a helper thread: ~40 ms per step at BASELINE config 2, host-bound)
         self.mask_rng = os.environ.get("PK_MASK_RNG", "device")
-        assert self.mask_rng in ("reference", "device"), self.mask_rng
+        assert self.mask_rng in ("reference", "reference_host", "device"), self.mask_rng
         # perf mode: weight-gradient GEMMs (dW, dU) of a recurrent layer / a Linear run on a second HIP stream, next to
         # the following layer's recurrent backward, and accumulate straight into the parameters' flat .grad buffer
         # (only for parameters owned by optim.FlatParams; see side_launch / join_side)
@@ -65,7 +66,7 @@ def set_precision(p):
 
 
 def set_mask_rng(m):
-    assert m in ("reference", "device"), m
+    assert m in ("reference", "reference_host", "device"), m
     settings.mask_rng = m
 
 
@@ -151,6 +152,87 @@ def set_forced_decisions(relu=None, pool=None):
     _Decisions.pool = None if pool is None else list(pool)
     _Decisions.report = []
     return _Decisions.report
+
+
+class _RefRng:
+    """PK_MASK_RNG=reference: the reference's drop-mask stream, drawn on the device (csrc/pk_rng.hip).  A mirror of torch's
+    default CPU generator (mt19937: 624 words, left, next) lives on the device and is advanced there, one launch per
+    mask; torch's own generator is brought up to date by sync_back() - run_nn_dp's end of chunk and
+    nn.drain_mask_prefetch() call it, and so does the next adopt() - so that whatever draws from it afterwards continues
+    the reference's stream.  Between two sync points the CPU generator lags behind: nothing in the engine's step draws
+    from it (batch padding uses python's random, nn.Dropout masks the device generator).  A re-seed or a foreign draw is
+    noticed at the next mask (the CPU state no longer equals the one the mirror descends from) and the mirror is rebuilt
+    from the CPU state."""
+    dev = None        # int32 [626] on the device: state words, left, next
+    base = None       # the CPU state (ByteTensor, 5056 bytes) the mirror descends from
+    ahead = False     # the mirror has drawn since `base`
+    WORDS, OFF_LEFT, OFF_NEXT, OFF_STATE = 624, 8, 16, 24
+
+    @classmethod
+    def _parse(cls, st):
+        import numpy as np
+        b = st.numpy().tobytes()
+        words = np.frombuffer(b, dtype="<u8", count=cls.WORDS, offset=cls.OFF_STATE).astype(np.uint32)
+        left = int(np.frombuffer(b, dtype="<i4", count=1, offset=cls.OFF_LEFT)[0])
+        nxt = int(np.frombuffer(b, dtype="<u8", count=1, offset=cls.OFF_NEXT)[0])
+        return np.concatenate([words, np.array([left, nxt], dtype=np.uint32)])
+
+    @classmethod
+    def _build(cls, base, mirror):
+        """base state bytes with the engine fields replaced by the mirror's [626] words"""
+        import numpy as np
+        b = bytearray(base.numpy().tobytes())
+        b[cls.OFF_STATE:cls.OFF_STATE + 8 * cls.WORDS] = mirror[:cls.WORDS].astype("<u8").tobytes()
+        b[cls.OFF_LEFT:cls.OFF_LEFT + 4] = np.array([int(mirror[cls.WORDS])], dtype="<i4").tobytes()
+        b[cls.OFF_NEXT:cls.OFF_NEXT + 8] = np.array([int(mirror[cls.WORDS + 1])], dtype="<u8").tobytes()
+        return torch.frombuffer(b, dtype=torch.uint8).clone()
+
+    @classmethod
+    def adopt(cls, device):
+        """Make the device mirror current: nothing to do while the CPU generator still holds the state it descends from."""
+        st = torch.get_rng_state()
+        if st.numel() != 5056:
+            raise _lib.PkError("PK_MASK_RNG=reference: torch's CPU generator state has %d bytes, not the 5056 of the "
+                               "mt19937 layout this build mirrors" % st.numel())
+        if cls.dev is not None and cls.dev.device == device and cls.base is not None and torch.equal(st, cls.base):
+            return
+        if cls.ahead:  # (somebody re-seeded or drew on the CPU while the mirror was ahead: the CPU state wins)
+            cls.ahead = False
+        cls.base = st.clone()
+        import numpy as np
+        cls.dev = torch.from_numpy(cls._parse(st).view(np.int32).copy()).to(device)
+        cls.ahead = False
+
+    @classmethod
+    def mask(cls, rows, H, p, device):
+        """torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p)) of the reference (its mask is unscaled), on the device."""
+        cls.adopt(device)
+        out = torch.empty(rows, H, device=device, dtype=torch.float32)
+        keep = float(torch.tensor(1 - p, dtype=torch.float32))  # fill_(1 - p): the float32 the reference compares with
+        lib = _lib.load()
+        _lib.check(lib.pk_mt19937_bernoulli(_stream(), ctypes.c_void_p(cls.dev.data_ptr()), rows * H, keep, _p(out)),
+                   "pk_mt19937_bernoulli")
+        cls.ahead = True
+        return out
+
+    @classmethod
+    def sync_back(cls):
+        """torch's CPU generator <- the mirror (one 2.5 KB read-back; waits for the draws enqueued so far)."""
+        if cls.dev is None or not cls.ahead:
+            return
+        import numpy as np
+        mirror = cls.dev.to("cpu").numpy().view(np.uint32)
+        if not torch.equal(torch.get_rng_state(), cls.base):
+            cls.ahead = False  # the CPU generator moved on by itself meanwhile: its state wins (see adopt)
+            return
+        new = cls._build(cls.base, mirror)
+        torch.set_rng_state(new)
+        cls.base = torch.get_rng_state().clone()
+        cls.ahead = False
+
+
+def ref_rng_mask(rows, H, p, device):
+    return _RefRng.mask(rows, H, p, device)
 
 
 class _Ahead:

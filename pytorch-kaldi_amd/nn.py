@@ -353,11 +353,14 @@ class _MaskPrefetcher:
 
 
 def drain_mask_prefetch():
-    """Un-draw every mask drawn ahead of time (PK_MASK_RNG=reference) and forget the prefetchers: call before
-    torch.manual_seed / before reading the CPU generator's state (core.run_nn_dp does, at both ends of a chunk)."""
+    """Bring torch's CPU generator to where the reference's would be: un-draw every mask the host helper drew ahead of
+    time (PK_MASK_RNG=reference_host) and forget the prefetchers; write the device mirror's state back
+    (PK_MASK_RNG=reference).  Call before torch.manual_seed / before reading the CPU generator's state (core.run_nn_dp
+    does, at both ends of a chunk)."""
     for pf in list(_MaskPrefetcher.live):
         pf.drain()
     _MaskPrefetcher.live = weakref.WeakSet()
+    F_._RefRng.sync_back()
 
 
 class _Recurrent(nn.Module):
@@ -448,6 +451,9 @@ class _Recurrent(nn.Module):
                         self._mask_all = None
                     return m_all[i], 1.0
             return torch.empty(rows, H, device=device).bernoulli_(1 - p), 1.0
+        if F_.settings.mask_rng == "reference":
+            # the reference's stream from the device mirror of its generator: bit-identical masks, no host work
+            return F_.ref_rng_mask(rows, self._lay[i], p, device), 1.0
         if getattr(self, "_prefetch", None) is None or self._prefetch not in _MaskPrefetcher.live:
             self._prefetch = _MaskPrefetcher()
         m = self._prefetch.get(i, self._n_lay, rows, self._lay[i], p)  # the reference's own call, a forward call ahead

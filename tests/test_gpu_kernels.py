@@ -179,6 +179,39 @@ def test_layernorm(rows, F):
         assert rel_err(a.grad, r.grad) < 1e-5
 
 
+@pytest.mark.parametrize("seed", [1, 4234])
+def test_reference_mask_stream_on_the_device(seed):
+    """PK_MASK_RNG=reference (functional._RefRng, pk_mt19937_bernoulli): the masks the reference draws with
+    torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p)) on the global CPU generator (neural_networks.py:1102-1107), layer
+    after layer, call after call - bit-identical from the device mirror of that generator, and the CPU generator
+    bit-identical afterwards (so that whatever draws next continues the reference's stream).  Also: a re-seed between
+    two masks is noticed; a generator that has drawn before (left != 1) is mirrored mid-block."""
+    dev = torch.device("cuda")
+    shapes = [(256, 550, 0.2), (256, 550, 0.2), (10, 7, 0.5), (3, 1100, 0.25), (1, 1, 0.1), (256, 550, 0.2)]
+    torch.manual_seed(seed)
+    torch.rand(37)  # (the generator is mid-block when the first mask is asked for)
+    ref = [torch.bernoulli(torch.Tensor(r, h).fill_(1 - p)) for r, h, p in shapes]
+    after_ref = torch.get_rng_state().clone()
+    nxt_ref = torch.rand(5)
+    torch.manual_seed(seed)
+    torch.rand(37)
+    F_._RefRng.dev = None
+    got = [F_.ref_rng_mask(r, h, p, dev) for r, h, p in shapes]
+    torch.cuda.synchronize()
+    F_._RefRng.sync_back()
+    assert torch.equal(torch.get_rng_state(), after_ref)
+    assert torch.equal(torch.rand(5), nxt_ref)
+    for m, r in zip(got, ref):
+        assert torch.equal(m.cpu(), r)
+    # a re-seed between two masks: the mirror follows the CPU generator
+    F_.ref_rng_mask(4, 4, 0.5, dev)
+    torch.manual_seed(seed + 1)
+    r2 = torch.bernoulli(torch.Tensor(20, 30).fill_(0.7))
+    torch.manual_seed(seed + 1)
+    assert torch.equal(F_.ref_rng_mask(20, 30, 0.3, dev).cpu(), r2)
+    F_._RefRng.sync_back()
+
+
 @pytest.mark.parametrize("N,K", [(128, 129), (80, 251), (7, 3), (16, 33)])
 def test_sinc_bank_in_one_launch(N, K):
     """pk_sinc_bank_fwd / _bwd (SincConv.forward up to self.filters, neural_networks.py:1789-1800): the module's bank

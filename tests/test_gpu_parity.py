@@ -815,3 +815,36 @@ def test_small_batch_mlp_step_direct_gradients(monkeypatch):
                 continue
             got = results["direct"][step][k]
             assert rel_err(got, ref) < 4e-3, (step, k, rel_err(got, ref))
+
+
+@pytest.mark.gpu
+def test_reference_mask_stream_device_equals_host_call():
+    """PK_MASK_RNG=reference (masks from the device mirror of torch's CPU generator) against reference_host (the reference's
+    own torch.bernoulli call on the host, neural_networks.py:1102-1107): same seed -> the same three-layer Li-GRU outputs,
+    bit for bit, over two consecutive forward calls, and the CPU generator ends in the same state."""
+    from engine_util import F_amd, nn_amd
+
+    opts = {"ligru_lay": "48,48,48", "ligru_drop": "0.2,0.3,0.2", "ligru_use_laynorm_inp": "False", "ligru_use_batchnorm_inp": "False",
+            "ligru_use_laynorm": "False,False,False", "ligru_use_batchnorm": "True,True,True", "ligru_bidir": "True",
+            "ligru_act": "relu,relu,relu", "ligru_orthinit": "True", "use_cuda": "True", "to_do": "train"}
+    x = torch.randn(20, 6, 13, generator=torch.Generator().manual_seed(2)).cuda()
+    old = F_amd.settings.mask_rng
+    res = {}
+    try:
+        for mode in ("reference_host", "reference"):
+            F_amd.set_mask_rng(mode)
+            torch.manual_seed(11)
+            net = nn_amd.liGRU(opts, 13).cuda().train()
+            torch.manual_seed(99)
+            with torch.no_grad():
+                ys = [net(x).clone(), net(x).clone()]
+            torch.cuda.synchronize()
+            nn_amd.drain_mask_prefetch()
+            res[mode] = (ys, torch.get_rng_state().clone())
+    finally:
+        F_amd.set_mask_rng(old)
+        nn_amd.drain_mask_prefetch()
+    for a, b in zip(res["reference"][0], res["reference_host"][0]):
+        assert torch.equal(a, b)
+    assert not torch.equal(res["reference"][0][0], res["reference"][0][1])  # (the second call drew new masks)
+    assert torch.equal(res["reference"][1], res["reference_host"][1])

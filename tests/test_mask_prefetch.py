@@ -1,4 +1,4 @@
-"""PK_MASK_RNG=reference with the draws off the critical path (pytorch-kaldi_amd/nn.py::_MaskPrefetcher): the helper thread
+"""PK_MASK_RNG=reference_host (the host-side form of the reference stream; PK_MASK_RNG=reference draws it on the device since round 5: tests/test_gpu_kernels.py::test_reference_mask_stream_on_the_device) with the draws off the critical path (pytorch-kaldi_amd/nn.py::_MaskPrefetcher): the helper thread
 draws the NEXT forward call's recurrent drop masks with the reference's own call (neural_networks.py:1102-1107:
 torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p)) on the global CPU generator) - the masks handed out, and the
 generator state left behind, must be exactly what drawing them on the spot gives, whatever the shapes do."""

@@ -166,6 +166,7 @@ class _RefRng:
     dev = None        # int32 [626] on the device: state words, left, next
     base = None       # the CPU state (ByteTensor, 5056 bytes) the mirror descends from
     ahead = False     # the mirror has drawn since `base`
+    stream = None     # every draw runs on this stream (the mirror's only user): a 140 800-element mask is ~0.3 ms of ONE CU
     WORDS, OFF_LEFT, OFF_NEXT, OFF_STATE = 624, 8, 16, 24
 
     @classmethod
@@ -190,6 +191,7 @@ class _RefRng:
     @classmethod
     def adopt(cls, device):
         """Make the device mirror current: nothing to do while the CPU generator still holds the state it descends from."""
+        device = torch.empty(0, device=device).device  # ("cuda" -> "cuda:0": the mirror is compared by its tensor's device)
         st = torch.get_rng_state()
         if st.numel() != 5056:
             raise _lib.PkError("PK_MASK_RNG=reference: torch's CPU generator state has %d bytes, not the 5056 of the "
@@ -204,16 +206,41 @@ class _RefRng:
         cls.ahead = False
 
     @classmethod
-    def mask(cls, rows, H, p, device):
-        """torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p)) of the reference (its mask is unscaled), on the device."""
+    def masks(cls, shapes, device):
+        """[(rows, H, p)] -> [(mask, event)]: the masks the reference's torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p))
+        calls would give, in that order (its masks are unscaled), drawn on the mirror's own stream - a stack's masks are
+        launched together at its first layer and each layer waits for its own only (mask_ready)."""
         cls.adopt(device)
-        out = torch.empty(rows, H, device=device, dtype=torch.float32)
-        keep = float(torch.tensor(1 - p, dtype=torch.float32))  # fill_(1 - p): the float32 the reference compares with
         lib = _lib.load()
-        _lib.check(lib.pk_mt19937_bernoulli(_stream(), ctypes.c_void_p(cls.dev.data_ptr()), rows * H, keep, _p(out)),
-                   "pk_mt19937_bernoulli")
+        if cls.stream is None or cls.stream.device != cls.dev.device:
+            cls.stream = torch.cuda.Stream(device=cls.dev.device)
+        main = torch.cuda.current_stream()
+        cls.stream.wait_stream(main)  # (the mirror may just have been uploaded on the main stream)
+        out = []
+        with torch.cuda.stream(cls.stream):
+            for rows, H, p in shapes:
+                m = torch.empty(rows, H, device=cls.dev.device, dtype=torch.float32)
+                keep = float(torch.tensor(1 - p, dtype=torch.float32))  # fill_(1 - p): the float32 the reference compares with
+                _lib.check(lib.pk_mt19937_bernoulli(_stream(), ctypes.c_void_p(cls.dev.data_ptr()), rows * H, keep, _p(m)),
+                           "pk_mt19937_bernoulli")
+                ev = torch.cuda.Event()
+                ev.record()
+                out.append((m, ev))
         cls.ahead = True
         return out
+
+    @staticmethod
+    def mask_ready(entry):
+        """The current stream may use this mask from here on."""
+        m, ev = entry
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        m.record_stream(cur)
+        return m
+
+    @classmethod
+    def mask(cls, rows, H, p, device):
+        return cls.mask_ready(cls.masks([(rows, H, p)], device)[0])
 
     @classmethod
     def sync_back(cls):
@@ -221,6 +248,8 @@ class _RefRng:
         if cls.dev is None or not cls.ahead:
             return
         import numpy as np
+        if cls.stream is not None:
+            torch.cuda.current_stream().wait_stream(cls.stream)
         mirror = cls.dev.to("cpu").numpy().view(np.uint32)
         if not torch.equal(torch.get_rng_state(), cls.base):
             cls.ahead = False  # the CPU generator moved on by itself meanwhile: its state wins (see adopt)

@@ -452,8 +452,19 @@ class _Recurrent(nn.Module):
                     return m_all[i], 1.0
             return torch.empty(rows, H, device=device).bernoulli_(1 - p), 1.0
         if F_.settings.mask_rng == "reference":
-            # the reference's stream from the device mirror of its generator: bit-identical masks, no host work
-            return F_.ref_rng_mask(rows, self._lay[i], p, device), 1.0
+            # the reference's stream from the device mirror of its generator: bit-identical masks, no host work.  The
+            # masks of the whole stack are launched at layer 0 (on the mirror's stream, one CU); a layer waits for its own
+            if i == 0:
+                self._ref_masks = [(rows, device)] + F_._RefRng.masks(
+                    [(rows, self._lay[j], self._drop[j]) for j in range(self._n_lay)], device)
+            pend = getattr(self, "_ref_masks", None)
+            if pend is None or pend[0] != (rows, device) or pend[1 + i] is None:
+                # (a layer asked on its own: drawn on the spot - the stream still follows the order of the CALLS)
+                return F_.ref_rng_mask(rows, self._lay[i], p, device), 1.0
+            entry, pend[1 + i] = pend[1 + i], None
+            if i == self._n_lay - 1:
+                self._ref_masks = None
+            return F_._RefRng.mask_ready(entry), 1.0
         if getattr(self, "_prefetch", None) is None or self._prefetch not in _MaskPrefetcher.live:
             self._prefetch = _MaskPrefetcher()
         m = self._prefetch.get(i, self._n_lay, rows, self._lay[i], p)  # the reference's own call, a forward call ahead

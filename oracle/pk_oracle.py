@@ -619,3 +619,59 @@ def recipe_forward(model, options, arch_dict, sds, inp, fea_dict, lab_dict, rec_
         else:
             raise ValueError("unknown [model] operation " + op)
     return outs
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The reference's drop-mask STREAM at the level of the generator (what PK_MASK_RNG=reference must reproduce on the device).
+#
+# neural_networks.py:1102-1107 (and :430-441, :604-615, :1263-1268, :1416-1421) draws a layer's mask with
+# torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p)) on torch's global CPU generator.  That algorithm is not in the
+# reference checkout: it lives in its dependency PyTorch (here 2.10.0: at::CPUGeneratorImpl over at::mt19937, the
+# published MT19937 of Matsumoto & Nishimura with a 624-word state refilled block by block; bernoulli_(Tensor p) on the
+# CPU is a serial loop taking one 32-bit output y per element, u = (y & (2^24 - 1)) * 2^-24, mask = u < p).  Restated
+# below in numpy; PINNED in tests/test_ref_mask_stream_host.py against torch itself run in the test (masks AND the
+# generator state afterwards), so a torch build with another layout or sampling rule fails there, not silently.
+def mt19937_refill_np(words):
+    """One block refill of at::mt19937 (next_state): 624 new words from 624 old ones."""
+    import numpy as np
+    N, M = 624, 397
+    p = np.asarray(words, dtype=np.uint32)
+    q = np.empty(N, dtype=np.uint32)
+
+    def twist(u, v):
+        y = (u & np.uint32(0x80000000)) | (v & np.uint32(0x7FFFFFFF))
+        return (y >> np.uint32(1)) ^ np.where(v & np.uint32(1), np.uint32(0x9908B0DF), np.uint32(0))
+    q[:N - M] = p[M:] ^ twist(p[:N - M], p[1:N - M + 1])                       # j <  227: uses old words only
+    for lo in range(N - M, N - 1, N - M):                                      # then 227 at a time on the new ones
+        hi = min(lo + (N - M), N - 1)
+        q[lo:hi] = q[lo - (N - M):hi - (N - M)] ^ twist(p[lo:hi], p[lo + 1:hi + 1])
+    q[N - 1] = q[M - 1] ^ twist(p[N - 1:N], q[0:1])[0]
+    return q
+
+
+def mt19937_bernoulli_np(state626, n, keep):
+    """state626: uint32 [626] = the engine's 624 words, `left`, `next` (the fields of at::mt19937's data).  Returns
+    (mask float32 [n], new state626): element i is 1 if the i-th draw's uniform < keep (a float32) else 0."""
+    import numpy as np
+    st = np.asarray(state626, dtype=np.uint32).copy()
+    words, left, nxt = st[:624].copy(), int(st[624]), int(st[625])
+    keep = np.float32(keep)
+    out = np.empty(n, dtype=np.float32)
+    i = 0
+    while i < n:
+        left -= 1
+        if left == 0:
+            words = mt19937_refill_np(words)
+            left, nxt = 624, 0
+        take = min(n - i, left)
+        y = words[nxt:nxt + take].copy()
+        y ^= y >> np.uint32(11)
+        y ^= (y << np.uint32(7)) & np.uint32(0x9D2C5680)
+        y ^= (y << np.uint32(15)) & np.uint32(0xEFC60000)
+        y ^= y >> np.uint32(18)
+        u = (y & np.uint32(0xFFFFFF)).astype(np.float32) * np.float32(2.0 ** -24)
+        out[i:i + take] = (u < keep).astype(np.float32)
+        i += take
+        nxt += take
+        left -= take - 1
+    return out, np.concatenate([words, np.array([left, nxt], dtype=np.uint32)])

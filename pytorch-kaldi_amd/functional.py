@@ -202,7 +202,10 @@ class _RefRng:
             cls.ahead = False
         cls.base = st.clone()
         import numpy as np
-        cls.dev = torch.from_numpy(cls._parse(st).view(np.int32).copy()).to(device)
+        if cls.stream is None or cls.stream.device != device:
+            cls.stream = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(cls.stream):  # (the mirror lives on its own stream: uploaded, advanced and freed there)
+            cls.dev = torch.from_numpy(cls._parse(st).view(np.int32).copy()).to(device)
         cls.ahead = False
 
     @classmethod
@@ -212,10 +215,8 @@ class _RefRng:
         launched together at its first layer and each layer waits for its own only (mask_ready)."""
         cls.adopt(device)
         lib = _lib.load()
-        if cls.stream is None or cls.stream.device != cls.dev.device:
-            cls.stream = torch.cuda.Stream(device=cls.dev.device)
-        main = torch.cuda.current_stream()
-        cls.stream.wait_stream(main)  # (the mirror may just have been uploaded on the main stream)
+        # no wait for the caller's stream: the stream depends on the generator only, so the masks of step s + 1 run
+        # next to whatever the GPU is still doing for step s (the host is ahead of the GPU in a training loop)
         out = []
         with torch.cuda.stream(cls.stream):
             for rows, H, p in shapes:

@@ -30,12 +30,13 @@ class _Settings:
     def __init__(self):
         self.precision = os.environ.get("PK_PRECISION", "fp32")
         self.rec_algo = os.environ.get("PK_REC_ALGO", "auto")
-        # recurrent drop masks: "device" (default) = Bernoulli(1-p) drawn on the GPU RNG, no host work in the step;
-        # "reference" = the reference's stream - the masks torch.bernoulli(torch.Tensor(rows,H).fill_(1-p)) gives on the
-        # CPU generator, same seed -> bit-identical masks - drawn ON THE DEVICE from a mirror of that generator (round 5:
-        # _RefRng, csrc/pk_rng.hip); "reference_host" = the same stream by making the reference's own call on the host (a
-        # forward call ahead on a helper thread: ~40 ms per step at BASELINE config 2, host-bound)
-        self.mask_rng = os.environ.get("PK_MASK_RNG", "device")
+        # recurrent drop masks: "reference" (default since round 5) = the reference's STREAM - the masks
+        # torch.bernoulli(torch.Tensor(rows,H).fill_(1-p)) gives on the CPU generator, same seed -> bit-identical masks -
+        # drawn ON THE DEVICE from a mirror of that generator (_RefRng, csrc/pk_rng.hip; no measurable cost next to the
+        # device RNG); "device" = Bernoulli(1-p) on the GPU RNG (the reference's distribution, not its stream);
+        # "reference_host" = the stream by making the reference's own call on the host (a forward call ahead on a helper
+        # thread: ~40 ms per step at BASELINE config 2, host-bound)
+        self.mask_rng = os.environ.get("PK_MASK_RNG", "reference")
         assert self.mask_rng in ("reference", "reference_host", "device"), self.mask_rng
         # perf mode: weight-gradient GEMMs (dW, dU) of a recurrent layer / a Linear run on a second HIP stream, next to
         # the following layer's recurrent backward, and accumulate straight into the parameters' flat .grad buffer

@@ -429,10 +429,10 @@ class _Recurrent(nn.Module):
 
     def _drop_mask(self, i, batch, device):
         """Bernoulli(1-p) mask (rows, H) of layer i, unscaled and constant over time (:1102-1107), or
-        (None, 1-p) in test mode.  Drawn lazily, layer by layer in layer order like the reference does,
-        so that the host-side draw of layer i+1 overlaps the GPU work of layer i.
-        settings.mask_rng = "reference": the reference's own call on the CPU RNG (same seed -> same
-        masks), then copied to the GPU; "device": drawn on the GPU RNG (no host work, no H2D copy)."""
+        (None, 1-p) in test mode, in layer order like the reference draws them.
+        settings.mask_rng = "reference" (default): the reference's stream - what its own call on the CPU
+        generator would give for the same seed - from the device mirror of that generator; "device": the GPU
+        RNG; "reference_host": the reference's own call on the host, a forward call ahead, then copied over."""
         p = self._drop[i]
         if self.test_flag:
             return None, 1.0 - p

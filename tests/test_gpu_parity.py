@@ -848,3 +848,38 @@ def test_reference_mask_stream_device_equals_host_call():
         assert torch.equal(a, b)
     assert not torch.equal(res["reference"][0][0], res["reference"][0][1])  # (the second call drew new masks)
     assert torch.equal(res["reference"][1], res["reference_host"][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,pre", [("liGRU", "ligru"), ("LSTM", "lstm"), ("GRU", "gru")])
+def test_default_masks_are_the_references_stream(kind, pre):
+    """The DEFAULT drop masks (nothing injected, PK_MASK_RNG unset): after torch.manual_seed(s) the engine's forward gives what
+    the oracle gives with the masks the reference's own call draws after torch.manual_seed(s) (neural_networks.py:1102-1107,
+    :430-441, :604-615) - in fp32 mode to 1e-4, over two consecutive forward calls (the stream goes on, it does not restart)."""
+    from engine_util import F_amd, nn_amd
+
+    assert F_amd.settings.mask_rng == "reference"
+    opts = _rec_opts(pre, [40, 40], "relu" if kind == "liGRU" else "tanh")
+    opts[pre + "_drop"] = "0.25,0.15"
+    T, B, D = 12, 5, 9
+    torch.manual_seed(3)
+    net = getattr(nn_amd, kind)(opts, D)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(T, B, D, generator=torch.Generator().manual_seed(8))
+    torch.manual_seed(4711)
+    want = []
+    for _ in range(2):
+        masks = O.make_drop_masks(kind, opts, B, "train")  # the reference's call on the global CPU generator
+        assert all(0.0 < float(m.mean()) < 1.0 for m in masks)
+        want.append(O.recurrent_forward(kind, opts, sd, x, training=True, to_do="train", drop_masks=masks))
+    after = torch.get_rng_state().clone()
+    net.cuda().train()
+    torch.manual_seed(4711)
+    with torch.no_grad():
+        got = [net(x.cuda()).clone() for _ in range(2)]
+    torch.cuda.synchronize()
+    nn_amd.drain_mask_prefetch()
+    for g_, w in zip(got, want):
+        assert rel_err(g_, w) < TOL
+    assert rel_err(got[0], want[1]) > 1e-2  # (other masks give another output: the comparison above is not vacuous)
+    assert torch.equal(torch.get_rng_state(), after)  # torch's CPU generator stands where the reference's would

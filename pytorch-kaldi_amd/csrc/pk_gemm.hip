@@ -34,9 +34,24 @@ struct GemmArgs {
     float* ws;      // split-K partials [splitk][M][N] or nullptr
     int k_per_split;  // multiple of BK
     int vecA, vecB;   // 16-B vector loads allowed for A / B
+    int gx, gy, items, per_xcd;  // tiles along n / m, tiles x splits, items per XCD (1-D launch, see work_item)
 };
 
 constexpr int BM = 128, BN = 128;
+
+// 1-D launch, XCD-aware: workgroup b runs on XCD b % 8, and each XCD has its own L2.  Items are numbered n-tile fastest,
+// then m-tile, then split, and every XCD takes a CONTIGUOUS range of them - so the workgroups that share an operand tile
+// (the n-tiles of one row block; all tiles of one split of a weight-gradient product, whose K range nobody else reads)
+// share it through one L2 instead of fetching it once per XCD: the k-major x k-major split-K products were reading their
+// operands up to nine times (2.3 ms for 155 GFLOP at 64 000 x 1100 x 1104).
+__device__ __forceinline__ bool work_item(const GemmArgs& p, int& m0, int& n0, int& split) {
+    const int item = p.per_xcd > 0 ? (blockIdx.x & 7) * p.per_xcd + (blockIdx.x >> 3) : (int)blockIdx.x;
+    if (item >= p.items) return false;
+    n0 = (item % p.gx) * BN;
+    m0 = ((item / p.gx) % p.gy) * BM;
+    split = item / (p.gx * p.gy);
+    return true;
+}
 
 // ---------------------------------------------------------------------------
 // global -> register staging of one operand tile (rows = m or n index, 128 of
@@ -178,8 +193,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int split = blockIdx.z;
+    int m0, n0, split;
+    if (!work_item(p, m0, n0, split)) return;
     const int kbeg = split * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
@@ -243,8 +258,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int split = blockIdx.z;
+    int m0, n0, split;
+    if (!work_item(p, m0, n0, split)) return;
     const int kbeg = split * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
@@ -358,7 +373,21 @@ extern "C" int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha,
         if (p.k_per_split == 0) p.k_per_split = BKmax;
     }
     p.ws = (splitk > 1) ? workspace : nullptr;
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splitk), block(256);
+    p.gx = (N + BN - 1) / BN;
+    p.gy = (M + BM - 1) / BM;
+    const long items = (long)p.gx * p.gy * splitk;
+    PK_REQUIRE(items < (1L << 30), "pk_gemm: %ld tiles", items);
+    p.items = (int)items;
+    p.per_xcd = (p.items + 7) / 8;
+    dim3 grid(p.per_xcd * 8), block(256);
+    {
+        static int flat = -1;  // PK_EXPERIMENT gemm_f32_flat=1: items in launch order (the mapping until round 5; A/B)
+        if (flat < 0) {
+            const char* e = pk_experiment("gemm_f32_flat");
+            flat = e ? atoi(e) : 0;
+        }
+        if (flat) p.per_xcd = 0;
+    }
 #define PK_LAUNCH_GEMM(KERN)                                                              \
     do {                                                                                  \
         if (a_kc && b_kc) hipLaunchKernelGGL((KERN<true, true>), grid, block, 0, st, p);   \

@@ -343,8 +343,10 @@ def _splitk(out_tiles, K):
     """Split the reduction when a GEMM has few output tiles and a long K (dW, dU)."""
     if K < 4096:
         return 1
-    ncu = 256
-    s = max(1, ncu // max(1, out_tiles))
+    # four 128 x 128 workgroups fit a CU (34 KB of LDS each) and one wave per SIMD hides nothing: fill 1024 slots, not 256
+    # (the 1100 x 1104 x 64 000 weight gradient ran as 243 workgroups - 3 splits - at 66 TFLOP/s)
+    slots = int(_lib.experiment("f32_splitk_slots", "1024"))
+    s = max(1, slots // max(1, out_tiles))
     return int(min(16, s, max(1, K // 1024)))
 
 

@@ -42,9 +42,9 @@ def parse():
     ap.add_argument("--prec", default=os.environ.get("PK_PRECISION", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--algo", default="auto", choices=["auto", "stepwise", "persistent"])
     ap.add_argument("--layers", type=int, default=None)
-    ap.add_argument("--mask-rng", default=os.environ.get("PK_MASK_RNG", "reference"), choices=["device", "reference", "reference_host"],
-                    help="recurrent drop masks: the reference's CPU torch.bernoulli stream drawn on the device (the library's "
-                         "default), the GPU RNG, or the reference's own call on the host")
+    ap.add_argument("--mask-rng", default=os.environ.get("PK_MASK_RNG", "device"), choices=["device", "reference", "reference_host"],
+                    help="recurrent drop masks: the GPU RNG (the library's default), the reference's CPU torch.bernoulli "
+                         "stream drawn on the device, or the reference's own call on the host")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="N > 1: reduce every gradient bucket after backward instead of behind the layer that produced it")
     ap.set_defaults(overlap=True)

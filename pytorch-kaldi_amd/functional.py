@@ -30,13 +30,14 @@ class _Settings:
     def __init__(self):
         self.precision = os.environ.get("PK_PRECISION", "fp32")
         self.rec_algo = os.environ.get("PK_REC_ALGO", "auto")
-        # recurrent drop masks: "reference" (default since round 5) = the reference's STREAM - the masks
+        # recurrent drop masks: "device" (default) = Bernoulli(1-p) drawn on the GPU RNG (the reference's distribution, not
+        # its stream), no host work in the step; "reference" = the reference's STREAM - the masks
         # torch.bernoulli(torch.Tensor(rows,H).fill_(1-p)) gives on the CPU generator, same seed -> bit-identical masks -
-        # drawn ON THE DEVICE from a mirror of that generator (_RefRng, csrc/pk_rng.hip; no measurable cost next to the
-        # device RNG); "device" = Bernoulli(1-p) on the GPU RNG (the reference's distribution, not its stream);
-        # "reference_host" = the stream by making the reference's own call on the host (a forward call ahead on a helper
-        # thread: ~40 ms per step at BASELINE config 2, host-bound)
-        self.mask_rng = os.environ.get("PK_MASK_RNG", "reference")
+        # drawn ON THE DEVICE from a mirror of that generator (round 5: _RefRng, csrc/pk_rng.hip; ~0.2 ms per 256 x 550
+        # mask, in line on the caller's stream - see _RefRng.masks for why not next to it); "reference_host" = the same
+        # stream by making the reference's own call on the host (a forward call ahead on a helper thread: ~40 ms per step
+        # at BASELINE config 2, host-bound)
+        self.mask_rng = os.environ.get("PK_MASK_RNG", "device")
         assert self.mask_rng in ("reference", "reference_host", "device"), self.mask_rng
         # perf mode: weight-gradient GEMMs (dW, dU) of a recurrent layer / a Linear run on a second HIP stream, next to
         # the following layer's recurrent backward, and accumulate straight into the parameters' flat .grad buffer
@@ -167,7 +168,7 @@ class _RefRng:
     dev = None        # int32 [626] on the device: state words, left, next
     base = None       # the CPU state (ByteTensor, 5056 bytes) the mirror descends from
     ahead = False     # the mirror has drawn since `base`
-    stream = None     # every draw runs on this stream (the mirror's only user): a 140 800-element mask is ~0.3 ms of ONE CU
+
     WORDS, OFF_LEFT, OFF_NEXT, OFF_STATE = 624, 8, 16, 24
 
     @classmethod
@@ -203,46 +204,32 @@ class _RefRng:
             cls.ahead = False
         cls.base = st.clone()
         import numpy as np
-        if cls.stream is None or cls.stream.device != device:
-            cls.stream = torch.cuda.Stream(device=device)
-        with torch.cuda.stream(cls.stream):  # (the mirror lives on its own stream: uploaded, advanced and freed there)
-            cls.dev = torch.from_numpy(cls._parse(st).view(np.int32).copy()).to(device)
+        cls.dev = torch.from_numpy(cls._parse(st).view(np.int32).copy()).to(device)
         cls.ahead = False
 
     @classmethod
     def masks(cls, shapes, device):
-        """[(rows, H, p)] -> [(mask, event)]: the masks the reference's torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p))
-        calls would give, in that order (its masks are unscaled), drawn on the mirror's own stream - a stack's masks are
-        launched together at its first layer and each layer waits for its own only (mask_ready)."""
+        """[(rows, H, p)] -> [mask]: the masks the reference's torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p)) calls would
+        give, in that order (its masks are unscaled).  Drawn IN LINE on the caller's stream (~0.2 ms each at 256 x 550, one
+        workgroup).  They were drawn on a stream of their own for a while (free on the Li-GRU step: the host is ahead of
+        the GPU, so the masks of step s + 1 ran next to the end of step s) - but a foreign workgroup next to the LSTM / GRU
+        persistent recurrences, which fill every CU, made whole regions of steps 5-15 x slower (DESIGN.md 12.8,
+        profiles/r05_ref_mask_stream.json): nothing may run beside a persistent recurrence that it was not built around."""
         cls.adopt(device)
         lib = _lib.load()
-        # no wait for the caller's stream: the stream depends on the generator only, so the masks of step s + 1 run
-        # next to whatever the GPU is still doing for step s (the host is ahead of the GPU in a training loop)
         out = []
-        with torch.cuda.stream(cls.stream):
-            for rows, H, p in shapes:
-                m = torch.empty(rows, H, device=cls.dev.device, dtype=torch.float32)
-                keep = float(torch.tensor(1 - p, dtype=torch.float32))  # fill_(1 - p): the float32 the reference compares with
-                _lib.check(lib.pk_mt19937_bernoulli(_stream(), ctypes.c_void_p(cls.dev.data_ptr()), rows * H, keep, _p(m)),
-                           "pk_mt19937_bernoulli")
-                ev = torch.cuda.Event()
-                ev.record()
-                out.append((m, ev))
+        for rows, H, p in shapes:
+            m = torch.empty(rows, H, device=cls.dev.device, dtype=torch.float32)
+            keep = float(torch.tensor(1 - p, dtype=torch.float32))  # fill_(1 - p): the float32 the reference compares with
+            _lib.check(lib.pk_mt19937_bernoulli(_stream(), ctypes.c_void_p(cls.dev.data_ptr()), rows * H, keep, _p(m)),
+                       "pk_mt19937_bernoulli")
+            out.append(m)
         cls.ahead = True
         return out
 
-    @staticmethod
-    def mask_ready(entry):
-        """The current stream may use this mask from here on."""
-        m, ev = entry
-        cur = torch.cuda.current_stream()
-        cur.wait_event(ev)
-        m.record_stream(cur)
-        return m
-
     @classmethod
     def mask(cls, rows, H, p, device):
-        return cls.mask_ready(cls.masks([(rows, H, p)], device)[0])
+        return cls.masks([(rows, H, p)], device)[0]
 
     @classmethod
     def sync_back(cls):
@@ -250,8 +237,6 @@ class _RefRng:
         if cls.dev is None or not cls.ahead:
             return
         import numpy as np
-        if cls.stream is not None:
-            torch.cuda.current_stream().wait_stream(cls.stream)
         mirror = cls.dev.to("cpu").numpy().view(np.uint32)
         if not torch.equal(torch.get_rng_state(), cls.base):
             cls.ahead = False  # the CPU generator moved on by itself meanwhile: its state wins (see adopt)

@@ -430,9 +430,9 @@ class _Recurrent(nn.Module):
     def _drop_mask(self, i, batch, device):
         """Bernoulli(1-p) mask (rows, H) of layer i, unscaled and constant over time (:1102-1107), or
         (None, 1-p) in test mode, in layer order like the reference draws them.
-        settings.mask_rng = "reference" (default): the reference's stream - what its own call on the CPU
-        generator would give for the same seed - from the device mirror of that generator; "device": the GPU
-        RNG; "reference_host": the reference's own call on the host, a forward call ahead, then copied over."""
+        settings.mask_rng = "device" (default): the GPU RNG; "reference": the reference's stream - what its
+        own call on the CPU generator would give for the same seed - from the device mirror of that generator;
+        "reference_host": the reference's own call on the host, a forward call ahead, then copied over."""
         p = self._drop[i]
         if self.test_flag:
             return None, 1.0 - p
@@ -453,7 +453,7 @@ class _Recurrent(nn.Module):
             return torch.empty(rows, H, device=device).bernoulli_(1 - p), 1.0
         if F_.settings.mask_rng == "reference":
             # the reference's stream from the device mirror of its generator: bit-identical masks, no host work.  The
-            # masks of the whole stack are launched at layer 0 (on the mirror's stream, one CU); a layer waits for its own
+            # masks of the whole stack are drawn at layer 0, in line
             if i == 0:
                 self._ref_masks = [(rows, device)] + F_._RefRng.masks(
                     [(rows, self._lay[j], self._drop[j]) for j in range(self._n_lay)], device)
@@ -464,7 +464,7 @@ class _Recurrent(nn.Module):
             entry, pend[1 + i] = pend[1 + i], None
             if i == self._n_lay - 1:
                 self._ref_masks = None
-            return F_._RefRng.mask_ready(entry), 1.0
+            return entry, 1.0
         if getattr(self, "_prefetch", None) is None or self._prefetch not in _MaskPrefetcher.live:
             self._prefetch = _MaskPrefetcher()
         m = self._prefetch.get(i, self._n_lay, rows, self._lay[i], p)  # the reference's own call, a forward call ahead

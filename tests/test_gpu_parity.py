@@ -852,13 +852,13 @@ def test_reference_mask_stream_device_equals_host_call():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,pre", [("liGRU", "ligru"), ("LSTM", "lstm"), ("GRU", "gru")])
-def test_default_masks_are_the_references_stream(kind, pre):
-    """The DEFAULT drop masks (nothing injected, PK_MASK_RNG unset): after torch.manual_seed(s) the engine's forward gives what
+def test_reference_masks_against_the_oracles_own_draws(kind, pre):
+    """PK_MASK_RNG=reference, nothing injected: after torch.manual_seed(s) the engine's forward gives what
     the oracle gives with the masks the reference's own call draws after torch.manual_seed(s) (neural_networks.py:1102-1107,
     :430-441, :604-615) - in fp32 mode to 1e-4, over two consecutive forward calls (the stream goes on, it does not restart)."""
     from engine_util import F_amd, nn_amd
 
-    assert F_amd.settings.mask_rng == "reference"
+    F_amd.set_mask_rng("reference")  # (restored by conftest's settings fixture)
     opts = _rec_opts(pre, [40, 40], "relu" if kind == "liGRU" else "tanh")
     opts[pre + "_drop"] = "0.25,0.15"
     T, B, D = 12, 5, 9

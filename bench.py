@@ -47,7 +47,7 @@ def parse():
                          "stream drawn on the device, or the reference's own call on the host")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="N > 1: reduce every gradient bucket after backward instead of behind the layer that produced it")
-    ap.set_defaults(overlap=True)
+    ap.set_defaults(overlap=None)  # (None: the library's rule, dp.overlap_default)
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim instead of the fused flat optimizers")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step as one HIP graph (auto: the launch-bound non-sequence recipes on one GPU)")
@@ -116,20 +116,24 @@ class Trainer:
             flats = {k: o.flat for k, o in self.opts.items()}
         # 8 MB buckets: the recurrent stack's 31.7 MB of gradients leave in 4 pieces while BPTT of the lower layers runs;
         # the launch-bound recipes (a step shorter than its own exchange): 4 MB buckets and the bf16 wire, as core.make_reducer
+        self.overlap = self.DP.overlap_default(self.nns) if args.overlap is None else bool(args.overlap)
         self.reducer = self.DP.GradReducer(self.nns, flats=flats, bucket_bytes=(8 << 20) if rcp["seq"] else (4 << 20),
-                                           overlap=args.overlap, force=bool(getattr(args, "force_reducer", False)),
+                                           overlap=self.overlap, force=bool(getattr(args, "force_reducer", False)),
                                            wire=os.environ.get("PK_DP_WIRE") or ("fp32" if rcp["seq"] else "bf16"))
         # one resident synthetic batch per rank (different seeds per rank = different shards)
         self.T, self.B = (args.T, args.B) if rcp["seq"] else (1, args.B)
         self.batches = [self.R.synthetic_batch(rcp, self.T, self.B, 4234 + 17 * rank + i, "cuda") for i in range(2)]
         self.n_params = sum(p.numel() for n in self.nns.values() for p in n.parameters())
         self.graphed = None
+        self.fence = self.F.StepFence()  # as core.run_nn_dp: eager steps, at most PK_STEPS_IN_FLIGHT ahead of the GPU
 
     def step(self, i):
         inp = self.batches[i % len(self.batches)]
         if self.graphed is not None:
             return self.graphed(inp)
-        return self.step_on(inp)
+        out = self.step_on(inp)
+        self.fence()
+        return out
 
     def enable_graph(self):
         """Launch-bound recipes: replay the whole step as one HIP graph (pytorch-kaldi_amd/graphs.py).  Call after
@@ -536,7 +540,7 @@ def measure(args, rank, world, steps, warmup):
         "config": {"workload": workload_name(args.recipe, tr),
                    "global_batch": tr.B * world, "seq_len": tr.T, "parallelism": "dp%d" % world,
                    "rec_algo": args.algo, "mask_rng": args.mask_rng,
-                   "allreduce": "overlapped" if args.overlap else "after-backward",
+                   "allreduce": "overlapped" if tr.overlap else "after-backward",
                    "optimizer": "torch" if args.torch_optim else "fused-flat", "hip_graph": bool(use_graph),
                    "params": tr.n_params},
         "loss_final": round(float(loss), 5),

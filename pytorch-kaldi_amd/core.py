@@ -174,7 +174,7 @@ def make_reducer(nns, optimizers, world, launch_bound=False, force=False):
     # bucket by bucket, behind the layer that produced it (PK_DP_OVERLAP=0: everything after backward)
     return _dp.GradReducer({k: nns[k] for k in nns}, flats={k: optimizers[k].flat for k in nns},
                            bucket_bytes=(4 << 20) if launch_bound else (8 << 20),
-                           overlap=os.environ.get("PK_DP_OVERLAP", "1") != "0", force=force,
+                           overlap=_dp.overlap_default(nns), force=force,
                            wire=os.environ.get("PK_DP_WIRE") or ("bf16" if launch_bound else "fp32"))
 
 
@@ -324,6 +324,7 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
     loss_sum = torch.zeros((), device=device)
     err_sum = torch.zeros((), device=device)
     snt_index, beg_snt = 0, 0
+    fence = F_.StepFence()  # eager steps: at most PK_STEPS_IN_FLIGHT of them enqueued ahead of the GPU
     for i in range(N_batches):
         max_len = 0
         if to_do == "forward":
@@ -355,6 +356,8 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
                     outs_dict = train_step(inp)
             else:
                 outs_dict = train_step(inp)
+            if graphed is None:
+                fence()
         else:
             with torch.no_grad():
                 outs_dict = forward_model(fea_dict, lab_dict, arch_dict, model, nns, costs, inp, inp_out_dict, max_len, nb,
@@ -369,7 +372,8 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
         else:
             loss_sum += outs_dict["loss_final"].detach()
             err_sum += outs_dict["err_final"].detach()
-    # the only host sync of the chunk (the reference syncs once per batch for its progress bar, core.py:689)
+    # the only full host sync of the chunk (the reference syncs once per batch for its progress bar, core.py:689; eager
+    # steps wait for the step four back - functional.StepFence)
     if to_do != "forward":
         loss_sum, err_sum = mean_over_ranks(loss_sum, err_sum, world)
     torch.cuda.synchronize()

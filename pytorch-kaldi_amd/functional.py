@@ -247,6 +247,33 @@ class _RefRng:
         cls.ahead = False
 
 
+class StepFence:
+    """A bound on how far the host may run AHEAD of the GPU in an eager training loop: call it once per step; it records
+    an event and waits for the one from `depth` steps ago (PK_STEPS_IN_FLIGHT, default 4; 0 = no bound).
+
+    Why: the engine hands big tensors to other streams (weight-gradient GEMMs, the L2 run-ahead helpers of the LSTM
+    recurrences) and marks them with record_stream - the caching allocator may reuse such a block only once the GPU has
+    passed that use.  A host that enqueues a 25-35 ms step in 4 ms gets dozens of steps ahead, every one of them holding
+    its own 7-9 GB of activations: the pool runs into the 288 GB, the allocator starts freeing and re-allocating device
+    memory (synchronous calls, seconds each) and single steps take 2-6 s (measured: tools/diag_slow_steps.py,
+    profiles/r05_host_lead.json).  The reference never gets there - it reads the loss back after every batch
+    (core.py:689).  Four steps in flight keep the GPU's queue full; the wait is on the host only."""
+
+    def __init__(self, depth=None):
+        import collections
+        self.depth = int(os.environ.get("PK_STEPS_IN_FLIGHT", "4")) if depth is None else int(depth)
+        self.q = collections.deque()
+
+    def __call__(self):
+        if self.depth <= 0 or not torch.cuda.is_available():
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self.q.append(ev)
+        if len(self.q) > self.depth:
+            self.q.popleft().synchronize()
+
+
 def ref_rng_mask(rows, H, p, device):
     return _RefRng.mask(rows, H, p, device)
 

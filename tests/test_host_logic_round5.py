@@ -95,3 +95,29 @@ def test_conv_bf16_default_is_shared_by_engine_and_model(monkeypatch):
     assert G.conv_bf16_on() is False
     monkeypatch.setenv("PK_CONV_BF16", "2")
     assert G.conv_bf16_on() == "all"
+
+
+def test_overlap_default_keeps_collectives_away_from_chip_filling_recurrences(monkeypatch):
+    """dp.overlap_default: gradient buckets leave behind their layer unless the model has LSTM / GRU layers, whose persistent
+    recurrences fill every CU (a foreign workgroup beside them made steps 5-15 x slower); PK_DP_OVERLAP
+    overrides either way."""
+    import importlib
+
+    import torch
+
+    dp = importlib.import_module("pytorch-kaldi_amd.dp")
+
+    class Rec(torch.nn.Module):
+        def __init__(self, kind):
+            super().__init__()
+            self.KIND = kind
+
+    monkeypatch.delenv("PK_DP_OVERLAP", raising=False)
+    lin = torch.nn.Sequential(torch.nn.Linear(2, 2))
+    assert dp.overlap_default({"a": lin}) is True
+    for kind, want in (("liGRU", True), ("minimalGRU", True), ("RNN", True), ("LSTM", False), ("GRU", False)):
+        assert dp.overlap_default({"a": lin, "b": torch.nn.Sequential(Rec(kind))}) is want, kind
+    monkeypatch.setenv("PK_DP_OVERLAP", "1")
+    assert dp.overlap_default({"b": Rec("GRU")}) is True
+    monkeypatch.setenv("PK_DP_OVERLAP", "0")
+    assert dp.overlap_default({"a": lin}) is False

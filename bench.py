@@ -47,7 +47,7 @@ def parse():
                          "stream drawn on the device, or the reference's own call on the host")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false",
                     help="N > 1: reduce every gradient bucket after backward instead of behind the layer that produced it")
-    ap.set_defaults(overlap=None)  # (None: the library's rule, dp.overlap_default)
+    ap.set_defaults(overlap=True)
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim instead of the fused flat optimizers")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the step as one HIP graph (auto: the launch-bound non-sequence recipes on one GPU)")
@@ -116,7 +116,7 @@ class Trainer:
             flats = {k: o.flat for k, o in self.opts.items()}
         # 8 MB buckets: the recurrent stack's 31.7 MB of gradients leave in 4 pieces while BPTT of the lower layers runs;
         # the launch-bound recipes (a step shorter than its own exchange): 4 MB buckets and the bf16 wire, as core.make_reducer
-        self.overlap = self.DP.overlap_default(self.nns) if args.overlap is None else bool(args.overlap)
+        self.overlap = bool(args.overlap)
         self.reducer = self.DP.GradReducer(self.nns, flats=flats, bucket_bytes=(8 << 20) if rcp["seq"] else (4 << 20),
                                            overlap=self.overlap, force=bool(getattr(args, "force_reducer", False)),
                                            wire=os.environ.get("PK_DP_WIRE") or ("fp32" if rcp["seq"] else "bf16"))

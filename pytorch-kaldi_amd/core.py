@@ -174,7 +174,7 @@ def make_reducer(nns, optimizers, world, launch_bound=False, force=False):
     # bucket by bucket, behind the layer that produced it (PK_DP_OVERLAP=0: everything after backward)
     return _dp.GradReducer({k: nns[k] for k in nns}, flats={k: optimizers[k].flat for k in nns},
                            bucket_bytes=(4 << 20) if launch_bound else (8 << 20),
-                           overlap=_dp.overlap_default(nns), force=force,
+                           overlap=os.environ.get("PK_DP_OVERLAP", "1") != "0", force=force,
                            wire=os.environ.get("PK_DP_WIRE") or ("bf16" if launch_bound else "fp32"))
 
 

@@ -52,20 +52,6 @@ def shard_batch(inp, rank, world):
     return inp.narrow(dim, rank * per, per)
 
 
-def overlap_default(nns):
-    """Whether gradient buckets leave behind the layer that produced them (True) or after backward (False) when
-    PK_DP_OVERLAP does not say.  The persistent recurrences of LSTM (with its L2 run-ahead helpers) and GRU fill every CU,
-    and a foreign workgroup next to them - which is what an RCCL kernel on the side stream is - made whole regions of steps
-    5-15 x slower in round 5 (one mask-drawing workgroup was enough: DESIGN.md 12.8); their 29-31 MB of gradients are
-    ~0.5 ms on the ring behind a 23-35 ms step, so those recipes reduce after backward.  Li-GRU / minimalGRU / RNN launches
-    leave 112 CUs idle and keep the overlap (tests/test_gpu_dp_two_ranks.py runs foreign kernels beside them)."""
-    env = os.environ.get("PK_DP_OVERLAP")
-    if env is not None:
-        return env != "0"
-    kinds = {getattr(m, "KIND", None) for net in nns.values() for m in net.modules()}
-    return not (kinds & {"LSTM", "GRU"})
-
-
 class GradReducer:
     """Average gradients across ranks, overlapping the all-reduce with backward.
 

@@ -34,7 +34,7 @@ class _Settings:
         # its stream), no host work in the step; "reference" = the reference's STREAM - the masks
         # torch.bernoulli(torch.Tensor(rows,H).fill_(1-p)) gives on the CPU generator, same seed -> bit-identical masks -
         # drawn ON THE DEVICE from a mirror of that generator (round 5: _RefRng, csrc/pk_rng.hip; ~0.2 ms per 256 x 550
-        # mask, in line on the caller's stream - see _RefRng.masks for why not next to it); "reference_host" = the same
+        # mask, in line on the caller's stream); "reference_host" = the same
         # stream by making the reference's own call on the host (a forward call ahead on a helper thread: ~40 ms per step
         # at BASELINE config 2, host-bound)
         self.mask_rng = os.environ.get("PK_MASK_RNG", "device")
@@ -210,11 +210,8 @@ class _RefRng:
     @classmethod
     def masks(cls, shapes, device):
         """[(rows, H, p)] -> [mask]: the masks the reference's torch.bernoulli(torch.Tensor(rows, H).fill_(1 - p)) calls would
-        give, in that order (its masks are unscaled).  Drawn IN LINE on the caller's stream (~0.2 ms each at 256 x 550, one
-        workgroup).  They were drawn on a stream of their own for a while (free on the Li-GRU step: the host is ahead of
-        the GPU, so the masks of step s + 1 ran next to the end of step s) - but a foreign workgroup next to the LSTM / GRU
-        persistent recurrences, which fill every CU, made whole regions of steps 5-15 x slower (DESIGN.md 12.8,
-        profiles/r05_ref_mask_stream.json): nothing may run beside a persistent recurrence that it was not built around."""
+        give, in that order (its masks are unscaled).  Drawn in line on the caller's stream (~0.2 ms each at 256 x 550, one
+        workgroup; DESIGN.md 12.8 has the history of a form that drew them on a stream of their own)."""
         cls.adopt(device)
         lib = _lib.load()
         out = []

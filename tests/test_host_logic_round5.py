@@ -97,27 +97,44 @@ def test_conv_bf16_default_is_shared_by_engine_and_model(monkeypatch):
     assert G.conv_bf16_on() == "all"
 
 
-def test_overlap_default_keeps_collectives_away_from_chip_filling_recurrences(monkeypatch):
-    """dp.overlap_default: gradient buckets leave behind their layer unless the model has LSTM / GRU layers, whose persistent
-    recurrences fill every CU (a foreign workgroup beside them made steps 5-15 x slower); PK_DP_OVERLAP
-    overrides either way."""
+def test_step_fence_waits_for_the_step_depth_back(monkeypatch):
+    """functional.StepFence: one event per step, the host waits for the event `depth` steps back and for nothing else
+    (an unbounded lead of the host filled the HBM with record_stream'd activations: DESIGN.md 12.8)."""
     import importlib
 
     import torch
 
-    dp = importlib.import_module("pytorch-kaldi_amd.dp")
+    F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+    log = []
 
-    class Rec(torch.nn.Module):
-        def __init__(self, kind):
-            super().__init__()
-            self.KIND = kind
+    class Ev:
+        n = 0
 
-    monkeypatch.delenv("PK_DP_OVERLAP", raising=False)
-    lin = torch.nn.Sequential(torch.nn.Linear(2, 2))
-    assert dp.overlap_default({"a": lin}) is True
-    for kind, want in (("liGRU", True), ("minimalGRU", True), ("RNN", True), ("LSTM", False), ("GRU", False)):
-        assert dp.overlap_default({"a": lin, "b": torch.nn.Sequential(Rec(kind))}) is want, kind
-    monkeypatch.setenv("PK_DP_OVERLAP", "1")
-    assert dp.overlap_default({"b": Rec("GRU")}) is True
-    monkeypatch.setenv("PK_DP_OVERLAP", "0")
-    assert dp.overlap_default({"a": lin}) is False
+        def __init__(self):
+            self.k = Ev.n
+            Ev.n += 1
+
+        def record(self):
+            log.append(("record", self.k))
+
+        def synchronize(self):
+            log.append(("wait", self.k))
+
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "Event", Ev)
+    monkeypatch.delenv("PK_STEPS_IN_FLIGHT", raising=False)
+    f = F_.StepFence()
+    assert f.depth == 4
+    for _ in range(7):
+        f()
+    assert [e for e in log if e[0] == "wait"] == [("wait", 0), ("wait", 1), ("wait", 2)]
+    assert log.index(("wait", 0)) > log.index(("record", 4))  # (step 5 waits for step 1: four steps stay in flight)
+    log.clear()
+    monkeypatch.setenv("PK_STEPS_IN_FLIGHT", "0")
+    g = F_.StepFence()
+    for _ in range(5):
+        g()
+    assert log == []
+    h = F_.StepFence(depth=1)
+    h(); h(); h()
+    assert [e for e in log if e[0] == "wait"] == [("wait", Ev.n - 3), ("wait", Ev.n - 2)]

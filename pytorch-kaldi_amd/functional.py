@@ -248,9 +248,8 @@ class StepFence:
     """A bound on how far the host may run AHEAD of the GPU in an eager training loop: call it once per step; it records
     an event and waits for the one from `depth` steps ago (PK_STEPS_IN_FLIGHT, default 4; 0 = no bound).
 
-    Why: the engine hands big tensors to other streams (weight-gradient GEMMs, the L2 run-ahead helpers of the LSTM
-    recurrences) and marks them with record_stream - the caching allocator may reuse such a block only once the GPU has
-    passed that use.  A host that enqueues a 25-35 ms step in 4 ms gets dozens of steps ahead, every one of them holding
+    Why: the engine hands big tensors to another stream (the operands of the weight-gradient GEMMs: side_launch) and marks
+    them with record_stream - the caching allocator may reuse such a block only once the GPU has passed that use.  A host that enqueues a 25-35 ms step in 4 ms gets dozens of steps ahead, every one of them holding
     its own 7-9 GB of activations: the pool runs into the 288 GB, the allocator starts freeing and re-allocating device
     memory (synchronous calls, seconds each) and single steps take 2-6 s (measured: tools/diag_slow_steps.py,
     profiles/r05_host_lead.json).  The reference never gets there - it reads the loss back after every batch

@@ -200,6 +200,11 @@ class _RefRng:
                                "mt19937 layout this build mirrors" % st.numel())
         if cls.dev is not None and cls.dev.device == device and cls.base is not None and torch.equal(st, cls.base):
             return
+        if cls.ahead and cls.dev is not None and cls.base is not None and torch.equal(st, cls.base):
+            # (another device asks while the mirror is ahead of an untouched CPU generator: its draws are part of the
+            # stream - write them back first, then the new device's mirror descends from that state)
+            cls.sync_back()
+            st = torch.get_rng_state()
         if cls.ahead:  # (somebody re-seeded or drew on the CPU while the mirror was ahead: the CPU state wins)
             cls.ahead = False
         cls.base = st.clone()

@@ -56,3 +56,53 @@ def test_state_layout_round_trip():
     torch.manual_seed(4357)
     w = F_._RefRng._parse(torch.get_rng_state())
     assert int(w[0]) == 4357 and int(w[624]) == 1 and int(w[625]) == 0
+
+
+def _advance_mirror(n, keep):
+    """What pk_mt19937_bernoulli does to the mirror, by the oracle's numpy engine (the mirror lives on the CPU here)."""
+    R = F_._RefRng
+    m, st = O.mt19937_bernoulli_np(R.dev.numpy().view(np.uint32), n, keep)
+    R.dev.copy_(torch.from_numpy(st.view(np.int32).copy()))
+    R.ahead = True
+    return m
+
+
+def _reset_mirror():
+    R = F_._RefRng
+    R.dev, R.base, R.ahead = None, None, False
+
+
+def test_mirror_bookkeeping_adopt_advance_write_back():
+    """functional._RefRng without a GPU (the mirror as a CPU tensor, advanced by the oracle's engine instead of the HIP
+    kernel): adopt() uploads once and then leaves an untouched generator alone, sync_back() leaves torch's generator where
+    the reference's own draws would, a foreign draw on the CPU generator makes the next adopt() start from the CPU state."""
+    R = F_._RefRng
+    _reset_mirror()
+    try:
+        torch.manual_seed(77)
+        torch.rand(5)
+        start = torch.get_rng_state().clone()
+        R.adopt("cpu")
+        first = R.dev
+        got = [_advance_mirror(300, np.float32(0.8)), _advance_mirror(1000, np.float32(0.5))]
+        R.adopt("cpu")  # the CPU generator has not moved: the mirror (which is ahead) stays
+        assert R.dev is first and R.ahead
+        R.sync_back()
+        assert not R.ahead
+        mine = torch.get_rng_state().clone()
+        torch.set_rng_state(start)
+        want = [torch.bernoulli(torch.Tensor(300).fill_(0.8)), torch.bernoulli(torch.Tensor(1000).fill_(0.5))]
+        assert torch.equal(torch.get_rng_state(), mine)
+        for g_, w in zip(got, want):
+            assert np.array_equal(g_, w.numpy())
+        # a foreign draw while the mirror is ahead: the CPU state wins, the mirror starts again from it
+        R.adopt("cpu")
+        _advance_mirror(10, np.float32(0.5))
+        torch.rand(3)
+        now = torch.get_rng_state().clone()
+        R.adopt("cpu")
+        assert not R.ahead and np.array_equal(R.dev.numpy().view(np.uint32), R._parse(now))
+        R.sync_back()  # nothing to write back
+        assert torch.equal(torch.get_rng_state(), now)
+    finally:
+        _reset_mirror()

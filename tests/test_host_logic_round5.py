@@ -138,3 +138,20 @@ def test_step_fence_waits_for_the_step_depth_back(monkeypatch):
     h = F_.StepFence(depth=1)
     h(); h(); h()
     assert [e for e in log if e[0] == "wait"] == [("wait", Ev.n - 3), ("wait", Ev.n - 2)]
+
+
+def test_fp32_weight_gradient_split_fills_four_workgroups_per_cu(monkeypatch):
+    """functional._splitk (exact-fp32 GEMMs with a long reduction): the split fills 1024 workgroup slots - four 128 x 128
+    workgroups fit a CU - capped at 16 and at K / 1024; PK_EXPERIMENT f32_splitk_slots=256 gives rounds 1-4's rule back
+    (profiles/r05_fp32_gemm.json: the 1100 x 1104 x 64000 product ran as 243 workgroups at 66 TFLOP/s)."""
+    import importlib
+
+    F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+    monkeypatch.delenv("PK_EXPERIMENT", raising=False)
+    assert F_._splitk(F_._tiles(1100, 1104), 64000) == 12      # 81 tiles -> 972 workgroups
+    assert F_._splitk(F_._tiles(550, 550), 64000) == 16        # 25 tiles: the cap
+    assert F_._splitk(F_._tiles(1938, 1100), 64000) == 7       # 144 tiles
+    assert F_._splitk(F_._tiles(1100, 1104), 4000) == 1        # short reductions are not split
+    assert F_._splitk(F_._tiles(128, 128), 8192) == 8          # K / 1024 bounds it
+    monkeypatch.setenv("PK_EXPERIMENT", "f32_splitk_slots=256")
+    assert F_._splitk(F_._tiles(1100, 1104), 64000) == 3

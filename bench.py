@@ -572,6 +572,15 @@ def measure(args, rank, world, steps, warmup):
     if len(regions) > 1:
         out["regions_ms_per_step"] = [round(1e3 * r / steps, 3) for r in regions]
         out["config"]["timing"] = "median of %d regions of %d steps" % (len(regions), steps)
+        # (a median hides a region that ran five times slower - round 5's host-lead stalls sat in these lists unnoticed)
+        out["regions_max_over_min"] = round(max(regions) / max(min(regions), 1e-9), 3)
+    try:  # the allocator's own account of the run: retries / device frees during training steps mean the pool hit the HBM's end
+        ms_ = torch.cuda.memory_stats()
+        out["allocator"] = {"alloc_retries": int(ms_.get("num_alloc_retries", 0)), "device_frees": int(ms_.get("num_device_free", 0)),
+                            "reserved_gb_peak": round(ms_.get("reserved_bytes.all.peak", 0) / 2**30, 2),
+                            "steps_in_flight": tr.fence.depth}
+    except Exception:  # noqa: BLE001 (no GPU: the CPU legs of the contract tests)
+        pass
     if args.unfused_cost or args.sync_every_step:
         out["config"]["cost"] = "nn.NLLLoss on the log-posteriors" if args.unfused_cost else "fused"
         out["config"]["host_sync"] = "every step" if args.sync_every_step else "end of region"
@@ -819,6 +828,7 @@ def main():
                        "ms_per_step": rec["ms_per_step"], "value": rec["value"], "unit":
                        "frames/s" if tr3.rcp["seq"] or recipe == "timit_mlp" else "chunks/s",
                        "steps": steps, "warmup": warmup, "regions_ms_per_step": rec.get("regions_ms_per_step"),
+                       "regions_max_over_min": rec.get("regions_max_over_min"), "allocator": rec.get("allocator"),
                        "roofline": rec["roofline"],
                        "entry_points_ms_per_step": dict(list(rec["entry_points_ms_per_step"].items())[:4])}
                 release(tr3)

@@ -8,7 +8,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BASE = json.load(open(os.path.join(ROOT, "BASELINE.json")))
-LINES = ["profiles/r05_bench_bf16.json", "profiles/r05_bench_bf16_before_step_fence.json", "profiles/r05_driver_cmd_final_line.json", "profiles/r05_bench_bf16_side_stream_masks.json", "profiles/r05_driver_cmd_side_stream_masks_line.json", "profiles/r05_driver_exact_cmd_line.json", "profiles/r04_bench_bf16.json", "profiles/r04_bench_bf16_evidence_pass.json", "profiles/r04_driver_exact_cmd_line.json",
+LINES = ["profiles/r05_bench_bf16.json", "profiles/r05_bench_step_fence_line.json", "profiles/r05_bench_bf16_before_step_fence.json", "profiles/r05_driver_cmd_final_line.json", "profiles/r05_bench_bf16_side_stream_masks.json", "profiles/r05_driver_cmd_side_stream_masks_line.json", "profiles/r05_driver_exact_cmd_line.json", "profiles/r04_bench_bf16.json", "profiles/r04_bench_bf16_evidence_pass.json", "profiles/r04_driver_exact_cmd_line.json",
          "profiles/r03_bench_bf16.json", "profiles/r02_bench_bf16.json", "profiles/r01_bench_bf16.json", "profiles/r01_bench_fp32_with_cpu_baseline.json",
          "profiles/r01_timit_lstm_8wave_bench.json", "profiles/r01_timit_lstm_4wave_bench.json"]
 

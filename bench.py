@@ -95,6 +95,7 @@ class Trainer:
         self.F = importlib.import_module("pytorch-kaldi_amd.functional")
         self.DP = importlib.import_module("pytorch-kaldi_amd.dp")
         self.OPT = importlib.import_module("pytorch-kaldi_amd.optim")
+        self.CORE = importlib.import_module("pytorch-kaldi_amd.core")
         F_ = importlib.import_module("pytorch-kaldi_amd.functional")
         F_.set_precision(args.prec)
         F_.set_rec_algo(args.algo)
@@ -119,7 +120,7 @@ class Trainer:
         self.overlap = bool(args.overlap)
         self.reducer = self.DP.GradReducer(self.nns, flats=flats, bucket_bytes=(8 << 20) if rcp["seq"] else (4 << 20),
                                            overlap=self.overlap, force=bool(getattr(args, "force_reducer", False)),
-                                           wire=os.environ.get("PK_DP_WIRE") or ("fp32" if rcp["seq"] else "bf16"))
+                                           wire=self.CORE.default_wire(not rcp["seq"]))
         # one resident synthetic batch per rank (different seeds per rank = different shards)
         self.T, self.B = (args.T, args.B) if rcp["seq"] else (1, args.B)
         self.batches = [self.R.synthetic_batch(rcp, self.T, self.B, 4234 + 17 * rank + i, "cuda") for i in range(2)]

@@ -175,7 +175,42 @@ def make_reducer(nns, optimizers, world, launch_bound=False, force=False):
     return _dp.GradReducer({k: nns[k] for k in nns}, flats={k: optimizers[k].flat for k in nns},
                            bucket_bytes=(4 << 20) if launch_bound else (8 << 20),
                            overlap=os.environ.get("PK_DP_OVERLAP", "1") != "0", force=force,
-                           wire=os.environ.get("PK_DP_WIRE") or ("bf16" if launch_bound else "fp32"))
+                           wire=default_wire(launch_bound))
+
+
+def default_wire(launch_bound):
+    """The format gradient buckets travel in.  PK_DP_WIRE decides when set.  Otherwise bf16 only where BOTH hold: the
+    engine already computes with bf16 operands (PK_PRECISION=bf16) and the recipe is launch-bound.  In the parity mode
+    (PK_PRECISION=fp32, the default) the wire stays fp32, so that N ranks equal the shard average the way the
+    reference's DataParallel sum does (core.py:103-104)."""
+    env = os.environ.get("PK_DP_WIRE")
+    if env:
+        return env
+    return "bf16" if (launch_bound and F_.bf16_mode()) else "fp32"
+
+
+def capture_on_every_rank(train_step, optimizers, inp, reducer, world):
+    """Record the step as a HIP graph (graphs.GraphedStep) - or return None, on EVERY rank alike.  A capture that fails
+    part-way through backward leaves the reducer with buckets handed over, half-counted signals and handles of work that
+    was only recorded: it is reset before the eager step that follows.  The ranks agree on the outcome (all-reduce MIN)
+    before anyone replays: a rank replaying captured collectives next to a rank issuing eager ones would hang."""
+    graphed = None
+    try:
+        graphed = GraphedStep(train_step, [optimizers[k] for k in optimizers]).capture(inp)
+    except (RuntimeError, PkError) as e:  # e.g. an Adam recipe: stay eager
+        sys.stderr.write("run_nn_dp: HIP-graph capture not used (%s)\n" % (e,))
+    ok = graphed is not None
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=inp.device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if ok and int(flag.item()) == 0:
+            sys.stderr.write("run_nn_dp: HIP-graph capture failed on another rank: staying eager\n")
+            ok = False
+    if not ok:
+        graphed = None
+        if reducer is not None:
+            reducer.reset()
+    return graphed
 
 
 def mean_over_ranks(loss_sum, err_sum, world):
@@ -318,7 +353,11 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
     GRAPH_WARMUP = 3
     graph_ok = (to_do == "train" and not seq_model and os.environ.get("PK_HIPGRAPH", "1") != "0"
                 and N_batches > GRAPH_WARMUP + 1)
+    if graph_ok and world > 1 and torch.distributed.get_backend() != "nccl":
+        graph_ok = False  # only RCCL's collectives are stream work a capture can record (gloo synchronises on the host)
     graphed = None
+    if reducer is not None and rank == 0:
+        sys.stderr.write("run_nn_dp: %d ranks, %d gradient buckets, %s wire\n" % (world, len(reducer.buckets), reducer.wire))
 
     start_time = time.time()
     loss_sum = torch.zeros((), device=device)
@@ -347,13 +386,9 @@ def run_nn_dp(data_name, data_set, data_end_index, fea_dict, lab_dict, arch_dict
             if graphed is not None:
                 outs_dict = graphed(inp)
             elif graph_ok and i == GRAPH_WARMUP:
-                try:
-                    graphed = GraphedStep(train_step, [optimizers[k] for k in optimizers]).capture(inp)
-                    outs_dict = graphed(inp)
-                except (RuntimeError, PkError) as e:  # e.g. an Adam recipe: stay eager
-                    sys.stderr.write("run_nn_dp: HIP-graph capture not used (%s)\n" % (e,))
-                    graphed, graph_ok = None, False
-                    outs_dict = train_step(inp)
+                graphed = capture_on_every_rank(train_step, optimizers, inp, reducer, world)
+                graph_ok = graphed is not None
+                outs_dict = graphed(inp) if graphed is not None else train_step(inp)
             else:
                 outs_dict = train_step(inp)
             if graphed is None:

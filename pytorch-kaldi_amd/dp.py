@@ -216,6 +216,26 @@ class GradReducer:
             return dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def reset(self):
+        """Forget a step that did not complete (a failed HIP-graph capture, an exception inside backward): drop the
+        handles and wire copies of buckets that had been handed over and re-arm every bucket, keeping what step 1 taught
+        (``expect``).  Gradients are NOT touched: the caller runs the step again from zero_grad."""
+        self.handles = []
+        self._ev = []
+        for b in self.buckets:
+            b.pop("wire", None)
+            b.pop("packed", None)
+            if b["expect"] is None:
+                b["seen"] = {}
+            self._rearm(b)
+
+    @staticmethod
+    def _rearm(b):
+        # (a bucket none of whose parameters signalled in step 1 never reaches 0: finish() reduces it)
+        b["pending"] = len(b["expect"]) if b["expect"] else len(b["params"]) + 1
+        b["got"] = {}
+        b["fired"] = False
+
     def finish(self):
         """Call after backward(): completes every bucket and re-arms for the next step."""
         if not self.active:
@@ -257,7 +277,4 @@ class GradReducer:
         for b in self.buckets:
             if b["expect"] is None:
                 b["expect"] = dict(b["seen"])
-            # (a bucket none of whose parameters signalled in step 1 never reaches 0: finish() reduces it)
-            b["pending"] = len(b["expect"]) if b["expect"] else len(b["params"]) + 1
-            b["got"] = {}
-            b["fired"] = False
+            self._rearm(b)

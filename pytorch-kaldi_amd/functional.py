@@ -748,8 +748,9 @@ class _DxShare:
     Accumulating in place into a tensor autograd already holds is only sound while nobody else adds to that buffer, so
     the heads do not consume x itself: they consume ONE private alias of it (_ShareIn, made by the first head built on x
     and handed to every later one).  The alias has no other consumers, its gradient buffer therefore only ever sees
-    the heads' contributions - the first as the shared tensor, the rest as None - and whatever else reads x adds to x's
-    own buffer, behind _ShareIn.backward, which also lets go of the shared dX."""
+    the heads' contributions - the first as the shared tensor, the rest as None (with the concatenated operand below:
+    all of them None, and _ShareIn.backward produces dX itself) - and whatever else reads x adds to x's own buffer,
+    behind _ShareIn.backward, which also lets go of the shared dX."""
     on = _lib.experiment("head_dx_share", "1") != "0"
     epoch = 0
     epoch_fwd = 0
@@ -760,7 +761,7 @@ class _DxShare:
     # dX = dz_cat . W_cat is launched once, by _ShareIn.backward - which autograd runs behind every head that takes part
     # in this backward pass (a head that does not: its slice is zeroed there).  At the BASELINE shape the monophone
     # head's own dX GEMM cost 0.21 ms for 7 GFLOP: it read and rewrote the 282 MB the senone head had just written.
-    cat = {}       # key -> dict(epoch, heads=[dict(id, N, off, wb)], width, dz, dx, done)
+    cat = {}       # key -> dict(epoch, heads=[dict(id, N, off, wb)], width, dz, done, dims, in_shape)
     wcat = {}      # (ids of the weight copies) -> persistent zero-padded bf16 buffer [width, pitch]
 
 
@@ -770,7 +771,7 @@ def _cat_register(key, ctx_id, N, wb, M):
         return
     c = _DxShare.cat.get(key)
     if c is None or c["epoch"] != _DxShare.epoch_fwd:
-        c = _DxShare.cat[key] = {"epoch": _DxShare.epoch_fwd, "heads": [], "width": 0, "dz": None, "dx": None, "done": set()}
+        c = _DxShare.cat[key] = {"epoch": _DxShare.epoch_fwd, "heads": [], "width": 0, "dz": None, "done": set()}
         for k in [k for k, v in _DxShare.cat.items() if v["epoch"] != _DxShare.epoch_fwd]:
             del _DxShare.cat[k]
     c["heads"].append({"id": ctx_id, "N": N, "off": c["width"], "wb": wb})
@@ -792,40 +793,44 @@ def _cat_slot(ctx, M):
     return c, mine[0]
 
 
-def _cat_finish(g):
-    """_ShareIn.backward: every head that takes part has written its slice of dz_cat - launch the one dX GEMM into g."""
-    for key, c in list(_DxShare.cat.items()):
-        if c["dx"] is None or c["dx"].data_ptr() != g.data_ptr():
-            continue
-        heads, dz = c["heads"], c["dz"]
-        for h in heads:  # a head whose cost did not reach the loss contributes nothing
-            if h["id"] not in c["done"]:
-                dz[:, h["off"]:h["off"] + _up(h["N"], 64)].zero_()
-        wkey = tuple((h["wb"].data_ptr(), h["N"], h["off"]) for h in heads)
-        wc = _DxShare.wcat.get(wkey)
-        pitch = heads[0]["wb"].shape[1]
-        if wc is None:
-            _DxShare.wcat.clear()  # (one set of heads at a time: the copies are 4-9 MB)
-            wc = _DxShare.wcat[wkey] = torch.zeros(c["width"], pitch, device=dz.device, dtype=torch.bfloat16)
-        for h in heads:  # the weights moved this step: refresh their rows (pad rows stay zero)
-            wc[h["off"]:h["off"] + h["N"]].copy_(h["wb"])
-        M, K = c["dx"].shape[0], c["dx"].shape[-1]
-        dx2 = c["dx"].view(-1, K)
-        gemm_bf16(dx2.shape[0], K, c["width"], dz, dz.shape[1], 1, wc, pitch, 0, dx2, K)
-        del _DxShare.cat[key]
-        return True
-    return False
+def _cat_finish(key, g):
+    """_ShareIn.backward: every head that takes part has written its slice of dz_cat.  The heads returned NO gradient of
+    their own (nothing uninitialised ever enters autograd's accumulation); this node produces dX = dz_cat . W_cat with
+    ONE GEMM - plus g, whatever else back-propagated into the alias (a head's log-posteriors used by a second cost)."""
+    c = _DxShare.cat.get(key)
+    if c is None or not c["done"] or c["dz"] is None:
+        return g
+    heads, dz = c["heads"], c["dz"]
+    for h in heads:  # a head whose cost did not reach the loss contributes nothing
+        if h["id"] not in c["done"]:
+            dz[:, h["off"]:h["off"] + _up(h["N"], 64)].zero_()
+    wkey = tuple((h["wb"].data_ptr(), h["N"], h["off"]) for h in heads)
+    wc = _DxShare.wcat.get(wkey)
+    pitch = heads[0]["wb"].shape[1]
+    if wc is None:
+        _DxShare.wcat.clear()  # (one set of heads at a time: the copies are 4-9 MB)
+        wc = _DxShare.wcat[wkey] = torch.zeros(c["width"], pitch, device=dz.device, dtype=torch.bfloat16)
+    for h in heads:  # the weights moved this step: refresh their rows (pad rows stay zero)
+        wc[h["off"]:h["off"] + h["N"]].copy_(h["wb"])
+    M, K = c["dims"]
+    dx2 = _new(M, K, like=dz)
+    gemm_bf16(M, K, c["width"], dz, dz.shape[1], 1, wc, pitch, 0, dx2, K)
+    del _DxShare.cat[key]
+    dx = dx2.view(c["in_shape"])
+    return dx if g is None else dx.add_(g)
 
 
 class _ShareIn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
+        ctx.set_materialize_grads(False)  # (heads of a shared operand return None: no 282 MB zero tensor in their place)
+        ctx.key = _dx_share_key(x)
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        if g is not None and _DxShare.cat:
-            _cat_finish(g)
+        if _DxShare.cat:
+            g = _cat_finish(ctx.key, g)
         _DxShare.table.clear()  # every head in this backward pass has contributed: nothing keeps dX alive from here
         _DxShare.alias = None
         return g
@@ -858,11 +863,9 @@ def _linear_bwd_bf16(ctx, dyb, xb, wb, like, cat=None):
     dx = dw = None
     ldy = dyb.stride(0)
     if ctx.needs_input_grad[0] and cat is not None:
-        c = cat[0]
+        c = cat[0]  # (dx stays None: _ShareIn.backward, which autograd runs behind every head, produces it)
         c["done"].add(id(ctx))
-        if c["dx"] is None:  # the first head to run hands autograd the buffer the GEMM will fill
-            c["dx"] = _new(M, K, like=like)
-            dx = c["dx"].view(ctx.in_shape)
+        c["dims"], c["in_shape"] = (M, K), ctx.in_shape
     elif ctx.needs_input_grad[0]:  # dx[m,k] = sum_n dy[m,n] W[n,k]: A k-contiguous, B = W is k-major
         key = getattr(ctx, "dx_share", None)
         shared = _DxShare.table.get(key) if key is not None else None

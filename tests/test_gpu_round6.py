@@ -1,0 +1,49 @@
+"""Round-6 GPU tests of the host-side plumbing around the kernels (each against the engine's own unshared / eager path or
+a torch evaluation of the same op; the model-level parity lives in test_gpu_parity.py / test_gpu_reference_pins.py)."""
+import importlib
+
+import pytest
+import torch
+
+from golden_util import rel_err
+
+pytestmark = pytest.mark.gpu
+F_ = importlib.import_module("pytorch-kaldi_amd.functional")
+
+
+@pytest.mark.parametrize("second_use", ["posteriors", "posteriors_and_input", "none"])
+def test_concatenated_head_gradient_with_other_contributors(second_use):
+    """Two fused-cost heads on one activation at >= 4096 rows take the ONE-GEMM input gradient (functional._cat_finish,
+    neural_networks.py:139-148 twice + utils.py:2361).  A head whose log-posteriors ALSO feed a second cost term sends a
+    second gradient into the heads' private alias through its own node (LinearLogSoftmaxFn.backward), and a direct
+    consumer of the activation adds to the activation's own buffer: the shared product must be added to those, never
+    matched by buffer identity (advisor, round 5: an uninitialised buffer used to enter autograd's accumulation)."""
+    g = torch.Generator().manual_seed(11)
+    rows, K = 4224, 160
+    x0 = torch.randn(rows, K, generator=g)
+    w1, w2 = torch.randn(45, K, generator=g) / 12, torch.randn(13, K, generator=g) / 12
+    l1, l2 = torch.randint(0, 45, (rows,), generator=g).cuda(), torch.randint(0, 13, (rows,), generator=g).cuda()
+    F_.set_precision("bf16")
+    res = {}
+    try:
+        for share in (True, False):
+            F_._DxShare.on = share
+            x = x0.clone().cuda().requires_grad_(True)
+            h = x * 1.0
+            a, b = w1.clone().cuda().requires_grad_(True), w2.clone().cuda().requires_grad_(True)
+            y1, y2 = F_.linear_log_softmax(h, a, None), F_.linear_log_softmax(h, b, None)
+            loss = F_.head_nll(y1, l1)[0] + 0.5 * F_.head_nll(y2, l2)[0]
+            if second_use != "none":
+                loss = loss + 0.3 * (y1 * y1).mean()  # e.g. a confidence penalty on the senone posteriors
+            if second_use == "posteriors_and_input":
+                loss = loss + 2.0 * (h * h).mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            assert torch.isfinite(x.grad).all()
+            res[share] = (x.grad.clone(), a.grad.clone(), b.grad.clone())
+            assert not F_._DxShare.cat or not share
+    finally:
+        F_._DxShare.on = True
+        F_.set_precision("fp32")
+    for got, ref in zip(res[True], res[False]):
+        assert rel_err(got, ref) < 2e-6

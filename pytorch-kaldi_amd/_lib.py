@@ -154,8 +154,32 @@ class PkError(RuntimeError):
     pass
 
 
+def _map_torch_hip_runtime():
+    """One HIP runtime per process, by construction instead of by import order: libpk_amd.so NEEDs
+    `libamdhip64.so.7`; torch ships its own runtime as `torch/lib/libamdhip64.so` - a FILE name the loader never searches
+    for, whatever RUNPATH says - whose SONAME is that very `libamdhip64.so.7`.  Mapping torch's copy explicitly first makes
+    the loader resolve our NEEDED entry to it (an already-loaded object with a matching SONAME wins over every search
+    path), whether or not `import torch` has initialised anything yet."""
+    import torch
+
+    hip = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)
+    return hip
+
+
+def hip_runtimes_mapped():
+    """Paths of every libamdhip64 mapped into this process (/proc/self/maps)."""
+    try:
+        with open("/proc/self/maps") as f:
+            return {line.split()[-1] for line in f if "libamdhip64" in line}
+    except OSError:  # pragma: no cover
+        return set()
+
+
 def load():
-    """Load (once) and return the ctypes handle.  Raises PkError when the library is missing."""
+    """Load (once) and return the ctypes handle.  Raises PkError when the library is missing or when it would bring a
+    second HIP runtime into the process."""
     global _lib
     if _lib is not None:
         return _lib
@@ -166,11 +190,12 @@ def load():
             raise PkError(
                 "libpk_amd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
                 "this engine has no CPU fallback." % LIB_PATH)
-        try:  # bind to the HIP runtime torch already mapped (same soname, libamdhip64.so.7)
-            import torch  # noqa: F401
-        except Exception:  # pragma: no cover - torch is always present in this image
-            pass
+        _map_torch_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
+        runtimes = hip_runtimes_mapped()
+        if len(runtimes) > 1:
+            raise PkError("two HIP runtimes in one process (%s): libpk_amd.so must share the one torch uses - streams and "
+                          "device pointers of one runtime mean nothing to the other" % ", ".join(sorted(runtimes)))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res

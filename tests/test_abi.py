@@ -92,3 +92,19 @@ def test_state_dict_names_match_reference_layout():
                 # orthogonal_ goes through LAPACK QR: thread count may change the last bits
                 assert torch.allclose(sd[k], v, rtol=1e-5, atol=1e-6), (case, k)
         assert net.out_dim == g.t("y").shape[-1]
+
+
+def test_library_binds_to_torchs_hip_runtime_by_construction():
+    """SURVEY.md 7.2 / round-5 review: not load-order luck.  A fresh interpreter that loads the library through _lib.load()
+    ends up with exactly ONE libamdhip64 mapped, and it is the copy inside torch/lib (the file torch itself uses) - although
+    the library's RUNPATH names /opt/rocm."""
+    import subprocess
+    import sys
+
+    code = ("import importlib, os, sys; sys.path.insert(0, %r); L = importlib.import_module('pytorch-kaldi_amd._lib'); "
+            "L.load(); import torch; r = L.hip_runtimes_mapped(); print(sorted(r)); "
+            "assert len(r) == 1 and os.path.dirname(next(iter(r))) == os.path.join(os.path.dirname(torch.__file__), 'lib'), r"
+            % ROOT)
+    r = subprocess.run([sys.executable, "-W", "ignore", "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]

@@ -1,7 +1,17 @@
-"""The headline shape, value for value, inside the GPU suite (round-4 review: "the full-shape parity run is a tool, not a
-test"): ONE bf16 training step of Li-GRU 5 x 550 + heads at T = 500, B = 128 - 16 clusters x 500 steps per launch -
-against the oracle's bf16-operand model run on the box's host cores (neural_networks.py:1130-1141, utils.py:2296-2420),
-kink-forced.  ~20-40 s of host time.  TEST INFRASTRUCTURE: the tool imports oracle/."""
+"""The headline shape, value for value, inside the GPU suite: ONE training step of Li-GRU 5 x 550 + heads at T = 500,
+B = 128 - 16 clusters x 500 steps per launch - against the oracle run on the box's host cores
+(neural_networks.py:1130-1141, utils.py:2296-2420), kink-forced.  ~20-40 s of host time per mode.
+
+  fp32   the parity mode against the exact fp32 oracle at north_star's 1e-4: posteriors, CE loss, every gradient tensor
+         (round-5 review, row n1: "1e-4 fp32 parity at the metric's own shape");
+  bf16   the timed mode against the oracle's bf16-operand model, every weight-gradient family / layer held to the
+         model's OWN distance from itself under fp32 rounding noise (tests/golden/bf16_model_floor_full_shape.json, made
+         by tools/diag_bf16_model_floor.py on the host: the same model, input x (1 + 1e-7 N(0,1)), same kinks forced).
+         That floor reproduces the round-5 picture number for number - update-gate family rising with depth 5.8e-3 ->
+         1.03e-2, candidate family falling 5.8e-3 -> 4.2e-3, kink flips 17 k -> 97 k, top hidden state 3.4e-3 - so the
+         growth is the bf16-operand algorithm's sensitivity on this network, not a term of the engine's.
+
+TEST INFRASTRUCTURE: the tool imports oracle/."""
 import json
 import os
 import subprocess
@@ -10,24 +20,54 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FLOOR = os.path.join(ROOT, "tests", "golden", "bf16_model_floor_full_shape.json")
+# engine / floor per family and layer, measured in round 5: 1.01-1.17 (the engine additionally reads bf16 gate gradients
+# in BatchNorm backward); the floor itself moves a few per cent with the noise draw
+FLOOR_FACTOR = 1.35
+
+
+def _run(precision, tmp_path):
+    out = tmp_path / ("full_shape_%s.json" % precision)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "full_shape_parity.py"), "--precision", precision,
+                        "--out", str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:]
+    res = json.loads(out.read_text())
+    keep = os.environ.get("PK_FULL_SHAPE_JSON")  # (the evidence pass keeps the records for profiles/)
+    if keep:
+        with open(keep.replace(".json", "_%s.json" % precision) if precision != "bf16" else keep, "w") as f:
+            json.dump(res, f, indent=1)
+    print("full shape %s: loss %.3e  outputs %s  worst gradient %s  by layer %s" % (
+        precision, res["loss_rel_diff"], [round(res["out_rel_err/out_dnn%d" % i], 7) for i in (1, 2, 3)],
+        res["grad_rel_err_worst"], res["grad_rel_err_by_layer"]))
+    return res
+
+
+@pytest.mark.gpu
+def test_full_headline_shape_fp32_within_1e_4(tmp_path):
+    res = _run("fp32", tmp_path)
+    assert res["pass"], res
+    assert res["loss_rel_diff"] < 1e-4
+    for k in ("out_dnn1", "out_dnn2", "out_dnn3"):
+        assert res["out_rel_err/" + k] < 1e-4, (k, res["out_rel_err/" + k])
+    assert res["grad_rel_err_worst"]["err"] < 1e-4, res["grad_rel_err_worst"]
 
 
 @pytest.mark.gpu
 def test_full_headline_shape_value_for_value(tmp_path):
-    out = tmp_path / "full_shape.json"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "full_shape_parity.py"), "--out", str(out)],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:]
-    res = json.loads(out.read_text())
-    keep = os.environ.get("PK_FULL_SHAPE_JSON")  # (the evidence pass keeps the record for profiles/)
-    if keep:
-        with open(keep, "w") as f:
-            json.dump(res, f, indent=1)
-    print("full shape: loss %.3e  outputs %s  worst gradient %s  by layer %s" % (
-        res["loss_rel_diff"], [round(res["out_rel_err/out_dnn%d" % i], 6) for i in (1, 2, 3)], res["grad_rel_err_worst"],
-        res["grad_rel_err_by_layer"]["wz"]))
+    res = _run("bf16", tmp_path)
     assert res["pass"], res
     assert res["loss_rel_diff"] < 1e-5, res["loss_rel_diff"]
-    # limits of step (A) of tests/test_gpu_reference_pins.py are 5e-3 / 2e-2; the review asks for the worst gradient
-    # (wz.4.weight, 1.04e-2 in round 4) to stay under 1.5e-2
-    assert res["grad_rel_err_worst"]["err"] < 1.5e-2, res["grad_rel_err_worst"]
+    with open(FLOOR) as f:
+        floor = json.load(f)
+    assert (floor["T"], floor["B"], floor["layers"]) == (res["T"], res["B"], res["layers"])
+    ratios = {}
+    for fam, per_layer in res["grad_rel_err_by_layer"].items():
+        for i, e in enumerate(per_layer):
+            ratios["%s.%d" % (fam, i)] = e / floor["grad_rel_diff_by_layer"][fam][i]
+    print("engine-vs-model / model-vs-itself, per family and layer:", {k: round(v, 3) for k, v in ratios.items()})
+    worst = max(ratios, key=ratios.get)
+    assert ratios[worst] < FLOOR_FACTOR, (worst, ratios[worst])
+    # every other gradient tensor (BatchNorm affine, heads): under the largest floor value
+    assert res["grad_rel_err_worst"]["err"] < FLOOR_FACTOR * max(max(v) for v in floor["grad_rel_diff_by_layer"].values())
+    # the forward pass: the top layer's hidden states drift like the model's own (3.4e-3), the posteriors stay at 1e-5
+    assert res["out_rel_err/out_dnn1"] < FLOOR_FACTOR * floor["hidden_rel_diff_by_layer"][-1]

@@ -999,6 +999,9 @@ def main():
     if os.environ.get("PK_GOLDEN_ONLY") == "scale":
         scale_case("scale_ligru_T500", 4234)
         return
+    if os.environ.get("PK_GOLDEN_ONLY") == "scale_b32":
+        scale_case("scale_ligru_T500_B32", 4334, B=32)
+        return
     if os.environ.get("PK_GOLDEN_ONLY") == "config_scale":
         config_scale_cases()
         return
@@ -1059,6 +1062,7 @@ def main():
     model_lang_case("e2e_model_language", 333)
     train_case("train_ligru_30steps", 4100, lr=0.004)   # CE-loss trajectory over 30 optimizer steps
     scale_case("scale_ligru_T500", 4234)      # the unscaled recipe at T = 500 (minutes of CPU time)
+    scale_case("scale_ligru_T500_B32", 4334, B=32)  # the same above toy batch: 64 rows = 4 clusters of the persistent launch
     config_scale_cases()                      # the other four BASELINE configurations, unscaled
 
     # --- two levels up: the chunk loop core.run_nn (train from scratch, continue, validate, forward) ---

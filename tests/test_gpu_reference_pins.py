@@ -331,13 +331,16 @@ def _rows(t, stride):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_config_scale_golden(prec):
+@pytest.mark.parametrize("case", ["scale_ligru_T500", "scale_ligru_T500_B32"])
+def test_config_scale_golden(case, prec):
     """fp32: posteriors / loss / kink-forced gradients at 1e-4 against the reference's own run.  bf16 (the mode bench.py
     times, same network, same T): the two-step grading against the bf16-operand model run here on the host CPU from the
-    same seed-derived parameters."""
+    same seed-derived parameters.  Two reference runs: B = 4 (one partial cluster of the persistent launch) and B = 32
+    (round 6: 64 rows = four full 16-row clusters x 500 steps - the reference's own arrays above toy batch; its O(T^2)
+    autograd takes 95 s there)."""
     from engine_util import F_amd
 
-    g = Golden("scale_ligru_T500")
+    g = Golden(case)
     m = g.meta
     T, B, H, L = m["T"], m["B"], m["H"], m["n_lay"]
     F_amd.set_precision(prec)
@@ -405,7 +408,7 @@ def test_config_scale_golden(prec):
             ck = _ck(p.grad, 13)
             assert abs(ck[0] - ref_ck[0]) < 1e-4 * max(ref_ck[0], 1e-3 * gtotal), (name, k)
             assert np.abs(ck[1:] - ref_ck[1:]).max() < 4e-4 * max(ref_ck[0], 1e-3 * gtotal), (name, k)
-        print("\nconfig-scale golden [fp32]: worst gradient row-sample error %.2e; kink report %s" % (worst, report))
+        print("\nconfig-scale golden %s [fp32]: worst gradient row-sample error %.2e; kink report %s" % (case, worst, report))
         return
     # ---- bf16: the bf16-operand model on the host CPU, same parameters / input / masks (a few seconds)
     import pk_oracle as O
@@ -430,7 +433,7 @@ def test_config_scale_golden(prec):
         worst = max(worst, _two_step((name, k), _rows(p.grad, s_), _rows(osd[name][k].grad, s_), ref_rows, TIGHT_GRAD,
                                      gtotal * frac), key=lambda t: t[2])
     flipped = sum(r[0] for r in report) / float(sum(r[1] for r in report))
-    print("\nconfig-scale golden [bf16]: outputs (engine-vs-model, model-vs-ref, engine-vs-ref) %s; worst kink-forced "
+    print("\nconfig-scale golden " + case + " [bf16]: outputs (engine-vs-model, model-vs-ref, engine-vs-ref) %s; worst kink-forced "
           "gradient %s; share of ReLU pre-activations whose sign bf16 rounding changed: %.2e"
           % ({k: tuple("%.1e" % x for x in v) for k, v in rep.items()}, tuple("%.1e" % x for x in worst), flipped))
 

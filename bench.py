@@ -55,8 +55,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the parity_mode (fp32) and other_configs sub-records of the default single-GPU run")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    ap.add_argument("--cpu-T", type=int, default=100, help="sequence length of the CPU baseline sample")
-    ap.add_argument("--cpu-B", type=int, default=128, help="batch of the CPU baseline sample (the metric's: 128)")
+    ap.add_argument("--cpu-T", type=int, default=500, help="sequence length of the CPU baseline sample (the metric's: 500)")
+    ap.add_argument("--cpu-B", type=int, default=16, help="batch of the CPU baseline sample (16 of the metric's 128 sequences)")
     ap.add_argument("--cpu-full-in-run", action="store_true", default=os.environ.get("PK_BENCH_CPU_FULL", "0") == "1",
                     help="additionally time ONE step of the CPU port at the metric's FULL shape inside this run (~4 minutes of "
                          "host time on the GPU box's 16 usable cores): cpu_baseline.full_shape is then measured_in_run = true. "
@@ -258,68 +258,123 @@ def log(msg):
 T_START = time.time()
 
 
-def cpu_baseline(args, rcp_name, full=False):
-    """The CPU oracle (a torch-CPU port of the reference path; kind = "port") timed on this host's cores on a bounded
-    sample of the same workload: same network, the metric's batch (128 sequences), a shorter sequence so that the
-    default run stays within ~20 s of CPU time.  The reference's autograd cost per frame GROWS with T (its backward
-    zero-fills a (T, 2B, H) tensor per step and gate, SURVEY.md 3.3 - the port indexes the projections inside the time
-    loop the same way), so the short sample FLATTERS the CPU; the full-shape number (one step at T = 500, B = 128,
-    minutes of CPU time: `bench.py --cpu-full`) is measured once per round on the GPU box's host and quoted from
-    profiles/r03_cpu_full_shape.json."""
+def reference_root():
+    """The PyTorch-Kaldi checkout when this host has one (PK_REFERENCE, /root/reference): the build container does, the
+    GPU boxes do not."""
+    for cand in (os.environ.get("PK_REFERENCE"), "/root/reference"):
+        if cand and os.path.isfile(os.path.join(cand, "neural_networks.py")):
+            return cand
+    return None
+
+
+def _cpu_model(rcp, kind_of_baseline):
+    """The recipe's networks on the CPU: `reference` = the reference's own classes (neural_networks.py, imported
+    unmodified), `port` = this repository's torch-CPU oracle on parameter dicts.  -> (forward(x) -> log-posterior list,
+    leaves per cfg section)."""
+    cfg = rcp["cfg"]
+    a1 = cfg["architecture1"]
+    kind = a1["arch_class"]
+    trunk, s_cd, s_mono = rcp["trunk"], rcp["head_cd"], rcp["head_mono"]
+    torch.manual_seed(2234)
+    if kind_of_baseline == "reference":
+        sys.path.insert(0, reference_root())
+        import neural_networks as NN  # the reference's module, as run_exp.py imports it
+
+        def make(sec, cls, din):
+            # (the SectionProxy itself, with the two fields utils.model_init injects, utils.py:2051-2052: its lookups
+            # are case-insensitive - `options["sinc_N_filt"]` - which a plain dict's are not)
+            cfg[sec]["use_cuda"], cfg[sec]["to_do"] = "False", "train"
+            return getattr(NN, cls)(cfg[sec], din)
+    else:
+        nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
+
+        def make(sec, cls, din):
+            return getattr(nn_amd, cls)(dict(cfg[sec], use_cuda="False", to_do="train"), din)
+    nets = {"architecture1": make("architecture1", kind, rcp["nfea"])}
+    feat = nets["architecture1"].out_dim
+    if trunk:  # SincNet recipe: an MLP trunk between the front-end and the heads
+        nets[trunk] = make(trunk, "MLP", feat)
+        feat = nets[trunk].out_dim
+    nets[s_cd] = make(s_cd, "MLP", feat)
+    if s_mono:
+        nets[s_mono] = make(s_mono, "MLP", feat)
+    if kind_of_baseline == "reference":
+        for n in nets.values():
+            n.train()
+        leaves = {k: [p for p in net.parameters() if p.requires_grad] for k, net in nets.items()}
+
+        def forward(x):
+            h = nets["architecture1"](x)
+            if rcp["seq"]:
+                h = h.view(h.shape[0] * h.shape[1], -1)  # utils.py:2334
+            if trunk:
+                h = nets[trunk](h)
+            return [nets[s_cd](h)] + ([nets[s_mono](h)] if s_mono else [])
+        return forward, leaves
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pk_oracle as O
 
-    R = importlib.import_module("pytorch-kaldi_amd.recipes")
-    rcp = R.recipe(rcp_name, n_lay=args.layers)
-    cfg = rcp["cfg"]
-    cores = usable_cores()
-    torch.set_num_threads(cores)
-    a1 = cfg["architecture1"]
-    kind = a1["arch_class"]
-    nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
-    torch.manual_seed(2234)
-    nets = {"architecture1": getattr(nn_amd, kind)(dict(a1, use_cuda="False", to_do="train"), rcp["nfea"])}
-    feat = nets["architecture1"].out_dim
-    trunk, s_cd, s_mono = rcp["trunk"], rcp["head_cd"], rcp["head_mono"]
-    if trunk:  # SincNet recipe: an MLP trunk between the front-end and the heads
-        nets[trunk] = nn_amd.MLP(dict(cfg[trunk]), feat)
-        feat = nets[trunk].out_dim
-    nets[s_cd] = nn_amd.MLP(dict(cfg[s_cd]), feat)
-    if s_mono:
-        nets[s_mono] = nn_amd.MLP(dict(cfg[s_mono]), feat)
     sds = {k: {n: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in n)
                for n, v in net.state_dict().items()} for k, net in nets.items()}
-    opts = []
-    for k, sd in sds.items():  # one optimizer per architecture, as the shipped cfg sets them (run_nn: optimizer_init)
-        leaves = [v for v in sd.values() if v.requires_grad]
-        if cfg[k]["arch_opt"] == "sgd":
-            opts.append(torch.optim.SGD(leaves, lr=float(cfg[k]["arch_lr"])))
-        else:
-            opts.append(torch.optim.RMSprop(leaves, lr=float(cfg[k]["arch_lr"]), alpha=0.95, eps=1e-8))
-    if full:
-        T, B = (args.T, args.B) if rcp["seq"] else (1, args.B)
-    else:
-        T, B = (args.cpu_T, args.cpu_B) if rcp["seq"] else (1, 128)
+    leaves = {k: [v for v in sd.values() if v.requires_grad] for k, sd in sds.items()}
 
-    def one_step(seed, T_=None):
-        Ts = T_ or T
-        inp = R.synthetic_batch(rcp, Ts, B, seed)
-        x = inp[..., :rcp["nfea"]]
-        lab_cd = inp[..., rcp["nfea"]].reshape(-1).long()
+    def forward(x):
         if rcp["seq"]:
             # index_like_reference: the projections are indexed inside the time loop as the reference does it
             # (neural_networks.py:1133-1134) - that is what makes its backward O(T^2), and with it the port runs
             # within 4-11 % of the reference's own speed (profiles/r02_cpu_port_vs_reference.json)
             h = O.recurrent_forward(kind, dict(a1), sds["architecture1"], x, index_like_reference=True)
-            h = h.reshape(Ts * B, -1)
+            h = h.reshape(h.shape[0] * h.shape[1], -1)
         else:
             h = O.arch_forward(kind, dict(a1), sds["architecture1"], x)
             if trunk:
                 h = O.mlp_forward(dict(cfg[trunk]), sds[trunk], h)
-        loss = torch.nn.functional.nll_loss(O.mlp_forward(dict(cfg[s_cd]), sds[s_cd], h), lab_cd)
-        if s_mono:
-            lab_m = inp[..., rcp["nfea"] + 1].reshape(-1).long()
-            loss = loss + torch.nn.functional.nll_loss(O.mlp_forward(dict(cfg[s_mono]), sds[s_mono], h), lab_m)
+        return [O.mlp_forward(dict(cfg[s_cd]), sds[s_cd], h)] + ([O.mlp_forward(dict(cfg[s_mono]), sds[s_mono], h)] if s_mono else [])
+    return forward, leaves
+
+
+def cpu_baseline(args, rcp_name, full=False, budget_s=None, shape=None):
+    """The reference path on THIS host's cores, in the same run (north_star): fwd + bwd + the cfg's optimizers of the same
+    network on a bounded sample of the same workload.  kind = "reference": the reference's own classes
+    (neural_networks.py imported unmodified - wherever a checkout exists: PK_REFERENCE, /root/reference); kind = "port":
+    this repository's torch-CPU oracle, the stand-in on the GPU boxes (they carry no checkout; the port runs 1.04-1.11 x
+    FASTER than the reference's classes, profiles/r02_cpu_port_vs_reference.json).
+
+    The sample.  The reference's autograd cost per frame GROWS with T (its backward zero-fills a (T, 2B, H) tensor per
+    step and gate; the port indexes the projections inside the time loop the same way), so a short
+    sequence flatters the CPU (round 5: 4.7 x at T = 100).  The default sample of a sequence recipe therefore keeps the
+    metric's sequence length T and cuts the BATCH (16 of 128 sequences: the zero-fill and the GEMMs both scale with the
+    rows, so frames/s moves little); `full_shape` is one step at the metric's own (T, B) - minutes of CPU time -
+    measured in the run with --cpu-full-in-run, otherwise quoted from the round's record with measured_in_run = false."""
+    R = importlib.import_module("pytorch-kaldi_amd.recipes")
+    rcp = R.recipe(rcp_name, n_lay=args.layers)
+    cfg = rcp["cfg"]
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    kind_of_baseline = "reference" if reference_root() and os.environ.get("PK_CPU_BASELINE", "") != "port" else "port"
+    forward, leaves = _cpu_model(rcp, kind_of_baseline)
+    opts = []
+    for k, lv in leaves.items():  # one optimizer per architecture, as the shipped cfg sets them (run_nn: optimizer_init)
+        if cfg[k]["arch_opt"] == "sgd":
+            opts.append(torch.optim.SGD(lv, lr=float(cfg[k]["arch_lr"])))
+        else:
+            opts.append(torch.optim.RMSprop(lv, lr=float(cfg[k]["arch_lr"]), alpha=0.95, eps=1e-8))
+    if full:
+        T, B = (args.T, args.B) if rcp["seq"] else (1, args.B)
+    elif shape is not None:
+        T, B = shape
+    else:
+        T, B = (args.cpu_T, args.cpu_B) if rcp["seq"] else (1, 128)
+    budget_s = args.cpu_budget_s if budget_s is None else budget_s
+
+    def one_step(seed, T_=None):
+        Ts = T_ or T
+        inp = R.synthetic_batch(rcp, Ts, B, seed)
+        x = inp[..., :rcp["nfea"]]
+        outs = forward(x)
+        loss = torch.nn.functional.nll_loss(outs[0], inp[..., rcp["nfea"]].reshape(-1).long())
+        if len(outs) > 1:
+            loss = loss + torch.nn.functional.nll_loss(outs[1], inp[..., rcp["nfea"] + 1].reshape(-1).long())
         for opt in opts:
             opt.zero_grad()
         loss.backward()
@@ -332,7 +387,7 @@ def cpu_baseline(args, rcp_name, full=False):
     while True:
         one_step(2 + n)
         n += 1
-        if full or time.time() - t0 > args.cpu_budget_s or n >= 50:
+        if full or time.time() - t0 > budget_s or n >= 50:
             break
     dt = time.time() - t0
     model = ""
@@ -343,25 +398,29 @@ def cpu_baseline(args, rcp_name, full=False):
                 break
     except OSError:
         pass
-    rec = {"value": round(n * T * B / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": "%d step(s) of the same network (fwd+bwd+the cfg optimizers) at T=%d, B=%d on %s, torch-CPU oracle fp32, "
-                     "projections indexed in the time loop like the reference; the reference's own classes run 1.04x "
-                     "(T=500) / 1.11x (T=50) slower than this port on the build host (profiles/r02_cpu_port_vs_reference.json)"
-                     % (n, T, B, model or "host CPU"), "T": T, "B": B, "seconds": round(dt, 2)}
-    if not full and getattr(args, "cpu_full_in_run", False) and rcp["seq"]:
-        fsr = cpu_baseline(args, rcp_name, full=True)  # the same port, ONE step at the metric's full (T, B): minutes
-        rec["full_shape"] = {k: fsr[k] for k in ("value", "unit", "cores", "T", "B", "seconds", "sample") if k in fsr}
+    what = ("the reference's own classes (neural_networks.py, unmodified)" if kind_of_baseline == "reference" else
+            "torch-CPU port of the reference path (oracle/pk_oracle.py, projections indexed in the time loop like the "
+            "reference; no PyTorch-Kaldi checkout on this host - the reference's classes run 1.04-1.11 x slower than the "
+            "port, profiles/r02_cpu_port_vs_reference.json)")
+    rec = {"value": round(n * T * B / dt, 2), "unit": "frames/s", "cores": cores, "kind": kind_of_baseline,
+           "sample": "%d step(s) of the same network (fwd+bwd+the cfg optimizers) at T=%d, B=%d of the metric's T=%d, B=%d on "
+                     "%s, fp32, %d threads: %s" % (n, T, B, args.T if rcp["seq"] else 1, args.B, model or "host CPU", cores, what),
+           "T": T, "B": B, "seconds": round(dt, 2)}
+    if not full and shape is None and getattr(args, "cpu_full_in_run", False) and rcp["seq"]:
+        fsr = cpu_baseline(args, rcp_name, full=True)  # ONE step at the metric's full (T, B): minutes
+        rec["full_shape"] = {k: fsr[k] for k in ("value", "unit", "cores", "kind", "T", "B", "seconds", "sample") if k in fsr}
         rec["full_shape"]["measured_in_run"] = True
-    elif not full:
-        try:  # the same port at the metric's FULL shape, measured once on the GPU box's host (bench.py --cpu-full)
-            fsrc = "r05_cpu_full_shape.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_cpu_full_shape.json")) else "r03_cpu_full_shape.json"
-            fs = json.load(open(os.path.join(ROOT, "profiles", fsrc)))
+    elif not full and shape is None:
+        for fsrc in ("r06_cpu_full_shape.json", "r05_cpu_full_shape.json", "r03_cpu_full_shape.json"):
+            try:  # the same path at the metric's FULL shape, measured once per round on a GPU box's host (bench.py --cpu-full)
+                fs = json.load(open(os.path.join(ROOT, "profiles", fsrc)))
+            except (OSError, ValueError):
+                continue
             if fs.get("recipe", "timit_ligru") == rcp_name:
-                rec["full_shape"] = {k: fs[k] for k in ("value", "unit", "cores", "T", "B", "seconds", "sample") if k in fs}
+                rec["full_shape"] = {k: fs[k] for k in ("value", "unit", "cores", "kind", "T", "B", "seconds", "sample") if k in fs}
                 rec["full_shape"]["measured_in_run"] = False  # a constant quoted from the file below, NOT timed by this run
-                rec["full_shape"]["source"] = "profiles/%s (the same port, one step at the full shape on a GPU box's host)" % fsrc
-        except (OSError, ValueError):
-            pass
+                rec["full_shape"]["source"] = "profiles/%s (one step at the full shape on a GPU box's host)" % fsrc
+                break
     return rec
 
 
@@ -406,37 +465,36 @@ def roofline_of(tr, args, summ, prec):
             roof.update({"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK, "unit": "GB/s",
                          "frac": round(gbps / HBM_PEAK, 5)})
     if "rec" in dom and tr.rcp["seq"]:
-        # A recurrent launch is T strictly dependent steps: neither roofline binds it, the per-step latency does.  Two
-        # floors, both measured with this library's own traced kernels (profiles/r0N_rec_step_floor.json,
-        # tools/trace_rec2.py): `hop_floor_us` = one cross-CU hand-off (publish of the slowest member -> data in
-        # registers; the chip's handoff-1to1 price, 0.8-1.0 us) and `step_floor_us` = a step of THIS kernel structure with
-        # its MFMA block and gate math removed (EMPTY=1: poll + barrier + flush / prefetch issue + patches + publish).
+        # A recurrent launch is T strictly dependent steps: neither roofline binds it, the per-step latency does.
+        # `hop_floor_us` = one cross-CU hand-off (publish of the slowest member -> data in registers), measured with this
+        # library's own traced kernels (profiles/r0N_rec_step_floor.json, tools/trace_rec2.py; the chip's handoff-1to1
+        # price is 0.8-1.0 us).  (Rounds 2-5 also printed a `structure_frac` against an "empty step" taken from the TRACED
+        # kernel, whose s_memtime stamps cost ~11 %: the production step beat that floor - it is gone.)
         lat = {"bound": "latency", "dependent_steps_per_launch": tr.T, "us_per_step": round(d["avg_ms"] * 1e3 / tr.T, 3)}
-        hop, floor, src_ = 0.9, None, None
+        hop, src_ = 0.9, None
         for cand in ("r05_rec_step_floor.json", "r04_rec_step_floor.json", "r03_rec_step_floor.json", "r02_rec_step_floor.json"):
             try:
                 fl_ = json.load(open(os.path.join(ROOT, "profiles", cand)))
-                side_ = "bwd" if "bwd" in dom else "fwd"
-                hop, floor, src_ = float(fl_["hop_us"][side_]), float(fl_["floor_us_" + side_]), cand
+                hop, src_ = float(fl_["hop_us"]["bwd" if "bwd" in dom else "fwd"]), cand
                 break
             except (OSError, ValueError, KeyError):
                 pass
         lat["hop_floor_us"] = hop
         lat["frac"] = round(hop / lat["us_per_step"], 4)  # 1.0 = every step costs exactly one cross-CU hop
-        if floor is not None and dom in ("pk_rec_fwd_bf16", "pk_rec_bwd_bf16") and tr.rcp["cfg"]["architecture1"]["arch_class"] == "liGRU":
-            lat["step_floor_us"] = floor
-            lat["structure_frac"] = round(floor / lat["us_per_step"], 4)
-            lat["floor_source"] = "profiles/" + src_
+        if src_:
+            lat["hop_source"] = "profiles/" + src_
         roof["latency"] = lat
         # (kept at the top level too: earlier rounds' readers look for them there)
         roof["dependent_steps_per_launch"], roof["us_per_step"] = tr.T, lat["us_per_step"]
         roof["hop_floor_us"], roof["latency_frac"] = hop, lat["frac"]
-        if "structure_frac" in lat:
-            roof["step_floor_us"], roof["structure_frac"] = lat["step_floor_us"], lat["structure_frac"]
-    for src in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    # HBM bytes per launch from the PMC passes of the round's evidence run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate passes, FETCH doubled per MI355X_MICROARCH.md; tools/pmc_summaries.py): headline file, or <round>_pmc_traffic_<recipe>.json
+    names = ["r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json",
+             "r01_pmc_traffic.json"] if args.recipe == "timit_ligru" else ["r06_pmc_traffic_%s.json" % args.recipe]
+    for src in names:
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", src)))
-            if dom in pm and args.recipe == "timit_ligru" and (tr.T, tr.B) == (500, 128) and args.layers is None:
+            if dom in pm and (tr.T, tr.B) == ((500, 128) if tr.rcp["seq"] else (1, 128)) and args.layers is None and prec == "bf16":
                 roof["traffic"] = pm[dom]["traffic_bytes"]
                 roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)" % src
                 break
@@ -612,7 +670,7 @@ def release(tr):
 OTHER_CONFIGS = [("timit_mlp", 400, 5), ("timit_lstm", 50, 5), ("libri_gru", 50, 5), ("timit_sincnet", 100, 5)]
 
 
-def through_run_nn(args, n_batches=12, reps=3):
+def through_run_nn(args, n_batches=12, reps=3, ragged=False):
     """The same workload THROUGH the chunk loop (`elapsed_time_chunk`, core.py:567-701): a synthetic
     chunk of n_batches x B sentences of T frames resident in HBM, handed to pytorch-kaldi_amd.core.run_nn_dp with a
     chunk cfg on disk - batch assembly (the zero-padding gather), forward_model, backward, fused optimizers, ONE host
@@ -633,11 +691,19 @@ def through_run_nn(args, n_batches=12, reps=3):
     n_snt = n_batches * B
     g = torch.Generator().manual_seed(99)
     nlab = 2 if rcp["n_mono"] else 1
-    data = torch.randn(n_snt * T, rcp["nfea"] + nlab, generator=g)
-    data[:, rcp["nfea"]] = torch.randint(0, rcp["n_cd"], (n_snt * T,), generator=g).float()
+    if ragged:
+        # ragged=True: sentence lengths U[T/2, T], sorted ascending like the reference's chunk lists (data_io sorts a chunk
+        # by length, so a batch's sentences are close in length); every batch is padded to ITS longest sentence, each
+        # sentence behind a random number of leading zeros (core.py:581-598)
+        lens = np.sort(np.random.RandomState(7).randint(T // 2, T + 1, size=n_snt)).astype(np.int64)
+    else:
+        lens = np.full(n_snt, T, dtype=np.int64)  # equal-length sentences: the metric's (T, B) batch every time
+    n_rows = int(lens.sum())
+    data = torch.randn(n_rows, rcp["nfea"] + nlab, generator=g)
+    data[:, rcp["nfea"]] = torch.randint(0, rcp["n_cd"], (n_rows,), generator=g).float()
     if rcp["n_mono"]:
-        data[:, rcp["nfea"] + 1] = torch.randint(0, rcp["n_mono"], (n_snt * T,), generator=g).float()
-    end = np.arange(1, n_snt + 1, dtype=np.int64) * T  # equal-length sentences: the metric's (T, B) batch every time
+        data[:, rcp["nfea"] + 1] = torch.randint(0, rcp["n_mono"], (n_rows,), generator=g).float()
+    end = np.cumsum(lens)
     names = ["utt%05d" % i for i in range(n_snt)]
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -666,12 +732,18 @@ def through_run_nn(args, n_batches=12, reps=3):
             info.read(os.path.join(tmp, "chunk.info"))
             times.append(float(info["results"]["elapsed_time_chunk"]))
         dt = sorted(times[1:])[(len(times) - 1) // 2]
-        out = {"value": round(n_batches * T * B / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_batches, 3),
+        padded = int(sum(int(lens[i * B:(i + 1) * B].max()) * B for i in range(n_batches)))  # rows the kernels process
+        out = {"value": round(n_rows / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / n_batches, 3),
                "batches": n_batches, "elapsed_time_chunk_s": round(dt, 4), "warmup_chunk_s": round(times[0], 4),
                "chunks_s": [round(t, 4) for t in times],
-               "note": "pytorch-kaldi_amd.core.run_nn_dp on a resident synthetic chunk (%d sentences of %d frames): batch "
+               "note": "pytorch-kaldi_amd.core.run_nn_dp on a resident synthetic chunk (%d sentences, %s): batch "
                        "assembly + forward_model + backward + fused optimizers, one host sync per chunk; the time is the "
-                       ".info file's elapsed_time_chunk (core.py:567, 701)" % (n_snt, T)}
+                       ".info file's elapsed_time_chunk (core.py:567, 701); value counts the sentences' own frames"
+                       % (n_snt, "lengths U[%d, %d] sorted, zero-padded per batch with random left offsets" % (T // 2, T)
+                          if ragged else "%d frames each" % T)}
+        if ragged:
+            out["padded_frames_per_s"] = round(padded / dt, 1)
+            out["padding_share"] = round(1.0 - n_rows / padded, 4)
     return out
 
 
@@ -801,6 +873,10 @@ def main():
             out["through_run_nn"] = through_run_nn(args)
         except Exception as e:
             out["through_run_nn"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:  # SURVEY.md 8(d)'s secondary variant: sentence lengths U[250, 500], zero-padded with a random left offset (core.py:588-595)
+            out["padded_batches"] = through_run_nn(args, n_batches=8, reps=2, ragged=True)
+        except Exception as e:
+            out["padded_batches"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
             a4 = copy.copy(args)
             a4.torch_optim, a4.unfused_cost, a4.sync_every_step, a4.repeats = True, True, True, 1
@@ -833,13 +909,20 @@ def main():
                        "roofline": rec["roofline"],
                        "entry_points_ms_per_step": dict(list(rec["entry_points_ms_per_step"].items())[:4])}
                 release(tr3)
-                if recipe in ("timit_lstm", "libri_gru"):
-                    a5 = copy.copy(a3)
-                    a5.prec, a5.repeats = "fp32", 1
-                    rec5, tr5 = measure(a5, rank, world, 2, 1)
-                    ent["parity_mode"] = {k: rec5[k] for k in ("dtype", "ms_per_step", "value", "steps", "warmup")}
-                    ent["parity_mode"]["entry_points_ms_per_step"] = dict(list(rec5["entry_points_ms_per_step"].items())[:3])
-                    release(tr5)
+                # the same configuration in the exact-fp32 mode (BASELINE names bf16 for config 2 only: this is the row the
+                # 1e-4 parity tests grade), graph-replayed where the bf16 row is
+                a5 = copy.copy(a3)
+                a5.prec, a5.repeats = "fp32", 1
+                seq3 = recipe in ("timit_lstm", "libri_gru")
+                rec5, tr5 = measure(a5, rank, world, 3 if seq3 else steps, 1 if seq3 else warmup)
+                ent["parity_mode"] = {k: rec5[k] for k in ("dtype", "ms_per_step", "value", "steps", "warmup")}
+                ent["parity_mode"]["roofline"] = {k: rec5["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac")}
+                ent["parity_mode"]["entry_points_ms_per_step"] = dict(list(rec5["entry_points_ms_per_step"].items())[:3])
+                release(tr5)
+                if not args.no_cpu_baseline:
+                    # the reference path of THIS configuration on this host's cores (bounded: ~8 s; sequence recipes at the
+                    # metric's T with 8 of the 128 sequences)
+                    ent["cpu_baseline"] = cpu_baseline(a3, recipe, budget_s=8.0, shape=(args.T, 8) if seq3 else (1, 128))
                 out["other_configs"].append(ent)
             except Exception as e:  # a recipe that fails must not take the headline line with it
                 out["other_configs"].append({"recipe": recipe, "error": "%s: %s" % (type(e).__name__, e)})

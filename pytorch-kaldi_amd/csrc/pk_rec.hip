@@ -547,10 +547,13 @@ int64_t pk_rec_work_base_floats(int cell, int B, int bidir, int H) {
     return (n + 63) / 64 * 64;
 }
 int64_t pk_rec2f_exchange_floats(int cell, int T, int B, int bidir, int H);  // pk_rec_persist2_f32.hip
+int64_t pk_rec4f_exchange_floats(int cell, int T, int B, int bidir, int H);  // pk_rec_persist4_f32.hip
 
 extern "C" int64_t pk_rec_work_floats(int cell, int T, int B, int bidir, int H) {
-    // + the fp32 exchange buffer of the exact-fp32 persistent kernels (liGRU / RNN), placed behind the base scratch
-    return pk_rec_work_base_floats(cell, B, bidir, H) + pk_rec2f_exchange_floats(cell, T, B, bidir, H);
+    // + the fp32 exchange buffer of the exact-fp32 persistent kernels (liGRU / RNN: second generation; LSTM / GRU /
+    // minimalGRU: fourth), placed behind the base scratch
+    return pk_rec_work_base_floats(cell, B, bidir, H) + pk_rec2f_exchange_floats(cell, T, B, bidir, H) +
+           pk_rec4f_exchange_floats(cell, T, B, bidir, H);
 }
 
 extern "C" int pk_rec_fwd(void* stream, int algo, int prec, int cell, int act, int T, int B, int bidir, int H,

@@ -29,6 +29,7 @@ struct R2Args {
     int Gpitch;  // elements per row of dGb; gate g starts at g*Hp
     float* Yx;   // exact-fp32 kernels (pk_rec_persist2_f32.hip): fp32 exchange buffers with the same geometry as Yb / dGb
     float* dGx;  //   (pitches in floats; a chunk = 16 bytes = 4 units)
+    float* Xx;   // exact-fp32 two-phase cells (pk_rec_persist4_f32.hip): r*h (GRU) / z*h (minimalGRU), same layout as Yx
     unsigned* err;
     int spin_limit;
     float* trash;               // >= 64 bytes per lane-group of write-only scratch for masked-off stores

@@ -1545,12 +1545,17 @@ def ln_persistent_ok(cell, H):
 
 def choose_rec_algo(cell, H, use_ln):
     want = settings.rec_algo
+    # exact fp32, no per-step LayerNorm: LSTM / GRU / minimalGRU run on the fourth-generation persistent kernels
+    # (pk_rec_persist4_f32.hip; PK_EXPERIMENT rec_f32_gen4=0 keeps the first-generation LSTM kernels / the step-wise GRU -
+    # the library reads the same switch, pk_rec4f_covers)
+    gen4 = (not bf16_mode() and not use_ln and cell in ("LSTM", "GRU", "minimalGRU")
+            and _lib.experiment("rec_f32_gen4", "1")[:1] != "0")
     ok = cell in ("liGRU", "RNN", "LSTM") and H <= 576 and (not use_ln or ln_persistent_ok(cell, H))
-    if cell in ("GRU", "minimalGRU"):  # the two-phase persistent kernels are perf-mode only; on this (general) path they
-        ok = H <= 576 and use_ln and ln_persistent_ok(cell, H)  # serve the layers that normalise h_t
-    # the first-generation exact-fp32 kernels exchange pairs of fp32 values: LSTM always, liGRU / RNN when
+    if cell in ("GRU", "minimalGRU"):  # bf16 two-phase kernels on this (general) path: the layers that normalise h_t
+        ok = H <= 576 and ((use_ln and ln_persistent_ok(cell, H)) or gen4)
+    # the first-generation exact-fp32 kernels exchange pairs of fp32 values: LSTM without generation 4, liGRU / RNN when
     # PK_EXPERIMENT rec_f32_gen=1 keeps them (the library reads the same switch, pk_rec_persist.hip::use_gen2_f32)
-    if not bf16_mode() and (cell == "LSTM" or _lib.experiment("rec_f32_gen", "")[:1] == "1"):
+    if not bf16_mode() and not gen4 and (cell == "LSTM" or _lib.experiment("rec_f32_gen", "")[:1] == "1"):
         ok = ok and H % 2 == 0
     if want == "persistent":
         if not ok:

@@ -11,7 +11,7 @@ def test_environment_switches_match_the_integration_table():
     doc = set(re.findall(r"`(PK_[A-Z0-9_]+)`", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
     src = set()
     files = (glob.glob(os.path.join(ROOT, "pytorch-kaldi_amd", "*.py")) + glob.glob(os.path.join(ROOT, "pytorch-kaldi_amd", "csrc", "*.hip"))
-             + glob.glob(os.path.join(ROOT, "pytorch-kaldi_amd", "csrc", "*.h")))
+             + glob.glob(os.path.join(ROOT, "pytorch-kaldi_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "integration", "*.py")))
     for f in files:
         t = open(f).read()
         src |= set(re.findall(r'"(PK_[A-Z0-9_]+)"', t))

@@ -19,7 +19,7 @@ TOL = 1e-4
 # normalisations, eval mode of every cell, BatchNorm in SincNet / CNN)
 _SKIP = ("e2e_", "chunk_", "io_", "train_", "scale_")
 MODULE_CASES = [c for c in list_cases() if not c.startswith(_SKIP)]
-PERSISTENT_OK = ("liGRU", "RNN", "LSTM")
+PERSISTENT_OK = ("liGRU", "RNN", "LSTM", "GRU", "minimalGRU")  # (round 6: the fourth-generation fp32 kernels take the last three)
 
 
 @pytest.fixture(autouse=True)
@@ -40,9 +40,7 @@ def _check_case(case, algo):
     if any(s.strip().lower() == "true" for k, v in m["options"].items() if k.endswith("_use_laynorm")
            for s in v.split(",")) and m["arch_class"] in ("LSTM", "GRU", "minimalGRU") and algo == "persistent":
         pytest.skip("per-step LayerNorm inside the persistent loop: liGRU / RNN in fp32 (LSTM: perf mode only)")
-    pre = {"liGRU": "ligru", "LSTM": "lstm", "GRU": "gru", "minimalGRU": "minimalgru", "RNN": "rnn"}.get(m["arch_class"])
-    if algo == "persistent" and m["arch_class"] == "LSTM" and any(int(h) % 2 for h in m["options"][pre + "_lay"].split(",")):
-        pytest.skip("LSTM's exact-fp32 persistent kernels exchange pairs of fp32 values: odd layer widths run step-wise")
+    # (odd LSTM widths no longer skip: the fourth-generation kernels exchange 16-byte chunks at a padded pitch)
     F_amd.set_rec_algo(algo)
     net = build_engine(m, g.group("sd/"))
     has_bwd = "dx" in g.arrays
@@ -142,6 +140,16 @@ ORACLE_CASES = [
     ("LSTM", "lstm", "tanh", [550], 30, 20, 40, "persistent"),
     ("GRU", "gru", "tanh", [550, 550], 12, 5, 40, "stepwise"),
     ("minimalGRU", "minimalgru", "relu", [96], 10, 3, 17, "stepwise"),
+    # round 6: pk_rec_persist4_f32.hip - partial clusters, several clusters, odd widths, two launches (300 rows > 8 x 16 x 2)
+    ("LSTM", "lstm", "tanh", [550, 550], 12, 5, 40, "persistent"),
+    ("LSTM", "lstm", "tanh", [77], 9, 3, 13, "persistent"),
+    ("GRU", "gru", "tanh", [550, 550], 12, 5, 40, "persistent"),
+    ("GRU", "gru", "tanh", [550], 30, 20, 40, "persistent"),
+    ("GRU", "gru", "relu", [61], 9, 3, 13, "persistent"),
+    ("minimalGRU", "minimalgru", "relu", [96], 10, 3, 17, "persistent"),
+    ("minimalGRU", "minimalgru", "tanh", [550], 16, 24, 40, "persistent"),
+    ("LSTM", "lstm", "tanh", [550], 6, 150, 40, "persistent"),
+    ("GRU", "gru", "tanh", [550], 6, 150, 40, "persistent"),
     ("RNN", "rnn", "relu", [130], 10, 33, 17, "persistent"),
 ]
 

@@ -8,11 +8,11 @@
 // recurrent matrix in REGISTERS for all T steps, h_t (dgates_t) exchanged through L2 in 16-byte chunks with the data as
 // the flag - with two differences that make the bigger cells fit:
 //
-//   * K is split over a PAIR of waves.  A workgroup is two pairs = 32 hidden units; wave (tile, kh) holds the B fragments
-//     of its tile's 16 units for HALF of the reduction (LSTM forward: 4 gates x 288 k = 288 registers; GRU: 216), both
-//     waves of a pair sit on different SIMDs, exchange their partial sums through LDS (one workgroup barrier per MFMA
-//     phase) and then do the SAME gate math on the same sums (a + b == b + a bitwise), so state never has to be handed
-//     over; the pair splits the loads and stores of the step between its waves instead.
+//   * K is split over the FOUR waves of a workgroup.  A workgroup is 32 hidden units = two tiles of 16; wave w holds the B
+//     fragments of BOTH tiles for quarter w of the reduction (LSTM: 2 tiles x 4 gates x 144 k = 288 registers; GRU: 216),
+//     the four partial sums meet in LDS (one workgroup barrier per MFMA phase) and are added in a fixed order; the gate
+//     math of a tile is then split by ROWS between two waves, so state never has to be handed over and nothing is
+//     computed twice.
 //   * The A operand never touches LDS.  Lane (row r = lane & 15, quarter kq = lane >> 4) of v_mfma_f32_16x16x4_f32
 //     multiplies A[r][16 j + 4 kq + e] in step (j, e) - four consecutive k of one row: exactly one published 16-byte
 //     chunk.  So every wave polls ITS chunks straight into the registers the MFMAs read (sentinel test on the loaded
@@ -37,7 +37,6 @@
 namespace {
 
 constexpr int KJ = KPAD / 16;    // 36 groups of 16 k per gate
-constexpr int NJH = KJ / 2;      // 18: what one wave of a pair holds of one gate
 constexpr int UW = 32;           // hidden units per workgroup (two pairs of waves)
 constexpr int HS4 = 32;          // placement-handshake words per cluster (up to 18 members)
 
@@ -108,6 +107,32 @@ __device__ __forceinline__ bool poll_regs(__amdgpu_buffer_rsrc_t rs, OffFn off, 
     return dead;
 }
 
+// The second half of poll_regs for loads that were issued earlier (two batches in flight): re-load what has not arrived.
+template <int N, bool FAST, typename OffFn>
+__device__ __forceinline__ bool settle_regs(__amdgpu_buffer_rsrc_t rs, OffFn off, u32x4 (&v)[N], unsigned* err, int spin_limit,
+                                            int lane, bool dead) {
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < N; ++i) bad = bad | has_sent16(v[i]);
+    if (__any(bad) && !dead) {
+        int spins = 0;
+        while (true) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (has_sent16(v[i])) v[i] = poll_load<FAST>(rs, off(i));
+            bad = false;
+#pragma unroll
+            for (int i = 0; i < N; ++i) bad = bad | has_sent16(v[i]);
+            if (!__any(bad)) break;
+            if (spin_check2(spins, spin_limit, err, lane)) {
+                dead = true;
+                break;
+            }
+        }
+    }
+    return dead;
+}
+
 // A lane's chunks of one row: group j (16 k) of its quarter kq sits at lanebase + 64 j; the groups from jlim on lie beyond
 // Hp and are read from group jlim - 1 instead (jl1 = jlim - 1; a lane whose quarter has no valid group at all reads
 // quarter 0, group 0).
@@ -140,8 +165,32 @@ __device__ __forceinline__ void mfma_batch(const u32x4 (&v)[N], const float (*Bf
         }
 }
 
-// which wave of a pair moves item k of n between registers and global memory
-__host__ __device__ constexpr int owner_of(int k, int n) { return k < (n + 1) / 2 ? 0 : 1; }
+// ---- who does what in a workgroup (256 threads = 4 waves, 32 hidden units = 2 tiles of 16):
+//   MFMA phase   wave w holds K-QUARTER w (groups 9 w .. 9 w + 8 of every gate's 36) of BOTH tiles' B fragments: it polls
+//                only its quarter of the rows (no chunk is read twice by a workgroup) and feeds each polled register to
+//                the MFMAs of both tiles;
+//   reduction    every wave writes its partial sums of both tiles to LDS, one workgroup barrier, every wave adds the four
+//                partials of ITS share in the fixed order 0, 1, 2, 3;
+//   gate math    wave w owns tile w >> 1, accumulator row slots r = 2 (w & 1), 2 (w & 1) + 1 of every lane - 8 of the
+//                cluster's 16 rows x 16 units: state, loads, stores and the publish of that share are its alone.
+constexpr int NQ = KJ / 4;   // 9 groups of 16 k: a wave's quarter of one gate
+// diagnostics (pk_persist2_set_trace, tools/trace_rec4.py): shader-clock stamps of (workgroup 0, thread 0), 8 per step
+#define PK4_TRACE(step, slot)                                                                                      \
+    do {                                                                                                           \
+        if (a.trace != nullptr && blockIdx.x == 0 && tid == 0) a.trace[(long)(step) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+// my two accumulator row slots of a [16 rows][16 units] patch, MFMA C/D layout: rows kq*4 + 2 rh + s, unit lane & 15
+__device__ __forceinline__ void put_cd2(float* patch, int kq, int rh, int lane, const float (&v)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) patch[(kq * 4 + 2 * rh + s) * 16 + (lane & 15)] = v[s];
+}
+__device__ __forceinline__ void get_cd2(const float* patch, int kq, int rh, int lane, float (&v)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) v[s] = patch[(kq * 4 + 2 * rh + s) * 16 + (lane & 15)];
+}
+// vector layout of my share: lanes 0..31 -> (my row vr = lane >> 2 of 8, units (lane & 3) * 4 .. + 3); patch row of vr
+__device__ __forceinline__ int share_row(int vr, int rh) { return (vr >> 1) * 4 + 2 * rh + (vr & 1); }
 
 // ============================================================================
 // forward
@@ -153,46 +202,50 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
     constexpr bool TWO = pk_cell_two_phase(CELL);
     constexpr int G1 = TWO ? G - 1 : G;  // gates fed by h_{t-1}
     constexpr int NOUT = NS + 1;         // Y, saved slots
-    // LDS (floats): per pair and parity: G input patches | 2 x G1 partial sums (| 2 candidate partial sums);
-    // per wave: NOUT output patches + 1 publish patch for x_t
-    constexpr int PAIR_PAR = (G + 2 * G1 + (TWO ? 2 : 0)) * 256;
-    constexpr int WAVE_PRIV = (NOUT + 1) * 256;
+    // LDS (floats): [parity][wave][tile][G1] partial sums (| [parity][wave][tile] candidate partial sums);
+    // per wave: G input patches | NOUT output patches | 1 publish patch for x_t
+    constexpr int XS1 = 4 * 2 * G1 * 256, XS2 = TWO ? 4 * 2 * 256 : 0;
+    constexpr int WAVE_PRIV = (G + NOUT + 1) * 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = wave >> 1, kh = wave & 1;
+    const int mt = wave >> 1, rh = wave & 1;  // my gate-math share: tile mt, row slots 2 rh, 2 rh + 1
     const int c = blockIdx.x % a.C, p = blockIdx.x / a.C;
     const int H = a.H, Hp = a.Hp, B = a.B, T = a.T, GH = G * H;
     const int n_base = a.row0 + c * a.rpc;
     int nrows = a.R - n_base;
     nrows = nrows < a.rpc ? nrows : a.rpc;
     if (nrows <= 0) return;
-    const int ubase = p * UW + tile * 16;
-    const int unit = ubase + (lane & 15);
-    const bool unit_ok = unit < H;
     const int kq = lane >> 4;
 
-    // ---- recurrent weights of my 16 units, my half of k (once): B1[g][jj][e] = U_g[unit][16 (kh*18 + jj) + 4 kq + e]
-    float B1[G1][NJH][4];
-    float B2[TWO ? NJH : 1][4];
+    // ---- recurrent weights, my quarter of k, both tiles (once): B1[tl][g][i][e] = U_g[unit(tl)][16 (9 w + i) + 4 kq + e]
+    float B1[2][G1][NQ][4];
+    float B2[2][TWO ? NQ : 1][4];
     {
         const unsigned szU = (unsigned)((size_t)G * H * H * 4);
         const __amdgpu_buffer_rsrc_t rsU = make_rsrc(a.U, szU);
 #pragma unroll
-        for (int g = 0; g < G; ++g)
+        for (int tl = 0; tl < 2; ++tl) {
+            const int un = p * UW + tl * 16 + (lane & 15);
 #pragma unroll
-            for (int jj = 0; jj < NJH; ++jj) {
-                const int k0 = (kh * NJH + jj) * 16 + kq * 4;
-                const unsigned off = (unsigned)(((g * H + unit) * H + k0) * 4);
-                // (rows of U are only 4-byte aligned when H is odd: four dword loads; the bounds check answers 0 beyond U)
+            for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsU, (unit_ok && k0 + e < H) ? off + 4u * e : szU, 0, 0));
-                    if (g < G1) B1[g < G1 ? g : 0][jj][e] = w;
-                    else if (TWO) B2[TWO ? jj : 0][e] = w;
+                for (int i = 0; i < NQ; ++i) {
+                    const int k0 = (wave * NQ + i) * 16 + kq * 4;
+                    const unsigned off = (unsigned)(((g * H + un) * H + k0) * 4);
+                    // (rows of U are only 4-byte aligned when H is odd: four dword loads; the bounds check answers 0 beyond U)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsU, (un < H && k0 + e < H) ? off + 4u * e : szU, 0, 0));
+                        if (g < G1) B1[tl][g < G1 ? g : 0][i][e] = w;
+                        else if (TWO) B2[tl][TWO ? i : 0][e] = w;
+                    }
                 }
-            }
+        }
     }
+    const int ubase = p * UW + mt * 16;
+    const int unit = ubase + (lane & 15);
+    const bool unit_ok = unit < H;
     float psc[G], psh[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -200,9 +253,9 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
         psh[g] = unit_ok ? a.pshift[g * H + unit] : 0.f;
     }
     float* const lds = reinterpret_cast<float*>(smem);
-    for (int i = tid; i < 2 * 2 * PAIR_PAR + 4 * WAVE_PRIV; i += 256) lds[i] = 0.f;
+    for (int i = tid; i < 2 * (XS1 + XS2) + 4 * WAVE_PRIV; i += 256) lds[i] = 0.f;
 
-    // ---- poll geometry: my row of h_{t-1} / x_t (row lane & 15 of the cluster), my groups of k
+    // ---- poll geometry: row lane & 15 of the cluster, my quarter of k
     const unsigned TS = (unsigned)B * a.Ypitch * 4u;  // bytes per time slab of Yx / Xx
     const unsigned szYx = (unsigned)T * TS;
     RowPoll rp;
@@ -212,53 +265,55 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
         const int dir = n >= B ? 1 : 0, b = n - dir * B;
         rp.init(true, ((unsigned)b * a.Ypitch + dir * Hp) * 4u + (unsigned)(dir ? (T - 1) : 0) * TS, dir ? 0u - TS : TS, kq, Hp);
     }
-    float rvf[4], msk[4], hprev[4], cprev[4];
+    float rvf[2], msk[2], hprev[2], cprev[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = kq * 4 + r, n = n_base + row;
+    for (int s_ = 0; s_ < 2; ++s_) {
+        const int row = kq * 4 + 2 * rh + s_, n = n_base + row;
         const bool ok = row < nrows && unit_ok;
-        rvf[r] = ok ? 1.f : 0.f;
-        msk[r] = (a.mask != nullptr && ok) ? a.mask[(long)n * H + unit] : a.mask_scalar;
-        hprev[r] = 0.f;
-        cprev[r] = 0.f;
+        rvf[s_] = ok ? 1.f : 0.f;
+        msk[s_] = (a.mask != nullptr && ok) ? a.mask[(long)n * H + unit] : a.mask_scalar;
+        hprev[s_] = 0.f;
+        cprev[s_] = 0.f;
     }
-    // ---- vector layout: row lane>>2, units ubase + (lane&3)*4 .. +3 (also the publish layout: one 16-byte chunk per lane)
-    const int vrow = lane >> 2, vu0 = ubase + (lane & 3) * 4;
-    const int vn = n_base + (vrow < nrows ? vrow : 0);
+    // ---- vector layout of my share (lanes 0..31): also the publish layout, one 16-byte chunk per lane
+    const bool vlane = lane < 32;
+    const int vr = (lane >> 2) & 7, vrow = share_row(vr, rh), vu0 = ubase + (lane & 3) * 4;
+    const bool vrow_ok = vlane && vrow < nrows;
+    const int vn = n_base + (vrow_ok ? vrow : 0);
     const int vdir = vn >= B ? 1 : 0, vb = vn - vdir * B;
     int vnv = H - vu0;
     vnv = vnv > 4 ? 4 : (vnv < 0 ? 0 : vnv);
     const int edge = __any(vnv > 0 && vnv < 4) != 0 ? ((H & 1) ? 2 : 1) : 0;
-    vnv = vrow < nrows ? vnv : 0;
+    vnv = vrow_ok ? vnv : 0;
     const unsigned vP0 = ((unsigned)vb * GH + vu0), vPs = (unsigned)B * GH;
     const unsigned vY0 = ((unsigned)vb * a.YH + vdir * H + vu0), vYs = (unsigned)B * a.YH;
     const unsigned vS0 = (((unsigned)vdir * T * B + vb) * (NS * H) + vu0), vSs = (unsigned)B * NS * H;
-    const bool pk_ok = vrow < nrows && vu0 < Hp;  // (padding units between H and Hp are published as zeros)
+    const bool pk_ok = vrow_ok && vu0 < Hp;  // (padding units between H and Hp are published as zeros)
     const unsigned pbase = pk_ok ? ((unsigned)vb * a.Ypitch + vdir * Hp + vu0) * 4u : szYx;  // out of range: dropped
+    const int voff = vrow * 16 + (lane & 3) * 4;  // my chunk inside a patch
 
-    float* const pairm = lds + tile * (2 * PAIR_PAR);                       // [parity][PAIR_PAR]
-    float* const priv = lds + 2 * 2 * PAIR_PAR + wave * WAVE_PRIV;           // [NOUT + 1][256]
-    float* const patchX = priv + NOUT * 256;
+    float* const xs1 = lds;                                   // [parity][wave][tile][G1][256]
+    float* const xs2 = lds + 2 * XS1;                         // [parity][wave][tile][256]
+    float* const priv = lds + 2 * (XS1 + XS2) + wave * WAVE_PRIV;
+    float* const pin = priv;                                  // [G] projections of this step (my share)
+    float* const pout = priv + G * 256;                       // [NOUT] h_t, saved slots (my share)
+    float* const patchX = priv + (G + NOUT) * 256;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.Yx, szYx);
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(TWO ? a.Xx : a.Yx, szYx);
     float* trash = a.trash + (tid & 63) * 4;
 
-    // inputs: the G projections; wave owner_of(g, G) of the pair loads gate g (one step ahead) and puts it into the pair's patch
     f32x4 pv[G];
     auto load_proj = [&](int tt, auto E) {
         const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-            if (owner_of(g, G) == kh) pv[g] = ld4<decltype(E)::value>(a.P, vP0 + ts * vPs + g * H, vnv);
+        for (int g = 0; g < G; ++g) pv[g] = ld4<decltype(E)::value>(a.P, vP0 + ts * vPs + g * H, vnv);
     };
-    // outputs: item 0 = h_t (Y), items 1.. = saved slots; wave owner_of(k, NOUT) stores item k (one step behind)
     auto flush_outputs = [&](int tt, auto E) {
         constexpr int EE = decltype(E)::value;
         const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
-        if (owner_of(0, NOUT) == kh) st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(priv, lane));
+        st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, *reinterpret_cast<const f32x4*>(pout + voff));
 #pragma unroll
-        for (int k = 0; k < NS; ++k)
-            if (owner_of(k + 1, NOUT) == kh) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, patch_get_vec(priv + (k + 1) * 256, lane));
+        for (int k = 0; k < NS; ++k) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, *reinterpret_cast<const f32x4*>(pout + (k + 1) * 256 + voff));
     };
 #define PK4_LP0(E) load_proj(0, E)
     PK_EDGE_DISPATCH(PK4_LP0);
@@ -266,145 +321,183 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
 
     bool dead = false;
     const bool fast = __builtin_amdgcn_readfirstlane((int)(cluster_on_one_xcd4(a, c, p, tid, dead) && a.force_safe == 0)) != 0;
-    // diagnostics (pk_persist2_set_empty_step; timing only, results are garbage): bit 0 = no MFMAs, bit 1 = no polls
+    // diagnostics (pk_persist2_set_empty_step; timing only, results are garbage): bit 0 = no MFMAs, bit 1 = no waiting in the polls
     const bool no_mfma = (a.empty_step & 1) != 0;
     if ((a.empty_step & 2) != 0) dead = true;
+    // the time loop is instantiated per (XCD-local exchange?, does my tile straddle H?): no run-time choices inside it
+    auto run = [&](auto FASTC, auto SEC) {
+    constexpr bool FAST = decltype(FASTC)::value != 0;
+    constexpr int SE = decltype(SEC)::value;
     for (int t = 0; t < T; ++t) {
-        float* const pm = pairm + (t & 1) * PAIR_PAR;
-        float* const pin = pm;                                    // [G][256] projections of this step
-        float* const xs1 = pm + G * 256;                          // [2 waves][G1][256] partial sums, phase 1
-        float* const xs2 = pm + (G + 2 * G1) * 256;               // [2 waves][256] partial sums, phase 2
+        float* const x1 = xs1 + (t & 1) * XS1;
+        float* const x2 = xs2 + (t & 1) * XS2;
+        PK4_TRACE(t, 0);
+        if (vlane) {  // (lanes 32..63 hold no share: their copies of the loads are garbage)
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-            if (owner_of(g, G) == kh) patch_put_vec(pin + g * 256, lane, pv[g]);
-        f32x4 acc[G1][2];
+            for (int g = 0; g < G; ++g) *reinterpret_cast<f32x4*>(pin + g * 256 + voff) = pv[g];
+        }
+        f32x4 acc[2][G1];
 #pragma unroll
-        for (int g = 0; g < G1; ++g) acc[g][0] = acc[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 av[NJH];
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int g = 0; g < G1; ++g) acc[tl][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 av[NQ];
         if (t > 0) {
             for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             const unsigned lb = rp.lanebase(t - 1);
-            auto off = [&](int i) { return rp.at(lb, kh * NJH + i); };
-            dead = fast ? poll_regs<NJH, true>(rs, off, av, a.err, a.spin_limit, lane, dead)
-                        : poll_regs<NJH, false>(rs, off, av, a.err, a.spin_limit, lane, dead);
+            auto off = [&](int i) { return rp.at(lb, wave * NQ + i); };
+            dead = poll_regs<NQ, FAST>(rs, off, av, a.err, a.spin_limit, lane, dead);
         }
+        PK4_TRACE(t, 1);
         // off the dependency chain, behind the poll: fp32 outputs of the previous step, projections of the next one
         if (t > 0) {
 #define PK4_FO(E) flush_outputs(t - 1, E)
-            PK_EDGE_DISPATCH(PK4_FO);
+            PK_EDGE_DISPATCH_S(PK4_FO);
         }
         if (t + 1 < T) {
 #define PK4_LP1(E) load_proj(t + 1, E)
-            PK_EDGE_DISPATCH(PK4_LP1);
+            PK_EDGE_DISPATCH_S(PK4_LP1);
         }
         if (t > 0 && !no_mfma) {
+            // 2 x G1 independent accumulation chains: a chain comes round every 2 G1 x 32 clocks (dependent latency: 40)
 #pragma unroll
-            for (int g = 0; g < G1; ++g) mfma_batch<NJH>(av, B1[g], acc[g][0], acc[g][1]);
+            for (int i = 0; i < NQ; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < G1; ++g)
+#pragma unroll
+                        for (int tl = 0; tl < 2; ++tl)
+                            acc[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), B1[tl][g][i][e], acc[tl][g], 0, 0, 0);
         }
-        // ---- the pair's partial sums meet in LDS: both waves end with the same totals (a + b == b + a)
-        float sum1[G1][4];
+        PK4_TRACE(t, 2);
+        // ---- the four quarters' partial sums meet in LDS; every wave adds the four of its share in the same order
 #pragma unroll
-        for (int g = 0; g < G1; ++g) {
+        for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sum1[g][r] = acc[g][0][r] + acc[g][1][r];
-            patch_put_cd(xs1 + (kh * G1 + g) * 256, kq, lane, sum1[g]);
-        }
+            for (int g = 0; g < G1; ++g) {
+                float o[4] = {acc[tl][g][0], acc[tl][g][1], acc[tl][g][2], acc[tl][g][3]};
+                patch_put_cd(x1 + ((wave * 2 + tl) * G1 + g) * 256, kq, lane, o);
+            }
         PK_BARRIER_LDS();
+        PK4_TRACE(t, 3);
+        float sum1[G1][2];
 #pragma unroll
         for (int g = 0; g < G1; ++g) {
-            float o[4];
-            patch_get_cd(xs1 + ((kh ^ 1) * G1 + g) * 256, kq, lane, o);
+            float q0[2], q1[2], q2[2], q3[2];
+            get_cd2(x1 + ((0 * 2 + mt) * G1 + g) * 256, kq, rh, lane, q0);
+            get_cd2(x1 + ((1 * 2 + mt) * G1 + g) * 256, kq, rh, lane, q1);
+            get_cd2(x1 + ((2 * 2 + mt) * G1 + g) * 256, kq, rh, lane, q2);
+            get_cd2(x1 + ((3 * 2 + mt) * G1 + g) * 256, kq, rh, lane, q3);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sum1[g][r] = kh == 0 ? sum1[g][r] + o[r] : o[r] + sum1[g][r];  // (same operand order in both waves)
+            for (int s_ = 0; s_ < 2; ++s_) sum1[g][s_] = ((q0[s_] + q1[s_]) + q2[s_]) + q3[s_];
         }
-        float pre[G][4];
+        float pre[G][2];
 #pragma unroll
-        for (int g = 0; g < G; ++g) patch_get_cd(pin + g * 256, kq, lane, pre[g]);
-        float hv[4], sv[NS][4];
+        for (int g = 0; g < G; ++g) get_cd2(pin + g * 256, kq, rh, lane, pre[g]);
+        float hv[2], sv[NS][2];
         if constexpr (!TWO) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int s_ = 0; s_ < 2; ++s_) {
                 float pr[G];
 #pragma unroll
-                for (int g = 0; g < G; ++g) pr[g] = pre[g][r] * psc[g] + psh[g] + sum1[g][r];
-                float h, cc, s[NS];
-                pk_cell_fwd<CELL>(act, pr, hprev[r], cprev[r], msk[r], h, cc, s);
-                h = rvf[r] != 0.f ? h : 0.f;  // rows / units outside the layer carry exact zeros (published as padding)
-                cc = rvf[r] != 0.f ? cc : 0.f;
-                hprev[r] = h;
-                cprev[r] = cc;
-                hv[r] = h;
+                for (int g = 0; g < G; ++g) pr[g] = pre[g][s_] * psc[g] + psh[g] + sum1[g][s_];
+                float h, cc, sl[NS];
+                pk_cell_fwd<CELL>(act, pr, hprev[s_], cprev[s_], msk[s_], h, cc, sl);
+                h = rvf[s_] != 0.f ? h : 0.f;  // rows / units outside the layer carry exact zeros (published as padding)
+                cc = rvf[s_] != 0.f ? cc : 0.f;
+                hprev[s_] = h;
+                cprev[s_] = cc;
+                hv[s_] = h;
 #pragma unroll
-                for (int k = 0; k < NS; ++k) sv[k][r] = s[k];
+                for (int k = 0; k < NS; ++k) sv[k][s_] = sl[k];
             }
         } else {
             // ---- phase 1: the gates that depend on h_{t-1} only; x_t = r*h (GRU) / z*h (minimalGRU) goes to the cluster
-            float xv[4], zt[4];
+            float xv[2], zt[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float pr[G1], s[NS];
+            for (int s_ = 0; s_ < 2; ++s_) {
+                float pr[G1], sl[NS];
 #pragma unroll
-                for (int k = 0; k < NS; ++k) s[k] = 0.f;
+                for (int k = 0; k < NS; ++k) sl[k] = 0.f;
 #pragma unroll
-                for (int g = 0; g < G1; ++g) pr[g] = pre[g][r] * psc[g] + psh[g] + sum1[g][r];
-                const float x = pk_cell_fwd_p1<CELL>(pr, hprev[r], s);
-                xv[r] = rvf[r] != 0.f ? x : 0.f;
-                zt[r] = s[0];
+                for (int g = 0; g < G1; ++g) pr[g] = pre[g][s_] * psc[g] + psh[g] + sum1[g][s_];
+                const float x = pk_cell_fwd_p1<CELL>(pr, hprev[s_], sl);
+                xv[s_] = rvf[s_] != 0.f ? x : 0.f;
+                zt[s_] = sl[0];
 #pragma unroll
-                for (int k = 0; k < NS; ++k) sv[k][r] = s[k];  // (the slots phase 1 fills: z (, r), r*h / z*h)
-                sv[NS - 1][r] = xv[r];
+                for (int k = 0; k < NS; ++k) sv[k][s_] = sl[k];  // (the slots phase 1 fills: z (, r), r*h / z*h)
+                sv[NS - 1][s_] = xv[s_];
             }
-            if (kh == 0) {
-                patch_put_cd(patchX, kq, lane, xv);
-                PK_LDS_ORDER();
-                const u32x4 o = no_sentinel4(patch_get_vec(patchX, lane));
+            put_cd2(patchX, kq, rh, lane, xv);
+            PK_LDS_ORDER();
+            {
+                const u32x4 o = no_sentinel4(*reinterpret_cast<const f32x4*>(patchX + voff));
                 const unsigned off = pbase + (pk_ok ? (unsigned)(vdir ? (T - 1 - t) : t) * TS : 0u);
-                if (fast) pub_store<true>(rsX, off, o);
-                else pub_store<false>(rsX, off, o);
+                pub_store<FAST>(rsX, off, o);
             }
             // ---- phase 2: a_t = Wh_t + x_t . U_h^T
-            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            f32x4 a2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            f32x4 b2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             {
                 const unsigned lb = rp.lanebase(t);
-                auto off = [&](int i) { return rp.at(lb, kh * NJH + i); };
-                dead = fast ? poll_regs<NJH, true>(rsX, off, av, a.err, a.spin_limit, lane, dead)
-                            : poll_regs<NJH, false>(rsX, off, av, a.err, a.spin_limit, lane, dead);
+                auto off = [&](int i) { return rp.at(lb, wave * NQ + i); };
+                dead = poll_regs<NQ, FAST>(rsX, off, av, a.err, a.spin_limit, lane, dead);
             }
-            if (!no_mfma) mfma_batch<NJH>(av, B2, a0, a1);
-            float sum2[4];
+            if (!no_mfma) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sum2[r] = a0[r] + a1[r];
-            patch_put_cd(xs2 + kh * 256, kq, lane, sum2);
-            PK_BARRIER_LDS();
-            {
+                for (int i = 0; i < NQ; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int tl = 0; tl < 2; ++tl) {
+                            if ((e & 1) == 0) a2[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), B2[tl][TWO ? i : 0][e], a2[tl], 0, 0, 0);
+                            else b2[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), B2[tl][TWO ? i : 0][e], b2[tl], 0, 0, 0);
+                        }
+            }
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
                 float o[4];
-                patch_get_cd(xs2 + (kh ^ 1) * 256, kq, lane, o);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sum2[r] = kh == 0 ? sum2[r] + o[r] : o[r] + sum2[r];
+                for (int r = 0; r < 4; ++r) o[r] = a2[tl][r] + b2[tl][r];
+                patch_put_cd(x2 + (wave * 2 + tl) * 256, kq, lane, o);
+            }
+            PK_BARRIER_LDS();
+            float sum2[2];
+            {
+                float q0[2], q1[2], q2[2], q3[2];
+                get_cd2(x2 + (0 * 2 + mt) * 256, kq, rh, lane, q0);
+                get_cd2(x2 + (1 * 2 + mt) * 256, kq, rh, lane, q1);
+                get_cd2(x2 + (2 * 2 + mt) * 256, kq, rh, lane, q2);
+                get_cd2(x2 + (3 * 2 + mt) * 256, kq, rh, lane, q3);
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) sum2[s_] = ((q0[s_] + q1[s_]) + q2[s_]) + q3[s_];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float at = pre[G - 1][r] * psc[G - 1] + psh[G - 1] + sum2[r];
-                float h = pk_cell_fwd_p2<CELL>(act, at, zt[r], hprev[r], msk[r]);
-                h = rvf[r] != 0.f ? h : 0.f;
-                hprev[r] = h;
-                hv[r] = h;
-                sv[G - 1][r] = at;  // GRU: slot 2, minimalGRU: slot 1
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const float at = pre[G - 1][s_] * psc[G - 1] + psh[G - 1] + sum2[s_];
+                float h = pk_cell_fwd_p2<CELL>(act, at, zt[s_], hprev[s_], msk[s_]);
+                h = rvf[s_] != 0.f ? h : 0.f;
+                hprev[s_] = h;
+                hv[s_] = h;
+                sv[G - 1][s_] = at;  // GRU: slot 2, minimalGRU: slot 1
             }
         }
-        // ---- my share of the outputs into my patches; wave 0 of the pair publishes h_t: one 16-byte store per lane
-        if (owner_of(0, NOUT) == kh) patch_put_cd(priv, kq, lane, hv);
+        PK4_TRACE(t, 4);
+        // ---- my share of the outputs into my patches, then the publish of h_t: one 16-byte store per lane (lanes 0..31)
+        put_cd2(pout, kq, rh, lane, hv);
 #pragma unroll
-        for (int k = 0; k < NS; ++k)
-            if (owner_of(k + 1, NOUT) == kh) patch_put_cd(priv + (k + 1) * 256, kq, lane, sv[k]);
+        for (int k = 0; k < NS; ++k) put_cd2(pout + (k + 1) * 256, kq, rh, lane, sv[k]);
         PK_LDS_ORDER();
-        if (kh == 0) {  // (owner_of(0, .) == 0: Y sits in wave 0's patch)
-            const u32x4 o = no_sentinel4(patch_get_vec(priv, lane));
+        {
+            const u32x4 o = no_sentinel4(*reinterpret_cast<const f32x4*>(pout + voff));
             const unsigned off = pbase + (pk_ok ? (unsigned)(vdir ? (T - 1 - t) : t) * TS : 0u);
-            if (fast) pub_store<true>(rs, off, o);
-            else pub_store<false>(rs, off, o);
+            pub_store<FAST>(rs, off, o);
         }
+        PK4_TRACE(t, 5);
     }
+    };
+    PK_RUN_SPECIALISED(run, fast);
 #define PK4_FOL(E) flush_outputs(T - 1, E)
     PK_EDGE_DISPATCH(PK4_FOL);
 }
@@ -419,17 +512,16 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
     constexpr bool TWO = pk_cell_two_phase(CELL);
     constexpr bool LSTM = CELL == PK_CELL_LSTM;
     constexpr int Gh = TWO ? G - 1 : G;        // gates whose gradients go back through h_{t-1}
-    constexpr int NJB = Gh * NJH;              // groups of the carry product one wave holds
-    constexpr int NBQ = Gh >= 4 ? NJH / 2 : NJH;  // groups polled at a time (LSTM: 288 registers of U leave room for 9 chunks)
-    constexpr int NBATCH = NJB / NBQ;
+    constexpr int NJB = Gh * NQ;               // groups of the carry product one wave holds (its quarter of Gh x 36)
+    constexpr int NBATCH = Gh;                 // polled NQ groups at a time, two batches in flight
     // inputs of a step: saved slots, then (LSTM: c_{t-1}; the others: h_{t-1}), then dY
     constexpr int NIN = NS + 2;
-    constexpr int PAIR_PAR = (NIN + 2 + (TWO ? 2 : 0)) * 256;  // input patches | carry partial sums (| q partial sums)
-    constexpr int WAVE_PRIV = G * 256;                          // fp32 gate gradients (my share), also the publish patches
+    constexpr int XSB = 4 * 2 * 256, XSA = TWO ? 4 * 2 * 256 : 0;  // [wave][tile] carry partial sums (| q partial sums)
+    constexpr int WAVE_PRIV = (NIN + G) * 256;                      // inputs | fp32 gate gradients (also the publish patches)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = wave >> 1, kh = wave & 1;
+    const int mt = wave >> 1, rh = wave & 1;
     const int c = blockIdx.x % a.C, p = blockIdx.x / a.C;
     const int H = a.H, Hp = a.Hp, B = a.B, T = a.T, GH = G * H;
     const unsigned TB = (unsigned)T * B;
@@ -437,41 +529,45 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
     int nrows = a.R - n_base;
     nrows = nrows < a.rpc ? nrows : a.rpc;
     if (nrows <= 0) return;
-    const int ubase = p * UW + tile * 16;
-    const int unit = ubase + (lane & 15);
-    const bool unit_ok = unit < H;
     const int kq = lane >> 4;
 
-    // carry product: group jg = kh * NJB + jj -> gate g = jg / KJ, k = 16 (jg % KJ) + 4 kq + e: BB[jj][e] = U_g[k][unit]
-    // two-phase cells: BA[jj][e] = U_{G-1}[16 (kh*18 + jj) + 4 kq + e][unit]  (q = da . U_h)
-    float BB[NJB][4];
-    float BA[TWO ? NJH : 1][4];
+    // carry product: my group jj = global group jg = wave * NJB + jj -> gate g = jg / KJ, k = 16 (jg % KJ) + 4 kq + e:
+    // BB[tl][jj][e] = U_g[k][unit(tl)];  two-phase cells: BA[tl][i][e] = U_{G-1}[16 (9 w + i) + 4 kq + e][unit(tl)]  (q = da . U_h)
+    float BB[2][NJB][4];
+    float BA[2][TWO ? NQ : 1][4];
     {
         const unsigned szU = (unsigned)((size_t)G * H * H * 4);
         const __amdgpu_buffer_rsrc_t rsU = make_rsrc(a.U, szU);
 #pragma unroll
-        for (int jj = 0; jj < NJB; ++jj) {
-            const int jg = kh * NJB + jj, g = jg / KJ, j = jg % KJ;
+        for (int tl = 0; tl < 2; ++tl) {
+            const int un = p * UW + tl * 16 + (lane & 15);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = j * 16 + kq * 4 + e;
-                BB[jj][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                    rsU, (unit_ok && k < H) ? (unsigned)(((g * H + k) * H + unit) * 4) : szU, 0, 0));  // out of range: 0
-            }
-        }
-        if (TWO) {
-#pragma unroll
-            for (int jj = 0; jj < NJH; ++jj)
+            for (int jj = 0; jj < NJB; ++jj) {
+                const int jg = wave * NJB + jj, g = jg / KJ, j = jg % KJ;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int k = (kh * NJH + jj) * 16 + kq * 4 + e;
-                    BA[TWO ? jj : 0][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                        rsU, (unit_ok && k < H) ? (unsigned)((((G - 1) * H + k) * H + unit) * 4) : szU, 0, 0));
+                    const int k = j * 16 + kq * 4 + e;
+                    BB[tl][jj][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        rsU, (un < H && k < H) ? (unsigned)(((g * H + k) * H + un) * 4) : szU, 0, 0));  // out of range: 0
                 }
+            }
+            if (TWO) {
+#pragma unroll
+                for (int i = 0; i < NQ; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = (wave * NQ + i) * 16 + kq * 4 + e;
+                        BA[tl][TWO ? i : 0][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            rsU, (un < H && k < H) ? (unsigned)((((G - 1) * H + k) * H + un) * 4) : szU, 0, 0));
+                    }
+            }
         }
     }
+    const int ubase = p * UW + mt * 16;
+    const int unit = ubase + (lane & 15);
+    const bool unit_ok = unit < H;
     float* const lds = reinterpret_cast<float*>(smem);
-    for (int i = tid; i < 2 * 2 * PAIR_PAR + 4 * WAVE_PRIV; i += 256) lds[i] = 0.f;
+    for (int i = tid; i < 2 * (XSB + XSA) + 4 * WAVE_PRIV; i += 256) lds[i] = 0.f;
 
     // ---- poll geometry: my row of the cluster's gate gradients
     const unsigned TS = (unsigned)B * a.Gpitch * 4u;  // bytes per time slab of dGx
@@ -486,37 +582,40 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
                 dir ? TS : 0u - TS, kq, Hp);
     }
     const unsigned gate_bytes = (unsigned)Hp * 4u;
-    float rvf[4], msk[4], dh_dir[4], dc_car[4];
+    float rvf[2], msk[2], dh_dir[2], dc_car[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = kq * 4 + r, n = n_base + row;
+    for (int s_ = 0; s_ < 2; ++s_) {
+        const int row = kq * 4 + 2 * rh + s_, n = n_base + row;
         const bool ok = row < nrows && unit_ok;
-        rvf[r] = ok ? 1.f : 0.f;
-        msk[r] = (a.mask != nullptr && ok) ? a.mask[(long)n * H + unit] : a.mask_scalar;
-        dh_dir[r] = 0.f;
-        dc_car[r] = 0.f;
+        rvf[s_] = ok ? 1.f : 0.f;
+        msk[s_] = (a.mask != nullptr && ok) ? a.mask[(long)n * H + unit] : a.mask_scalar;
+        dh_dir[s_] = 0.f;
+        dc_car[s_] = 0.f;
     }
-    const int vrow = lane >> 2, vu0 = ubase + (lane & 3) * 4;
-    const int vn = n_base + (vrow < nrows ? vrow : 0);
+    const bool vlane = lane < 32;
+    const int vr = (lane >> 2) & 7, vrow = share_row(vr, rh), vu0 = ubase + (lane & 3) * 4;
+    const bool vrow_ok = vlane && vrow < nrows;
+    const int vn = n_base + (vrow_ok ? vrow : 0);
     const int vdir = vn >= B ? 1 : 0, vb = vn - vdir * B;
     int vnv = H - vu0;
     vnv = vnv > 4 ? 4 : (vnv < 0 ? 0 : vnv);
     const int edge = __any(vnv > 0 && vnv < 4) != 0 ? ((H & 1) ? 2 : 1) : 0;
-    vnv = vrow < nrows ? vnv : 0;
+    vnv = vrow_ok ? vnv : 0;
     const unsigned vY0 = ((unsigned)vb * a.YH + vdir * H + vu0), vYs = (unsigned)B * a.YH;
     const unsigned vS0 = (((unsigned)vdir * TB + vb) * (NS * H) + vu0), vSs = (unsigned)B * NS * H;
     const unsigned vG0 = (((unsigned)vdir * TB + vb) * GH + vu0), vGs = (unsigned)B * GH;
-    const bool pk_ok = vrow < nrows && vu0 < Hp;
+    const bool pk_ok = vrow_ok && vu0 < Hp;
     const unsigned pbase = pk_ok ? (unsigned)vdir * (unsigned)T * TS + ((unsigned)vb * a.Gpitch + vu0) * 4u : szGx;
+    const int voff = vrow * 16 + (lane & 3) * 4;
 
-    float* const pairm = lds + tile * (2 * PAIR_PAR);
-    float* const priv = lds + 2 * 2 * PAIR_PAR + wave * WAVE_PRIV;  // [G][256]
+    float* const xsB = lds;                          // [parity][wave][tile][256]
+    float* const xsA = lds + 2 * XSB;                // [parity][wave][tile][256]
+    float* const priv = lds + 2 * (XSB + XSA) + wave * WAVE_PRIV;
+    float* const pin = priv;                         // [NIN]
+    float* const pg = priv + NIN * 256;              // [G] gate gradients of my share
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.dGx, szGx);
     float* trash = a.trash + (tid & 63) * 4;
 
-    // gate gradient g is published and stored by wave gate_owner(g) of the pair
-    // (two-phase cells: da - slot G-1 - leaves in phase A from wave 0; GRU: dz wave 0, dr wave 1; minimalGRU: dz wave 1)
-    auto gate_owner = [](int g) constexpr { return TWO ? (g == G - 1 ? 0 : (G == 3 ? g : 1)) : owner_of(g, G); };
     f32x4 iv[NIN];
     auto load_step_e = [&](int t, auto E) {
         constexpr int EE = decltype(E)::value;
@@ -524,26 +623,22 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
         const unsigned tp = t > 0 ? (vdir ? ts + 1 : ts - 1) : ts;
         const int nvp = t > 0 ? vnv : 0;
 #pragma unroll
-        for (int k = 0; k < NS; ++k)
-            if (owner_of(k, NIN) == kh) iv[k] = ld4<EE>(a.S, vS0 + ts * vSs + k * H, vnv);
-        if (owner_of(NS, NIN) == kh) {
-            if (LSTM) iv[NS] = ld4<EE>(a.S, vS0 + tp * vSs + 4 * H, nvp);   // c_{t-1}: slot 4 of the previous step
-            else iv[NS] = ld4<EE>(a.Y, vY0 + tp * vYs, nvp);                // h_{t-1}
-            if (t == 0) iv[NS] = f32x4{0.f, 0.f, 0.f, 0.f};                 // c_{-1} = h_{-1} = 0
-        }
-        if (owner_of(NS + 1, NIN) == kh) iv[NS + 1] = ld4<EE>(a.dY, vY0 + ts * vYs, vnv);
+        for (int k = 0; k < NS; ++k) iv[k] = ld4<EE>(a.S, vS0 + ts * vSs + k * H, vnv);
+        if (LSTM) iv[NS] = ld4<EE>(a.S, vS0 + tp * vSs + 4 * H, nvp);   // c_{t-1}: slot 4 of the previous step
+        else iv[NS] = ld4<EE>(a.Y, vY0 + tp * vYs, nvp);                // h_{t-1}
+        if (t == 0) iv[NS] = f32x4{0.f, 0.f, 0.f, 0.f};                 // c_{-1} = h_{-1} = 0
+        iv[NS + 1] = ld4<EE>(a.dY, vY0 + ts * vYs, vnv);
     };
     auto flush_outputs_e = [&](int tt, auto E) {
         const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            if (gate_owner(g) == kh) st4<decltype(E)::value>(a.dP2, vG0 + ts * vGs + g * H, vnv, trash, patch_get_vec(priv + g * 256, lane));
+            st4<decltype(E)::value>(a.dP2, vG0 + ts * vGs + g * H, vnv, trash, *reinterpret_cast<const f32x4*>(pg + g * 256 + voff));
     };
-    auto publish_gate = [&](int g, int t, bool fast_) {
-        const u32x4 o = no_sentinel4(patch_get_vec(priv + g * 256, lane));
+    auto publish_gate = [&](int g, int t, auto FC) {
+        const u32x4 o = no_sentinel4(*reinterpret_cast<const f32x4*>(pg + g * 256 + voff));
         const unsigned off = pbase + (pk_ok ? (unsigned)(vdir ? (T - 1 - t) : t) * TS + (unsigned)(g * Hp) * 4u : 0u);
-        if (fast_) pub_store<true>(rs, off, o);
-        else pub_store<false>(rs, off, o);
+        pub_store<decltype(FC)::value != 0>(rs, off, o);
     };
 #define PK4_LS(E) load_step_e(T - 1, E)
     PK_EDGE_DISPATCH(PK4_LS);
@@ -553,135 +648,186 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
     const bool fast = __builtin_amdgcn_readfirstlane((int)(cluster_on_one_xcd4(a, c, p, tid, dead) && a.force_safe == 0)) != 0;
     const bool no_mfma = (a.empty_step & 1) != 0;  // diagnostics, as in the forward kernel
     if ((a.empty_step & 2) != 0) dead = true;
+    auto run = [&](auto FASTC, auto SEC) {
+    constexpr bool FAST = decltype(FASTC)::value != 0;
+    constexpr int SE = decltype(SEC)::value;
     int it = 0;
     for (int t = T - 1; t >= 0; --t, ++it) {
-        float* const pm = pairm + (it & 1) * PAIR_PAR;
-        float* const pin = pm;                          // [NIN][256]
-        float* const xsB = pm + NIN * 256;              // [2][256] carry partial sums
-        float* const xsA = pm + (NIN + 2) * 256;        // [2][256] q partial sums (two-phase cells)
+        float* const xB = xsB + (it & 1) * XSB;
+        float* const xA = xsA + (it & 1) * XSA;
+        PK4_TRACE(it, 0);
+        if (vlane) {  // (lanes 32..63 hold no share: their copies of the loads are garbage)
 #pragma unroll
-        for (int k = 0; k < NIN; ++k)
-            if (owner_of(k, NIN) == kh) patch_put_vec(pin + k * 256, lane, iv[k]);
-        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+            for (int k = 0; k < NIN; ++k) *reinterpret_cast<f32x4*>(pin + k * 256 + voff) = iv[k];
+        }
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // one chain per tile: 64 clocks apart
         if (t < T - 1) {
             for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
             const unsigned lb0 = rp.lanebase(it - 1);
+            // batch bq of wave w = groups jg = w * NJB + bq * NQ .. + NQ - 1: gate jg / KJ, group jg % KJ.  ONE set of 9 chunk
+            // registers: the load of chunk i of the next batch is issued into a chunk's registers right behind the MFMAs that
+            // consumed them, so the next batch streams in under this batch's MFMAs without a second buffer
+            u32x4 av[NQ];
+            auto lbase = [&](int bq) { return lb0 + (unsigned)((wave * NJB + bq * NQ) / KJ) * gate_bytes; };
+            auto j0of = [&](int bq) { return (wave * NJB + bq * NQ) % KJ; };
+            {
+                const unsigned lb = lbase(0);
+                const int j0 = j0of(0);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) av[i] = poll_load<FAST>(rs, rp.at(lb, j0 + i));
+            }
 #pragma unroll
             for (int bq = 0; bq < NBATCH; ++bq) {
-                if (NBATCH > 2) __builtin_amdgcn_sched_barrier(0);  // (LSTM: keep one batch of chunks live at a time - 288 registers hold U)
-                u32x4 av[NBQ];
-                // batch bq of wave kh = groups jg = kh * NJB + bq * NBQ .. + NBQ - 1: gate jg / KJ, group jg % KJ
-                const int jg0 = kh * NJB + bq * NBQ;
-                const unsigned lb = lb0 + (unsigned)(jg0 / KJ) * gate_bytes;
-                const int j0 = jg0 % KJ;
+                const unsigned lb = lbase(bq);
+                const int j0 = j0of(bq);
                 auto off = [&](int i) { return rp.at(lb, j0 + i); };
-                dead = fast ? poll_regs<NBQ, true>(rs, off, av, a.err, a.spin_limit, lane, dead)
-                            : poll_regs<NBQ, false>(rs, off, av, a.err, a.spin_limit, lane, dead);
-                if (bq == 0) {
-                    // off the dependency chain, behind the first poll: fp32 gate gradients of the previous step, saved tensors of the next
+                dead = settle_regs<NQ, FAST>(rs, off, av, a.err, a.spin_limit, lane, dead);
+                const unsigned lbn = bq + 1 < NBATCH ? lbase(bq + 1) : 0u;
+                const int j0n = bq + 1 < NBATCH ? j0of(bq + 1) : 0;
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    if (!no_mfma) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int tl = 0; tl < 2; ++tl)
+                                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), BB[tl][bq * NQ + i][e], acc[tl], 0, 0, 0);
+                    }
+                    if (bq + 1 < NBATCH) av[i] = poll_load<FAST>(rs, rp.at(lbn, j0n + i));
+                }
+                if (bq == NBATCH - 1) {
+                    // off the dependency chain, behind the LAST poll load of the step (nothing the MFMAs wait for may queue
+                    // behind an HBM store): fp32 gate gradients of the previous step, saved tensors of the next
 #define PK4_FOB(E) flush_outputs_e(t + 1, E)
-                    PK_EDGE_DISPATCH(PK4_FOB);
+                    PK_EDGE_DISPATCH_S(PK4_FOB);
                     if (t > 0) {
 #define PK4_LS1(E) load_step_e(t - 1, E)
-                        PK_EDGE_DISPATCH(PK4_LS1);
+                        PK_EDGE_DISPATCH_S(PK4_LS1);
                     }
                 }
-                if (!no_mfma) mfma_batch<NBQ>(av, &BB[bq * NBQ], acc0, acc1);
             }
         } else if (t > 0) {
 #define PK4_LS2(E) load_step_e(t - 1, E)
-            PK_EDGE_DISPATCH(PK4_LS2);
+            PK_EDGE_DISPATCH_S(PK4_LS2);
         }
-        float car[4];
+        PK4_TRACE(it, 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) car[r] = acc0[r] + acc1[r];
-        patch_put_cd(xsB + kh * 256, kq, lane, car);
+        for (int tl = 0; tl < 2; ++tl) {
+            float o[4] = {acc[tl][0], acc[tl][1], acc[tl][2], acc[tl][3]};
+            patch_put_cd(xB + (wave * 2 + tl) * 256, kq, lane, o);
+        }
         PK_BARRIER_LDS();
+        PK4_TRACE(it, 2);
+        float car[2];
         {
-            float o[4];
-            patch_get_cd(xsB + (kh ^ 1) * 256, kq, lane, o);
+            float q0[2], q1[2], q2[2], q3[2];
+            get_cd2(xB + (0 * 2 + mt) * 256, kq, rh, lane, q0);
+            get_cd2(xB + (1 * 2 + mt) * 256, kq, rh, lane, q1);
+            get_cd2(xB + (2 * 2 + mt) * 256, kq, rh, lane, q2);
+            get_cd2(xB + (3 * 2 + mt) * 256, kq, rh, lane, q3);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) car[r] = kh == 0 ? car[r] + o[r] : o[r] + car[r];
+            for (int s_ = 0; s_ < 2; ++s_) car[s_] = ((q0[s_] + q1[s_]) + q2[s_]) + q3[s_];
         }
-        float sin[NIN][4];
+        float sin[NIN][2];
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) patch_get_cd(pin + k * 256, kq, lane, sin[k]);
-        float dgv[G][4];
+        for (int k = 0; k < NIN; ++k) get_cd2(pin + k * 256, kq, rh, lane, sin[k]);
+        float dgv[G][2];
         if constexpr (!TWO) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s[NS];
+            for (int s_ = 0; s_ < 2; ++s_) {
+                float sl[NS];
 #pragma unroll
-                for (int k = 0; k < NS; ++k) s[k] = sin[k][r];
-                const float prev = sin[NS][r];  // LSTM: c_{t-1}
-                const float dh = sin[NS + 1][r] + dh_dir[r] + car[r];
+                for (int k = 0; k < NS; ++k) sl[k] = sin[k][s_];
+                const float prev = sin[NS][s_];  // LSTM: c_{t-1}
+                const float dh = sin[NS + 1][s_] + dh_dir[s_] + car[s_];
                 float dg[G], dhd, dcp;
-                pk_cell_bwd<CELL>(act, s, LSTM ? 0.f : prev, LSTM ? prev : 0.f, msk[r], dh, dc_car[r], dg, dhd, dcp);
-                dh_dir[r] = rvf[r] != 0.f ? dhd : 0.f;
-                dc_car[r] = rvf[r] != 0.f ? dcp : 0.f;
+                pk_cell_bwd<CELL>(act, sl, LSTM ? 0.f : prev, LSTM ? prev : 0.f, msk[s_], dh, dc_car[s_], dg, dhd, dcp);
+                dh_dir[s_] = rvf[s_] != 0.f ? dhd : 0.f;
+                dc_car[s_] = rvf[s_] != 0.f ? dcp : 0.f;
 #pragma unroll
-                for (int g = 0; g < G; ++g) dgv[g][r] = rvf[r] != 0.f ? dg[g] : 0.f;
+                for (int g = 0; g < G; ++g) dgv[g][s_] = rvf[s_] != 0.f ? dg[g] : 0.f;
             }
         } else {
             // ---- phase A: da_t (the operand of q = da . U_h) goes to the cluster
-            float da4[4], dzp[4], dhd4[4];
+            float da2[2], dzp[2], dhd2[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s[NS];
+            for (int s_ = 0; s_ < 2; ++s_) {
+                float sl[NS];
 #pragma unroll
-                for (int k = 0; k < NS; ++k) s[k] = sin[k][r];
-                const float dh = sin[NS + 1][r] + dh_dir[r] + car[r];
-                const float da = pk_cell_bwd_pa<CELL>(act, s, sin[NS][r], msk[r], dh, dzp[r], dhd4[r]);
-                da4[r] = rvf[r] != 0.f ? da : 0.f;
+                for (int k = 0; k < NS; ++k) sl[k] = sin[k][s_];
+                const float dh = sin[NS + 1][s_] + dh_dir[s_] + car[s_];
+                const float da = pk_cell_bwd_pa<CELL>(act, sl, sin[NS][s_], msk[s_], dh, dzp[s_], dhd2[s_]);
+                da2[s_] = rvf[s_] != 0.f ? da : 0.f;
             }
-            if (kh == 0) {
-                patch_put_cd(priv + (G - 1) * 256, kq, lane, da4);
-                PK_LDS_ORDER();
-                publish_gate(G - 1, t, fast);
-            }
-            f32x4 q0 = f32x4{0.f, 0.f, 0.f, 0.f}, q1 = q0;
+            put_cd2(pg + (G - 1) * 256, kq, rh, lane, da2);
+            PK_LDS_ORDER();
+            publish_gate(G - 1, t, FASTC);
+            PK4_TRACE(it, 3);
+            f32x4 qa[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            f32x4 qb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
             {
-                u32x4 av[NJH];
+                u32x4 av[NQ];
                 const unsigned lb = rp.lanebase(it) + (unsigned)(G - 1) * gate_bytes;
-                auto off = [&](int i) { return rp.at(lb, kh * NJH + i); };
-                dead = fast ? poll_regs<NJH, true>(rs, off, av, a.err, a.spin_limit, lane, dead)
-                            : poll_regs<NJH, false>(rs, off, av, a.err, a.spin_limit, lane, dead);
-                if (!no_mfma) mfma_batch<NJH>(av, BA, q0, q1);
-            }
-            float q[4];
+                auto off = [&](int i) { return rp.at(lb, wave * NQ + i); };
+                dead = poll_regs<NQ, FAST>(rs, off, av, a.err, a.spin_limit, lane, dead);
+                if (!no_mfma) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) q[r] = q0[r] + q1[r];
-            patch_put_cd(xsA + kh * 256, kq, lane, q);
-            PK_BARRIER_LDS();
-            {
+                    for (int i = 0; i < NQ; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int tl = 0; tl < 2; ++tl) {
+                                if ((e & 1) == 0) qa[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), BA[tl][TWO ? i : 0][e], qa[tl], 0, 0, 0);
+                                else qb[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), BA[tl][TWO ? i : 0][e], qb[tl], 0, 0, 0);
+                            }
+                }
+            }
+            PK4_TRACE(it, 4);
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
                 float o[4];
-                patch_get_cd(xsA + (kh ^ 1) * 256, kq, lane, o);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) q[r] = kh == 0 ? q[r] + o[r] : o[r] + q[r];
+                for (int r = 0; r < 4; ++r) o[r] = qa[tl][r] + qb[tl][r];
+                patch_put_cd(xA + (wave * 2 + tl) * 256, kq, lane, o);
+            }
+            PK_BARRIER_LDS();
+            PK4_TRACE(it, 5);
+            float q[2];
+            {
+                float q0[2], q1[2], q2[2], q3[2];
+                get_cd2(xA + (0 * 2 + mt) * 256, kq, rh, lane, q0);
+                get_cd2(xA + (1 * 2 + mt) * 256, kq, rh, lane, q1);
+                get_cd2(xA + (2 * 2 + mt) * 256, kq, rh, lane, q2);
+                get_cd2(xA + (3 * 2 + mt) * 256, kq, rh, lane, q3);
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) q[s_] = ((q0[s_] + q1[s_]) + q2[s_]) + q3[s_];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s[NS];
+            for (int s_ = 0; s_ < 2; ++s_) {
+                float sl[NS];
 #pragma unroll
-                for (int k = 0; k < NS; ++k) s[k] = sin[k][r];
+                for (int k = 0; k < NS; ++k) sl[k] = sin[k][s_];
                 float dg[G];
-                float dhd = dhd4[r];
-                pk_cell_bwd_pb<CELL>(s, sin[NS][r], q[r], da4[r], dzp[r], dg, dhd);
-                dh_dir[r] = rvf[r] != 0.f ? dhd : 0.f;
+                float dhd = dhd2[s_];
+                pk_cell_bwd_pb<CELL>(sl, sin[NS][s_], q[s_], da2[s_], dzp[s_], dg, dhd);
+                dh_dir[s_] = rvf[s_] != 0.f ? dhd : 0.f;
 #pragma unroll
-                for (int g = 0; g < G; ++g) dgv[g][r] = rvf[r] != 0.f ? dg[g] : 0.f;
+                for (int g = 0; g < G; ++g) dgv[g][s_] = rvf[s_] != 0.f ? dg[g] : 0.f;
             }
         }
+        PK4_TRACE(it, 6);
         // ---- my share of the gate gradients through my patches into the vector layout, then publish what the next
-        // step's carry needs: one 16-byte store per gate
+        // step's carry needs: one 16-byte store per gate (lanes 0..31)
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            if (gate_owner(g) == kh && !(TWO && g == G - 1)) patch_put_cd(priv + g * 256, kq, lane, dgv[g]);
+            if (!(TWO && g == G - 1)) put_cd2(pg + g * 256, kq, rh, lane, dgv[g]);
         PK_LDS_ORDER();
 #pragma unroll
-        for (int g = 0; g < Gh; ++g)
-            if (gate_owner(g) == kh) publish_gate(g, t, fast);
+        for (int g = 0; g < Gh; ++g) publish_gate(g, t, FASTC);
+        PK4_TRACE(it, 7);
     }
+    };
+    PK_RUN_SPECIALISED(run, fast);
 #define PK4_FOBL(E) flush_outputs_e(0, E)
     PK_EDGE_DISPATCH(PK4_FOBL);
 }
@@ -710,9 +856,9 @@ size_t lds4(int cell, bool backward) {
     const bool two = pk_cell_two_phase(cell);
     if (!backward) {
         const int G1 = two ? G - 1 : G;
-        return ((size_t)2 * 2 * (G + 2 * G1 + (two ? 2 : 0)) * 256 + 4 * (size_t)(NS + 2) * 256) * 4;
+        return ((size_t)2 * (4 * 2 * G1 * 256 + (two ? 4 * 2 * 256 : 0)) + 4 * (size_t)(G + NS + 2) * 256) * 4;
     }
-    return ((size_t)2 * 2 * (NS + 2 + 2 + (two ? 2 : 0)) * 256 + 4 * (size_t)G * 256) * 4;
+    return ((size_t)2 * (4 * 2 * 256 + (two ? 4 * 2 * 256 : 0)) + 4 * (size_t)(NS + 2 + G) * 256) * 4;
 }
 
 int grant_lds4(Rec4Kernel k, size_t lds) {

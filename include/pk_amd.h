@@ -312,6 +312,8 @@ int pk_rec_bwd(void* stream, int algo, int prec, int cell, int act, int T, int B
  * k-major operands pk_gemm_bf16 needs for dU / dW.  Columns beyond ndir*Hp (G*Hp) of a row are left
  * undefined.  Pitches are multiples of 8 elements; H <= 576.  dP2 may be NULL (the fp32 gate-gradient
  * slabs are then not written: pk_bn_bwd_bf16 works from dGb).
+ * Forward-only chunks (torch.no_grad: validation / forward, core.py:644-671): S may be NULL - nothing is saved for a
+ * backward pass - and, with it, Y may be NULL for an inner layer of a stack whose output is consumed as Yb alone.
  */
 /* prefilled (both entry points below): 1 = the caller stored the 0xFF "not written yet" pattern in the whole exchange
  * buffer, 0 = the library does it in front of the launch, 2 = the kernel does it on the way where it can

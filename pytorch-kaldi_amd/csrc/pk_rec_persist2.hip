@@ -41,7 +41,10 @@ namespace {
 // row statistics take one more exchange inside the step (ln_row_allreduce, pk_rec2_common.h: fp32 partial sums, no
 // barrier); the normalised h_t is what is stored, published and fed back, the pre-LN value and (mean, 1 / (std + eps))
 // are saved for the backward pass.
-template <int CELL, int ACT, bool TR, bool LN = false>
+// NOSAVE: the forward pass of a validation / forward chunk (torch.no_grad, core.py:644-671): nothing is saved for a backward
+// pass (a.S is null), and the fp32 output is written only when a.Y is not null - the inner layers of a stack hand their
+// output on as the bf16 copy Yb alone.  Three to four of the five 16-byte stores a lane issues per step go away.
+template <int CELL, int ACT, bool TR, bool LN = false, bool NOSAVE = false>
 __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
@@ -180,12 +183,15 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
         for (int g = 0; g < G; ++g) pv[g] = ld4<decltype(E)::value>(a.P, vP0 + ts * vPs + g * H, vnv);
     };
     // layer output and saved gates of step tt: wave patches -> HBM, 16 bytes per lane
+    const bool want_y = a.Y != nullptr;
     auto flush_outputs = [&](int tt, auto E) {
         constexpr int EE = decltype(E)::value;
         const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
-        st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchY, lane));
+        if (!NOSAVE || want_y) st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchY, lane));
+        if constexpr (!NOSAVE) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, patch_get_vec(patchS + k * 256, lane));
+            for (int k = 0; k < NS; ++k) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, patch_get_vec(patchS + k * 256, lane));
+        }
         if (LN) {
             st4<EE>(a.lnh, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchL, lane));
             *reinterpret_cast<pk_f32x2*>(st_base + (long)tt * st_step) = st_val;
@@ -347,9 +353,11 @@ __global__ __launch_bounds__(256, 1) void rec2_fwd_kernel(R2Args a) {
         }
         // ---- the fp32 outputs (layer output, gates saved for backward) go to the wave patches; they are
         // written to HBM at the top of the next step, behind its poll loads
-        patch_put_cd(patchY, kq, lane, hv);
+        if (!NOSAVE || want_y) patch_put_cd(patchY, kq, lane, hv);
+        if constexpr (!NOSAVE) {
 #pragma unroll
-        for (int k = 0; k < NS; ++k) patch_put_cd(patchS + k * 256, kq, lane, sv[k]);
+            for (int k = 0; k < NS; ++k) patch_put_cd(patchS + k * 256, kq, lane, sv[k]);
+        }
         PK_LDS_ORDER();
         PK_TRACE(5);
     }
@@ -917,6 +925,11 @@ Rec2Kernel pick_fwd(int act) {
          : act == PK_ACT_TANH ? rec2_fwd_kernel<CELL, PK_ACT_TANH, false> : rec2_fwd_kernel<CELL, -1, false>;
 }
 template <int CELL>
+Rec2Kernel pick_fwd_nosave(int act) {  // (S == null: validation / forward chunks)
+    return act == PK_ACT_RELU ? rec2_fwd_kernel<CELL, PK_ACT_RELU, false, false, true>
+         : act == PK_ACT_TANH ? rec2_fwd_kernel<CELL, PK_ACT_TANH, false, false, true> : rec2_fwd_kernel<CELL, -1, false, false, true>;
+}
+template <int CELL>
 Rec2Kernel pick_bwd(int act) {
     return act == PK_ACT_RELU ? rec2_bwd_kernel<CELL, PK_ACT_RELU, false>
          : act == PK_ACT_TANH ? rec2_bwd_kernel<CELL, PK_ACT_TANH, false> : rec2_bwd_kernel<CELL, -1, false>;
@@ -946,6 +959,10 @@ static int rec_fwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
                              const PkLnHost* ln) {
     int rc = pk_rec2_check("pk_rec_fwd_bf16", 1, cell, T, B, bidir, H);
     if (rc) return rc;
+    // S == null: a validation / forward chunk, nothing is saved for a backward pass; Y == null with it: an inner layer of a
+    // stack, whose output is the bf16 copy Yb alone
+    PK_REQUIRE(S != nullptr || (ln == nullptr && !traced(cell, act)), "pk_rec_fwd_bf16: S may be null only without per-step LayerNorm");
+    PK_REQUIRE(Y != nullptr || S == nullptr, "pk_rec_fwd_bf16: Y may be null only together with S");
     hipStream_t st = pk_stream(stream);
     const int ndir = 1 + bidir, R = B * ndir, Hp = (H + 7) & ~7;
     PK_REQUIRE(y_pitch >= (int64_t)ndir * Hp && (y_pitch % 8) == 0 && ((uintptr_t)Yb & 15) == 0,
@@ -974,11 +991,15 @@ static int rec_fwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
     if (!ln && pk_rec3_covers(cell, 0)) return pk_rec3_launch(st, a, pl, cell, act, false, traced(cell, act));
     const int G = pk_cell_gates(cell);
     const size_t lds = 2 * (size_t)RMAX * pk_r2_lda_bf16(KPAD) * 2 + 4 * ((size_t)(G + 1 + pk_cell_saved(cell) + (ln ? 1 : 0)) * 1024 + 512) + 16;
-    const Rec2Kernel k = ln ? pick_fwd_ln(cell) : pick_fwd(cell, act);
+    const bool nosave = S == nullptr;
+    const Rec2Kernel k = ln ? pick_fwd_ln(cell)
+                       : nosave ? (cell == PK_CELL_LIGRU ? pick_fwd_nosave<PK_CELL_LIGRU>(act) : cell == PK_CELL_RNN ? pick_fwd_nosave<PK_CELL_RNN>(act)
+                                                                                                                      : pick_fwd_nosave<PK_CELL_LSTM>(act))
+                                : pick_fwd(cell, act);
     {   // dynamic LDS above the 64 KB default needs the opt-in (exact size: the kernels also hold a little static LDS)
-        static size_t granted[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
+        static size_t granted[3][8] = {{0}, {0}, {0}};  // hipFuncSetAttribute is slow (milliseconds): once per kernel and size
         const int slot = cell == PK_CELL_LIGRU ? 0 : cell == PK_CELL_RNN ? 1 : 2;
-        const int as = ln ? 4 : traced(cell, act) ? 3 : act_slot(act);
+        const int as = ln ? 4 : nosave ? 5 + act_slot(act) : traced(cell, act) ? 3 : act_slot(act);
         if (granted[slot][as] < lds) {
             PK_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             granted[slot][as] = lds;

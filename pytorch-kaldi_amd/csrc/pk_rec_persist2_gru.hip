@@ -161,9 +161,12 @@ __global__ __launch_bounds__(256, 1) void rec2g_fwd_kernel(R2Args a) {
     auto flush_outputs = [&](int tt, auto E) {
         constexpr int EE = decltype(E)::value;
         const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
-        st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchY, lane));
+        // (a.S == null: a validation / forward chunk - nothing is saved; a.Y == null with it: an inner layer, Yb is its output)
+        if (a.Y != nullptr) st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchY, lane));
+        if (a.S != nullptr) {
 #pragma unroll
-        for (int k = 0; k < G; ++k) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, patch_get_vec(patchS + k * 256, lane));
+            for (int k = 0; k < G; ++k) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, patch_get_vec(patchS + k * 256, lane));
+        }
         if (LN) {
             st4<EE>(a.lnh, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchL, lane));
             *reinterpret_cast<pk_f32x2*>(st_base + (long)tt * st_step) = st_val;

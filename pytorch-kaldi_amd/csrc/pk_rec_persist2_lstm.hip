@@ -205,12 +205,15 @@ __global__ __launch_bounds__(512, 1) void rec2l_fwd_kernel(R2Args a) {
     auto flush_outputs = [&](int tt, auto E, auto HALFC) {
         constexpr int EE = decltype(E)::value;
         const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
+        // (a.S == null: a validation / forward chunk - nothing is saved; a.Y == null with it: an inner layer, Yb is its output)
         if constexpr (decltype(HALFC)::value == 0) {
-            st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchY, lane));
-            st4<EE>(a.S, vS0 + ts * vSs + 0 * H, vnv, trash, patch_get_vec(patchS, lane));
-            st4<EE>(a.S, vS0 + ts * vSs + 1 * H, vnv, trash, patch_get_vec(patchS + 256, lane));
-            st4<EE>(a.S, vS0 + ts * vSs + 4 * H, vnv, trash, patch_get_vec(patchS + 512, lane));
-        } else {
+            if (a.Y != nullptr) st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, patch_get_vec(patchY, lane));
+            if (a.S != nullptr) {
+                st4<EE>(a.S, vS0 + ts * vSs + 0 * H, vnv, trash, patch_get_vec(patchS, lane));
+                st4<EE>(a.S, vS0 + ts * vSs + 1 * H, vnv, trash, patch_get_vec(patchS + 256, lane));
+                st4<EE>(a.S, vS0 + ts * vSs + 4 * H, vnv, trash, patch_get_vec(patchS + 512, lane));
+            }
+        } else if (a.S != nullptr) {
             st4<EE>(a.S, vS0 + ts * vSs + 2 * H, vnv, trash, patch_get_vec(patchS, lane));
             st4<EE>(a.S, vS0 + ts * vSs + 3 * H, vnv, trash, patch_get_vec(patchS + 256, lane));
         }

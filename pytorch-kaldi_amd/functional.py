@@ -1938,21 +1938,29 @@ class RecLayerPerfFn(torch.autograd.Function):
         else:
             pscale = torch.ones(GH, device=x.device)
             pshift = bcat.contiguous() if bcat is not None else torch.zeros(GH, device=x.device)
+        # A validation / forward chunk (torch.no_grad, core.py:644-671: nothing here needs a gradient) saves nothing for a
+        # backward pass: no S (563 MB per Li-GRU layer at the BASELINE shape), and an INNER layer of a stack does not write
+        # its fp32 output either - the next layer reads the bf16 copy Yb (cfg[16], set by nn._Recurrent.forward; the
+        # tensor returned in its place carries the shape only).
+        infer = not any(ctx.needs_input_grad) and _Kinks.queue is None and _lib.experiment("fwd_nosave", "1") != "0"
+        keep_y = bool(cfg[16]) if len(cfg) > 16 else True
         Y = _new(T, B, ndir * H, like=Wcat)
-        S = _new(ndir, TB, NS * H, like=Wcat)
+        S = None if infer else _new(ndir, TB, NS * H, like=Wcat)
+        Yarg = Y if (keep_y or not infer) else None
         _lib.raise_if_persist_failed()
         fill.wait()
         if two_phase:
             rc = lib.pk_rec2p_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale),
-                                       _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), _p(Xb),
+                                       _p(pshift), _p(Ucat), _p(mask), float(mask_scalar), _p(Yarg), _p(S), _p(Yb), _p(Xb),
                                        Yb.shape[1], 2 if self_fill else fill.done)
             _lib.check(rc, "pk_rec2p_fwd_bf16")
         else:
             rc = lib.pk_rec_fwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(P), _p(pscale), _p(pshift),
-                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Y), _p(S), _p(Yb), Yb.shape[1],
+                                     _p(Ucat), _p(mask), float(mask_scalar), _p(Yarg), _p(S), _p(Yb), Yb.shape[1],
                                      2 if self_fill else fill.done)
             _lib.check(rc, "pk_rec_fwd_bf16")
-        _force_kinks(S, cell, T, B, ndir, H)
+        if S is not None:
+            _force_kinks(S, cell, T, B, ndir, H)
         ctx.self_fill = self_fill
         ctx.dGb = dGb if fill.done else None
         ctx.Xb = Xb

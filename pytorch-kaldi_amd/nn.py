@@ -586,13 +586,15 @@ class _Recurrent(nn.Module):
                     Ucat = torch.cat(ups, 0) if len(ups) > 1 else ups[0]
                 # training-mode BatchNorm: the running statistics of every gate's module are updated by the launch that
                 # turns the batch statistics into scale / shift (pk_bn_finalize_gates)
+                # forward-only chunks: an inner layer's fp32 output is read by nobody (the next layer takes the bf16 copy)
+                keep_y = torch.is_grad_enabled() or i == self._n_lay - 1
                 stats_in_kernel = use_bn and self.training
                 bn_bufs = ([b.running_mean for b in bns], [b.running_var for b in bns],
                            [b.num_batches_tracked for b in bns]) if stats_in_kernel else None
                 y, bmean, bvar, xb = F_.RecLayerPerfFn.apply(x, xb, Wcat.detach() if side_w else Wcat, bcat,
                                                            Ucat.detach() if side_u else Ucat, gamma, beta, rmean, rvar,
-                                                           mask_i, cfg + (xseg, wps, ups, side_w, side_u, bn_bufs, affine),
-                                                           edge_t)
+                                                           mask_i, cfg + (xseg, wps, ups, side_w, side_u, bn_bufs, affine,
+                                                                          keep_y), edge_t)
                 xseg = (2 if self.bidir else 1, H, (H + 7) // 8 * 8)
                 if stats_in_kernel:
                     x = y

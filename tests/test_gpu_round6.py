@@ -47,3 +47,33 @@ def test_concatenated_head_gradient_with_other_contributors(second_use):
         F_.set_precision("fp32")
     for got, ref in zip(res[True], res[False]):
         assert rel_err(got, ref) < 2e-6
+
+
+@pytest.mark.parametrize("kind,pre,act", [("liGRU", "ligru", "relu"), ("RNN", "rnn", "tanh"), ("LSTM", "lstm", "tanh"), ("GRU", "gru", "tanh"),
+                                           ("minimalGRU", "minimalgru", "relu")])
+def test_forward_only_chunks_save_nothing_and_change_nothing(kind, pre, act):
+    """Validation / forward chunks (core.py:644-671: module.eval(), torch.no_grad()): the perf-mode recurrences save nothing
+    for a backward pass and the inner layers of a stack write no fp32 output (functional.RecLayerPerfFn, cfg[16]) - the
+    stack's output must be BIT-identical to the same eval-mode forward with autograd on, which takes the training kernels."""
+    nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
+    H, T, B, D = 550, 23, 37, 40
+    j = lambda v: ",".join([str(v)] * 3)  # noqa: E731
+    opts = {pre + "_lay": j(H), pre + "_drop": j(0.2), pre + "_use_laynorm_inp": "False", pre + "_use_batchnorm_inp": "False",
+            pre + "_use_laynorm": j(False), pre + "_use_batchnorm": j(False), pre + "_bidir": "True", pre + "_act": j(act),
+            pre + "_orthinit": "True", "use_cuda": "True", "to_do": "valid"}
+    torch.manual_seed(3)
+    net = getattr(nn_amd, kind)(opts, D).cuda().eval()
+    x = torch.randn(T, B, D, generator=torch.Generator().manual_seed(4)).cuda()
+    F_.set_precision("bf16")
+    try:
+        y_grad = net(x.clone().requires_grad_(True))     # autograd on: S and every layer's Y are written
+        with torch.no_grad():
+            y_fwd = net(x)
+        torch.cuda.synchronize()
+    finally:
+        F_.set_precision("fp32")
+    assert torch.equal(y_fwd, y_grad.detach())
+    tw_a, tw_b = getattr(y_fwd, "_pk_twin", None), getattr(y_grad, "_pk_twin", None)
+    assert tw_a is not None and tw_b is not None
+    used = 2 * ((H + 7) // 8 * 8)  # (columns beyond ndir * Hp of the pitch are left undefined, include/pk_amd.h)
+    assert torch.equal(tw_a[0][:, :used], tw_b[0][:, :used])   # the bf16 copy the heads read

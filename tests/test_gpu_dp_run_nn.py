@@ -38,27 +38,26 @@ def test_run_nn_dp_on_n_ranks_of_one_gpu_equals_the_shard_average(tmp_path, worl
     assert r.returncode == 0, r.stdout[-4000:]
     ref, got = torch.load(ref_out), torch.load(dp_out)
     assert abs(got["loss"] - ref["loss"]) < 1e-5 * abs(ref["loss"]), (got["loss"], ref["loss"])
-    # The transport adds the N shares in another order than the replay: 1e-7 relative on a gradient element.  RMSprop's
-    # first steps move a parameter by +-lr / sqrt(1 - alpha) for ANY non-zero gradient, so an element whose gradient is
-    # rounding noise around zero (a BatchNorm shift of a unit that is almost never active) may land an lr-sized step apart:
-    # a tensor is held to 2e-4 outside at most 0.2 % of its elements, and those may differ by a few learning-rate steps only.
-    LR_STEPS = 3 * 4e-4 / (1 - 0.95) ** 0.5 * 1.5
-    worst, outliers = ("", 0.0), 0
+    # One SGD step: parameter - initial value = -lr x the averaged gradient.  The transport adds the N shares in another
+    # order than the replay (1e-7 relative per element); everything else is the same kernels on the same shards.
+    worst = ("", 0.0)
     for arch, sd in ref["sd"].items():
         for k, v in sd.items():
             if not v.is_floating_point():
                 assert int(got["sd"][arch][k]) == int(v), (arch, k)
                 continue
-            a, b = got["sd"][arch][k].double().reshape(-1), v.double().reshape(-1)
-            d = (a - b).abs()
-            far = d > 1e-5 + 1e-3 * b.abs()
-            n_far = int(far.sum())
-            assert n_far <= max(1, int(2e-3 * b.numel())), (arch, k, n_far, b.numel())
-            assert float(d.max()) < LR_STEPS, (arch, k, float(d.max()))
-            outliers += n_far
-            e = float(d[~far].norm()) / max(float(b.norm()), 1e-12)
+            if "running" in k:  # (rank 0's replica keeps its statistics: the replay keeps shard 0's)
+                assert float((got["sd"][arch][k].double() - v.double()).abs().max()) <= 1e-6 * float(v.double().abs().max() + 1e-12), (arch, k)
+                continue
+            upd_ref = v.double() - ref["init"][arch][k].double()
+            upd = got["sd"][arch][k].double() - ref["init"][arch][k].double()
+            if float(upd_ref.norm()) == 0.0:
+                assert float(upd.norm()) == 0.0, (arch, k)
+                continue
+            e = float((upd - upd_ref).norm()) / float(upd_ref.norm())
             if e > worst[1]:
                 worst = (arch + "/" + k, e)
-    print("run_nn_dp on %d ranks (%s) vs the shard average after 3 batches: loss %.6f vs %.6f, worst parameter %s, %d element(s) an "
-          "lr-sized step apart" % (world, prec, got["loss"], ref["loss"], worst, outliers))
-    assert worst[1] < 2e-4, worst
+    print("run_nn_dp on %d ranks (%s) vs the shard average, one SGD step: loss %.6f vs %.6f, worst update %s"
+          % (world, prec, got["loss"], ref["loss"], worst))
+    # (shard gradients cancel in the average: the 1e-7 of another summation order is relative to the shards, not to their mean)
+    assert worst[1] < 1e-4, worst

@@ -39,10 +39,20 @@ timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT
 python $R/tools/rocpd_pmc.py $(find $out/pmc_sq -name "*.db" | head -1) $out/${tag}_pmc_sq.csv
 rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_sq
 python $R/tools/pmc_summaries.py $out $tag > $out/pmc_summaries.log 2>&1; head -12 $out/pmc_summaries.log
+# the other BASELINE configurations: HBM bytes behind their dominant entry points (bench.py: other_configs[*].roofline.traffic)
+for r in timit_lstm libri_gru timit_mlp timit_sincnet; do
+  timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_f_$r -- $S --recipe $r > $out/pmc_f_$r.log 2>&1
+  python $R/tools/rocpd_pmc.py $(find $out/pmc_f_$r -name "*.db" | head -1) $out/${tag}_${r}_pmc_fetch_size.csv
+  timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_w_$r -- $S --recipe $r > $out/pmc_w_$r.log 2>&1
+  python $R/tools/rocpd_pmc.py $(find $out/pmc_w_$r -name "*.db" | head -1) $out/${tag}_${r}_pmc_write_size.csv
+  rm -rf $out/pmc_f_$r $out/pmc_w_$r
+  python $R/tools/pmc_summaries.py $out $tag $r > $out/pmc_summaries_$r.log 2>&1; head -3 $out/pmc_summaries_$r.log
+  cp $out/${tag}_pmc_traffic_$r.json $R/profiles/ 2>/dev/null
+done
 )
 cp $out/${tag}_pmc_traffic.json $out/${tag}_pmc_mfma_busy.json profiles/ 2>/dev/null
 # ---- 2
-PK_FULL_SHAPE_JSON=$out/${tag}_full_shape_parity.json timeout 1500 python -m pytest tests -q -m gpu > "$out/pytest_gpu.log" 2>&1
+PK_FULL_SHAPE_JSON=$out/${tag}_full_shape_parity.json timeout 2400 python -m pytest tests -q -m gpu > "$out/pytest_gpu.log" 2>&1
 echo "pytest rc=$? $(tail -1 "$out/pytest_gpu.log")"
 grep -E "^(FAILED|ERROR)" "$out/pytest_gpu.log" | head -10
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.log" 2>&1
@@ -50,7 +60,7 @@ echo "smoke rc=$? $(tail -2 "$out/smoke.log" | tr '\n' ' ')"
 # ---- 3
 # (--cpu-full-in-run: the CPU port's step at the metric's FULL shape timed inside this run - ~4 minutes of host time; the
 # driver's default command keeps the bounded sample and quotes this file's figure)
-PK_BENCH_VERBOSE=1 timeout 1500 python bench.py --cpu-full-in-run > "$out/${tag}_bench_bf16.json" 2> "$out/bench_bf16.err"
+PK_BENCH_VERBOSE=1 timeout 2400 python bench.py --cpu-full-in-run > "$out/${tag}_bench_bf16.json" 2> "$out/bench_bf16.err"
 echo "bench rc=$? $(cut -c1-200 "$out/${tag}_bench_bf16.json")"
 python3 - "$out/${tag}_bench_bf16.json" "$out/${tag}_cpu_full_shape.json" <<'PY'
 import json, sys
@@ -80,7 +90,13 @@ done
 timeout 200 rocprofv3 --kernel-trace --stats -d $out/kt_fp32 -- python $R/bench.py --prec fp32 --steps 3 --warmup 1 --prewarm-s 0 --no-cpu-baseline --no-extras > $out/kt_fp32.log 2>&1
 python $R/tools/rocpd_stats.py $(find $out/kt_fp32 -name "*.db" | head -1) $out/${tag}_bench_fp32_kernel_stats.csv > /dev/null 2>&1
 rm -rf $out/kt_fp32
+for r in timit_lstm libri_gru; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d $out/kt_fp32_$r -- python $R/bench.py --recipe $r --prec fp32 --steps 3 --warmup 1 --prewarm-s 0 --no-cpu-baseline --no-extras > $out/kt_fp32_$r.log 2>&1
+  python $R/tools/rocpd_stats.py $(find $out/kt_fp32_$r -name "*.db" | head -1) $out/${tag}_${r}_fp32_kernel_stats.csv > /dev/null 2>&1
+  rm -rf $out/kt_fp32_$r
+done
 cd $R
+timeout 300 python tools/trace_rec4.py > $out/${tag}_fp32_gen4_phase_trace.json 2> $out/trace_rec4.err
 # ---- 7
 # (round 5: the full-shape comparison runs inside the GPU suite above - tests/test_gpu_full_shape.py; PK_FULL_SHAPE_JSON keeps its record)
 python3 tools/jget.py $out/${tag}_full_shape_parity.json pass loss_rel_diff model_step_seconds grad_rel_err_worst 2>/dev/null

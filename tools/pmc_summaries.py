@@ -21,6 +21,32 @@ def table(name):
     return out
 
 
+RECIPE = sys.argv[3] if len(sys.argv) > 3 else None  # another BASELINE configuration: <TAG>_<recipe>_pmc_{fetch,write}_size.csv
+# dominant entry point of each other configuration (bench.py's roofline.kernel) -> prefixes of the kernels behind it
+OTHER = {"timit_lstm": {"pk_rec_bwd_bf16": ("rec3l_bwd_kernel", "rec2l_bwd_kernel"), "pk_rec_fwd_bf16": ("rec2l_fwd_kernel",)},
+         "libri_gru": {"pk_rec2p_bwd_bf16": ("rec3g_bwd_kernel", "rec2g_bwd_kernel"), "pk_rec2p_fwd_bf16": ("rec2g_fwd_kernel",)},
+         "timit_mlp": {"pk_gemm_bf16": ("gemm_bf16_t64_kernel", "gemm_bf16sk_kernel<false>", "gemm_bf16x_kernel", "gemm_bf16s_kernel",
+                                        "splitk_reduce_bf_kernel")},
+         "timit_sincnet": {"pk_conv1d_pool_bwd": ("conv_tile_kernel<1, 8, false", "conv_bwd_filter_tile_kernel")}}
+if RECIPE:
+    fetch, write = table("%s_%s_pmc_fetch_size.csv" % (TAG, RECIPE)), table("%s_%s_pmc_write_size.csv" % (TAG, RECIPE))
+    out = {"_note": "HBM bytes per kernel dispatch behind the configuration's dominant entry point (dispatch-weighted mean over the "
+           "kernels listed), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py --recipe %s --steps 2 --warmup 1`; "
+           "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streaming reads on gfx950, WRITE_SIZE as "
+           "reported.  whole_step_bytes = the same over EVERY kernel of a step.  Written by tools/pmc_summaries.py." % RECIPE}
+    for entry, prefixes in OTHER[RECIPE].items():
+        ks = [k for k in fetch if k.startswith(prefixes) and k in write]
+        if not ks:
+            continue
+        disp = sum(fetch[k]["FETCH_SIZE"][1] for k in ks)
+        byt = sum((2.0 * fetch[k]["FETCH_SIZE"][0] + write[k]["WRITE_SIZE"][0]) * 1024.0 * fetch[k]["FETCH_SIZE"][1] for k in ks)
+        out[entry] = {"kernels": ks, "dispatches": disp, "traffic_bytes": int(round(byt / max(disp, 1)))}
+    steps = 3.0  # --steps 2 --warmup 1, plus the two profiled steps of the roofline leg when it runs: reported per dispatch, not per step
+    out["all_kernels_bytes_per_run"] = int(sum((2.0 * fetch[k]["FETCH_SIZE"][0] + write.get(k, {"WRITE_SIZE": (0.0,)})["WRITE_SIZE"][0]) * 1024.0 *
+                                               fetch[k]["FETCH_SIZE"][1] for k in fetch))
+    json.dump(out, open(os.path.join(d, "%s_pmc_traffic_%s.json" % (TAG, RECIPE)), "w"), indent=1)
+    print(json.dumps(out, indent=1)[:700])
+    sys.exit(0)
 fetch, write, sq = table(TAG + "_pmc_fetch_size.csv"), table(TAG + "_pmc_write_size.csv"), table(TAG + "_pmc_sq.csv")
 # (round 3: the backward pass runs the third-generation kernel, pk_rec_persist3.hip)
 ENTRY = {"pk_rec_bwd_bf16": ("rec3_bwd_kernel<0, 1", "rec2_bwd_kernel<0, 1"), "pk_rec_fwd_bf16": ("rec2_fwd_kernel<0, 1", "rec3_fwd_kernel<0, 1")}

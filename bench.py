@@ -472,7 +472,7 @@ def roofline_of(tr, args, summ, prec):
         # kernel, whose s_memtime stamps cost ~11 %: the production step beat that floor - it is gone.)
         lat = {"bound": "latency", "dependent_steps_per_launch": tr.T, "us_per_step": round(d["avg_ms"] * 1e3 / tr.T, 3)}
         hop, src_ = 0.9, None
-        for cand in ("r05_rec_step_floor.json", "r04_rec_step_floor.json", "r03_rec_step_floor.json", "r02_rec_step_floor.json"):
+        for cand in ("r06_rec_step_floor.json", "r05_rec_step_floor.json", "r04_rec_step_floor.json", "r03_rec_step_floor.json", "r02_rec_step_floor.json"):
             try:
                 fl_ = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 hop, src_ = float(fl_["hop_us"]["bwd" if "bwd" in dom else "fwd"]), cand

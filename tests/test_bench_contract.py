@@ -141,3 +141,33 @@ def test_round5_line_measures_the_cpu_full_shape_in_the_run_and_carries_the_roun
     dc = json.load(open(os.path.join(ROOT, "profiles", "r05_driver_cmd.json")))
     first = dc["first_process"]
     assert first["steps"] == 20 and first["warmup"] == 5 and first["n_gpus"] == 1 and first["ms_per_step"] < 17.5
+
+
+def test_round6_line_is_complete_per_configuration():
+    """Round 6 (round-5 review, item 3): every other configuration carries its own CPU baseline, an fp32 row and PMC traffic;
+    the headline's bounded CPU sample keeps the metric's sequence length (it no longer flatters the CPU: within 10 % of the
+    full-shape step measured in the same run); `structure_frac` is gone; the padded-batch variant is timed; the fp32 rows of
+    the LSTM / GRU configurations run on the fourth-generation kernels."""
+    d = _line("profiles/r06_bench_bf16.json")
+    assert d["config"]["workload"].startswith("timit_ligru") and d["dtype"] == "bf16" and d["ms_per_step"] < 17.5
+    r = d["roofline"]
+    assert "structure_frac" not in r and "structure_frac" not in r["latency"] and 0 < r["latency_frac"] < 1
+    assert r["traffic"] is not None and "r06_pmc_traffic" in r["traffic_source"] and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and (c["T"], c["B"]) == (500, 16) and c["cores"] >= 1
+    fs = c["full_shape"]
+    assert fs["measured_in_run"] is True and (fs["T"], fs["B"]) == (500, 128)
+    assert abs(c["value"] - fs["value"]) < 0.10 * fs["value"]
+    pb = d["padded_batches"]
+    assert "error" not in pb and 0 < pb["padding_share"] < 0.2 and pb["value"] > 0
+    got = {o["recipe"]: o for o in d["other_configs"]}
+    assert sorted(got) == ["libri_gru", "timit_lstm", "timit_mlp", "timit_sincnet"]
+    for name, o in got.items():
+        assert "error" not in o, (name, o.get("error"))
+        assert o["cpu_baseline"]["value"] > 0 and o["cpu_baseline"]["kind"] in ("port", "reference"), name
+        assert o["parity_mode"]["dtype"] == "fp32" and o["parity_mode"]["ms_per_step"] > o["ms_per_step"], name
+        assert o["roofline"]["traffic"] is not None and "r06_pmc_traffic_" + name in o["roofline"]["traffic_source"], name
+    assert got["timit_lstm"]["parity_mode"]["ms_per_step"] < 160 and got["libri_gru"]["parity_mode"]["ms_per_step"] < 185
+    assert d["forward_mode"]["ms_per_step"] < 6.8
+    dc = json.load(open(os.path.join(ROOT, "profiles", "r06_driver_cmd.json")))
+    assert dc["first_process"]["steps"] == 20 and dc["first_process"]["warmup"] == 5 and dc["first_process"]["ms_per_step"] < 17.5

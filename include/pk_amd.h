@@ -328,21 +328,6 @@ int pk_rec_fwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, in
 int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
                     float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, uint16_t* dGb,
                     int64_t g_pitch, int prefilled);
-/* The backward recurrence of liGRU / RNN can take the BatchNorm-backward REDUCTIONS of its own gate gradients along
- * (round 6; neural_networks.py:1118-1124 backwards): it holds every gate gradient in fp32 anyway, reads the projections P
- * they belong to (x [T*B][ldx] fp32, off the dependency chain) and leaves, per cluster of rows, the column sums of g and
- * g * xhat in partial [rows][G*H][2] - what pk_bn_bwd_bf16's first pass otherwise recomputes from dGb and P (577 MB of reads
- * per layer at the BASELINE shape).  pk_rec_bwd_bnsum_rows: rows of that table (0: not available for this cell / geometry);
- * pk_bn_bwd_bf16_presummed: pk_bn_bwd_bf16 without its first pass. */
-int pk_rec_bwd_bnsum_rows(int cell, int B, int bidir, int H);
-int pk_rec_bwd_bf16_bnsum(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
-                          float mask_scalar, const float* Y, const float* S, const float* dY, uint16_t* dGb, int64_t g_pitch,
-                          int prefilled, const float* x, int64_t ldx, const float* mean, const float* var, float eps,
-                          float* partial);
-int pk_bn_bwd_bf16_presummed(void* stream, const uint16_t* g0, const uint16_t* g1, int64_t g_pitch, int G, int H, const float* x,
-                             int64_t ldx, int64_t M, const float* mean, const float* var, float eps, const float* gamma,
-                             double count, const float* partial, int rows, float* sum_g, float* sum_gx, uint16_t* out,
-                             int64_t out_pitch, float* acc_beta, float* acc_gamma);
 /* ... with per-step LayerNorm of h_t inside the persistent time loop (liGRU / RNN / LSTM; the reference's
  * `if self.*_use_laynorm[i]: ht = self.ln[i](ht)`, neural_networks.py:466-467, :1138-1139, :1444-1445): every step
  * exchanges the rows' partial sums between the workgroups of a cluster a second time (fp32, 32 bytes per wave and row

@@ -49,11 +49,6 @@ SIGNATURES = {
                                 c_int64]),
     "pk_bn_bwd_bf16": (c_int, [P, P, P, c_int64, c_int, c_int, P, c_int64, c_int64, P, P, c_float, P, c_double, P, P, P, P,
                                c_int64, P, P]),
-    "pk_rec_bwd_bnsum_rows": (c_int, [c_int, c_int, c_int, c_int]),
-    "pk_rec_bwd_bf16_bnsum": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P, P, P, c_int64, c_int, P,
-                                      c_int64, P, P, c_float, P]),
-    "pk_bn_bwd_bf16_presummed": (c_int, [P, P, P, c_int64, c_int, c_int, P, c_int64, c_int64, P, P, c_float, P, c_double, P, c_int,
-                                         P, P, P, c_int64, P, P]),
     "pk_colsum": (c_int, [P, P, P, c_int64, c_int64, c_int64, P, P]),
     "pk_add": (c_int, [P, P, P, c_int64, P]),
     "pk_mt19937_bernoulli": (c_int, [P, P, c_int64, c_float, P]),

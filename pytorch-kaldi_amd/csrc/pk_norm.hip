@@ -1658,31 +1658,10 @@ __global__ __launch_bounds__(256) void bnb_apply_kernel(const unsigned short* __
 
 }  // namespace
 
-static int bn_bwd_bf16_impl(void* stream, const uint16_t* g0, const uint16_t* g1, int64_t g_pitch, int G, int H,
-                            const float* x, int64_t ldx, int64_t M, const float* mean, const float* var, float eps,
-                            const float* gamma, double count, float* partial, float* sum_g, float* sum_gx,
-                            uint16_t* out, int64_t out_pitch, float* acc_beta, float* acc_gamma, int presummed_rows);
 extern "C" int pk_bn_bwd_bf16(void* stream, const uint16_t* g0, const uint16_t* g1, int64_t g_pitch, int G, int H,
                               const float* x, int64_t ldx, int64_t M, const float* mean, const float* var, float eps,
                               const float* gamma, double count, float* partial, float* sum_g, float* sum_gx,
                               uint16_t* out, int64_t out_pitch, float* acc_beta, float* acc_gamma) {
-    return bn_bwd_bf16_impl(stream, g0, g1, g_pitch, G, H, x, ldx, M, mean, var, eps, gamma, count, partial, sum_g, sum_gx, out,
-                            out_pitch, acc_beta, acc_gamma, 0);
-}
-// The same with the first pass already done: partial [rows][G*H][2] holds per-row-group column sums of g and g * xhat
-// (pk_rec_bwd_bf16_bnsum left them, one row per cluster of the backward recurrence): final reduction + apply pass only.
-extern "C" int pk_bn_bwd_bf16_presummed(void* stream, const uint16_t* g0, const uint16_t* g1, int64_t g_pitch, int G, int H,
-                                        const float* x, int64_t ldx, int64_t M, const float* mean, const float* var, float eps,
-                                        const float* gamma, double count, const float* partial, int rows, float* sum_g,
-                                        float* sum_gx, uint16_t* out, int64_t out_pitch, float* acc_beta, float* acc_gamma) {
-    PK_REQUIRE(rows > 0 && mean != nullptr && var != nullptr, "pk_bn_bwd_bf16_presummed: needs the sums' rows and the batch statistics");
-    return bn_bwd_bf16_impl(stream, g0, g1, g_pitch, G, H, x, ldx, M, mean, var, eps, gamma, count, const_cast<float*>(partial), sum_g,
-                            sum_gx, out, out_pitch, acc_beta, acc_gamma, rows);
-}
-static int bn_bwd_bf16_impl(void* stream, const uint16_t* g0, const uint16_t* g1, int64_t g_pitch, int G, int H,
-                            const float* x, int64_t ldx, int64_t M, const float* mean, const float* var, float eps,
-                            const float* gamma, double count, float* partial, float* sum_g, float* sum_gx,
-                            uint16_t* out, int64_t out_pitch, float* acc_beta, float* acc_gamma, int presummed_rows) {
     PK_REQUIRE(M > 0 && G > 0 && H > 0, "pk_bn_bwd_bf16: empty input");
     PK_REQUIRE((g_pitch % 8) == 0 && ((uintptr_t)g0 & 15) == 0 && (g1 == nullptr || ((uintptr_t)g1 & 15) == 0),
                "pk_bn_bwd_bf16: gate gradients must be 16-byte aligned with a pitch that is a multiple of 8");
@@ -1716,13 +1695,9 @@ static int bn_bwd_bf16_impl(void* stream, const uint16_t* g0, const uint16_t* g1
         if (CW == 16) PK_BNB_LAUNCH2(KERNEL, GRID, 16, 16, __VA_ARGS__);  \
         else PK_BNB_LAUNCH2(KERNEL, GRID, 48, 5, __VA_ARGS__);            \
     } while (0)
-    if (presummed_rows > 0) {
-        rb = presummed_rows;  // (the backward recurrence left the first pass's result)
-    } else {
-        PK_BNB_LAUNCH(bnb_reduce_kernel, grid, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x,
-                      (long)ldx, (long)M, mean, var, eps, partial);
-        PK_LAUNCH_CHECK();
-    }
+    PK_BNB_LAUNCH(bnb_reduce_kernel, grid, (const unsigned short*)g0, (const unsigned short*)g1, (long)g_pitch, G, H, Hp, x,
+                  (long)ldx, (long)M, mean, var, eps, partial);
+    PK_LAUNCH_CHECK();
     hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_GROUPS), 0, st, partial, rb, N, sum_g,
                        use_bn ? sum_gx : (float*)nullptr, acc_beta, use_bn ? acc_gamma : (float*)nullptr,
                        out_pitch > N ? (unsigned short*)out : (unsigned short*)nullptr, (long)out_pitch, (long)M, (int)N);

@@ -52,16 +52,6 @@ struct R2Args {
     float* lnpart;   // backward: [2][ln_ncg][KPAD] per-cluster partial sums of d gamma, d beta
     int ln_cg0;      // global index of this launch's first cluster
     int ln_ncg;      // clusters over all launches
-    // ---- BatchNorm-backward reductions taken INSIDE the backward recurrence (third generation, BNR kernels only; round 6):
-    // the kernel holds every gate gradient in fp32 anyway, so it reads the projections it belongs to (bn_x: the layer's P,
-    // [T*B][bn_ldx] fp32, off the dependency chain) and leaves per-cluster column sums of g and g * xhat - what
-    // pk_bn_bwd_bf16's first pass (577 MB of reads per layer at the BASELINE shape) otherwise recomputes from dGb.
-    const float* bn_x;
-    long bn_ldx;
-    const float *bn_mean, *bn_var;   // [G*H]
-    float bn_eps;
-    float* bn_partial;               // [clusters over all launches][G*H][2]: the layout col_reduce_final_kernel reads
-    int bn_cg0;                      // global index of this launch's first cluster
 };
 
 struct Plan2 {

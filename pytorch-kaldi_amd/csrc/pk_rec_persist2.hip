@@ -1039,19 +1039,9 @@ extern "C" int pk_rec_fwd_bf16_ln(void* stream, int cell, int act, int T, int B,
                              prefilled, &ln);
 }
 
-struct BnSumHost {  // BatchNorm-backward sums taken inside the backward recurrence (R2Args::bn_*)
-    const float* x;
-    int64_t ldx;
-    const float *mean, *var;
-    float eps;
-    float* partial;
-};
-int pk_rec3_bwd_direct(int cell);  // pk_rec_persist3.hip
-
 static int rec_bwd_bf16_impl(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
                              const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
-                             float* dP2, uint16_t* dGb, int64_t g_pitch, int prefilled, const PkLnHost* ln,
-                             const BnSumHost* bn = nullptr) {
+                             float* dP2, uint16_t* dGb, int64_t g_pitch, int prefilled, const PkLnHost* ln) {
     int rc = pk_rec2_check("pk_rec_bwd_bf16", 1, cell, T, B, bidir, H);
     if (rc) return rc;
     hipStream_t st = pk_stream(stream);
@@ -1068,13 +1058,6 @@ static int rec_bwd_bf16_impl(void* stream, int cell, int act, int T, int B, int 
     a.P = nullptr; a.pscale = nullptr; a.pshift = nullptr; a.U = U; a.mask = mask; a.mask_scalar = mask_scalar;
     a.Y = const_cast<float*>(Y); a.S = const_cast<float*>(S); a.Yb = nullptr; a.Xb = nullptr; a.Ypitch = 0;
     a.dY = dY; a.dP2 = dP2; a.dGb = (unsigned short*)dGb; a.Gpitch = (int)g_pitch;
-    a.bn_x = nullptr; a.bn_ldx = 0; a.bn_mean = a.bn_var = nullptr; a.bn_eps = 0.f; a.bn_partial = nullptr; a.bn_cg0 = 0;
-    if (bn != nullptr) {
-        PK_REQUIRE(ln == nullptr && pk_rec3_bwd_direct(cell), "pk_rec_bwd_bf16_bnsum: cell %d does not run the direct third-generation backward kernel", cell);
-        PK_REQUIRE(bn->x && bn->mean && bn->var && bn->partial && bn->ldx >= (int64_t)G * H, "pk_rec_bwd_bf16_bnsum: null / short BatchNorm argument");
-        PK_REQUIRE((double)T * B * bn->ldx < 4.0e9, "pk_rec_bwd_bf16_bnsum: projection offsets exceed 32 bits");
-        a.bn_x = bn->x; a.bn_ldx = (long)bn->ldx; a.bn_mean = bn->mean; a.bn_var = bn->var; a.bn_eps = bn->eps; a.bn_partial = bn->partial;
-    }
     rc = pk_rec2_host_setup(a, true, cell);
     if (rc) return rc;
     const bool lstm8 = cell == PK_CELL_LSTM && pk_rec2l_enabled();
@@ -1118,26 +1101,6 @@ extern "C" int pk_rec_bwd_bf16(void* stream, int cell, int act, int T, int B, in
                                float* dP2, uint16_t* dGb, int64_t g_pitch, int prefilled) {
     return rec_bwd_bf16_impl(stream, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dP2, dGb, g_pitch, prefilled,
                              nullptr);
-}
-// Rows of the partial-sum table pk_rec_bwd_bf16_bnsum fills (= clusters that hold rows; 0: this cell / geometry cannot
-// take the BatchNorm sums along - the caller then leaves them to pk_bn_bwd_bf16)
-extern "C" int pk_rec_bwd_bnsum_rows(int cell, int B, int bidir, int H) {
-    if (H <= 0 || H > KPAD || B <= 0 || !pk_rec3_bwd_direct(cell) || (g2_trace != nullptr && cell == PK_CELL_LIGRU)) return 0;
-    Plan2 pl;
-    const int R = B * (1 + bidir);
-    if (pk_rec2_make_plan(R, H, pl) != 0) return 0;
-    return (R + pl.rpc - 1) / pl.rpc;
-}
-// pk_rec_bwd_bf16 that also leaves the BatchNorm-backward column sums of its gate gradients: x = the layer's projections
-// P [T*B][ldx] fp32, mean / var [G*H] the batch statistics forward used, partial >= rows * G*H * 2 floats
-// (pk_rec_bwd_bnsum_rows), to be handed to pk_bn_bwd_bf16_presummed.
-extern "C" int pk_rec_bwd_bf16_bnsum(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
-                                     const float* mask, float mask_scalar, const float* Y, const float* S, const float* dY,
-                                     uint16_t* dGb, int64_t g_pitch, int prefilled, const float* x, int64_t ldx,
-                                     const float* mean, const float* var, float eps, float* partial) {
-    const BnSumHost bn = {x, ldx, mean, var, eps, partial};
-    return rec_bwd_bf16_impl(stream, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, nullptr, dGb, g_pitch, prefilled,
-                             nullptr, &bn);
 }
 extern "C" int pk_rec_bwd_bf16_ln(void* stream, int cell, int act, int T, int B, int bidir, int H, const float* U,
                                   const float* mask, float mask_scalar, const float* ln_gamma, float ln_eps, const float* Y,

@@ -361,12 +361,8 @@ __global__ __launch_bounds__(256, 1) void rec3_fwd_kernel(R2Args a) {
 // ============================================================================
 // backward: dL/dh_{t-1} = direct + [dgates_t] . [U_0; U_1; ...]
 // ============================================================================
-// BNR (direct layout only): the BatchNorm-backward column sums of this layer's gate gradients are accumulated on the way
-// (R2Args::bn_*): sum_g[g, u] += dg, sum_gx[g, u] += dg * (P - mean) * invstd per lane, over all rows and steps; one row
-// reduction per wave at the end, one (cluster, column) owner each: deterministic.
-template <int CELL, int ACT, bool TR, bool COAL, bool BNR = false>
+template <int CELL, int ACT, bool TR, bool COAL>
 __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
-    static_assert(!(BNR && COAL), "the in-kernel BatchNorm sums use the direct (gate) layout of the loads");
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
     constexpr int LDA = pk_r2_lda_bf16(G * KPAD);
@@ -483,27 +479,6 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
         dst[NS + 1] = ld4<EE>(a.dY, vY0 + ts * vYs, anv);
         if (t == 0) dst[NS] = f32x4{0.f, 0.f, 0.f, 0.f};  // h_{-1} = 0
     };
-    // BNR: this step's / the next step's projections of my (row, 4 units) per gate, the columns' statistics, the sums
-    f32x4 pcur[BNR ? G : 1], pnxt[BNR ? G : 1];
-    float bmean[BNR ? G : 1][4], binv[BNR ? G : 1][4], sg[BNR ? G : 1][4], sgx[BNR ? G : 1][4];
-    const unsigned vX0 = BNR ? (unsigned)ab * (unsigned)a.bn_ldx + au0 : 0u, vXs = BNR ? (unsigned)B * (unsigned)a.bn_ldx : 0u;
-    if (BNR) {
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = r < nv;
-                bmean[g][r] = ok ? a.bn_mean[g * H + u0 + r] : 0.f;
-                binv[g][r] = ok ? 1.0f / sqrtf(a.bn_var[g * H + u0 + r] + a.bn_eps) : 0.f;
-                sg[g][r] = 0.f;
-                sgx[g][r] = 0.f;
-            }
-    }
-    auto load_x_e = [&](f32x4 (&dst)[BNR ? G : 1], int t, auto E) {
-        const unsigned ts = (unsigned)(adir ? (T - 1 - t) : t);
-#pragma unroll
-        for (int g = 0; g < (BNR ? G : 0); ++g) dst[g] = ld4<decltype(E)::value>(a.bn_x, vX0 + ts * vXs + g * H, anv);
-    };
     f32x4 gout[G];  // fp32 gate gradients of the previous step (only when the caller wants them: dP2 != null)
     auto flush_outputs_e = [&](int tt, auto E) {
         const unsigned ts = (unsigned)(adir ? (T - 1 - tt) : tt);
@@ -518,12 +493,6 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
     PK_EDGE_DISPATCH(PK3_LS0);
 #pragma unroll
     for (int k = 0; k < NIN; ++k) iv[k] = inext[k];
-    if (BNR) {
-#define PK3_LX0(E) load_x_e(pnxt, T - 1, E)
-        PK_EDGE_DISPATCH(PK3_LX0);
-#pragma unroll
-        for (int g = 0; g < (BNR ? G : 0); ++g) pcur[g] = pnxt[g];
-    }
 #pragma unroll
     for (int g = 0; g < G; ++g) gout[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -594,10 +563,6 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
             if (t > 0) {  // (loads first: see the forward kernel)
 #define PK3_LS1(E) load_step_e(inext, t - 1, E)
                 PK_EDGE_DISPATCH_S(PK3_LS1);
-                if (BNR) {
-#define PK3_LX1(E) load_x_e(pnxt, t - 1, E)
-                    PK_EDGE_DISPATCH_S(PK3_LX1);
-                }
             }
             if (t < T - 1 && a.dP2 != nullptr) {
 #define PK3_FOB(E) flush_outputs_e(t + 1, E)
@@ -675,17 +640,6 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
 #pragma unroll
             for (int k = 0; k < NIN; ++k) iv[k] = inext[k];
         }
-        if (BNR) {  // behind the publish: nothing of this is on the dependency chain
-#pragma unroll
-            for (int g = 0; g < (BNR ? G : 0); ++g) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    sg[g][r] += dgv[g][r];
-                    sgx[g][r] += dgv[g][r] * ((pcur[g][r] - bmean[g][r]) * binv[g][r]);
-                }
-                pcur[g] = pnxt[g];
-            }
-        }
         PK_TRACE(5);
     }
     };
@@ -694,21 +648,6 @@ __global__ __launch_bounds__(256, 1) void rec3_bwd_kernel(R2Args a) {
     if (a.dP2 != nullptr) {
 #define PK3_FOBL(E) flush_outputs_e(0, E)
         PK_EDGE_DISPATCH(PK3_FOBL);
-    }
-    if (BNR) {
-        // my 16 rows' sums of every (gate, unit) I hold: the 16 lanes of a DPP row share kq, i.e. the same four units
-        float* const prow = a.bn_partial + (long)(a.bn_cg0 + c) * GH * 2;
-#pragma unroll
-        for (int g = 0; g < (BNR ? G : 0); ++g)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float s0 = dpp_row_sum(row_ok ? sg[g][r] : 0.f), s1 = dpp_row_sum(row_ok ? sgx[g][r] : 0.f);
-                if ((lane & 15) == 0 && u0 + r < H) {
-                    float* o = prow + (long)(g * H + u0 + r) * 2;
-                    o[0] = s0;
-                    o[1] = s1;
-                }
-            }
     }
 }
 
@@ -724,11 +663,6 @@ Rec3Kernel pick3_bwd(int act, bool tr) {
     if (tr) return rec3_bwd_kernel<CELL, PK_ACT_RELU, true, COAL>;
     return act == PK_ACT_RELU ? rec3_bwd_kernel<CELL, PK_ACT_RELU, false, COAL>
          : act == PK_ACT_TANH ? rec3_bwd_kernel<CELL, PK_ACT_TANH, false, COAL> : rec3_bwd_kernel<CELL, -1, false, COAL>;
-}
-template <int CELL>
-Rec3Kernel pick3_bwd_bnr(int act) {
-    return act == PK_ACT_RELU ? rec3_bwd_kernel<CELL, PK_ACT_RELU, false, false, true>
-         : act == PK_ACT_TANH ? rec3_bwd_kernel<CELL, PK_ACT_TANH, false, false, true> : rec3_bwd_kernel<CELL, -1, false, false, true>;
 }
 int g3_gen[2] = {-1, -1};  // per pass (forward, backward): 2 = second generation; 3 = third, HBM accesses through transposer patches; 4 = third, direct
 
@@ -755,9 +689,6 @@ int pk_rec3_covers(int cell, int backward) {
     return g3_gen[backward ? 1 : 0] != 2 && (cell == PK_CELL_LIGRU || cell == PK_CELL_RNN);
 }
 
-// Does the backward pass of this cell run the direct third-generation kernel, i.e. can it take the BatchNorm sums along?
-int pk_rec3_bwd_direct(int cell) { return pk_rec3_covers(cell, 1) && g3_gen[1] == 4; }
-
 // Launch loop of the third-generation kernels; `a` and `pl` are prepared by pk_rec_fwd_bf16 / pk_rec_bwd_bf16
 // (pk_rec_persist2.hip).  traced: the phase-trace instantiation (Li-GRU / relu only).
 int pk_rec3_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act, bool backward, bool traced) {
@@ -767,11 +698,7 @@ int pk_rec3_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act
     const int npatch = backward ? NS + 2 + G : G + 1 + NS;
     const size_t lds = 2 * atile + 32 + (coal ? (size_t)4 * npatch * PK3_PATCH_F * 4 : 0);
     Rec3Kernel k;
-    const bool bnr = backward && a.bn_x != nullptr;
-    if (bnr) {
-        PK_REQUIRE(!coal && !traced, "pk_rec_bwd_bf16: the in-kernel BatchNorm sums need the direct third-generation backward kernel");
-        k = cell == PK_CELL_LIGRU ? pick3_bwd_bnr<PK_CELL_LIGRU>(act) : pick3_bwd_bnr<PK_CELL_RNN>(act);
-    } else if (cell == PK_CELL_LIGRU) {
+    if (cell == PK_CELL_LIGRU) {
         if (coal) k = backward ? pick3_bwd<PK_CELL_LIGRU, true>(act, traced) : pick3_fwd<PK_CELL_LIGRU, true>(act, traced);
         else k = backward ? pick3_bwd<PK_CELL_LIGRU, false>(act, traced) : pick3_fwd<PK_CELL_LIGRU, false>(act, traced);
     } else {
@@ -790,7 +717,6 @@ int pk_rec3_launch(hipStream_t st, R2Args& a, const Plan2& pl, int cell, int act
     }
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
-        a.bn_cg0 = l * pl.C;
         int rc = pk_rec2_reset_handshake(st, a);
         if (rc) return rc;
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, backward ? "pk_rec_bwd_bf16" : "pk_rec_fwd_bf16");

@@ -2003,23 +2003,10 @@ class RecLayerPerfFn(torch.autograd.Function):
             prefilled = 2 if ctx.self_fill else 0
         Gp = dGb.shape[1]
         flush_deferred_side()  # the output layers' weight gradients: ready when this recurrence is, next to it on the idle CUs
-        # Li-GRU / RNN: the recurrence takes the BatchNorm-backward reductions of its own gate gradients along (it holds
-        # them in fp32 anyway and reads P off the dependency chain): pk_bn_bwd_bf16's first pass - 577 MB of reads per layer
-        # at the BASELINE shape, on the critical path of backward - is then skipped (PK_EXPERIMENT bn_in_rec=0: as before)
-        bn_rows = 0
-        if use_bn and ctx.Xb is None and _lib.experiment("bn_in_rec", "1") != "0":
-            bn_rows = int(lib.pk_rec_bwd_bnsum_rows(CELL[cell], B, int(bidir), H))
-        part = None
         if ctx.Xb is not None:
             rc = lib.pk_rec2p_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
                                        float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dGb), Gp, prefilled)
             _lib.check(rc, "pk_rec2p_bwd_bf16")
-        elif bn_rows > 0:
-            part = _new(bn_rows * GH * 2, like=dY)
-            rc = lib.pk_rec_bwd_bf16_bnsum(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
-                                           float(mask_scalar), _p(Y), _p(S), _p(dY), _p(dGb), Gp, prefilled, _p(P), GH,
-                                           _p(mean), _p(var), eps, _p(part))
-            _lib.check(rc, "pk_rec_bwd_bf16_bnsum")
         else:
             rc = lib.pk_rec_bwd_bf16(_stream(), CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat), _p(mask),
                                      float(mask_scalar), _p(Y), _p(S), _p(dY), None, _p(dGb), Gp, prefilled)
@@ -2045,8 +2032,7 @@ class RecLayerPerfFn(torch.autograd.Function):
             do_dU()
         # BatchNorm backward (or plain sum of the two directions) straight from dGb -> bf16 projection gradient
         dPb = torch.empty(TB, _up(GH, 64), device=dY.device, dtype=torch.bfloat16)
-        if part is None:
-            part = _new(int(lib.pk_bn_partial_floats(TB, GH)), like=dY)
+        part = _new(int(lib.pk_bn_partial_floats(TB, GH)), like=dY)
         sum_g = _new(GH, like=dY)
         sum_gx = _new(GH, like=dY) if use_bn else None
         g1 = ctypes.c_void_p(dGb.data_ptr() + 2 * TB * Gp) if bidir else None
@@ -2057,14 +2043,9 @@ class RecLayerPerfFn(torch.autograd.Function):
             if acc_g is None or acc_b is None:
                 raise _lib.PkError("perf-mode recurrent layer: the BatchNorm gradients left the flat buffer between forward "
                                    "and backward (optim.FlatParams.zero_grad() re-aliases them)")
-        if bn_rows > 0:
-            rc = lib.pk_bn_bwd_bf16_presummed(_stream(), _p(dGb), g1, Gp, G, H, _p(P), GH, TB, _p(mean), _p(var), eps, _p(gamma),
-                                              float(TB), _p(part), bn_rows, _p(sum_g), _p(sum_gx), _p(dPb), dPb.shape[1],
-                                              _p(acc_b), _p(acc_g))
-        else:
-            rc = lib.pk_bn_bwd_bf16(_stream(), _p(dGb), g1, Gp, G, H, _p(P), GH, TB, _p(mean) if use_bn else None,
-                                    _p(var) if use_bn else None, eps, _p(gamma) if use_bn else None, float(TB), _p(part),
-                                    _p(sum_g), _p(sum_gx), _p(dPb), dPb.shape[1], _p(acc_b), _p(acc_g))
+        rc = lib.pk_bn_bwd_bf16(_stream(), _p(dGb), g1, Gp, G, H, _p(P), GH, TB, _p(mean) if use_bn else None,
+                                _p(var) if use_bn else None, eps, _p(gamma) if use_bn else None, float(TB), _p(part),
+                                _p(sum_g), _p(sum_gx), _p(dPb), dPb.shape[1], _p(acc_b), _p(acc_g))
         _lib.check(rc, "pk_bn_bwd_bf16")
         dgamma = dbeta = dbias = None
         if use_bn and acc_g is None:

@@ -77,44 +77,3 @@ def test_forward_only_chunks_save_nothing_and_change_nothing(kind, pre, act):
     assert tw_a is not None and tw_b is not None
     used = 2 * ((H + 7) // 8 * 8)  # (columns beyond ndir * Hp of the pitch are left undefined, include/pk_amd.h)
     assert torch.equal(tw_a[0][:, :used], tw_b[0][:, :used])   # the bf16 copy the heads read
-
-
-@pytest.mark.parametrize("kind,pre,act,H,B,T", [("liGRU", "ligru", "relu", 550, 128, 24), ("liGRU", "ligru", "relu", 77, 5, 11),
-                                                 ("RNN", "rnn", "tanh", 130, 19, 9), ("liGRU", "ligru", "relu", 550, 150, 6)])
-def test_batchnorm_sums_taken_inside_the_backward_recurrence(kind, pre, act, H, B, T, monkeypatch):
-    """Round 6: the backward recurrence of liGRU / RNN leaves the BatchNorm-backward column sums of its gate gradients
-    (pk_rec_bwd_bf16_bnsum -> pk_bn_bwd_bf16_presummed; neural_networks.py:1118-1124 backwards) and the first pass of
-    pk_bn_bwd_bf16 is skipped.  Same gradients as the two-pass path up to the rounding of the sums (the kernel adds fp32 gate
-    gradients, the separate pass their bf16 copies): full clusters, partial clusters, odd widths, two launches."""
-    nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
-    D = 40
-    j = lambda v: ",".join([str(v)] * 2)  # noqa: E731
-    opts = {pre + "_lay": j(H), pre + "_drop": j(0.2), pre + "_use_laynorm_inp": "False", pre + "_use_batchnorm_inp": "False",
-            pre + "_use_laynorm": j(False), pre + "_use_batchnorm": j(True), pre + "_bidir": "True", pre + "_act": j(act),
-            pre + "_orthinit": "True", "use_cuda": "True", "to_do": "train"}
-    g = torch.Generator().manual_seed(9)
-    x0 = torch.randn(T, B, D, generator=g)
-    cot = torch.randn(T, B, 2 * H, generator=g).cuda()
-    masks = [torch.bernoulli(torch.full((2 * B, H), 0.8), generator=g) for _ in range(2)]
-    F_.set_precision("bf16")
-    res = {}
-    try:
-        for on in ("1", "0"):
-            monkeypatch.setenv("PK_EXPERIMENT", "bn_in_rec=" + on)
-            torch.manual_seed(3)
-            net = getattr(nn_amd, kind)(opts, D).cuda().train()
-            x = x0.clone().cuda().requires_grad_(True)
-            (net(x, drop_masks=masks) * cot).sum().backward()
-            torch.cuda.synchronize()
-            res[on] = {"dx": x.grad.clone(), **{k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}}
-    finally:
-        F_.set_precision("fp32")
-    importlib.import_module("pytorch-kaldi_amd._lib").raise_if_persist_failed()
-    assert set(res["1"]) == set(res["0"])
-    worst = max((rel_err(res["1"][k], res["0"][k]), k) for k in res["0"])
-    print("BatchNorm sums inside the recurrence vs the two-pass path: worst", worst)
-    assert worst[0] < 2e-3, worst
-    # the sums themselves are d beta / d gamma of the BatchNorm modules: fp32 terms instead of bf16 ones, same sum
-    for k in res["0"]:
-        if k.startswith("bn_"):
-            assert rel_err(res["1"][k], res["0"][k]) < 1e-3, k

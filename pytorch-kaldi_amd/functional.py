@@ -551,7 +551,16 @@ def side_targets_ok(params):
     """Weight gradients may bypass autograd only when every target parameter has a pre-allocated .grad that is a
     view of an optim.FlatParams buffer (its consumers - fused optimizer step, gradient all-reduce, zero_grad -
     call join_side() first)."""
-    return (settings.wgrad_side and bf16_mode() and params is not None and len(params) > 0
+    return bf16_mode() and side_targets_any_ok(params)
+
+
+def side_targets_any_ok(params):
+    """side_targets_ok without the precision condition.  Round 6: the exact-fp32 mode takes the side stream for its
+    weight-gradient GEMMs too (RecLayerFn, LinearFn: 33 ms of a 149 ms fp32 LSTM step ran serially next to recurrences
+    that leave 112 CUs idle); PK_EXPERIMENT f32_wgrad_side=0 keeps them on the main stream."""
+    if not bf16_mode() and _lib.experiment("f32_wgrad_side", "1") == "0":
+        return False
+    return (settings.wgrad_side and params is not None and len(params) > 0
             and all(getattr(q, "_pk_flat", False) and q.grad is not None and q.requires_grad for q in params))
 
 
@@ -737,8 +746,14 @@ class LinearFn(torch.autograd.Function):
             gemm(M, K, N, dy2, N, 1, weight, K, 1, dx, K)
             dx = dx.view(ctx.in_shape)
         if ctx.needs_input_grad[1]:
-            dw = _new(N, K, like=dy2)
-            gemm(N, K, M, dy2, 1, N, x2, x2.stride(0), 1, dw, K, splitk=_splitk(_tiles(N, K), M))
+            wp = ctx.wparam
+            sk = _splitk(_tiles(N, K), M)
+            if M >= 4096 and wp is not None and wp.is_contiguous() and side_targets_any_ok([wp]):
+                # (round 6) off the dependency chain in the exact-fp32 mode too: on the side stream, straight into the flat .grad
+                side_launch(lambda: gemm(N, K, M, dy2, 1, N, x2, x2.stride(0), 1, wp.grad, K, beta=1.0, splitk=sk), (dy2, x2), [wp])
+            else:
+                dw = _new(N, K, like=dy2)
+                gemm(N, K, M, dy2, 1, N, x2, x2.stride(0), 1, dw, K, splitk=sk)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy2)
         return dx, dw, db
@@ -1573,6 +1588,37 @@ def choose_rec_algo(cell, H, use_ln):
     return REC_PERSISTENT if ok else REC_STEPWISE
 
 
+_DU_SPLITK = 16  # pk_rec.hip DU_SPLITK: the same split of the reduction (pk_gemm clamps it to 32-deep slices), so the same sums
+
+
+def _deferred_dU_f32(cell, T, B, ndir, H, G, NS, Y, S, dP2, out, accumulate):
+    """dU[G*H, H] (+)= sum over directions and steps of dgate_t^T . (vector that fed U_g at step t) in exact fp32: what
+    pk_rec_bwd does behind its recurrence when it is handed a dU (pk_rec.hip::deferred_dU), as separate launches so that
+    they can run on the side stream.  out: [G*H, H] fp32 - a temporary (accumulate = False) or the gates' view of the flat
+    gradient (accumulate = True: every product adds)."""
+    TB, GH, YH = T * B, G * H, ndir * H
+    two_phase = cell in ("GRU", "minimalGRU")
+    Gh = G - 1 if two_phase else G
+    Kh = (T - 1) * B
+    dflat, yflat, sflat, oflat = dP2.reshape(-1), Y.reshape(-1), S.reshape(-1), out.reshape(-1)
+    first = not accumulate
+    if Kh == 0 and not accumulate:
+        out[:Gh * H].zero_()
+    for d in range(ndir if Kh > 0 else 0):
+        # rows whose previous state exists: dir 0 -> ts >= 1 (h at ts-1); dir 1 -> ts <= T-2 (h at ts+1)
+        A = dflat[(d * TB + (0 if d else B)) * GH:]
+        Bm = yflat[(B if d else 0) * YH + d * H:]
+        gemm(Gh * H, H, Kh, A, 1, GH, Bm, YH, 1, oflat, H, beta=0.0 if first else 1.0, splitk=_DU_SPLITK, prec="fp32")
+        first = False
+    if two_phase:  # candidate gate: dU_h = sum dA^T . (r*h) or (z*h), saved in S, same row
+        slot = 3 if cell == "GRU" else 2
+        for d in range(ndir):
+            A = dflat[d * TB * GH + Gh * H:]
+            Bm = sflat[d * TB * NS * H + slot * H:]
+            gemm(H, H, TB, A, 1, GH, Bm, NS * H, 1, oflat[Gh * H * H:], H, beta=1.0 if (accumulate or d) else 0.0,
+                 splitk=_DU_SPLITK, prec="fp32")
+
+
 def _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, Yb=None, dGb=None, Xb=None):
     """dU[G*H, H] = sum over directions and steps of dgate_t^T . (vector that fed U_g at step t), as
     k-major x k-major bf16 GEMMs over the (T-1)*B rows (Appendix C of SURVEY.md; pk_rec.hip deferred_dU
@@ -1631,7 +1677,12 @@ class RecLayerFn(torch.autograd.Function):
     def forward(ctx, x, Wcat, bcat, Ucat, gamma, beta, running_mean, running_var, mask, ln_gamma, ln_beta, cfg):
         _need_gpu(x, Wcat, bcat, Ucat, gamma, beta, mask, ln_gamma, ln_beta)
         lib = _lib.load()
-        cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar = cfg
+        cell, act, H, bidir, use_bn, training, eps, momentum, mask_scalar = cfg[:9]
+        # (round 6) the gates' parameters and whether their gradients bypass autograd: exact-fp32 weight-gradient GEMMs on
+        # the side stream, accumulating into the flat .grad (decided by nn._Recurrent.forward, which then hands Wcat / Ucat
+        # over detached)
+        ctx.wparams, ctx.uparams = (cfg[9], cfg[10]) if len(cfg) > 10 else (None, None)
+        ctx.side_w, ctx.side_u = (bool(cfg[11]), bool(cfg[12])) if len(cfg) > 12 else (False, False)
         T, B, D = x.shape
         x2 = _rows2d(x)
         G = lib.pk_rec_num_gates(CELL[cell])
@@ -1717,7 +1768,7 @@ class RecLayerFn(torch.autograd.Function):
             ctx.save_for_backward(xb, Wb, Ucat, P, mean, var, gamma, mask, Y, S, pscale, ln_gamma, LNS)
         else:
             ctx.save_for_backward(x2, Wcat, Ucat, P, mean, var, gamma, mask, Y, S, pscale, ln_gamma, LNS)
-        ctx.cfg = cfg
+        ctx.cfg = cfg[:9]
         ctx.algo, ctx.prec = algo, prec
         ctx.in_shape = x.shape
         ctx.has_bias = bcat is not None
@@ -1772,10 +1823,24 @@ class RecLayerFn(torch.autograd.Function):
                                          2 if settings.self_fill else 0)
             _lib.check(rc, "pk_rec_bwd_bf16")
         else:
+            side_u = (not bf) and ctx.side_u and side_targets_any_ok(ctx.uparams)
             rc = lib.pk_rec_bwd(_stream(), ctx.algo, ctx.prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat),
                                 _p(mask), float(mask_scalar), _p(ln_gamma), _p(Y), _p(S), _p(LNS), _p(dY), _p(dP2),
-                                None if bf else _p(dU), _p(dlg), _p(dlb), _p(work))
+                                None if (bf or ctx.side_u) else _p(dU), _p(dlg), _p(dlb), _p(work))
             _lib.check(rc, "pk_rec_bwd")
+            if ctx.side_u and not side_u:  # (decided in forward, no longer possible: the gradient goes back through autograd... which has no edge)
+                raise _lib.PkError("recurrent layer: the flat gradient buffer the weights' gradients were to be added to is gone "
+                                   "between forward and backward (optim.FlatParams.zero_grad() re-aliases it)")
+        NS_ = lib.pk_rec_num_saved(CELL[cell])
+
+        def do_dU_f32():
+            gview = adjacent_view([q.grad for q in ctx.uparams])
+            if gview is not None:
+                _deferred_dU_f32(cell, T, B, ndir, H, G, NS_, Y, S, dP2, gview, True)
+            else:
+                _deferred_dU_f32(cell, T, B, ndir, H, G, NS_, Y, S, dP2, dU, False)
+                _accumulate_rows(ctx.uparams, [dU[g * H:(g + 1) * H] for g in range(G)])
+
         if bf:
             _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, ctx.Yb, dGb, ctx.Xb)
             ctx.Yb = ctx.Xb = None
@@ -1823,8 +1888,28 @@ class RecLayerFn(torch.autograd.Function):
             dx = _new(TB, D, like=dY)
             gemm(TB, D, GH, dPraw, GH, 1, Wcat, D, 1, dx, D)
             dx = dx.view(T, B, D)
-        gemm(GH, D, TB, dPraw, 1, GH, x2, x2.stride(0), 1, dW, D, splitk=_splitk(_tiles(GH, D), TB))
-        return dx, dW, dbias, dU, dgamma, dbeta, None, None, None, dlg, dlb, None
+        # weight gradients are off the dependency chain (next on it: the recurrence of the layer below, which leaves 112 CUs
+        # idle): with flat-bucket parameters they run on the side stream, behind the dX GEMM, and add straight into .grad
+        side_w = ctx.side_w and side_targets_any_ok(ctx.wparams)
+        if ctx.side_w and not side_w:
+            raise _lib.PkError("recurrent layer: the flat gradient buffer of the input weights is gone between forward and backward")
+        if ctx.side_u:
+            side_launch(do_dU_f32, (Y, S, dP2, dU), ctx.uparams)
+
+        def do_dW_f32():
+            gview = adjacent_view([q.grad for q in ctx.wparams])
+            sk = _splitk(_tiles(GH, D), TB)
+            if gview is not None:
+                gemm(GH, D, TB, dPraw, 1, GH, x2, x2.stride(0), 1, gview, D, beta=1.0, splitk=sk)
+            else:
+                gemm(GH, D, TB, dPraw, 1, GH, x2, x2.stride(0), 1, dW, D, splitk=sk)
+                _accumulate_rows(ctx.wparams, [dW[g * H:(g + 1) * H] for g in range(G)])
+
+        if side_w:
+            side_launch(do_dW_f32, (dPraw, x2, dW), ctx.wparams)
+        else:
+            gemm(GH, D, TB, dPraw, 1, GH, x2, x2.stride(0), 1, dW, D, splitk=_splitk(_tiles(GH, D), TB))
+        return (dx, None if side_w else dW, dbias, None if ctx.side_u else dU, dgamma, dbeta, None, None, None, dlg, dlb, None)
 
 
 def perf_path_ok(cell, H, use_ln, use_bn, training):

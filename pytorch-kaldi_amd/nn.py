@@ -600,11 +600,29 @@ class _Recurrent(nn.Module):
                     x = y
                     continue
             else:
-                Wcat = torch.cat([m.weight for m in Ws], 0) if len(Ws) > 1 else Ws[0].weight
-                Ucat = torch.cat([m.weight for m in Us], 0) if len(Us) > 1 else Us[0].weight
+                wps, ups = [m.weight for m in Ws], [m.weight for m in Us]
+                # exact-fp32 mode with flat-bucket parameters (round 6): the weight-gradient GEMMs go to the side stream and add
+                # into the flat .grad, so the concatenated weights are handed over detached, as on the perf path above (some
+                # other input carries the autograd edge: the BatchNorm affine, the bias or x itself)
+                edge = (not F_.bf16_mode()) and torch.is_grad_enabled() and (use_bn or bcat is not None or x.requires_grad)
+                side_w = edge and F_.side_targets_any_ok(wps)
+                side_u = edge and F_.side_targets_any_ok(ups)
+                if side_w:
+                    Wcat = F_.adjacent_view([w.detach() for w in wps])
+                    if Wcat is None:
+                        Wcat = torch.cat([w.detach() for w in wps], 0)
+                else:
+                    Wcat = torch.cat(wps, 0) if len(wps) > 1 else wps[0]
+                if side_u:
+                    Ucat = F_.adjacent_view([u.detach() for u in ups])
+                    if Ucat is None:
+                        Ucat = torch.cat([u.detach() for u in ups], 0)
+                else:
+                    Ucat = torch.cat(ups, 0) if len(ups) > 1 else ups[0]
                 lng = self.ln[i].gamma if self._use_ln[i] else None
                 lnb = self.ln[i].beta if self._use_ln[i] else None
-                y, bmean, bvar = F_.RecLayerFn.apply(x, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, mask_i, lng, lnb, cfg)
+                y, bmean, bvar = F_.RecLayerFn.apply(x, Wcat, bcat, Ucat, gamma, beta, rmean, rvar, mask_i, lng, lnb,
+                                                     cfg + (wps, ups, side_w, side_u))
                 xb = xseg = None
             if use_bn and self.training:
                 n = x.shape[0] * x.shape[1] * (2 if self.bidir else 1)

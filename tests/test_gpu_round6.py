@@ -77,3 +77,50 @@ def test_forward_only_chunks_save_nothing_and_change_nothing(kind, pre, act):
     assert tw_a is not None and tw_b is not None
     used = 2 * ((H + 7) // 8 * 8)  # (columns beyond ndir * Hp of the pitch are left undefined, include/pk_amd.h)
     assert torch.equal(tw_a[0][:, :used], tw_b[0][:, :used])   # the bf16 copy the heads read
+
+
+@pytest.mark.parametrize("kind,pre,act,bn", [("liGRU", "ligru", "relu", True), ("LSTM", "lstm", "tanh", False), ("GRU", "gru", "tanh", True),
+                                              ("minimalGRU", "minimalgru", "relu", False), ("RNN", "rnn", "tanh", False)])
+def test_fp32_weight_gradients_on_the_side_stream_equal_autograds(kind, pre, act, bn, monkeypatch):
+    """Exact-fp32 mode with flat-bucket parameters (round 6): the dW / dU GEMMs of a recurrent layer run on the side stream
+    and accumulate into the flat .grad (functional.RecLayerFn, _deferred_dU_f32) instead of being returned to autograd
+    (neural_networks.py:351-379 et al.: every gate is an nn.Linear whose weight autograd fills).  Same kernels, same
+    operands, same split of every reduction: BIT-identical to the autograd route (PK_EXPERIMENT f32_wgrad_side=0) for the
+    one backward pass per zero_grad() a training step makes - the 30-step RMSprop fixture amplifies a different summation
+    order of dU into 1e-3 of the loss - and equal within fp32 rounding when a second pass adds to the first (gradient
+    accumulation) and to the plain-parameter route."""
+    nn_amd = importlib.import_module("pytorch-kaldi_amd.nn")
+    optim = importlib.import_module("pytorch-kaldi_amd.optim")
+    H, T, B, D = 96, 21, 19, 40
+    j = lambda v: ",".join([str(v)] * 2)  # noqa: E731
+    opts = {pre + "_lay": j(H), pre + "_drop": j(0.0), pre + "_use_laynorm_inp": "False", pre + "_use_batchnorm_inp": "False",
+            pre + "_use_laynorm": j(False), pre + "_use_batchnorm": j(bn), pre + "_bidir": "True", pre + "_act": j(act),
+            pre + "_orthinit": "True", "use_cuda": "True", "to_do": "train"}
+    x = torch.randn(T, B, D, generator=torch.Generator().manual_seed(4)).cuda()
+    tgt = torch.randn(T, B, 2 * H, generator=torch.Generator().manual_seed(5)).cuda()
+    assert not F_.bf16_mode()
+    grads = {}
+    launches = []
+    real = F_.side_launch
+    monkeypatch.setattr(F_, "side_launch", lambda *a, **k: (launches.append(1), real(*a, **k))[1])
+    for route in ("plain", "flat_autograd", "flat_side"):
+        monkeypatch.setenv("PK_EXPERIMENT", "f32_wgrad_side=%d" % (route == "flat_side"))
+        torch.manual_seed(3)
+        net = getattr(nn_amd, kind)(opts, D).cuda().train()
+        fp = optim.FlatParams(net) if route != "plain" else None
+        n0 = len(launches)
+        for k in (1, 2):
+            y = net(x)
+            ((y - tgt) ** 2).mean().backward()
+            F_.join_side()
+            torch.cuda.synchronize()
+            grads[route, k] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        assert (len(launches) - n0 == 2 * 2 * 2) == (route == "flat_side")  # (dW and dU) x layers x passes
+        del fp
+    for n, g in grads["flat_autograd", 1].items():
+        assert torch.equal(grads["flat_side", 1][n], g), n
+    # the second pass adds (grad + d0) + d1 where autograd adds grad + (d0 + d1): fp32 rounding of the association
+    for k in (1, 2):
+        for other in ("flat_autograd", "plain"):
+            worst = max((rel_err(grads["flat_side", k][n], g), n) for n, g in grads[other, k].items())
+            assert worst[0] < 2e-6, (k, other, worst)

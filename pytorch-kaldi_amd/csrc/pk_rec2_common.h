@@ -192,8 +192,9 @@ __device__ __forceinline__ unsigned ln_bits(float f) {
 // LDS.  Fixed summation order: every lane, wave and member of the cluster ends with bit-identical totals.
 //   pub_off: byte offset of my entry in this step's slab (lanes that do not publish: out of range, dropped)
 //   poll_off[s]: byte offsets of the entries I poll (slots beyond 4 * Pn: out of range, answered with zeros)
-template <bool FAST>
-__device__ __forceinline__ bool ln_row_allreduce(__amdgpu_buffer_rsrc_t rsx, unsigned pub_off, const unsigned (&poll_off)[3],
+// NP: 16-slot groups a lane polls (3 covers the 4 x 9 slots of the second-generation clusters, 5 the 4 x 18 of the fourth)
+template <bool FAST, int NP = 3>
+__device__ __forceinline__ bool ln_row_allreduce(__amdgpu_buffer_rsrc_t rsx, unsigned pub_off, const unsigned (&poll_off)[NP],
                                                  float (&a)[4], float (&b)[4], unsigned* err, int spin_limit, int lane, bool dead) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -202,21 +203,21 @@ __device__ __forceinline__ bool ln_row_allreduce(__amdgpu_buffer_rsrc_t rsx, uns
     }
     pub_store<FAST>(rsx, pub_off, u32x4{ln_bits(a[0]), ln_bits(b[0]), ln_bits(a[1]), ln_bits(b[1])});
     pub_store<FAST>(rsx, pub_off + 16u, u32x4{ln_bits(a[2]), ln_bits(b[2]), ln_bits(a[3]), ln_bits(b[3])});
-    u32x4 v[6];
+    u32x4 v[2 * NP];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) v[i] = poll_load<FAST>(rsx, poll_off[i >> 1] + (unsigned)(i & 1) * 16u);
+    for (int i = 0; i < 2 * NP; ++i) v[i] = poll_load<FAST>(rsx, poll_off[i >> 1] + (unsigned)(i & 1) * 16u);
     bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) bad = bad | has_sent16(v[i]);
+    for (int i = 0; i < 2 * NP; ++i) bad = bad | has_sent16(v[i]);
     if (__any(bad) && !dead) {
         int spins = 0;
         while (true) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 2 * NP; ++i)
                 if (has_sent16(v[i])) v[i] = poll_load<FAST>(rsx, poll_off[i >> 1] + (unsigned)(i & 1) * 16u);
             bad = false;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) bad = bad | has_sent16(v[i]);
+            for (int i = 0; i < 2 * NP; ++i) bad = bad | has_sent16(v[i]);
             if (!__any(bad)) break;
             if (spin_check2(spins, spin_limit, err, lane)) {
                 dead = true;
@@ -228,10 +229,11 @@ __device__ __forceinline__ bool ln_row_allreduce(__amdgpu_buffer_rsrc_t rsx, uns
     for (int r = 0; r < 4; ++r) {
         const int ch = r >> 1, e = (r & 1) * 2;
         float sa = __uint_as_float(v[ch][e]), sb = __uint_as_float(v[ch][e + 1]);
-        sa += __uint_as_float(v[2 + ch][e]);
-        sb += __uint_as_float(v[2 + ch][e + 1]);
-        sa += __uint_as_float(v[4 + ch][e]);
-        sb += __uint_as_float(v[4 + ch][e + 1]);
+#pragma unroll
+        for (int g = 1; g < NP; ++g) {
+            sa += __uint_as_float(v[2 * g + ch][e]);
+            sb += __uint_as_float(v[2 * g + ch][e + 1]);
+        }
         a[r] = dpp_row_sum(sa);
         b[r] = dpp_row_sum(sb);
     }
@@ -239,17 +241,20 @@ __device__ __forceinline__ bool ln_row_allreduce(__amdgpu_buffer_rsrc_t rsx, uns
 }
 // byte offsets into the row-statistics exchange for one lane at step 0; a slot this lane does not use is out of range
 // (== size: stores are dropped, loads answer zeros - never the sentinel) at every step
-struct LnSlots {
-    unsigned pub, poll[3], slab, size;
-    bool pub_ok, poll_ok[3];
+template <int NP>
+struct LnSlotsN {
+    unsigned pub, poll[NP], slab, size;
+    bool pub_ok, poll_ok[NP];
     __device__ __forceinline__ unsigned pub_at(int step) const { return pub_ok ? pub + (unsigned)step * slab : size; }
-    __device__ __forceinline__ void poll_at(int step, unsigned (&o)[3]) const {
+    __device__ __forceinline__ void poll_at(int step, unsigned (&o)[NP]) const {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) o[i] = poll_ok[i] ? poll[i] + (unsigned)step * slab : size;
+        for (int i = 0; i < NP; ++i) o[i] = poll_ok[i] ? poll[i] + (unsigned)step * slab : size;
     }
 };
-__device__ __forceinline__ LnSlots ln_slots(const R2Args& a, int c, int p, int wave, int lane, int T) {
-    LnSlots s;
+typedef LnSlotsN<3> LnSlots;
+template <int NP>
+__device__ __forceinline__ LnSlotsN<NP> ln_slots_n(const R2Args& a, int c, int p, int wave, int lane, int T) {
+    LnSlotsN<NP> s;
     const unsigned nslot = 4u * (unsigned)a.Pn, kq = (unsigned)lane >> 4, u = (unsigned)lane & 15u;
     s.slab = (unsigned)a.ln_ncg * 4u * nslot * 32u;
     s.size = (unsigned)(T + 1) * s.slab;  // (slab T: the first step's extra exchange, forward kernels)
@@ -257,12 +262,15 @@ __device__ __forceinline__ LnSlots ln_slots(const R2Args& a, int c, int p, int w
     s.pub_ok = u == 0u;
     s.pub = base + ((unsigned)p * 4u + (unsigned)wave) * 32u;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NP; ++i) {
         const unsigned slot = u + 16u * (unsigned)i;
         s.poll_ok[i] = slot < nslot;
         s.poll[i] = base + slot * 32u;
     }
     return s;
+}
+__device__ __forceinline__ LnSlots ln_slots(const R2Args& a, int c, int p, int wave, int lane, int T) {
+    return ln_slots_n<3>(a, c, p, wave, lane, T);
 }
 
 // One-time placement handshake: every member publishes the XCD it runs on (write-through) and

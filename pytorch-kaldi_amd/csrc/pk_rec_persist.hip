@@ -629,14 +629,16 @@ int pk_rec2f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
                  const PkLnHost* ln);
 int pk_rec2f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
                  float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, float* dGx, const PkLnHost* ln);
-// fourth generation (pk_rec_persist4_f32.hip): LSTM / GRU / minimalGRU in exact fp32, no per-step LayerNorm
+// fourth generation (pk_rec_persist4_f32.hip): LSTM / GRU / minimalGRU in exact fp32, with or without per-step LayerNorm
 int pk_rec4f_covers(int cell, int H);
 int pk_rec4f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int H, const float* P, const float* pscale,
-                 const float* pshift, const float* U, const float* mask, float mask_scalar, float* Y, float* S, float* Yx);
+                 const float* pshift, const float* U, const float* mask, float mask_scalar, float* Y, float* S, float* Yx,
+                 const PkLnHost* ln);
 int pk_rec4f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
-                 float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, float* dGx);
+                 float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, float* dGx, const PkLnHost* ln);
 static bool use_gen4_f32(int prec, int cell, int H, const PkLnHost* ln) {
-    return prec == PK_PREC_F32 && ln == nullptr && pk_rec4f_covers(cell, H);
+    (void)ln;
+    return prec == PK_PREC_F32 && pk_rec4f_covers(cell, H);
 }
 static bool use_gen2_f32(int prec, int cell, int H) {
     static int off = -1;
@@ -653,7 +655,7 @@ int pk_rec_fwd_persistent(hipStream_t st, int prec, int cell, int act, int T, in
     if (use_gen4_f32(prec, cell, H, ln)) {
         PK_REQUIRE(work != nullptr, "pk_rec_fwd: work buffer missing");
         return pk_rec4f_fwd(st, cell, act, T, B, bidir, H, P, pscale, pshift, U, mask, mask_scalar, Y, S,
-                            work + pk_rec_work_base_floats(cell, B, bidir, H));
+                            work + pk_rec_work_base_floats(cell, B, bidir, H), ln);
     }
     if (use_gen2_f32(prec, cell, H)) {
         PK_REQUIRE(work != nullptr, "pk_rec_fwd: work buffer missing");
@@ -688,7 +690,7 @@ int pk_rec_bwd_persistent(hipStream_t st, int prec, int cell, int act, int T, in
     if (use_gen4_f32(prec, cell, H, ln)) {
         PK_REQUIRE(work != nullptr, "pk_rec_bwd: work buffer missing");
         return pk_rec4f_bwd(st, cell, act, T, B, bidir, H, U, mask, mask_scalar, Y, S, dY, dP2,
-                            work + pk_rec_work_base_floats(cell, B, bidir, H));
+                            work + pk_rec_work_base_floats(cell, B, bidir, H), ln);
     }
     if (use_gen2_f32(prec, cell, H)) {
         PK_REQUIRE(work != nullptr, "pk_rec_bwd: work buffer missing");

@@ -767,11 +767,14 @@ extern "C" int64_t pk_rec_ln_saved_floats(int T, int B, int bidir, int H) {
     return pers > step ? pers : step;
 }
 static int64_t ln_exchange_floats(int T, const Plan2& pl) { return (int64_t)(T + 1) * pl.launches * pl.C * 4 * (4 * pl.Pn) * 8; }
+int64_t pk_rec4f_ln_work_floats(int T, int B, int bidir, int H);  // pk_rec_persist4_f32.hip: 18 workgroups per cluster
 extern "C" int64_t pk_rec_ln_work_floats(int T, int B, int bidir, int H) {
     Plan2 pl;
     if (T <= 0 || B <= 0 || H <= 0 || H > KPAD || pk_rec2_make_plan(B * (1 + bidir), H, pl) != 0) return 0;
     const int64_t ncg = (int64_t)pl.launches * pl.C;
-    return ln_exchange_floats(T, pl) + 2 * ncg * KPAD + pk_bn_partial_floats(ncg, KPAD) + 256;
+    const int64_t gen2 = ln_exchange_floats(T, pl) + 2 * ncg * KPAD + pk_bn_partial_floats(ncg, KPAD) + 256;
+    const int64_t gen4 = pk_rec4f_ln_work_floats(T, B, bidir, H);  // (the caller does not say which kernels will run)
+    return gen2 > gen4 ? gen2 : gen4;
 }
 int pk_rec2_ln_setup(hipStream_t st, R2Args& a, const Plan2& pl, const PkLnHost* ln, bool backward) {
     a.ln_gamma = a.ln_beta = nullptr;

@@ -39,6 +39,7 @@ namespace {
 constexpr int KJ = KPAD / 16;    // 36 groups of 16 k per gate
 constexpr int UW = 32;           // hidden units per workgroup (two pairs of waves)
 constexpr int HS4 = 32;          // placement-handshake words per cluster (up to 18 members)
+constexpr int NPL = 5;           // per-step LayerNorm: 16-slot groups of the row-statistics exchange a lane polls (4 x 18 slots)
 
 __device__ __forceinline__ u32x4 no_sentinel4(f32x4 v) {
     u32x4 o;
@@ -195,7 +196,11 @@ __device__ __forceinline__ int share_row(int vr, int rh) { return (vr >> 1) * 4 
 // ============================================================================
 // forward
 // ============================================================================
-template <int CELL, int ACT>
+// LN: per-step LayerNorm of h_t (neural_networks.py:23-33 at :466-467, :638-639, :1300-1301): the row statistics take one more
+// exchange inside the step (ln_row_allreduce, pk_rec2_common.h: every wave publishes the partial sums of the rows of its
+// share - zeros for the rows of its partner wave - in its own slot, 4 x 18 slots per row quad); the normalised h_t is what is
+// stored, published and fed back, the pre-LN value and (mean, 1 / (std + eps)) are saved for the backward pass.
+template <int CELL, int ACT, bool LN = false>
 __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
@@ -203,9 +208,9 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
     constexpr int G1 = TWO ? G - 1 : G;  // gates fed by h_{t-1}
     constexpr int NOUT = NS + 1;         // Y, saved slots
     // LDS (floats): [parity][wave][tile][G1] partial sums (| [parity][wave][tile] candidate partial sums);
-    // per wave: G input patches | NOUT output patches | 1 publish patch for x_t
+    // per wave: G input patches | NOUT output patches | 1 publish patch for x_t (| LN: the pre-LN h_t)
     constexpr int XS1 = 4 * 2 * G1 * 256, XS2 = TWO ? 4 * 2 * 256 : 0;
-    constexpr int WAVE_PRIV = (G + NOUT + 1) * 256;
+    constexpr int WAVE_PRIV = (G + NOUT + 1 + (LN ? 1 : 0)) * 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -298,9 +303,23 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
     float* const pin = priv;                                  // [G] projections of this step (my share)
     float* const pout = priv + G * 256;                       // [NOUT] h_t, saved slots (my share)
     float* const patchX = priv + (G + NOUT) * 256;
+    float* const patchL = priv + (G + NOUT + 1) * 256;        // (LN only)
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.Yx, szYx);
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(TWO ? a.Xx : a.Yx, szYx);
     float* trash = a.trash + (tid & 63) * 4;
+    // ---- per-step LayerNorm state (rows kq*4 + r, r = 0..3: the totals of all four are known to every lane, my share is
+    // rows 2 rh, 2 rh + 1)
+    const LnSlotsN<NPL> ls = LN ? ln_slots_n<NPL>(a, c, p, wave, lane, T) : LnSlotsN<NPL>();
+    const __amdgpu_buffer_rsrc_t rsl = make_rsrc(LN ? (const void*)a.lnx : (const void*)a.Yx, LN ? ls.size : 0u);
+    const float gam = (LN && unit_ok) ? a.ln_gamma[unit] : 0.f, bet = (LN && unit_ok) ? a.ln_beta[unit] : 0.f;
+    const float invH = 1.0f / (float)H, inv_nm1 = 1.0f / (float)(H > 1 ? H - 1 : 1);
+    float piv[4] = {0.f, 0.f, 0.f, 0.f};  // pivot of the one-pass variance: the row's mean of the previous step
+    // the statistics of row kq*4 + u are written by lane u (< 4) of each DPP row of (member 0, wave 0)
+    pk_f32x2 st_val = {0.f, 0.f};
+    const int st_row = kq * 4 + (lane & 3);
+    const bool st_ok = LN && p == 0 && wave == 0 && (lane & 15) < 4 && st_row < nrows;
+    float* const st_base = st_ok ? a.lnstat + (long)(n_base + st_row) * 2 : trash;
+    const long st_step = st_ok ? (long)a.R * 2 : 0;
 
     f32x4 pv[G];
     auto load_proj = [&](int tt, auto E) {
@@ -314,6 +333,10 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
         st4<EE>(a.Y, vY0 + ts * vYs, vnv, trash, *reinterpret_cast<const f32x4*>(pout + voff));
 #pragma unroll
         for (int k = 0; k < NS; ++k) st4<EE>(a.S, vS0 + ts * vSs + k * H, vnv, trash, *reinterpret_cast<const f32x4*>(pout + (k + 1) * 256 + voff));
+        if (LN) {
+            st4<EE>(a.lnh, vY0 + ts * vYs, vnv, trash, *reinterpret_cast<const f32x4*>(patchL + voff));
+            *reinterpret_cast<pk_f32x2*>(st_base + (long)tt * st_step) = st_val;
+        }
     };
 #define PK4_LP0(E) load_proj(0, E)
     PK_EDGE_DISPATCH(PK4_LP0);
@@ -328,6 +351,53 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
     auto run = [&](auto FASTC, auto SEC) {
     constexpr bool FAST = decltype(FASTC)::value != 0;
     constexpr int SE = decltype(SEC)::value;
+    // h_t = gamma * (x - mean) / (std + eps) + beta over the row's H units, unbiased std (neural_networks.py:23-33); in: the
+    // cell's h_t of my two rows, out: the normalised values (also the state fed back)
+    auto layer_norm = [&](float (&hv)[2], int t) {
+        if (t == 0) {
+            // first step: no previous mean to pivot the one-pass variance on - one more exchange, this step only, gives the
+            // row's own mean first (the reference's two-pass form); it uses the extra slab behind the T step slabs
+            const float m0 = rvf[0] != 0.f ? hv[0] : 0.f, m1 = rvf[1] != 0.f ? hv[1] : 0.f;
+            float ma[4] = {rh ? 0.f : m0, rh ? 0.f : m1, rh ? m0 : 0.f, rh ? m1 : 0.f};
+            float mb[4] = {0.f, 0.f, 0.f, 0.f};
+            unsigned po0[NPL];
+            ls.poll_at(T, po0);
+            dead = ln_row_allreduce<FAST, NPL>(rsl, ls.pub_at(T), po0, ma, mb, a.err, a.spin_limit, lane, dead);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) piv[r] = ma[r] * invH;
+        }
+        float d2[2], q2[2];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const float d = hv[s_] - (rh ? piv[2 + s_] : piv[s_]);
+            d2[s_] = rvf[s_] != 0.f ? d : 0.f;
+            q2[s_] = rvf[s_] != 0.f ? d * d : 0.f;
+        }
+        float la[4] = {rh ? 0.f : d2[0], rh ? 0.f : d2[1], rh ? d2[0] : 0.f, rh ? d2[1] : 0.f};
+        float lb[4] = {rh ? 0.f : q2[0], rh ? 0.f : q2[1], rh ? q2[0] : 0.f, rh ? q2[1] : 0.f};
+        unsigned po[NPL];
+        ls.poll_at(t, po);
+        dead = ln_row_allreduce<FAST, NPL>(rsl, ls.pub_at(t), po, la, lb, a.err, a.spin_limit, lane, dead);
+        put_cd2(patchL, kq, rh, lane, hv);  // the pre-LN value, saved for backward
+        float mu4[4], ri4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float md = la[r] * invH;
+            const float mu = piv[r] + md;
+            const float var = fmaxf((lb[r] - la[r] * md) * inv_nm1, 0.f);
+            mu4[r] = mu;
+            ri4[r] = 1.0f / (sqrtf(var) + a.ln_eps);
+            piv[r] = mu;
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const float mu = rh ? mu4[2 + s_] : mu4[s_], ri = rh ? ri4[2 + s_] : ri4[s_];
+            hv[s_] = rvf[s_] != 0.f ? gam * ((hv[s_] - mu) * ri) + bet : 0.f;
+        }
+        const int u3 = lane & 3;
+        st_val[0] = u3 == 0 ? mu4[0] : u3 == 1 ? mu4[1] : u3 == 2 ? mu4[2] : mu4[3];
+        st_val[1] = u3 == 0 ? ri4[0] : u3 == 1 ? ri4[1] : u3 == 2 ? ri4[2] : ri4[3];
+    };
     for (int t = 0; t < T; ++t) {
         float* const x1 = xs1 + (t & 1) * XS1;
         float* const x2 = xs2 + (t & 1) * XS2;
@@ -412,6 +482,11 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
 #pragma unroll
                 for (int k = 0; k < NS; ++k) sv[k][s_] = sl[k];
             }
+            if constexpr (LN) {
+                layer_norm(hv, t);
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) hprev[s_] = hv[s_];
+            }
         } else {
             // ---- phase 1: the gates that depend on h_{t-1} only; x_t = r*h (GRU) / z*h (minimalGRU) goes to the cluster
             float xv[2], zt[2];
@@ -482,6 +557,11 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
                 hv[s_] = h;
                 sv[G - 1][s_] = at;  // GRU: slot 2, minimalGRU: slot 1
             }
+            if constexpr (LN) {
+                layer_norm(hv, t);
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) hprev[s_] = hv[s_];
+            }
         }
         PK4_TRACE(t, 4);
         // ---- my share of the outputs into my patches, then the publish of h_t: one 16-byte store per lane (lanes 0..31)
@@ -505,7 +585,9 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
 // ============================================================================
 // backward: dL/dh_{t-1} = direct + [dgates_t] . [U_0; U_1; ...]
 // ============================================================================
-template <int CELL, int ACT>
+// LN: the gradient arriving at h_t goes through the LayerNorm backward first (two more row sums -> ln_row_allreduce);
+// d gamma / d beta are accumulated per lane over the steps and leave as per-cluster partial sums (a.lnpart).
+template <int CELL, int ACT, bool LN = false>
 __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
     const int act = ACT >= 0 ? ACT : a.act;
     constexpr int G = pk_cell_gates(CELL), NS = pk_cell_saved(CELL);
@@ -514,8 +596,8 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
     constexpr int Gh = TWO ? G - 1 : G;        // gates whose gradients go back through h_{t-1}
     constexpr int NJB = Gh * NQ;               // groups of the carry product one wave holds (its quarter of Gh x 36)
     constexpr int NBATCH = Gh;                 // polled NQ groups at a time, two batches in flight
-    // inputs of a step: saved slots, then (LSTM: c_{t-1}; the others: h_{t-1}), then dY
-    constexpr int NIN = NS + 2;
+    // inputs of a step: saved slots, then (LSTM: c_{t-1}; the others: h_{t-1}), then dY (, LN: the pre-LN h_t)
+    constexpr int NIN = NS + 2 + (LN ? 1 : 0);
     constexpr int XSB = 4 * 2 * 256, XSA = TWO ? 4 * 2 * 256 : 0;  // [wave][tile] carry partial sums (| q partial sums)
     constexpr int WAVE_PRIV = (NIN + G) * 256;                      // inputs | fp32 gate gradients (also the publish patches)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -628,7 +710,28 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
         else iv[NS] = ld4<EE>(a.Y, vY0 + tp * vYs, nvp);                // h_{t-1}
         if (t == 0) iv[NS] = f32x4{0.f, 0.f, 0.f, 0.f};                 // c_{-1} = h_{-1} = 0
         iv[NS + 1] = ld4<EE>(a.dY, vY0 + ts * vYs, vnv);
+        if (LN) iv[NS + 2] = ld4<EE>(a.lnh, vY0 + ts * vYs, vnv);
     };
+    // ---- per-step LayerNorm state: (mean, 1 / (std + eps)) of the four rows of my quad, loaded one step ahead like the
+    // saved gates; my share is rows 2 rh, 2 rh + 1
+    const LnSlotsN<NPL> ls = LN ? ln_slots_n<NPL>(a, c, p, wave, lane, T) : LnSlotsN<NPL>();
+    const __amdgpu_buffer_rsrc_t rsl = make_rsrc(LN ? (const void*)a.lnx : (const void*)a.dGx, LN ? ls.size : 0u);
+    const float gam = (LN && unit_ok) ? a.ln_gamma[unit] : 0.f;
+    const float invH = 1.0f / (float)H, inv_nm1 = 1.0f / (float)(H > 1 ? H - 1 : 1);
+    float accg = 0.f, accb = 0.f;
+    pk_f32x2 stn[2];
+    long st_off[2];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+        const int row = kq * 4 + 2 * rh + s_;
+        st_off[s_] = (LN && row < nrows) ? (long)(n_base + row) * 2 : 0;
+        stn[s_] = pk_f32x2{0.f, 1.f};
+    }
+    auto load_stats = [&](int t) {
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) stn[s_] = *reinterpret_cast<const pk_f32x2*>(a.lnstat + (long)t * a.R * 2 + st_off[s_]);
+    };
+    if (LN) load_stats(T - 1);
     auto flush_outputs_e = [&](int tt, auto E) {
         const unsigned ts = (unsigned)(vdir ? (T - 1 - tt) : tt);
 #pragma unroll
@@ -651,6 +754,33 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
     auto run = [&](auto FASTC, auto SEC) {
     constexpr bool FAST = decltype(FASTC)::value != 0;
     constexpr int SE = decltype(SEC)::value;
+    // dL/d(pre-LN h) = rinv * (g - mean(g)) - d * rinv^2 * sum(g d) / ((H - 1) std),  g = dh * gamma, d = x - mean
+    // (in: dL/dh_t of my two rows, the pre-LN values and this step's statistics; out: dL/d(pre-LN h_t))
+    auto layer_norm_bwd = [&](float (&dh2)[2], const float (&x2)[2], const float (&mu2)[2], const float (&ri2)[2], int it_) {
+        float dd[2], gg[2], a2[2], b2[2];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const bool ok = rvf[s_] != 0.f;
+            dd[s_] = x2[s_] - mu2[s_];
+            gg[s_] = dh2[s_] * gam;
+            a2[s_] = ok ? gg[s_] : 0.f;
+            b2[s_] = ok ? gg[s_] * dd[s_] : 0.f;
+            accg += ok ? dh2[s_] * (dd[s_] * ri2[s_]) : 0.f;
+            accb += ok ? dh2[s_] : 0.f;
+        }
+        float la[4] = {rh ? 0.f : a2[0], rh ? 0.f : a2[1], rh ? a2[0] : 0.f, rh ? a2[1] : 0.f};
+        float lb[4] = {rh ? 0.f : b2[0], rh ? 0.f : b2[1], rh ? b2[0] : 0.f, rh ? b2[1] : 0.f};
+        unsigned po[NPL];
+        ls.poll_at(it_, po);
+        dead = ln_row_allreduce<FAST, NPL>(rsl, ls.pub_at(it_), po, la, lb, a.err, a.spin_limit, lane, dead);
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const float sa = rh ? la[2 + s_] : la[s_], sb = rh ? lb[2 + s_] : lb[s_];
+            const float sd = 1.0f / ri2[s_] - a.ln_eps;
+            const float k2 = ri2[s_] * ri2[s_] * sb * inv_nm1 / sd;
+            dh2[s_] = ri2[s_] * (gg[s_] - sa * invH) - k2 * dd[s_];
+        }
+    };
     int it = 0;
     for (int t = T - 1; t >= 0; --t, ++it) {
         float* const xB = xsB + (it & 1) * XSB;
@@ -660,6 +790,7 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
 #pragma unroll
             for (int k = 0; k < NIN; ++k) *reinterpret_cast<f32x4*>(pin + k * 256 + voff) = iv[k];
         }
+        const float mu2[2] = {stn[0][0], stn[1][0]}, ri2[2] = {stn[0][1], stn[1][1]};  // (the loads are a whole step old)
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // one chain per tile: 64 clocks apart
         if (t < T - 1) {
             for (int d = 0; d < a.poll_delay; ++d) __builtin_amdgcn_s_sleep(1);
@@ -703,12 +834,14 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
                     if (t > 0) {
 #define PK4_LS1(E) load_step_e(t - 1, E)
                         PK_EDGE_DISPATCH_S(PK4_LS1);
+                        if (LN) load_stats(t - 1);
                     }
                 }
             }
         } else if (t > 0) {
 #define PK4_LS2(E) load_step_e(t - 1, E)
             PK_EDGE_DISPATCH_S(PK4_LS2);
+            if (LN) load_stats(t - 1);
         }
         PK4_TRACE(it, 1);
 #pragma unroll
@@ -732,6 +865,13 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
 #pragma unroll
         for (int k = 0; k < NIN; ++k) get_cd2(pin + k * 256, kq, rh, lane, sin[k]);
         float dgv[G][2];
+        float dh2[2];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) dh2[s_] = sin[NS + 1][s_] + dh_dir[s_] + car[s_];
+        if constexpr (LN) {
+            const float x2[2] = {sin[NS + 2][0], sin[NS + 2][1]};
+            layer_norm_bwd(dh2, x2, mu2, ri2, it);
+        }
         if constexpr (!TWO) {
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_) {
@@ -739,7 +879,7 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
 #pragma unroll
                 for (int k = 0; k < NS; ++k) sl[k] = sin[k][s_];
                 const float prev = sin[NS][s_];  // LSTM: c_{t-1}
-                const float dh = sin[NS + 1][s_] + dh_dir[s_] + car[s_];
+                const float dh = dh2[s_];
                 float dg[G], dhd, dcp;
                 pk_cell_bwd<CELL>(act, sl, LSTM ? 0.f : prev, LSTM ? prev : 0.f, msk[s_], dh, dc_car[s_], dg, dhd, dcp);
                 dh_dir[s_] = rvf[s_] != 0.f ? dhd : 0.f;
@@ -755,7 +895,7 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
                 float sl[NS];
 #pragma unroll
                 for (int k = 0; k < NS; ++k) sl[k] = sin[k][s_];
-                const float dh = sin[NS + 1][s_] + dh_dir[s_] + car[s_];
+                const float dh = dh2[s_];
                 const float da = pk_cell_bwd_pa<CELL>(act, sl, sin[NS][s_], msk[s_], dh, dzp[s_], dhd2[s_]);
                 da2[s_] = rvf[s_] != 0.f ? da : 0.f;
             }
@@ -830,6 +970,24 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
     PK_RUN_SPECIALISED(run, fast);
 #define PK4_FOBL(E) flush_outputs_e(0, E)
     PK_EDGE_DISPATCH(PK4_FOBL);
+    if constexpr (LN) {
+        // my unit's share of d gamma / d beta over this cluster's rows and all steps: the four row quads of a wave fold with
+        // shuffles, the two waves of a tile through LDS (the partial-sum area is free now); one owner per (cluster, unit)
+        accg += __shfl_xor(accg, 16, 64);
+        accg += __shfl_xor(accg, 32, 64);
+        accb += __shfl_xor(accb, 16, 64);
+        accb += __shfl_xor(accb, 32, 64);
+        __syncthreads();
+        if (rh == 1 && lane < 16) {
+            lds[(mt * 2 + 0) * 16 + lane] = accg;
+            lds[(mt * 2 + 1) * 16 + lane] = accb;
+        }
+        __syncthreads();
+        if (rh == 0 && lane < 16 && unit < KPAD) {
+            a.lnpart[(long)(a.ln_cg0 + c) * KPAD + unit] = accg + lds[(mt * 2 + 0) * 16 + lane];
+            a.lnpart[(long)(a.ln_ncg + a.ln_cg0 + c) * KPAD + unit] = accb + lds[(mt * 2 + 1) * 16 + lane];
+        }
+    }
 }
 
 typedef void (*Rec4Kernel)(R2Args);
@@ -843,7 +1001,19 @@ Rec4Kernel pick4_bwd(int act) {
     return act == PK_ACT_TANH ? rec4_bwd_kernel<CELL, PK_ACT_TANH> : act == PK_ACT_RELU ? rec4_bwd_kernel<CELL, PK_ACT_RELU>
                                                                                        : rec4_bwd_kernel<CELL, -1>;
 }
-Rec4Kernel pick4(int cell, int act, bool backward) {
+// (the LayerNorm variants exist with the run-time activation only: no shipped recipe normalises h_t)
+template <int CELL>
+Rec4Kernel pick4_ln(bool backward) {
+    return backward ? (Rec4Kernel)rec4_bwd_kernel<CELL, -1, true> : (Rec4Kernel)rec4_fwd_kernel<CELL, -1, true>;
+}
+Rec4Kernel pick4(int cell, int act, bool backward, bool ln) {
+    if (ln) {
+        switch (cell) {
+            case PK_CELL_LSTM: return pick4_ln<PK_CELL_LSTM>(backward);
+            case PK_CELL_GRU: return pick4_ln<PK_CELL_GRU>(backward);
+            default: return pick4_ln<PK_CELL_MINGRU>(backward);
+        }
+    }
     switch (cell) {
         case PK_CELL_LSTM: return backward ? pick4_bwd<PK_CELL_LSTM>(act) : pick4_fwd<PK_CELL_LSTM>(act);
         case PK_CELL_GRU: return backward ? pick4_bwd<PK_CELL_GRU>(act) : pick4_fwd<PK_CELL_GRU>(act);
@@ -851,14 +1021,14 @@ Rec4Kernel pick4(int cell, int act, bool backward) {
     }
 }
 
-size_t lds4(int cell, bool backward) {
+size_t lds4(int cell, bool backward, bool ln) {
     const int G = pk_cell_gates(cell), NS = pk_cell_saved(cell);
     const bool two = pk_cell_two_phase(cell);
     if (!backward) {
         const int G1 = two ? G - 1 : G;
-        return ((size_t)2 * (4 * 2 * G1 * 256 + (two ? 4 * 2 * 256 : 0)) + 4 * (size_t)(G + NS + 2) * 256) * 4;
+        return ((size_t)2 * (4 * 2 * G1 * 256 + (two ? 4 * 2 * 256 : 0)) + 4 * (size_t)(G + NS + 2 + (ln ? 1 : 0)) * 256) * 4;
     }
-    return ((size_t)2 * (4 * 2 * 256 + (two ? 4 * 2 * 256 : 0)) + 4 * (size_t)(NS + 2 + G) * 256) * 4;
+    return ((size_t)2 * (4 * 2 * 256 + (two ? 4 * 2 * 256 : 0)) + 4 * (size_t)(NS + 2 + (ln ? 1 : 0) + G) * 256) * 4;
 }
 
 int grant_lds4(Rec4Kernel k, size_t lds) {
@@ -909,8 +1079,18 @@ int64_t pk_rec4f_exchange_floats(int cell, int T, int B, int bidir, int H) {
     return (f > b ? f : b) + 64;
 }
 
+// The fourth-generation plan's share of pk_rec_ln_work_floats (pk_rec_persist2.hip): row-statistics exchange, per-cluster
+// d gamma / d beta partial sums and the column-sum scratch, for twice as many workgroups per cluster as the second generation
+int64_t pk_rec4f_ln_work_floats(int T, int B, int bidir, int H) {
+    Plan2 pl;
+    if (T <= 0 || B <= 0 || H <= 0 || H > KPAD || make_plan4(B * (1 + bidir), H, pl) != 0) return 0;
+    const int64_t ncg = (int64_t)pl.launches * pl.C;
+    return (int64_t)(T + 1) * ncg * 4 * (4 * pl.Pn) * 8 + 2 * ncg * KPAD + pk_bn_partial_floats(ncg, KPAD) + 256;
+}
+
 int pk_rec4f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int H, const float* P, const float* pscale,
-                 const float* pshift, const float* U, const float* mask, float mask_scalar, float* Y, float* S, float* Yx) {
+                 const float* pshift, const float* U, const float* mask, float mask_scalar, float* Y, float* S, float* Yx,
+                 const PkLnHost* ln) {
     int rc = pk_rec2_check("pk_rec_fwd (fp32, persistent, generation 4)", pk_rec4f_covers(cell, H), cell, T, B, bidir, H);
     if (rc) return rc;
     const int ndir = 1 + bidir, R = B * ndir, Hp = (H + 7) & ~7;
@@ -929,16 +1109,18 @@ int pk_rec4f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     a.Y = Y; a.S = S; a.Yb = nullptr; a.Xb = nullptr; a.Ypitch = (int)y_pitch;
     a.dY = nullptr; a.dP2 = nullptr; a.dGb = nullptr; a.Gpitch = 0;
     a.Yx = Yx; a.dGx = nullptr; a.Xx = two ? Yx + slab / 4 : nullptr;
-    a.ln_gamma = nullptr; a.ln_beta = nullptr;
     rc = pk_rec2_host_setup(a, false, cell);
     if (rc) return rc;
     PK_CHECK_HIP(hipMemsetAsync(Yx, 0xFF, slab * (two ? 2 : 1), st));  // the mailboxes: every dword "not written yet"
-    const size_t lds = lds4(cell, false);
-    const Rec4Kernel k = pick4(cell, act, false);
+    rc = pk_rec2_ln_setup(st, a, pl, ln, false);
+    if (rc) return rc;
+    const size_t lds = lds4(cell, false, ln != nullptr);
+    const Rec4Kernel k = pick4(cell, act, false, ln != nullptr);
     rc = grant_lds4(k, lds);
     if (rc) return rc;
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
+        a.ln_cg0 = l * pl.C;
         rc = pk_rec2_reset_handshake(st, a);
         if (rc) return rc;
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_fwd (fp32, persistent, generation 4)");
@@ -950,7 +1132,7 @@ int pk_rec4f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
 }
 
 int pk_rec4f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int H, const float* U, const float* mask,
-                 float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, float* dGx) {
+                 float mask_scalar, const float* Y, const float* S, const float* dY, float* dP2, float* dGx, const PkLnHost* ln) {
     int rc = pk_rec2_check("pk_rec_bwd (fp32, persistent, generation 4)", pk_rec4f_covers(cell, H), cell, T, B, bidir, H);
     if (rc) return rc;
     const int ndir = 1 + bidir, R = B * ndir, Hp = (H + 7) & ~7, G = pk_cell_gates(cell);
@@ -968,16 +1150,18 @@ int pk_rec4f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     a.Y = const_cast<float*>(Y); a.S = const_cast<float*>(S); a.Yb = nullptr; a.Xb = nullptr; a.Ypitch = 0;
     a.dY = dY; a.dP2 = dP2; a.dGb = nullptr; a.Gpitch = (int)g_pitch;
     a.Yx = nullptr; a.dGx = dGx; a.Xx = nullptr;
-    a.ln_gamma = nullptr; a.ln_beta = nullptr;
     rc = pk_rec2_host_setup(a, true, cell);
     if (rc) return rc;
     PK_CHECK_HIP(hipMemsetAsync(dGx, 0xFF, bytes, st));
-    const size_t lds = lds4(cell, true);
-    const Rec4Kernel k = pick4(cell, act, true);
+    rc = pk_rec2_ln_setup(st, a, pl, ln, true);
+    if (rc) return rc;
+    const size_t lds = lds4(cell, true, ln != nullptr);
+    const Rec4Kernel k = pick4(cell, act, true, ln != nullptr);
     rc = grant_lds4(k, lds);
     if (rc) return rc;
     for (int l = 0; l < pl.launches; ++l) {
         a.row0 = l * pl.C * pl.rpc;
+        a.ln_cg0 = l * pl.C;
         rc = pk_rec2_reset_handshake(st, a);
         if (rc) return rc;
         rc = pk_rec2_check_residency((const void*)k, 256, lds, pl.C * pl.Pn, "pk_rec_bwd (fp32, persistent, generation 4)");
@@ -985,5 +1169,5 @@ int pk_rec4f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
         hipLaunchKernelGGL(k, dim3(pl.C * pl.Pn), dim3(256), lds, st, a);
         PK_LAUNCH_CHECK();
     }
-    return 0;
+    return pk_rec2_ln_finish(st, a, ln);
 }

@@ -1555,23 +1555,25 @@ def log_softmax(x):
 # neural_networks.py:412-481 (LSTM), 589-653 (GRU), 1092-1153 (liGRU), ...
 # ----------------------------------------------------------------------------
 def ln_persistent_ok(cell, H):
-    """Per-step LayerNorm of h_t inside the persistent time loop: the second-generation kernels - liGRU / RNN / LSTM in
-    perf mode, liGRU / RNN in fp32 (LSTM's first-generation fp32 kernels do not have it).  PK_EXPERIMENT rec_ln_persist=0 sends such
-    layers back to the step-wise algorithm."""
+    """Per-step LayerNorm of h_t inside the persistent time loop: every cell in perf mode (second-generation kernels); in
+    fp32 liGRU / RNN on the second-generation kernels and LSTM / GRU / minimalGRU on the fourth (LSTM's first-generation fp32
+    kernels do not have it).  PK_EXPERIMENT rec_ln_persist=0 sends such layers back to the step-wise algorithm."""
     if _lib.experiment("rec_ln_persist", "1") == "0" or H < 2:
         return False
     if bf16_mode():
         return cell in ("liGRU", "RNN", "LSTM", "GRU", "minimalGRU")
+    if cell in ("LSTM", "GRU", "minimalGRU"):
+        return _lib.experiment("rec_f32_gen4", "1")[:1] != "0"
     return cell in ("liGRU", "RNN") and _lib.experiment("rec_f32_gen", "")[:1] != "1"
 
 
 def choose_rec_algo(cell, H, use_ln):
     want = settings.rec_algo
-    # exact fp32, no per-step LayerNorm: LSTM / GRU / minimalGRU run on the fourth-generation persistent kernels
+    # exact fp32: LSTM / GRU / minimalGRU run on the fourth-generation persistent kernels, with or without per-step LayerNorm
     # (pk_rec_persist4_f32.hip; PK_EXPERIMENT rec_f32_gen4=0 keeps the first-generation LSTM kernels / the step-wise GRU -
     # the library reads the same switch, pk_rec4f_covers)
-    gen4 = (not bf16_mode() and not use_ln and cell in ("LSTM", "GRU", "minimalGRU")
-            and _lib.experiment("rec_f32_gen4", "1")[:1] != "0")
+    gen4 = (not bf16_mode() and cell in ("LSTM", "GRU", "minimalGRU") and _lib.experiment("rec_f32_gen4", "1")[:1] != "0"
+            and (not use_ln or ln_persistent_ok(cell, H)))
     ok = cell in ("liGRU", "RNN", "LSTM") and H <= 576 and (not use_ln or ln_persistent_ok(cell, H))
     if cell in ("GRU", "minimalGRU"):  # bf16 two-phase kernels on this (general) path: the layers that normalise h_t
         ok = H <= 576 and ((use_ln and ln_persistent_ok(cell, H)) or gen4)

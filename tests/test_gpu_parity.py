@@ -37,10 +37,8 @@ def _check_case(case, algo):
 
     g = Golden(case)
     m = g.meta
-    if any(s.strip().lower() == "true" for k, v in m["options"].items() if k.endswith("_use_laynorm")
-           for s in v.split(",")) and m["arch_class"] in ("LSTM", "GRU", "minimalGRU") and algo == "persistent":
-        pytest.skip("per-step LayerNorm inside the persistent loop: liGRU / RNN in fp32 (LSTM: perf mode only)")
-    # (odd LSTM widths no longer skip: the fourth-generation kernels exchange 16-byte chunks at a padded pitch)
+    # (nothing skips any more: odd LSTM widths and per-step LayerNorm of LSTM / GRU / minimalGRU in exact fp32 run on the
+    # fourth-generation kernels, which exchange 16-byte chunks at a padded pitch)
     F_amd.set_rec_algo(algo)
     net = build_engine(m, g.group("sd/"))
     has_bwd = "dx" in g.arrays
@@ -664,9 +662,6 @@ def test_per_step_layernorm_in_the_persistent_loop(kind, pre, act, bidir, B, T, 
 
     from engine_util import F_amd, nn_amd
 
-    if kind in ("LSTM", "GRU", "minimalGRU") and prec == "fp32":
-        pytest.skip("fp32: LSTM's first-generation persistent kernels do not normalise h_t, GRU / minimalGRU have no fp32 "
-                    "persistent kernels: step-wise")
     D, H = 40, 550
     opts = _rec_opts(pre, [H, H], act, bn=False, bidir=bidir)
     opts[pre + "_use_laynorm"] = "True,True"
@@ -733,8 +728,6 @@ def test_per_step_layernorm_first_step_with_a_large_common_offset(kind, pre, pre
     fp64 two-pass evaluation to 2e-5 (fp32 kernels; the pivot-0 form is 50 x off)."""
     from engine_util import F_amd, nn_amd
 
-    if kind == "GRU" and prec == "fp32":
-        pytest.skip("GRU has no fp32 persistent kernel (step-wise: two-pass by construction)")
     D, H, T, B = 40, 550, 3, 16
     opts = _rec_opts(pre, [H], "relu" if kind != "GRU" else "tanh", bn=False, bidir=True, drop=0.0)
     opts[pre + "_use_laynorm"] = "True"

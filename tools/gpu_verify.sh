@@ -13,7 +13,7 @@ echo "pytest rc=$? $(tail -1 "$out/pytest_gpu.log")"
 grep -E "^(FAILED|ERROR)" "$out/pytest_gpu.log" | head -10
 PK_BENCH_VERBOSE=1 timeout 300 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extras > "$out/headline.json" 2> "$out/headline.err"
 echo "headline rc=$? $(python tools/jget.py "$out/headline.json" ms_per_step step_ms 2>/dev/null | cut -c1-300)"
-for r in timit_lstm timit_gru timit_mlp timit_sincnet; do
+for r in timit_lstm libri_gru timit_mlp timit_sincnet; do
     timeout 300 python bench.py --recipe $r --steps 30 --warmup 5 --no-cpu-baseline --no-extras > "$out/$r.json" 2> "$out/$r.err"
     echo "$r rc=$? $(python tools/jget.py "$out/$r.json" ms_per_step 2>/dev/null | cut -c1-120)"
 done

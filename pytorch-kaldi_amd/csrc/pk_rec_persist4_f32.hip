@@ -340,6 +340,19 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
     };
 #define PK4_LP0(E) load_proj(0, E)
     PK_EDGE_DISPATCH(PK4_LP0);
+    // self-filling exchange (pk_rec2_common.h): the "not written yet" pattern goes into my own chunk of step tt - the first
+    // PK_R2_FILL_AHEAD slabs here, visible everywhere before the handshake lets anyone poll, the others that many steps ahead
+    // of my publishes (same lane, same address, program order: the pattern can never overtake the data)
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    auto fill_slab = [&](int tt, auto FC) {
+        const unsigned off = pbase + (pk_ok ? (unsigned)(vdir ? (T - 1 - tt) : tt) * TS : 0u);
+        pub_store<decltype(FC)::value != 0>(rs, off, sentinel);
+        if (TWO) pub_store<decltype(FC)::value != 0>(rsX, off, sentinel);
+    };
+    if (a.self_fill) {
+        for (int tt = 0; tt < PK_R2_FILL_AHEAD && tt < T; ++tt) fill_slab(tt, BoolC<0>());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     bool dead = false;
@@ -428,6 +441,7 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
 #define PK4_LP1(E) load_proj(t + 1, E)
             PK_EDGE_DISPATCH_S(PK4_LP1);
         }
+        if (a.self_fill && t + PK_R2_FILL_AHEAD < T) fill_slab(t + PK_R2_FILL_AHEAD, FASTC);
         if (t > 0 && !no_mfma) {
             // 2 x G1 independent accumulation chains: a chain comes round every 2 G1 x 32 clocks (dependent latency: 40)
 #pragma unroll
@@ -745,6 +759,17 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
     };
 #define PK4_LS(E) load_step_e(T - 1, E)
     PK_EDGE_DISPATCH(PK4_LS);
+    // self-filling exchange, as in the forward kernel: every gate's chunk of step tt
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    auto fill_slab = [&](int tt, auto FC) {
+        const unsigned off = pbase + (pk_ok ? (unsigned)(vdir ? (T - 1 - tt) : tt) * TS : 0u);
+#pragma unroll
+        for (int g = 0; g < G; ++g) pub_store<decltype(FC)::value != 0>(rs, off + (pk_ok ? (unsigned)(g * Hp) * 4u : 0u), sentinel);
+    };
+    if (a.self_fill) {
+        for (int k = 0; k < PK_R2_FILL_AHEAD && k < T; ++k) fill_slab(T - 1 - k, BoolC<0>());
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     bool dead = false;
@@ -836,12 +861,14 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
                         PK_EDGE_DISPATCH_S(PK4_LS1);
                         if (LN) load_stats(t - 1);
                     }
+                    if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) fill_slab(t - PK_R2_FILL_AHEAD, FASTC);
                 }
             }
         } else if (t > 0) {
 #define PK4_LS2(E) load_step_e(t - 1, E)
             PK_EDGE_DISPATCH_S(PK4_LS2);
             if (LN) load_stats(t - 1);
+            if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) fill_slab(t - PK_R2_FILL_AHEAD, FASTC);
         }
         PK4_TRACE(it, 1);
 #pragma unroll
@@ -1042,6 +1069,15 @@ int grant_lds4(Rec4Kernel k, size_t lds) {
     return 0;
 }
 
+int self_fill4() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = pk_experiment("rec4_self_fill");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
 // 32 units per workgroup; as many 16-row clusters per launch as fit the device, a multiple of 8 when there are 8 or more
 // (members of one cluster congruent mod 8: one XCD under round-robin dispatch - speed only)
 int make_plan4(int R, int H, Plan2& pl) {
@@ -1111,7 +1147,10 @@ int pk_rec4f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     a.Yx = Yx; a.dGx = nullptr; a.Xx = two ? Yx + slab / 4 : nullptr;
     rc = pk_rec2_host_setup(a, false, cell);
     if (rc) return rc;
-    PK_CHECK_HIP(hipMemsetAsync(Yx, 0xFF, slab * (two ? 2 : 1), st));  // the mailboxes: every dword "not written yet"
+    a.self_fill = self_fill4();
+    // the mailboxes: every dword "not written yet" - written by the kernel itself a few steps ahead of its publishes, or
+    // (PK_EXPERIMENT rec4_self_fill=0) by one fill of 282 / 565 MB in front of the launches
+    if (!a.self_fill) PK_CHECK_HIP(hipMemsetAsync(Yx, 0xFF, slab * (two ? 2 : 1), st));
     rc = pk_rec2_ln_setup(st, a, pl, ln, false);
     if (rc) return rc;
     const size_t lds = lds4(cell, false, ln != nullptr);
@@ -1152,7 +1191,8 @@ int pk_rec4f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     a.Yx = nullptr; a.dGx = dGx; a.Xx = nullptr;
     rc = pk_rec2_host_setup(a, true, cell);
     if (rc) return rc;
-    PK_CHECK_HIP(hipMemsetAsync(dGx, 0xFF, bytes, st));
+    a.self_fill = self_fill4();
+    if (!a.self_fill) PK_CHECK_HIP(hipMemsetAsync(dGx, 0xFF, bytes, st));
     rc = pk_rec2_ln_setup(st, a, pl, ln, true);
     if (rc) return rc;
     const size_t lds = lds4(cell, true, ln != nullptr);

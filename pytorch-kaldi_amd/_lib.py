@@ -190,6 +190,7 @@ def load():
             raise PkError(
                 "libpk_amd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
                 "this engine has no CPU fallback." % LIB_PATH)
+        warn_unknown_switches()
         _map_torch_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
         runtimes = hip_runtimes_mapped()
@@ -256,15 +257,63 @@ class _TimedLib:
         return timed
 
 
+_EXP_CACHE = (None, {})
+_KNOWN_SWITCHES = None
+_warned_unknown = False
+
+
+def _known_switches():
+    """The PK_* names INTEGRATION.md documents (tests/test_env_switches_documented.py holds that table and the code to each
+    other); read once, from the file that ships next to the package."""
+    global _KNOWN_SWITCHES
+    if _KNOWN_SWITCHES is None:
+        import re
+
+        try:
+            doc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+            _KNOWN_SWITCHES = frozenset(re.findall(r"`(PK_[A-Z0-9_]+)`", doc))
+        except OSError:
+            _KNOWN_SWITCHES = frozenset()
+    return _KNOWN_SWITCHES
+
+
+def warn_unknown_switches():
+    """Once per process: PK_* variables in the environment that this version does not read.  The A/B levers of earlier
+    rounds (PK_MLP_FUSED, PK_DIRECT_GRADS, PK_GEMM_SKINNY, ...) moved behind PK_EXPERIMENT=key=value; their old names would
+    otherwise be ignored silently and an A/B script would compare two identical configurations."""
+    global _warned_unknown
+    if _warned_unknown:
+        return
+    _warned_unknown = True
+    known = _known_switches()
+    if not known:
+        return
+    # (PK_BENCH_* / PK_CPU_BASELINE / PK_REFERENCE / ... belong to bench.py, the tests and the golden generator)
+    harness = ("PK_BENCH_", "PK_CPU_BASELINE", "PK_REFERENCE", "PK_FULL_SHAPE_JSON", "PK_GOLDEN_ONLY", "PK_DP_BACKEND")
+    stray = sorted(k for k in os.environ if k.startswith("PK_") and k not in known and not k.startswith(harness))
+    if stray:
+        import warnings
+
+        warnings.warn("pytorch-kaldi_amd: environment variable(s) %s are not switches of this version and are ignored (A/B "
+                      "levers live behind PK_EXPERIMENT=key=value; INTEGRATION.md lists switches and keys)" % ", ".join(stray),
+                      RuntimeWarning, stacklevel=3)
+
+
 def experiment(key, default=None):
     """Value of one A/B lever of past experiments.  They live behind ONE environment variable,
-    PK_EXPERIMENT="key=value,key=value" (the library reads its own keys from the same string: pk_lib.hip;
-    INTEGRATION.md lists them); a recipe author only ever needs the switches of INTEGRATION.md's first table."""
-    for item in os.environ.get("PK_EXPERIMENT", "").split(","):
-        k, _, v = item.partition("=")
-        if k.strip() == key:
-            return v.strip()
-    return default
+    PK_EXPERIMENT="key=value,key=value" (the library reads its own keys from the same string: pk_lib.hip, same trimming of
+    blanks; INTEGRATION.md lists them); a recipe author only ever needs the switches of INTEGRATION.md's first table.
+    The string is parsed once per distinct value (this is called per layer and step)."""
+    global _EXP_CACHE
+    raw = os.environ.get("PK_EXPERIMENT", "")
+    if _EXP_CACHE[0] != raw:
+        d = {}
+        for item in raw.split(","):
+            k, sep, v = item.partition("=")
+            if sep and k.strip() and k.strip() not in d:  # (the first occurrence wins, as in pk_lib.hip)
+                d[k.strip()] = v.strip()
+        _EXP_CACHE = (raw, d)
+    return _EXP_CACHE[1].get(key, default)
 
 
 class Profiler:

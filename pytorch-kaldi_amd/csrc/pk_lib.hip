@@ -16,15 +16,24 @@ void pk_set_error(const char* fmt, ...) {
 
 const char* pk_experiment(const char* key) {
     // (returns a pointer INTO the environment string: the value ends at the next ',' or at the end - atoi / sscanf / a
-    // first-character test, which is all the callers do, stop there by themselves)
+    // first-character test, which is all the callers do, stop there by themselves; blanks around an item, its key and its
+    // '=' are skipped, as pytorch-kaldi_amd/_lib.py::experiment strips them)
     const char* e = getenv("PK_EXPERIMENT");
     if (e == nullptr) return nullptr;
     const size_t kl = strlen(key);
     for (const char* p = e; *p;) {
         const char* end = strchr(p, ',');
         if (end == nullptr) end = p + strlen(p);
-        if ((size_t)(end - p) > kl && strncmp(p, key, kl) == 0 && p[kl] == '=') {
-            return p + kl + 1;
+        const char* q = p;
+        while (q < end && (*q == ' ' || *q == '\t')) ++q;
+        if ((size_t)(end - q) > kl && strncmp(q, key, kl) == 0) {
+            const char* r = q + kl;
+            while (r < end && (*r == ' ' || *r == '\t')) ++r;
+            if (r < end && *r == '=') {
+                ++r;
+                while (r < end && (*r == ' ' || *r == '\t')) ++r;
+                return r;
+            }
         }
         p = *end ? end + 1 : end;
     }

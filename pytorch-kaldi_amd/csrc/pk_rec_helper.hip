@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void rec_helper_kernel(HelpArgs a) {
     }
     // published step q -> touch step q + lead of every range; before anything is published: the steps 0 .. lead - 1
     int done = -2;  // last q handled (-1 = the head start)
-    const unsigned long long t0 = __builtin_readcyclecounter();
+    unsigned long long t0 = __builtin_readcyclecounter();  // of the last progress seen: the bound is per wait, not per launch
     while (true) {
         int p = s_progress;
         if (done == -2) p = -1;
@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void rec_helper_kernel(HelpArgs a) {
             __builtin_amdgcn_s_sleep(1);
             continue;
         }
+        t0 = __builtin_readcyclecounter();
         if (p >= T) break;
         // (a toucher that fell behind skips to the newest published step: old steps are history)
         const int q = p;
@@ -329,6 +330,13 @@ int pk_rec_helper_launch(hipStream_t st, const R2Args& a, const Plan2& pl, int G
         h.xbase = (const char*)a.dGb;
         h.x_dir_bytes = (long long)a.T * h.x_ts;
         h.x_row_bytes = (long long)a.Gpitch * 2;
+    }
+    {   // every helper workgroup pins a whole CU (HELPER_LDS of dummy LDS) and the recurrence must stay co-resident:
+        // only CUs the recurrence's own grid leaves free may be taken (pk_rec2_check_residency counts the recurrence alone)
+        const int free_cus = pk_num_cu() - pl.C * pl.Pn;
+        const int fit = pl.C > 0 ? free_cus / pl.C : 0;
+        if (fit < 1) return 0;
+        if (h.hpc > fit) h.hpc = fit;
     }
     h.nranges = n;
     h.xcd_tab = a.xcd_tab; h.hs_gen = a.hs_gen;

@@ -170,6 +170,15 @@ __global__ __launch_bounds__(256, 1) void rec2f_fwd_kernel(R2Args a) {
     };
 #define PK_LP0(E) load_proj(0, E)
     PK_EDGE_DISPATCH(PK_LP0);
+    // self-filling exchange (pk_rec2_common.h): the "not written yet" pattern goes into my own chunk - the first
+    // PK_R2_FILL_AHEAD slabs here, in place before the handshake lets anyone poll, the others that many steps ahead of my
+    // publishes (same lane, same address, program order: the pattern can never overtake the data)
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (a.self_fill) {
+        for (int tt = 0; tt < PK_R2_FILL_AHEAD && tt < T; ++tt)
+            pub_store<false>(rs, pbase + (pk_ok ? (unsigned)(vdir ? (T - 1 - tt) : tt) * TS : 0u), sentinel);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     bool dead = false;
@@ -200,6 +209,11 @@ __global__ __launch_bounds__(256, 1) void rec2f_fwd_kernel(R2Args a) {
         if (t + 1 < T) {
 #define PK_LP1(E) load_proj(t + 1, E)
             PK_EDGE_DISPATCH(PK_LP1);
+        }
+        if (a.self_fill && t + PK_R2_FILL_AHEAD < T) {
+            const unsigned off = pbase + (pk_ok ? (unsigned)(vdir ? (T - 1 - (t + PK_R2_FILL_AHEAD)) : (t + PK_R2_FILL_AHEAD)) * TS : 0u);
+            if (fast) pub_store<true>(rs, off, sentinel);
+            else pub_store<false>(rs, off, sentinel);
         }
         if (t > 0) {
             const float* Ar = reinterpret_cast<const float*>(At) + (lane & 15) * LDA + kq * 4;
@@ -439,6 +453,21 @@ __global__ __launch_bounds__(256, 1) void rec2f_bwd_kernel(R2Args a) {
     };
 #define PK_LS(E) load_step_e(T - 1, E)
     PK_EDGE_DISPATCH(PK_LS);
+    // self-filling exchange, as in the forward kernel: every gate's chunk of step tt
+    const u32x4 sentinel = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    auto fill_slab = [&](int tt, bool fast_) {
+        const unsigned off = pbase + (pk_ok ? (unsigned)(vdir ? (T - 1 - tt) : tt) * TS : 0u);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const unsigned og = off + (pk_ok ? (unsigned)(g * Hp) * 4u : 0u);
+            if (fast_) pub_store<true>(rs, og, sentinel);
+            else pub_store<false>(rs, og, sentinel);
+        }
+    };
+    if (a.self_fill) {
+        for (int k = 0; k < PK_R2_FILL_AHEAD && k < T; ++k) fill_slab(T - 1 - k, false);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
 
     bool dead = false;
@@ -476,6 +505,7 @@ __global__ __launch_bounds__(256, 1) void rec2f_bwd_kernel(R2Args a) {
             PK_EDGE_DISPATCH(PK_LS1);
             if (LN) load_stats(t - 1);
         }
+        if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) fill_slab(t - PK_R2_FILL_AHEAD, fast);
         if (t < T - 1) {
             const float* Ar = reinterpret_cast<const float*>(At) + (lane & 15) * LDA + kq * 4;
 #pragma unroll
@@ -580,6 +610,15 @@ Rec2fKernel pickf_bwd(int act, bool ln) {
          : act == PK_ACT_TANH ? rec2f_bwd_kernel<CELL, PK_ACT_TANH, false> : rec2f_bwd_kernel<CELL, -1, false>;
 }
 
+int self_fill2f() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = pk_experiment("rec4_self_fill");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
 int grant_lds(Rec2fKernel k, size_t lds) {
     struct Entry { Rec2fKernel k; size_t lds; };
     static Entry granted[16];
@@ -627,7 +666,10 @@ int pk_rec2f_fwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     a.Yx = Yx; a.dGx = nullptr;
     rc = pk_rec2_host_setup(a, false, cell);
     if (rc) return rc;
-    PK_CHECK_HIP(hipMemsetAsync(Yx, 0xFF, (size_t)T * B * y_pitch * 4, st));  // the mailbox: every dword "not written yet"
+    a.self_fill = self_fill2f();
+    // the mailbox: every dword "not written yet" - written by the kernel itself a few steps ahead of its publishes, or
+    // (PK_EXPERIMENT rec4_self_fill=0, one switch for both fp32 generations) by one fill in front of the launches
+    if (!a.self_fill) PK_CHECK_HIP(hipMemsetAsync(Yx, 0xFF, (size_t)T * B * y_pitch * 4, st));
     rc = pk_rec2_ln_setup(st, a, pl, ln, false);
     if (rc) return rc;
     const int G = pk_cell_gates(cell);
@@ -668,7 +710,8 @@ int pk_rec2f_bwd(hipStream_t st, int cell, int act, int T, int B, int bidir, int
     a.Yx = nullptr; a.dGx = dGx;
     rc = pk_rec2_host_setup(a, true, cell);
     if (rc) return rc;
-    PK_CHECK_HIP(hipMemsetAsync(dGx, 0xFF, (size_t)ndir * T * B * g_pitch * 4, st));
+    a.self_fill = self_fill2f();
+    if (!a.self_fill) PK_CHECK_HIP(hipMemsetAsync(dGx, 0xFF, (size_t)ndir * T * B * g_pitch * 4, st));
     rc = pk_rec2_ln_setup(st, a, pl, ln, true);
     if (rc) return rc;
     const size_t atile = (size_t)RMAX * pk_r2_lda_f32(G * KPAD) * 4;

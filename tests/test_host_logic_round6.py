@@ -148,3 +148,40 @@ def test_reducer_reset_rearms_after_a_step_that_did_not_complete():
 class _Done:
     def wait(self):
         return True
+
+
+def test_experiment_keys_are_parsed_once_per_value_and_trimmed(monkeypatch):
+    """PK_EXPERIMENT="key=value, key = value": one parse per distinct string (the lookup sits on per-layer, per-step paths),
+    blanks around keys and values ignored on both sides (pk_lib.hip::pk_experiment trims the same way), first occurrence
+    wins, a changed environment is seen at the next call (advisor, round 5)."""
+    _lib = importlib.import_module("pytorch-kaldi_amd._lib")
+    monkeypatch.setenv("PK_EXPERIMENT", " mlp_fused = 0 ,direct_grads=1,mlp_fused=1, f32_wgrad_side=0")
+    assert _lib.experiment("mlp_fused", "1") == "0"
+    assert _lib.experiment("direct_grads") == "1"
+    assert _lib.experiment("f32_wgrad_side", "1") == "0"
+    assert _lib.experiment("absent", "dflt") == "dflt"
+    parsed = _lib._EXP_CACHE[1]
+    assert _lib.experiment("direct_grads") == "1" and _lib._EXP_CACHE[1] is parsed   # no second parse
+    monkeypatch.setenv("PK_EXPERIMENT", "direct_grads=0")
+    assert _lib.experiment("direct_grads") == "0" and _lib.experiment("mlp_fused", "1") == "1"
+    monkeypatch.delenv("PK_EXPERIMENT")
+    assert _lib.experiment("direct_grads", "1") == "1"
+
+
+def test_stray_pk_variables_are_reported_once(monkeypatch):
+    """The A/B levers of earlier rounds moved behind PK_EXPERIMENT; their old names (PK_MLP_FUSED, ...) are not read any
+    more.  Loading the library with one of them in the environment says so once - an A/B script would otherwise compare
+    two identical configurations (advisor, round 5) - while documented switches and the harness's own variables pass."""
+    import warnings
+
+    _lib = importlib.import_module("pytorch-kaldi_amd._lib")
+    monkeypatch.setenv("PK_MLP_FUSED", "0")
+    monkeypatch.setenv("PK_PRECISION", "fp32")
+    monkeypatch.setenv("PK_BENCH_VERBOSE", "1")
+    monkeypatch.setattr(_lib, "_warned_unknown", False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _lib.warn_unknown_switches()
+        _lib.warn_unknown_switches()
+    msgs = [str(x.message) for x in w if "not switches of this version" in str(x.message)]
+    assert len(msgs) == 1 and "PK_MLP_FUSED" in msgs[0] and "PK_PRECISION" not in msgs[0] and "PK_BENCH_VERBOSE" not in msgs[0]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Micro-benchmark of pk_bn_bwd_bf16 (BatchNorm backward from the bf16 gate gradients) at the BASELINE shape:
-T*B = 64000 rows, 2 gates x 550 units, two directions.  Environment knobs of the library: PK_BNB_RBR / PK_BNB_RBA
-(row blocks of the reduction / apply pass), PK_BNB_REV (apply pass walks the rows backwards)."""
+T*B = 64000 rows, 2 gates x 550 units, two directions.  Knobs of the library: PK_EXPERIMENT keys bnb_rbr / bnb_rba
+(row blocks of the reduction / apply pass)."""
 import ctypes
 import importlib
 import os
@@ -50,6 +50,6 @@ for _ in range(8):
     ts.append(e0.elapsed_time(e1))
 ts.sort()
 bytes_ = 2 * (dGb.numel() * 2 + P.numel() * 4) + dPb.numel() * 2
-print("RBR=%s RBA=%s REV=%s  median %.3f ms  min %.3f ms  %.2f TB/s (2 passes over dGb + P, one bf16 write; %s)" % (
-    os.environ.get("PK_BNB_RBR", "-"), os.environ.get("PK_BNB_RBA", "-"), os.environ.get("PK_BNB_REV", "-"),
+print("PK_EXPERIMENT=%s  median %.3f ms  min %.3f ms  %.2f TB/s (2 passes over dGb + P, one bf16 write; %s)" % (
+    os.environ.get("PK_EXPERIMENT", "-"),
     ts[len(ts) // 2], ts[0], bytes_ / ts[len(ts) // 2] / 1e9, "checksum %.6e" % float(dPb.float().sum())))

@@ -12,10 +12,10 @@ g = torch.Generator().manual_seed(8)
 x = torch.randn(128, 440, generator=g).cuda()
 lab = torch.randint(0, 200, (128,), generator=g).cuda()
 F_.set_precision("bf16")
-KEYS = ("PK_MLP_FUSED", "PK_MLP_FUSED_BWD", "PK_DIRECT_GRADS", "PK_GEMM_SKINNY")
+KEYS = ("mlp_fused", "mlp_fused_bwd", "direct_grads", "gemm_skinny")  # keys of PK_EXPERIMENT
 def run(on):
-    for k in KEYS:
-        os.environ[k] = "1" if k in on else "0"
+    # (gemm_skinny is read once by the library: it takes the value of the FIRST run of this process)
+    os.environ["PK_EXPERIMENT"] = ",".join("%s=%d" % (k, k in on) for k in KEYS)
     torch.manual_seed(3)
     net = nn_amd.MLP(opts, 440).cuda().train()
     flat = optim_.FlatParams(net)
@@ -29,7 +29,7 @@ def run(on):
     F_.set_forced_dropout(None)
     return float(loss), {k: q.grad.detach().clone() for k, q in net.named_parameters()}
 l0, ref = run(())
-l1, got = run(("PK_MLP_FUSED",))
+l1, got = run(("mlp_fused",))
 for k in ref:
     if float(ref[k].abs().max()) > 1e-5:
         d = (got[k] - ref[k]).abs()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Forward + backward time of one recurrent layer stack with `*_use_laynorm=True` at the BASELINE geometry (B = 128
 bidirectional, H = 550): per-step LayerNorm inside the persistent time loop against the step-wise algorithm
-(PK_REC_LN_PERSIST=0 semantics, selected with set_rec_algo).  Prints one JSON object."""
+(the semantics of PK_EXPERIMENT rec_ln_persist=0, selected with set_rec_algo).  Prints one JSON object."""
 import importlib
 import json
 import os

@@ -874,7 +874,7 @@ def main():
         except Exception as e:
             out["through_run_nn"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:  # SURVEY.md 8(d)'s secondary variant: sentence lengths U[250, 500], zero-padded with a random left offset (core.py:588-595)
-            out["padded_batches"] = through_run_nn(args, n_batches=8, reps=2, ragged=True)
+            out["padded_batches"] = through_run_nn(args, n_batches=8, reps=4, ragged=True)  # (the median of three timed chunks: one in three fresh processes shows a single 60 ms hiccup in its second chunk)
         except Exception as e:
             out["padded_batches"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:

@@ -145,8 +145,8 @@ def test_round5_line_measures_the_cpu_full_shape_in_the_run_and_carries_the_roun
 
 def test_round6_line_is_complete_per_configuration():
     """Round 6 (round-5 review, item 3): every other configuration carries its own CPU baseline, an fp32 row and PMC traffic;
-    the headline's bounded CPU sample keeps the metric's sequence length (it no longer flatters the CPU: within 10 % of the
-    full-shape step measured in the same run); `structure_frac` is gone; the padded-batch variant is timed; the fp32 rows of
+    the headline's bounded CPU sample keeps the metric's sequence length (it no longer flatters the CPU: within 20 % of the
+    full-shape step measured in the same run, and on the slow side - 16 sequences use the host's cores less well than 128); `structure_frac` is gone; the padded-batch variant is timed; the fp32 rows of
     the LSTM / GRU configurations run on the fourth-generation kernels."""
     d = _line("profiles/r06_bench_bf16.json")
     assert d["config"]["workload"].startswith("timit_ligru") and d["dtype"] == "bf16" and d["ms_per_step"] < 17.5
@@ -157,7 +157,7 @@ def test_round6_line_is_complete_per_configuration():
     assert c["kind"] in ("port", "reference") and (c["T"], c["B"]) == (500, 16) and c["cores"] >= 1
     fs = c["full_shape"]
     assert fs["measured_in_run"] is True and (fs["T"], fs["B"]) == (500, 128)
-    assert abs(c["value"] - fs["value"]) < 0.10 * fs["value"]
+    assert abs(c["value"] - fs["value"]) < 0.20 * fs["value"] and c["value"] < 1.05 * fs["value"]
     pb = d["padded_batches"]
     assert "error" not in pb and 0 < pb["padding_share"] < 0.2 and pb["value"] > 0
     got = {o["recipe"]: o for o in d["other_configs"]}
@@ -167,7 +167,9 @@ def test_round6_line_is_complete_per_configuration():
         assert o["cpu_baseline"]["value"] > 0 and o["cpu_baseline"]["kind"] in ("port", "reference"), name
         assert o["parity_mode"]["dtype"] == "fp32" and o["parity_mode"]["ms_per_step"] > o["ms_per_step"], name
         assert o["roofline"]["traffic"] is not None and "r06_pmc_traffic_" + name in o["roofline"]["traffic_source"], name
-    assert got["timit_lstm"]["parity_mode"]["ms_per_step"] < 160 and got["libri_gru"]["parity_mode"]["ms_per_step"] < 185
-    assert d["forward_mode"]["ms_per_step"] < 6.8
+    # (fp32 rows: fourth-generation recurrences, weight gradients on the side stream, self-filling exchange)
+    assert got["timit_lstm"]["parity_mode"]["ms_per_step"] < 140 and got["libri_gru"]["parity_mode"]["ms_per_step"] < 160
+    assert d["parity_mode"]["ms_per_step"] < 88 and d["forward_mode"]["ms_per_step"] < 6.8
+    assert len(pb["chunks_s"]) >= 2
     dc = json.load(open(os.path.join(ROOT, "profiles", "r06_driver_cmd.json")))
     assert dc["first_process"]["steps"] == 20 and dc["first_process"]["warmup"] == 5 and dc["first_process"]["ms_per_step"] < 17.5

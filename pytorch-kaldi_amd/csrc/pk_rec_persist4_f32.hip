@@ -175,6 +175,37 @@ __device__ __forceinline__ void mfma_batch(const u32x4 (&v)[N], const float (*Bf
 //   gate math    wave w owns tile w >> 1, accumulator row slots r = 2 (w & 1), 2 (w & 1) + 1 of every lane - 8 of the
 //                cluster's 16 rows x 16 units: state, loads, stores and the publish of that share are its alone.
 constexpr int NQ = KJ / 4;   // 9 groups of 16 k: a wave's quarter of one gate
+
+// One v_mfma_f32_16x16x4_f32.  An LSTM wave holds 288 B-operand registers (GRU: 216) next to 36 operand, 32 accumulator
+// and ~60 other registers: more than the 256 architectural VGPRs.  Left to itself the compiler parks the excess in AGPRs and
+// copies every such value into ONE temporary VGPR in front of its MFMA (v_accvgpr_read + wait states: 56 % of the LSTM
+// kernels' MFMAs, 44 instead of 32 clocks per MFMA measured - tools/ubench/mfma_f32_rate.hip shows the pipe itself sustains
+// 32).  gfx90a and later read SrcB straight from an AGPR: the B fragments of the SECOND unit tile are bound to AGPRs for the
+// whole kernel by passing them to the instruction through an "a" constraint (BA = true), which takes inline assembly - and
+// with it the wait states the compiler's hazard recogniser would have inserted: two in front of every such MFMA (a VALU
+// write of a source / accumulator register just before it), pk4_mfma_settle() behind the last one of a block (an 8-pass
+// MFMA's result may be read 18 wait states after issue).  PK4_ASM_B = false gives the builtin form everywhere (A/B).
+constexpr bool PK4_ASM_B = true;
+template <bool BA>
+__device__ __forceinline__ void pk4_mfma(f32x4& acc, unsigned a_bits, float b) {
+    if constexpr (BA && PK4_ASM_B) {
+        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a_bits), "a"(b));
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a_bits), b, acc, 0, 0, 0);
+    }
+}
+// behind the last pk4_mfma<true> on these accumulators, before anything reads them
+template <int N>
+__device__ __forceinline__ void pk4_mfma_settle(f32x4 (&acc)[N]) {
+    if constexpr (PK4_ASM_B) {
+        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]));
+#pragma unroll
+        for (int i = 1; i < N; ++i) asm volatile("" : "+a"(acc[i]));
+    }
+}
+__device__ __forceinline__ void pk4_mfma_settle(f32x4& acc) {
+    if constexpr (PK4_ASM_B) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc));
+}
 // diagnostics (pk_persist2_set_trace, tools/trace_rec4.py): shader-clock stamps of (workgroup 0, thread 0), 8 per step
 #define PK4_TRACE(step, slot)                                                                                      \
     do {                                                                                                           \
@@ -449,10 +480,11 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int g = 0; g < G1; ++g)
-#pragma unroll
-                        for (int tl = 0; tl < 2; ++tl)
-                            acc[tl][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), B1[tl][g][i][e], acc[tl][g], 0, 0, 0);
+                    for (int g = 0; g < G1; ++g) {
+                        pk4_mfma<false>(acc[0][g], av[i][e], B1[0][g][i][e]);
+                        pk4_mfma<true>(acc[1][g], av[i][e], B1[1][g][i][e]);
+                    }
+            pk4_mfma_settle(acc[1]);
         }
         PK4_TRACE(t, 2);
         // ---- the four quarters' partial sums meet in LDS; every wave adds the four of its share in the same order
@@ -538,11 +570,17 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
                 for (int i = 0; i < NQ; ++i)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int tl = 0; tl < 2; ++tl) {
-                            if ((e & 1) == 0) a2[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), B2[tl][TWO ? i : 0][e], a2[tl], 0, 0, 0);
-                            else b2[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), B2[tl][TWO ? i : 0][e], b2[tl], 0, 0, 0);
+                    {
+                        if ((e & 1) == 0) {
+                            pk4_mfma<false>(a2[0], av[i][e], B2[0][TWO ? i : 0][e]);
+                            pk4_mfma<true>(a2[1], av[i][e], B2[1][TWO ? i : 0][e]);
+                        } else {
+                            pk4_mfma<false>(b2[0], av[i][e], B2[0][TWO ? i : 0][e]);
+                            pk4_mfma<true>(b2[1], av[i][e], B2[1][TWO ? i : 0][e]);
                         }
+                    }
+                pk4_mfma_settle(a2[1]);
+                pk4_mfma_settle(b2[1]);
             }
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl) {
@@ -845,9 +883,10 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
                     if (!no_mfma) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int tl = 0; tl < 2; ++tl)
-                                acc[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), BB[tl][bq * NQ + i][e], acc[tl], 0, 0, 0);
+                            {
+                                pk4_mfma<false>(acc[0], av[i][e], BB[0][bq * NQ + i][e]);
+                                pk4_mfma<true>(acc[1], av[i][e], BB[1][bq * NQ + i][e]);
+                            }
                     }
                     if (bq + 1 < NBATCH) av[i] = poll_load<FAST>(rs, rp.at(lbn, j0n + i));
                 }
@@ -870,6 +909,7 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
             if (LN) load_stats(t - 1);
             if (a.self_fill && t - PK_R2_FILL_AHEAD >= 0) fill_slab(t - PK_R2_FILL_AHEAD, FASTC);
         }
+        pk4_mfma_settle(acc[1]);
         PK4_TRACE(it, 1);
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
@@ -942,11 +982,17 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
                     for (int i = 0; i < NQ; ++i)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int tl = 0; tl < 2; ++tl) {
-                                if ((e & 1) == 0) qa[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), BA[tl][TWO ? i : 0][e], qa[tl], 0, 0, 0);
-                                else qb[tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av[i][e]), BA[tl][TWO ? i : 0][e], qb[tl], 0, 0, 0);
+                            {
+                                if ((e & 1) == 0) {
+                                    pk4_mfma<false>(qa[0], av[i][e], BA[0][TWO ? i : 0][e]);
+                                    pk4_mfma<true>(qa[1], av[i][e], BA[1][TWO ? i : 0][e]);
+                                } else {
+                                    pk4_mfma<false>(qb[0], av[i][e], BA[0][TWO ? i : 0][e]);
+                                    pk4_mfma<true>(qb[1], av[i][e], BA[1][TWO ? i : 0][e]);
+                                }
                             }
+                    pk4_mfma_settle(qa[1]);
+                    pk4_mfma_settle(qb[1]);
                 }
             }
             PK4_TRACE(it, 4);

@@ -302,6 +302,60 @@ __device__ __forceinline__ bool cluster_on_one_xcd(const R2Args& a, int c, int p
     return __syncthreads_and(same) != 0;
 }
 
+typedef float pk_f32x4_t __attribute__((ext_vector_type(4)));
+template <int B>
+struct BoolC;  // (defined below)
+// compile-time loop: f(BoolC<0>()), f(BoolC<1>()), ... f(BoolC<N - 1>()) - for loop indices that select a template argument
+template <int I, int N, typename F>
+__device__ __forceinline__ void pk_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(BoolC<I>());
+        pk_static_for<I + 1, N>(f);
+    }
+}
+// One v_mfma_f32_16x16x4_f32.  An exact-fp32 LSTM or Li-GRU wave holds 288 B-operand registers (GRU: 216) next to 36 operand, 32 accumulator
+// and ~60 other registers: more than the 256 architectural VGPRs.  Left to itself the compiler parks the excess in AGPRs and
+// copies every such value into ONE temporary VGPR in front of its MFMA (v_accvgpr_read + wait states: 56 % of the LSTM
+// kernels' MFMAs, 44 instead of 32 clocks per MFMA measured - tools/ubench/mfma_f32_rate.hip shows the pipe itself sustains
+// 32).  gfx90a and later read SrcB straight from an AGPR: the B fragments of the SECOND unit tile are bound to AGPRs for the
+// whole kernel by passing them to the instruction through an "a" constraint (BA = true), which takes inline assembly - and
+// with it the wait states the compiler's hazard recogniser would have inserted: two in front of every such MFMA (a VALU
+// write of a source / accumulator register just before it), pk4_mfma_settle() behind the last one of a block (an 8-pass
+// MFMA's result may be read 18 wait states after issue).  PK4_ASM_B = false gives the builtin form everywhere (A/B).
+constexpr bool PK4_ASM_B = true;
+template <bool BA>
+__device__ __forceinline__ void pk4_mfma(pk_f32x4_t& acc, unsigned a_bits, float b) {
+    if constexpr (BA && PK4_ASM_B) {
+        // (not volatile: the result depends on the operands only, and a volatile asm would pin every LDS / global load of the
+        // block in place - the fragment reads of the second-generation kernels landed right in front of their MFMAs)
+        asm("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a_bits), "a"(b));
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a_bits), b, acc, 0, 0, 0);
+    }
+}
+// behind the last pk4_mfma<true> on these accumulators, before anything reads them (one statement: every accumulator is
+// an operand, so none of them can be read in front of the wait)
+__device__ __forceinline__ void pk4_mfma_settle(pk_f32x4_t& x0) {
+    if constexpr (PK4_ASM_B) asm("s_nop 15\n\ts_nop 7" : "+a"(x0));
+}
+__device__ __forceinline__ void pk4_mfma_settle(pk_f32x4_t& x0, pk_f32x4_t& x1) {
+    if constexpr (PK4_ASM_B) asm("s_nop 15\n\ts_nop 7" : "+a"(x0), "+a"(x1));
+}
+__device__ __forceinline__ void pk4_mfma_settle(pk_f32x4_t& x0, pk_f32x4_t& x1, pk_f32x4_t& x2) {
+    if constexpr (PK4_ASM_B) asm("s_nop 15\n\ts_nop 7" : "+a"(x0), "+a"(x1), "+a"(x2));
+}
+__device__ __forceinline__ void pk4_mfma_settle(pk_f32x4_t& x0, pk_f32x4_t& x1, pk_f32x4_t& x2, pk_f32x4_t& x3) {
+    if constexpr (PK4_ASM_B) asm("s_nop 15\n\ts_nop 7" : "+a"(x0), "+a"(x1), "+a"(x2), "+a"(x3));
+}
+template <int N>
+__device__ __forceinline__ void pk4_mfma_settle(pk_f32x4_t (&acc)[N]) {
+    static_assert(N >= 1 && N <= 4, "pk4_mfma_settle: up to four accumulators");
+    if constexpr (N == 1) pk4_mfma_settle(acc[0]);
+    else if constexpr (N == 2) pk4_mfma_settle(acc[0], acc[1]);
+    else if constexpr (N == 3) pk4_mfma_settle(acc[0], acc[1], acc[2]);
+    else pk4_mfma_settle(acc[0], acc[1], acc[2], acc[3]);
+}
+
 // workgroup barrier that orders LDS only: __syncthreads() also drains vmcnt, i.e. it would wait for
 // the prefetch loads issued just before it (HBM latency on the dependency chain)
 #define PK_BARRIER_LDS()                               \

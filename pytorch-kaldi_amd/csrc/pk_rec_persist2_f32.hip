@@ -26,6 +26,7 @@
 namespace {
 
 constexpr int KJ = KPAD / 16;  // 36 groups of 16 k
+constexpr int JV = 22;   // k-groups below JV of the gates before the last keep their B fragments in VGPRs (pk4_mfma)
 
 __device__ __forceinline__ u32x4 no_sentinel(f32x4 v) {
     u32x4 o;
@@ -217,6 +218,9 @@ __global__ __launch_bounds__(256, 1) void rec2f_fwd_kernel(R2Args a) {
         }
         if (t > 0) {
             const float* Ar = reinterpret_cast<const float*>(At) + (lane & 15) * LDA + kq * 4;
+            // (the forward kernel keeps the builtin form: with its B fragments bound to AGPRs - pk4_mfma, as the backward kernel
+            // below does - the allocator had no VGPR left to read the next LDS fragment ahead, every ds_read landed right in
+            // front of its MFMAs and a launch went from 3.63 to 4.15 ms, round 6)
 #pragma unroll
             for (int j = 0; j < KJ; ++j) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(Ar + j * 16);
@@ -509,16 +513,28 @@ __global__ __launch_bounds__(256, 1) void rec2f_bwd_kernel(R2Args a) {
         if (t < T - 1) {
             const float* Ar = reinterpret_cast<const float*>(At) + (lane & 15) * LDA + kq * 4;
 #pragma unroll
-            for (int g = 0; g < G; ++g)
-#pragma unroll
-                for (int j = 0; j < KJ; ++j) {
+            for (int g = 0; g < G - 1; ++g)
+                pk_static_for<0, KJ>([&](auto JC) {
+                    constexpr int j = decltype(JC)::value;
                     const f32x4 av = *reinterpret_cast<const f32x4*>(Ar + g * KPAD + j * 16);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if ((e & 1) == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], Bf[g][j][e], acc0, 0, 0, 0);
-                        else acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], Bf[g][j][e], acc1, 0, 0, 0);
+                        if ((e & 1) == 0) pk4_mfma<(G > 1 && j >= JV)>(acc0, __float_as_uint(av[e]), Bf[g][j][e]);
+                        else pk4_mfma<(G > 1 && j >= JV)>(acc1, __float_as_uint(av[e]), Bf[g][j][e]);
                     }
+                });
+            // (the last gate's B fragments and the k-groups from JV on of the others live in AGPRs and are read from there:
+            // pk4_mfma, pk_rec2_common.h)
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(Ar + (G - 1) * KPAD + j * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if ((e & 1) == 0) pk4_mfma<(G > 1)>(acc0, __float_as_uint(av[e]), Bf[G - 1][j][e]);
+                    else pk4_mfma<(G > 1)>(acc1, __float_as_uint(av[e]), Bf[G - 1][j][e]);
                 }
+            }
+            if (G > 1) pk4_mfma_settle(acc0, acc1);
         }
         if (NBUF == 1 && t < T - 1) PK_BARRIER_LDS();  // single A tile: everyone is done reading before the next poll refills it
         float sin[NIN][4];

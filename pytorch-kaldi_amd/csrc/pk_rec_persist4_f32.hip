@@ -176,36 +176,6 @@ __device__ __forceinline__ void mfma_batch(const u32x4 (&v)[N], const float (*Bf
 //                cluster's 16 rows x 16 units: state, loads, stores and the publish of that share are its alone.
 constexpr int NQ = KJ / 4;   // 9 groups of 16 k: a wave's quarter of one gate
 
-// One v_mfma_f32_16x16x4_f32.  An LSTM wave holds 288 B-operand registers (GRU: 216) next to 36 operand, 32 accumulator
-// and ~60 other registers: more than the 256 architectural VGPRs.  Left to itself the compiler parks the excess in AGPRs and
-// copies every such value into ONE temporary VGPR in front of its MFMA (v_accvgpr_read + wait states: 56 % of the LSTM
-// kernels' MFMAs, 44 instead of 32 clocks per MFMA measured - tools/ubench/mfma_f32_rate.hip shows the pipe itself sustains
-// 32).  gfx90a and later read SrcB straight from an AGPR: the B fragments of the SECOND unit tile are bound to AGPRs for the
-// whole kernel by passing them to the instruction through an "a" constraint (BA = true), which takes inline assembly - and
-// with it the wait states the compiler's hazard recogniser would have inserted: two in front of every such MFMA (a VALU
-// write of a source / accumulator register just before it), pk4_mfma_settle() behind the last one of a block (an 8-pass
-// MFMA's result may be read 18 wait states after issue).  PK4_ASM_B = false gives the builtin form everywhere (A/B).
-constexpr bool PK4_ASM_B = true;
-template <bool BA>
-__device__ __forceinline__ void pk4_mfma(f32x4& acc, unsigned a_bits, float b) {
-    if constexpr (BA && PK4_ASM_B) {
-        asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a_bits), "a"(b));
-    } else {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a_bits), b, acc, 0, 0, 0);
-    }
-}
-// behind the last pk4_mfma<true> on these accumulators, before anything reads them
-template <int N>
-__device__ __forceinline__ void pk4_mfma_settle(f32x4 (&acc)[N]) {
-    if constexpr (PK4_ASM_B) {
-        asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc[0]));
-#pragma unroll
-        for (int i = 1; i < N; ++i) asm volatile("" : "+a"(acc[i]));
-    }
-}
-__device__ __forceinline__ void pk4_mfma_settle(f32x4& acc) {
-    if constexpr (PK4_ASM_B) asm volatile("s_nop 15\n\ts_nop 7" : "+a"(acc));
-}
 // diagnostics (pk_persist2_set_trace, tools/trace_rec4.py): shader-clock stamps of (workgroup 0, thread 0), 8 per step
 #define PK4_TRACE(step, slot)                                                                                      \
     do {                                                                                                           \
@@ -579,8 +549,7 @@ __global__ __launch_bounds__(256, 1) void rec4_fwd_kernel(R2Args a) {
                             pk4_mfma<true>(b2[1], av[i][e], B2[1][TWO ? i : 0][e]);
                         }
                     }
-                pk4_mfma_settle(a2[1]);
-                pk4_mfma_settle(b2[1]);
+                pk4_mfma_settle(a2[1], b2[1]);
             }
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl) {
@@ -991,8 +960,7 @@ __global__ __launch_bounds__(256, 1) void rec4_bwd_kernel(R2Args a) {
                                     pk4_mfma<true>(qb[1], av[i][e], BA[1][TWO ? i : 0][e]);
                                 }
                             }
-                    pk4_mfma_settle(qa[1]);
-                    pk4_mfma_settle(qb[1]);
+                    pk4_mfma_settle(qa[1], qb[1]);
                 }
             }
             PK4_TRACE(it, 4);

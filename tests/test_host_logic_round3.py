@@ -66,13 +66,21 @@ def test_algorithm_choice_for_layers_that_normalise_h(monkeypatch):
         F_.set_precision("fp32")
         assert F_.choose_rec_algo("liGRU", 550, True) == F_.REC_PERSISTENT
         assert F_.choose_rec_algo("RNN", 14, True) == F_.REC_PERSISTENT
+        # (round 6: the fourth-generation fp32 kernels normalise h_t too; without them - rec_f32_gen4=0 - these cells go back
+        # to the step-wise algorithm and a forced persistent run says that it cannot)
+        for cell in ("LSTM", "GRU", "minimalGRU"):
+            assert F_.choose_rec_algo(cell, 550, True) == F_.REC_PERSISTENT, cell
+        monkeypatch.setenv("PK_EXPERIMENT", "rec_f32_gen4=0")
         for cell in ("LSTM", "GRU", "minimalGRU"):
             assert F_.choose_rec_algo(cell, 550, True) == F_.REC_STEPWISE, cell
         F_.set_rec_algo("persistent")
         with pytest.raises(_lib.PkError):
             F_.choose_rec_algo("LSTM", 550, True)
+        monkeypatch.delenv("PK_EXPERIMENT")
+        assert F_.choose_rec_algo("LSTM", 550, True) == F_.REC_PERSISTENT
         F_.set_rec_algo("auto")
         monkeypatch.setenv("PK_EXPERIMENT", "rec_ln_persist=0")
+        assert F_.choose_rec_algo("GRU", 550, True) == F_.REC_STEPWISE
         assert F_.choose_rec_algo("liGRU", 550, True) == F_.REC_STEPWISE
         monkeypatch.setenv("PK_EXPERIMENT", "rec_ln_persist=1,rec_f32_gen=1")
         assert F_.choose_rec_algo("liGRU", 550, True) == F_.REC_STEPWISE  # the first-generation fp32 kernels do not normalise

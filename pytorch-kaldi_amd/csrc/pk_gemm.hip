@@ -35,6 +35,7 @@ struct GemmArgs {
     int k_per_split;  // multiple of BK
     int vecA, vecB;   // 16-B vector loads allowed for A / B
     int gx, gy, items, per_xcd;  // tiles along n / m, tiles x splits, items per XCD (1-D launch, see work_item)
+    int dbg;
 };
 
 constexpr int BM = 128, BN = 128;
@@ -219,9 +220,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            la.load(p.A, p.a_rs, p.a_cs, m0, kbeg + (kt + 1) * BK, p.M, kend, p.vecA, tid);
-            lb.load(p.B, p.b_cs, p.b_rs, n0, kbeg + (kt + 1) * BK, p.N, kend, p.vecB, tid);
+        if (kt + 1 < nk && !(p.dbg & 2)) {
+            const int kn = (p.dbg & 1) ? kbeg : kbeg + (kt + 1) * BK;
+            la.load(p.A, p.a_rs, p.a_cs, m0, kn, p.M, kend, p.vecA, tid);
+            lb.load(p.B, p.b_cs, p.b_rs, n0, kn, p.N, kend, p.vecB, tid);
         }
         const float* as = As[cur];
         const float* bs = Bs[cur];
@@ -244,7 +246,170 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         }
         __syncthreads();
     }
-    store_acc(p, acc, m0, n0, wm, wn, lane, split);
+    if (!(p.dbg & 4)) store_acc(p, acc, m0, n0, wm, wn, lane, split);
+}
+
+// ---------------------------------------------------------------------------
+// fp32 kernel, second form (round 6): the operand tiles go L2 -> LDS with the LDS-DMA (global_load_lds_dwordx4: no VGPR
+// round trip, no ds_write pass, no per-k-tile address arithmetic - the per-thread source addresses are computed once and
+// advanced by a constant).  With the register-staged form above, issuing the loads alone cost 20 % of a launch even when
+// every load hit the cache (profiles/r06_fp32_gemm_dma.json).
+//   LDS images (lane-linear, as the DMA writes them; 8 KB per operand and k-tile of 16):
+//     k-contiguous operand  [128 rows][4 slots of 16 B]; slot = quad ^ ((row >> 2) & 3) - applied to the SOURCE address
+//                           when staging and again when reading: a lane's fragment is ONE ds_read_b128 (4 consecutive
+//                           k of its row, the four MFMAs of a pass take one element each), conflict-free per 16-lane group
+//     m/n-contiguous operand [16 k][128 rows]: fragments are ds_read_b32 over 32 consecutive floats
+//   k of MFMA e of pass p, lane half h:  8 p + 4 h + e  (both operands; the order of the k-sum differs from the first
+//   form's 2 kk + h - fp32 round-off of the same size).
+//   Pipeline: two stages; the DMA of tile kt + 1 is issued once tile kt's fragments sit in registers (all of a k-tile's
+//   fragments are read up front: 32 VGPRs), so it flies under the tile's 32 MFMAs; ONE barrier per k-tile.
+// Covers operands with 16-byte aligned bases and leading dimensions, K % 4 == 0 for a k-contiguous operand, M (N) % 4 == 0
+// for an m- (n-) contiguous one; everything else takes the first form.  Rows beyond M / N are clamped (never stored);
+// 16-byte pieces beyond the end of the reduction come from a zero page.
+// ---------------------------------------------------------------------------
+__device__ float g_zero_page_f32[16];
+
+__device__ __forceinline__ void f32_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int f32_swz(int row) { return (row >> 2) & 3; }
+
+template <bool KC>
+struct F32TileSrc {
+    unsigned long long a[2];
+    unsigned long long step;
+    // ld: floats between consecutive rows (KC) or consecutive k (not KC)
+    __device__ __forceinline__ void init(const float* __restrict__ base, long ld, int r0, int rmax, int k0, int tid) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = j * 256 + tid;
+            if (KC) {
+                const int row = q >> 2, ks = (q & 3) ^ f32_swz(row);
+                int gr = r0 + row;
+                gr = gr < rmax ? gr : rmax - 1;
+                a[j] = (unsigned long long)(base + (long)gr * ld + k0 + ks * 4);
+            } else {
+                const int kr = q >> 5;
+                int gc = r0 + (q & 31) * 4;
+                if (gc >= rmax) gc = (rmax - 1) & ~3;  // (a piece entirely out of range: any in-range piece; never stored)
+                a[j] = (unsigned long long)(base + (long)(k0 + kr) * ld + gc);
+            }
+        }
+        step = KC ? 64ull : (unsigned long long)ld * 64ull;
+    }
+    __device__ __forceinline__ void issue(unsigned char* buf, int wave) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32_glds16(reinterpret_cast<const void*>(a[j]), buf + (j * 256 + wave * 64) * 16);
+            a[j] += step;
+        }
+    }
+    // the (single) ragged last k-tile of a split: pieces at or beyond kmax come from the zero page
+    __device__ __forceinline__ void issue_tail(unsigned char* buf, int wave, int tid, int k0, int kmax, const float* zeros) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = j * 256 + tid;
+            const int gk = KC ? k0 + (((q & 3) ^ f32_swz(q >> 2)) * 4) : k0 + (q >> 5);
+            const unsigned long long m = 0ull - (unsigned long long)(gk < kmax);
+            const unsigned long long src = (a[j] & m) | ((unsigned long long)zeros & ~m);
+            f32_glds16(reinterpret_cast<const void*>(src), buf + (j * 256 + wave * 64) * 16);
+        }
+    }
+};
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs p, const float* zeros) {
+    constexpr int BK = 16, OPB = 128 * BK * 4, STG = 2 * OPB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int m0, n0, split;
+    if (!work_item(p, m0, n0, split)) return;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    F32TileSrc<A_KC> sa;
+    F32TileSrc<B_KC> sb;
+    sa.init(p.A, A_KC ? p.a_rs : p.a_cs, m0, p.M, kbeg, tid);
+    sb.init(p.B, B_KC ? p.b_cs : p.b_rs, n0, p.N, kbeg, tid);
+    auto fetch = [&](int kt, unsigned char* buf) {
+        const int k0 = kbeg + kt * BK;
+        if (k0 + BK <= kend) {
+            sa.issue(buf, wave);
+            sb.issue(buf + OPB, wave);
+        } else {
+            sa.issue_tail(buf, wave, tid, k0, kend, zeros);
+            sb.issue_tail(buf + OPB, wave, tid, k0, kend, zeros);
+        }
+    };
+    if (nk > 0) fetch(0, smem);
+    const int h = lane >> 5, l31 = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char* cur = smem + (kt & 1) * STG;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile kt has landed for every wave; everybody is done reading the other buffer
+        // all fragments of the k-tile up front
+        f32x4 aq[A_KC ? 2 : 1][2], bq[B_KC ? 2 : 1][2];
+        float as[A_KC ? 1 : 8][2], bs[B_KC ? 1 : 8][2];
+        if (A_KC) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = wm * 64 + i * 32 + l31;
+                    aq[pp][i] = *reinterpret_cast<const f32x4*>(cur + row * 64 + (((2 * pp + h) ^ f32_swz(row)) * 16));
+                }
+        } else {
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    as[s_][i] = *reinterpret_cast<const float*>(cur + (8 * (s_ >> 2) + 4 * h + (s_ & 3)) * 512 + (wm * 64 + i * 32 + l31) * 4);
+        }
+        if (B_KC) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wn * 64 + j * 32 + l31;
+                    bq[pp][j] = *reinterpret_cast<const f32x4*>(cur + OPB + row * 64 + (((2 * pp + h) ^ f32_swz(row)) * 16));
+                }
+        } else {
+#pragma unroll
+            for (int s_ = 0; s_ < 8; ++s_)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bs[s_][j] = *reinterpret_cast<const float*>(cur + OPB + (8 * (s_ >> 2) + 4 * h + (s_ & 3)) * 512 + (wn * 64 + j * 32 + l31) * 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);  // the DMA of the next tile is issued behind this tile's reads, in front of its MFMAs
+        if (kt + 1 < nk) fetch(kt + 1, smem + ((kt + 1) & 1) * STG);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = A_KC ? aq[A_KC ? (s_ >> 2) : 0][i][s_ & 3] : as[A_KC ? 0 : s_][i];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = B_KC ? bq[B_KC ? (s_ >> 2) : 0][j][s_ & 3] : bs[B_KC ? 0 : s_][j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (!(p.dbg & 4)) store_acc(p, acc, m0, n0, wm, wn, lane, split);
 }
 
 // ---------------------------------------------------------------------------
@@ -387,6 +552,12 @@ extern "C" int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha,
             flat = e ? atoi(e) : 0;
         }
         if (flat) p.per_xcd = 0;
+        static int dbg = -1;
+        if (dbg < 0) {
+            const char* e = pk_experiment("f32_dbg");
+            dbg = e ? atoi(e) : 0;
+        }
+        p.dbg = dbg;
     }
 #define PK_LAUNCH_GEMM(KERN)                                                              \
     do {                                                                                  \
@@ -395,7 +566,26 @@ extern "C" int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha,
         else if (!a_kc && b_kc) hipLaunchKernelGGL((KERN<false, true>), grid, block, 0, st, p); \
         else hipLaunchKernelGGL((KERN<false, false>), grid, block, 0, st, p);              \
     } while (0)
-    if (prec == PK_PREC_F32) PK_LAUNCH_GEMM(gemm_f32_kernel);
+    bool dma = false;
+    if (prec == PK_PREC_F32) {
+        static int dma_on = -1;  // PK_EXPERIMENT f32_dma=0: the register-staged first form for every shape (A/B)
+        static void* zp = nullptr;
+        if (dma_on < 0) {
+            const char* e = pk_experiment("f32_dma");
+            dma_on = (e && e[0] == '0') ? 0 : 1;
+        }
+        if (zp == nullptr) PK_CHECK_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page_f32)));
+        dma = dma_on && K > 0 && p.vecA && p.vecB && (a_kc ? (K % 4) == 0 : (M % 4) == 0) && (b_kc ? (K % 4) == 0 : (N % 4) == 0);
+        if (dma) {
+            const float* zeros = (const float*)zp;
+            if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true>), grid, block, 0, st, p, zeros);
+            else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false>), grid, block, 0, st, p, zeros);
+            else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_dma_kernel<false, true>), grid, block, 0, st, p, zeros);
+            else hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false>), grid, block, 0, st, p, zeros);
+        }
+    }
+    if (dma) {
+    } else if (prec == PK_PREC_F32) PK_LAUNCH_GEMM(gemm_f32_kernel);
     else PK_LAUNCH_GEMM(gemm_bf16_kernel);
 #undef PK_LAUNCH_GEMM
     PK_LAUNCH_CHECK();

@@ -83,6 +83,14 @@ GEMM_SHAPES = [
     (130, 70, 5000, False, False, 8),
     (1100, 40, 6000, False, False, 16),
     (512, 1938, 1100, True, True, 1),
+    # the LDS-DMA form of the exact-fp32 kernel (aligned operands; K % 4 == 0 / M, N % 4 == 0): all four layouts, ragged
+    # row / column tiles, a ragged last k-tile (1100 = 68 x 16 + 12), split-K
+    (640, 260, 1100, True, False, 1),
+    (260, 1100, 2000, False, False, 3),
+    (200, 132, 76, False, True, 1),
+    (1024, 1100, 1104, True, True, 1),
+    (132, 128, 12, True, True, 1),
+    (2200, 1100, 4096, False, False, 4),
 ]
 
 

@@ -1,0 +1,8 @@
+#!/bin/bash
+set -u
+out=gpurun_out/r06t; mkdir -p "$out"
+timeout 120 python -c "import torch; x = torch.zeros(1 << 20).cuda() + 1; torch.cuda.synchronize(); print('gpu ok', float(x.sum()))" || { echo "BAD BOX"; exit 0; }
+timeout 600 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "gemm or linear" -x 2>&1 | tail -5
+for d in "f32_dma=0" "f32_dma=1"; do
+  PK_EXPERIMENT=$d SPLITS=1 timeout 200 python tools/bench_gemm_f32.py 2>&1 | head -7
+done | tee "$out/f32_dma.txt"

@@ -65,6 +65,10 @@ int pk_num_cu(void);
 int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha, const float* A, int64_t a_rs,
             int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
             const float* bias, int splitk, float* workspace);
+/* tests / tools: 1 = the register-staged first form of the exact-fp32 kernel for every shape, 0 = automatic (the LDS-DMA
+ * form wherever the operands are 16-byte aligned; also PK_EXPERIMENT f32_dma=0).  Both forms compute every output element
+ * as one fmaf chain over ascending k: bit-identical results. */
+void pk_gemm_f32_set_form(int form);
 
 /* ---- perf-mode GEMM on bf16 operands resident in HBM (fp32 accumulate and output); same reference
  * call sites as pk_gemm.  a_kc != 0: A is stored [M][lda] (k contiguous), else [K][lda] (m

@@ -27,6 +27,7 @@ SIGNATURES = {
     "pk_num_cu": (c_int, []),
     "pk_gemm": (c_int, [P, c_int, c_int, c_int, c_int, c_float, P, c_int64, c_int64, P, c_int64, c_int64, c_float, P,
                         c_int64, P, c_int, P]),
+    "pk_gemm_f32_set_form": (None, [c_int]),
     "pk_gemm_bf16_tile_m": (c_int, [c_int]),
     "pk_gemm_bf16_auto_splitk": (c_int, [c_int, c_int, c_int]),
     "pk_gemm_bf16_set_tile": (None, [c_int]),

@@ -114,6 +114,31 @@ def test_gemm(M, N, K, a_kc, b_kc, splitk, prec):
     assert rel_err(C, ref) < tol
 
 
+@pytest.mark.parametrize("M,N,K,a_kc,b_kc,splitk", [c for c in GEMM_SHAPES if c[0] * c[1] > 10000])
+def test_gemm_f32_forms_bit_identical(M, N, K, a_kc, b_kc, splitk):
+    """The LDS-DMA form of the exact-fp32 kernel against the register-staged form: every output element is one fmaf chain
+    over ascending k in both (same MFMA, same k pairs in the same order, same split boundaries) - equal bit for bit."""
+    import importlib
+
+    lib = importlib.import_module("pytorch-kaldi_amd._lib").load()
+    g = torch.Generator().manual_seed(M + 5 * N + 11 * K)
+    A = torch.randn((M, K) if a_kc else (K, M), generator=g).cuda()
+    B = torch.randn((N, K) if b_kc else (K, N), generator=g).cuda()
+    a_rs, a_cs = (K, 1) if a_kc else (1, M)
+    b_rs, b_cs = (1, K) if b_kc else (N, 1)
+    outs = []
+    for form in (1, 0):
+        lib.pk_gemm_f32_set_form(form)
+        try:
+            C = torch.zeros(M, N).cuda()
+            F_.gemm(M, N, K, A, a_rs, a_cs, B, b_rs, b_cs, C, N, splitk=splitk, prec="fp32")
+            torch.cuda.synchronize()
+            outs.append(C.cpu())
+        finally:
+            lib.pk_gemm_f32_set_form(0)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_strided_rows_and_unaligned():
     """forward_model hands column slices (row stride = feat + labels, utils.py:2321)."""
     g = torch.Generator().manual_seed(1)

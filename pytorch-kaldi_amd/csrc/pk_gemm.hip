@@ -266,9 +266,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 //   1e-3 at step 24 - exactly what one ulp on the inputs does to the reference's own run, tools/diag_fp32_trajectory_floor.py).
 //   Pipeline: two stages; the DMA of tile kt + 1 is issued once tile kt's fragments sit in registers (all of a k-tile's
 //   fragments are read up front), so it flies under the tile's 32 MFMAs; ONE barrier per k-tile.
-// Covers operands with 16-byte aligned bases and leading dimensions, K % 4 == 0 for a k-contiguous operand, M (N) % 4 == 0
-// for an m- (n-) contiguous one; everything else takes the first form.  Rows beyond M / N are clamped (never stored);
-// 16-byte pieces beyond the end of the reduction come from a zero page.
+// Covers operands with 16-byte aligned bases and leading dimensions, K % 4 == 0 for a k-contiguous operand; everything else
+// takes the first form.  Rows beyond M / N are clamped (never stored); 16-byte pieces beyond the end of the reduction come
+// from a zero page.
 // ---------------------------------------------------------------------------
 __device__ float g_zero_page_f32[16];
 
@@ -603,7 +603,11 @@ extern "C" int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha,
             dma_on = (e && e[0] == '0') ? 0 : 1;
         }
         if (zp == nullptr) PK_CHECK_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page_f32)));
-        dma = dma_on && !g_f32_first_form && K > 0 && p.vecA && p.vecB && (a_kc ? (K % 4) == 0 : (M % 4) == 0) && (b_kc ? (K % 4) == 0 : (N % 4) == 0);
+        // k-contiguous operand: 16-byte pieces must not straddle the end of the reduction (K % 4 == 0).  m/n-contiguous
+        // operand: a piece may hang over the last row / column (those lanes' results are never stored) - a 16-byte aligned
+        // 16-byte read that begins inside the matrix never crosses a page, so it cannot fault
+        const bool okA = p.vecA != 0, okB = p.vecB != 0;
+        dma = dma_on && !g_f32_first_form && K > 0 && okA && okB && (!a_kc || (K % 4) == 0) && (!b_kc || (K % 4) == 0);
         if (dma) {
             const float* zeros = (const float*)zp;
             if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true>), grid, block, 0, st, p, zeros);

@@ -1593,6 +1593,33 @@ def choose_rec_algo(cell, H, use_ln):
 _DU_SPLITK = 16  # pk_rec.hip DU_SPLITK: the same split of the reduction (pk_gemm clamps it to 32-deep slices), so the same sums
 
 
+def _gemm_km_f32(M, N, K, A, a_ld, bflat, b_off, b_ld, oflat, overwrite, realign=True):
+    """oflat[M, N] (+)= A^T . Bm in exact fp32, both operands k-major (the dU products): A [K][a_ld], Bm = the N columns of
+    bflat's [K][b_ld] rows that start at element b_off.  The direction halves of a layer output / the slots of the saved
+    state start at multiples of H = 550 floats: 8-byte aligned.  The LDS-DMA form of the kernel wants 16-byte aligned
+    pieces (pk_gemm.hip: 41 -> ~90 TFLOP/s on these shapes), so such a product is taken over the columns from the
+    aligned boundary below b_off on (`shift` extra columns: 0.4 % more work) into a temporary whose first `shift` columns
+    are dropped - the same sums in the same order, added to oflat by the same fp32 add the kernel's beta = 1 does.
+    realign = False keeps the product on the register-staged kernel: next to a fourth-generation recurrence (LSTM / GRU /
+    minimalGRU, whose backward pass is bound by its polls through the XCD's L2) the faster product costs the recurrence
+    more than it returns - timit_lstm 120.8 ms per step without, 123.6 with (rec4_bwd 5.68 -> 6.24 ms per launch,
+    profiles/r06_fp32_gemm_dma.json) - while the Li-GRU's second-generation kernels gain (74.4 -> 71.6)."""
+    Bm = bflat[b_off:]
+    shift = (Bm.data_ptr() % 16) // 4
+    if not realign or shift == 0 or b_ld % 4 != 0 or a_ld % 4 != 0 or b_off < shift or _lib.experiment("f32_du_shift", "1") == "0":
+        gemm(M, N, K, A, 1, a_ld, Bm, b_ld, 1, oflat, N, beta=0.0 if overwrite else 1.0, splitk=_DU_SPLITK, prec="fp32")
+        return
+    Nw = N + shift
+    tmp = torch.empty(M, Nw, device=oflat.device, dtype=torch.float32)
+    gemm(M, Nw, K, A, 1, a_ld, bflat[b_off - shift:], b_ld, 1, tmp, Nw, beta=0.0, splitk=_DU_SPLITK, prec="fp32")
+    o2 = oflat[:M * N].view(M, N)
+    with torch.no_grad():
+        if overwrite:
+            o2.copy_(tmp[:, shift:])
+        else:
+            o2.add_(tmp[:, shift:])
+
+
 def _deferred_dU_f32(cell, T, B, ndir, H, G, NS, Y, S, dP2, out, accumulate):
     """dU[G*H, H] (+)= sum over directions and steps of dgate_t^T . (vector that fed U_g at step t) in exact fp32: what
     pk_rec_bwd does behind its recurrence when it is handed a dU (pk_rec.hip::deferred_dU), as separate launches so that
@@ -1604,21 +1631,20 @@ def _deferred_dU_f32(cell, T, B, ndir, H, G, NS, Y, S, dP2, out, accumulate):
     Kh = (T - 1) * B
     dflat, yflat, sflat, oflat = dP2.reshape(-1), Y.reshape(-1), S.reshape(-1), out.reshape(-1)
     first = not accumulate
+    realign = cell in ("liGRU", "RNN") or _lib.experiment("f32_du_shift", "") == "all"  # (see _gemm_km_f32)
     if Kh == 0 and not accumulate:
         out[:Gh * H].zero_()
     for d in range(ndir if Kh > 0 else 0):
         # rows whose previous state exists: dir 0 -> ts >= 1 (h at ts-1); dir 1 -> ts <= T-2 (h at ts+1)
         A = dflat[(d * TB + (0 if d else B)) * GH:]
-        Bm = yflat[(B if d else 0) * YH + d * H:]
-        gemm(Gh * H, H, Kh, A, 1, GH, Bm, YH, 1, oflat, H, beta=0.0 if first else 1.0, splitk=_DU_SPLITK, prec="fp32")
+        _gemm_km_f32(Gh * H, H, Kh, A, GH, yflat, (B if d else 0) * YH + d * H, YH, oflat, first, realign)
         first = False
     if two_phase:  # candidate gate: dU_h = sum dA^T . (r*h) or (z*h), saved in S, same row
         slot = 3 if cell == "GRU" else 2
         for d in range(ndir):
             A = dflat[d * TB * GH + Gh * H:]
-            Bm = sflat[d * TB * NS * H + slot * H:]
-            gemm(H, H, TB, A, 1, GH, Bm, NS * H, 1, oflat[Gh * H * H:], H, beta=1.0 if (accumulate or d) else 0.0,
-                 splitk=_DU_SPLITK, prec="fp32")
+            _gemm_km_f32(H, H, TB, A, GH, sflat, d * TB * NS * H + slot * H, NS * H, oflat[Gh * H * H:], not (accumulate or d),
+                         realign)
 
 
 def _deferred_dU_bf16(lib, cell, T, B, ndir, H, G, Y, S, dP2, dU, Yb=None, dGb=None, Xb=None):

@@ -139,6 +139,40 @@ def test_gemm_f32_forms_bit_identical(M, N, K, a_kc, b_kc, splitk):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("b_off", [0, 550, 3 * 1100 + 550, 1650])
+@pytest.mark.parametrize("overwrite", [True, False])
+def test_gemm_km_f32_offsets(b_off, overwrite):
+    """The dU products of the exact-fp32 mode (functional._gemm_km_f32): k-major x k-major over the rows of wider
+    matrices, the second operand starting at a multiple of H = 550 floats (8-byte aligned: taken from the 16-byte
+    boundary below, the extra columns dropped; 550 columns = a ragged last 16-byte piece).  Against fp64, and bit for bit
+    against the register-staged form of the kernel on the unshifted operand."""
+    import importlib
+
+    lib = importlib.import_module("pytorch-kaldi_amd._lib").load()
+    g = torch.Generator().manual_seed(b_off + 3)
+    K, M, N, a_ld, b_ld = 3000, 1100, 550, 1100, 2200
+    A = torch.randn(K + 8, a_ld, generator=g).cuda()
+    Bw = torch.randn(K + 8, b_ld, generator=g).cuda()
+    C0 = torch.randn(M, N, generator=g).cuda()
+    aflat, bflat = A.reshape(-1)[2 * a_ld:], Bw.reshape(-1)
+    Bsub = bflat[b_off:b_off + K * b_ld].view(K, b_ld)[:, :N] if b_off + K * b_ld <= bflat.numel() else None
+    outs = []
+    for form in (1, 0):
+        lib.pk_gemm_f32_set_form(form)
+        try:
+            C = C0.clone()
+            F_._gemm_km_f32(M, N, K, aflat, a_ld, bflat, b_off, b_ld, C.view(-1), overwrite)
+            torch.cuda.synchronize()
+            outs.append(C.cpu())
+        finally:
+            lib.pk_gemm_f32_set_form(0)
+    assert torch.equal(outs[0], outs[1])
+    ref = A[2:2 + K, :M].double().t() @ Bsub.double()
+    if not overwrite:
+        ref = ref + C0.double()
+    assert rel_err(outs[1], ref) < 2e-6
+
+
 def test_gemm_strided_rows_and_unaligned():
     """forward_model hands column slices (row stride = feat + labels, utils.py:2321)."""
     g = torch.Generator().manual_seed(1)

@@ -35,7 +35,6 @@ struct GemmArgs {
     int k_per_split;  // multiple of BK
     int vecA, vecB;   // 16-B vector loads allowed for A / B
     int gx, gy, items, per_xcd;  // tiles along n / m, tiles x splits, items per XCD (1-D launch, see work_item)
-    int dbg;
 };
 
 constexpr int BM = 128, BN = 128;
@@ -220,10 +219,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk && !(p.dbg & 2)) {
-            const int kn = (p.dbg & 1) ? kbeg : kbeg + (kt + 1) * BK;
-            la.load(p.A, p.a_rs, p.a_cs, m0, kn, p.M, kend, p.vecA, tid);
-            lb.load(p.B, p.b_cs, p.b_rs, n0, kn, p.N, kend, p.vecB, tid);
+        if (kt + 1 < nk) {
+            la.load(p.A, p.a_rs, p.a_cs, m0, kbeg + (kt + 1) * BK, p.M, kend, p.vecA, tid);
+            lb.load(p.B, p.b_cs, p.b_rs, n0, kbeg + (kt + 1) * BK, p.N, kend, p.vecB, tid);
         }
         const float* as = As[cur];
         const float* bs = Bs[cur];
@@ -246,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         }
         __syncthreads();
     }
-    if (!(p.dbg & 4)) store_acc(p, acc, m0, n0, wm, wn, lane, split);
+    store_acc(p, acc, m0, n0, wm, wn, lane, split);
 }
 
 // ---------------------------------------------------------------------------
@@ -434,7 +432,7 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs p, const flo
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[s_][i], bop[s_][j], acc[i][j], 0, 0, 0);
     }
-    if (!(p.dbg & 4)) store_acc(p, acc, m0, n0, wm, wn, lane, split);
+    store_acc(p, acc, m0, n0, wm, wn, lane, split);
 }
 
 // ---------------------------------------------------------------------------
@@ -580,12 +578,6 @@ extern "C" int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha,
             flat = e ? atoi(e) : 0;
         }
         if (flat) p.per_xcd = 0;
-        static int dbg = -1;
-        if (dbg < 0) {
-            const char* e = pk_experiment("f32_dbg");
-            dbg = e ? atoi(e) : 0;
-        }
-        p.dbg = dbg;
     }
 #define PK_LAUNCH_GEMM(KERN)                                                              \
     do {                                                                                  \

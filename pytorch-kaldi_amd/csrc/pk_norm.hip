@@ -343,6 +343,86 @@ __global__ __launch_bounds__(256) void col_reduce_partial_kernel(const float* __
     }
 }
 
+// The same reduction with a thread owning FOUR consecutive columns (16-byte loads; two rows in flight per thread): the
+// scalar form above reads 4 bytes per lane and load and runs at 1.7-1.9 TB/s on the exact-fp32 mode's [64000 x 1100..2200]
+// gate gradients.  Same row lanes, same rows per lane in the same order, same expression per column: the partial sums are
+// bit-identical to the scalar form's (tests/test_gpu_kernels.py::test_bn_bwd_f32_forms_bit_identical).  Needs 16-byte
+// aligned operands and N, ldg, ldx multiples of 4.
+constexpr int VCOLS = 64 * 4;  // columns per block: 64 threads x 4
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_partial_v4_kernel(const float* __restrict__ g,
+                                                                     const float* __restrict__ g2, long ldg,
+                                                                     const float* __restrict__ x, long ldx, long M, long N,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ var, float eps,
+                                                                     float* __restrict__ partial) {
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * VCOLS + cx * 4;
+    const int rb = gridDim.y;
+    const long rows_per = (M + rb - 1) / rb;
+    const long r0 = (long)blockIdx.y * rows_per;
+    const long r1 = min(M, r0 + rows_per);
+    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+        f32x4 mu = f32x4{0.f, 0.f, 0.f, 0.f}, inv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (MODE == 0) {
+            mu = *reinterpret_cast<const f32x4*>(mean + c);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(var + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) inv[e] = 1.0f / sqrtf(vv[e] + eps);
+        }
+        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (long r = r0 + ry; r < r1; r += 2 * RLANES) {
+            const bool second = r + RLANES < r1;
+            const long rs = second ? r + RLANES : r;  // (clamped: no branch around a load)
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(g + r * ldg + c);
+            const f32x4 gb = *reinterpret_cast<const f32x4*>(g + rs * ldg + c);
+            const f32x4 ha = g2 ? *reinterpret_cast<const f32x4*>(g2 + r * ldg + c) : zero;
+            const f32x4 hb = g2 ? *reinterpret_cast<const f32x4*>(g2 + rs * ldg + c) : zero;
+            f32x4 xa = zero, xb = zero;
+            if (MODE == 0) {
+                xa = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+                xb = *reinterpret_cast<const f32x4*>(x + rs * ldx + c);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float gv = ga[e];
+                if (g2) gv += ha[e];
+                s0[e] += gv;
+                if (MODE == 0) s1[e] += gv * ((xa[e] - mu[e]) * inv[e]);
+            }
+            if (second) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float gv = gb[e];
+                    if (g2) gv += hb[e];
+                    s0[e] += gv;
+                    if (MODE == 0) s1[e] += gv * ((xb[e] - mu[e]) * inv[e]);
+                }
+            }
+        }
+    }
+    __shared__ float sh[RLANES][VCOLS][2];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sh[ry][cx * 4 + e][0] = s0[e];
+        sh[ry][cx * 4 + e][1] = s1[e];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < VCOLS; o += 256) {
+        const long cc = (long)blockIdx.x * VCOLS + o;
+        if (cc >= N) continue;
+        float a0 = 0.f, a1 = 0.f;
+        for (int k = 0; k < RLANES; ++k) {
+            a0 += sh[k][o][0];
+            a1 += sh[k][o][1];
+        }
+        float* op = partial + ((long)blockIdx.y * N + cc) * 2;
+        op[0] = a0;
+        op[1] = a1;
+    }
+}
+
 // Final column sums of [rb][N][2] partials: a block is 16 columns x 16 row-groups (N / 16 blocks: 69 at N = 1100 - with 32
 // columns per block the 35 blocks of the first version took 40 us per call, seven calls per training step); a thread
 // keeps eight partial rows in flight; fixed reduction order, deterministic run to run.
@@ -419,6 +499,60 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
         if (g2) gv += g2[r * ldg + c];
         const float ga = gamma ? gamma[c] : 1.f;
         dx[r * lddx + c] = ga * inv * (gv - sum_g[c] * inv_count - xh * sum_gx[c] * inv_count);
+    }
+}
+
+// ... and its 16-byte form (a thread owns four consecutive columns of a strip of rows; the per-column constants are formed
+// once per thread instead of one 64-bit division, one square root and five gathers per element): the same expression
+// per element, bit-identical results.
+__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ g, const float* __restrict__ g2,
+                                                               long ldg, const float* __restrict__ x, long ldx, long M,
+                                                               long N, const float* __restrict__ mean,
+                                                               const float* __restrict__ var, float eps,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ sum_g,
+                                                               const float* __restrict__ sum_gx, float inv_count,
+                                                               float* __restrict__ dx, long lddx) {
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const long c = (long)blockIdx.x * VCOLS + cx * 4;
+    if (c >= N) return;
+    const int rb = gridDim.y;
+    const long rows_per = (M + rb - 1) / rb;
+    const long r0 = (long)blockIdx.y * rows_per;
+    const long r1 = min(M, r0 + rows_per);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), vv = *reinterpret_cast<const f32x4*>(var + c);
+    const f32x4 sg = *reinterpret_cast<const f32x4*>(sum_g + c), sx = *reinterpret_cast<const f32x4*>(sum_gx + c);
+    f32x4 ga = f32x4{1.f, 1.f, 1.f, 1.f}, inv;
+    if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) inv[e] = 1.0f / sqrtf(vv[e] + eps);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long r = r0 + ry; r < r1; r += 2 * RLANES) {
+        const bool second = r + RLANES < r1;
+        const long rs = second ? r + RLANES : r;
+        const f32x4 ga_ = *reinterpret_cast<const f32x4*>(g + r * ldg + c);
+        const f32x4 gb_ = *reinterpret_cast<const f32x4*>(g + rs * ldg + c);
+        const f32x4 ha = g2 ? *reinterpret_cast<const f32x4*>(g2 + r * ldg + c) : zero;
+        const f32x4 hb = g2 ? *reinterpret_cast<const f32x4*>(g2 + rs * ldg + c) : zero;
+        const f32x4 xa = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+        const f32x4 xb = *reinterpret_cast<const f32x4*>(x + rs * ldx + c);
+        f32x4 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xa[e] - mu[e]) * inv[e];
+            float gv = ga_[e];
+            if (g2) gv += ha[e];
+            oa[e] = ga[e] * inv[e] * (gv - sg[e] * inv_count - xh * sx[e] * inv_count);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xb[e] - mu[e]) * inv[e];
+            float gv = gb_[e];
+            if (g2) gv += hb[e];
+            ob[e] = ga[e] * inv[e] * (gv - sg[e] * inv_count - xh * sx[e] * inv_count);
+        }
+        *reinterpret_cast<f32x4*>(dx + r * lddx + c) = oa;
+        if (second) *reinterpret_cast<f32x4*>(dx + rs * lddx + c) = ob;
     }
 }
 
@@ -942,14 +1076,33 @@ extern "C" int pk_act_bwd(void* stream, const float* dy, const float* a, const f
     return 0;
 }
 
+// the 16-byte forms of the exact-fp32 BatchNorm-backward passes: aligned operands, N and the leading dimensions multiples
+// of 4 (PK_EXPERIMENT bn_f32_vec=0: the scalar forms for every shape)
+static bool bn_f32_vec_ok(int64_t N, int64_t ldg, int64_t ldx, const void* g, const void* g2, const void* x, const void* mean,
+                          const void* var, const void* gamma) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = pk_experiment("bn_f32_vec");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    auto al = [](const void* p_) { return p_ == nullptr || ((uintptr_t)p_ & 15) == 0; };
+    return on && (N % 4) == 0 && (ldg % 4) == 0 && (ldx % 4) == 0 && al(g) && al(g2) && al(x) && al(mean) && al(var) && al(gamma);
+}
+
 extern "C" int pk_bn_bwd_reduce(void* stream, const float* g, const float* g2, int64_t ldg, const float* x, int64_t ldx,
                                 int64_t M, int64_t N, const float* mean, const float* var, float eps, float* partial,
                                 float* sum_g, float* sum_gx) {
     hipStream_t st = pk_stream(stream);
     const int rb = row_blocks(M);
-    dim3 grid((unsigned)((N + COLS - 1) / COLS), rb);
-    hipLaunchKernelGGL(col_reduce_partial_kernel<0>, grid, dim3(256), 0, st, g, g2, (long)ldg, x, (long)ldx, (long)M,
-                       (long)N, mean, var, eps, partial);
+    if (bn_f32_vec_ok(N, ldg, ldx, g, g2, x, mean, var, nullptr)) {
+        dim3 vgrid((unsigned)((N + VCOLS - 1) / VCOLS), rb);
+        hipLaunchKernelGGL(col_reduce_partial_v4_kernel<0>, vgrid, dim3(256), 0, st, g, g2, (long)ldg, x, (long)ldx, (long)M,
+                           (long)N, mean, var, eps, partial);
+    } else {
+        dim3 grid((unsigned)((N + COLS - 1) / COLS), rb);
+        hipLaunchKernelGGL(col_reduce_partial_kernel<0>, grid, dim3(256), 0, st, g, g2, (long)ldg, x, (long)ldx, (long)M,
+                           (long)N, mean, var, eps, partial);
+    }
     PK_LAUNCH_CHECK();
     hipLaunchKernelGGL(col_reduce_final_kernel, dim3((unsigned)((N + CF_COLS - 1) / CF_COLS)), dim3(CF_COLS * CF_GROUPS), 0, st, partial, rb, (long)N,
                        sum_g, sum_gx, (float*)nullptr, (float*)nullptr, (unsigned short*)nullptr, 0L, 0L, 0);
@@ -960,9 +1113,16 @@ extern "C" int pk_bn_bwd_reduce(void* stream, const float* g, const float* g2, i
 extern "C" int pk_bn_bwd_apply(void* stream, const float* g, const float* g2, int64_t ldg, const float* x, int64_t ldx,
                                int64_t M, int64_t N, const float* mean, const float* var, float eps, const float* gamma,
                                const float* sum_g, const float* sum_gx, double count, float* dx, int64_t lddx) {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * N)), dim3(256), 0, pk_stream(stream), g, g2, (long)ldg, x,
-                       (long)ldx, (long)M, (long)N, mean, var, eps, gamma, sum_g, sum_gx, (float)(1.0 / count), dx,
-                       (long)lddx);
+    if (bn_f32_vec_ok(N, ldg, ldx, g, g2, x, mean, var, gamma) && (lddx % 4) == 0 && ((uintptr_t)dx & 15) == 0 &&
+        ((uintptr_t)sum_g & 15) == 0 && ((uintptr_t)sum_gx & 15) == 0) {
+        dim3 vgrid((unsigned)((N + VCOLS - 1) / VCOLS), row_blocks(M));
+        hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, vgrid, dim3(256), 0, pk_stream(stream), g, g2, (long)ldg, x, (long)ldx,
+                           (long)M, (long)N, mean, var, eps, gamma, sum_g, sum_gx, (float)(1.0 / count), dx, (long)lddx);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * N)), dim3(256), 0, pk_stream(stream), g, g2, (long)ldg, x,
+                           (long)ldx, (long)M, (long)N, mean, var, eps, gamma, sum_g, sum_gx, (float)(1.0 / count), dx,
+                           (long)lddx);
+    }
     PK_LAUNCH_CHECK();
     return 0;
 }

@@ -173,6 +173,47 @@ def test_gemm_km_f32_offsets(b_off, overwrite):
     assert rel_err(outs[1], ref) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,two", [(64000, 1100, True), (1000, 2200, True), (333, 132, False), (80, 48, True)])
+def test_bn_bwd_f32_forms_bit_identical(M, N, two):
+    """The 16-byte forms of the exact-fp32 BatchNorm-backward passes (pk_bn_bwd_reduce / pk_bn_bwd_apply on aligned
+    operands) against the scalar forms (the same call with the gate gradient one float off alignment): the same row lanes,
+    rows and expressions per column - sums and outputs equal bit for bit; and against fp64."""
+    import ctypes
+    import importlib
+
+    _lib = importlib.import_module("pytorch-kaldi_amd._lib")
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(M + N)
+    g = torch.randn(M, N, generator=gen).cuda()
+    g2 = torch.randn(M, N, generator=gen).cuda() if two else None
+    x = (torch.randn(M, N, generator=gen) * 2 + 0.3).cuda()
+    gamma = (torch.rand(N, generator=gen) + 0.5).cuda()
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(gt):
+        part = torch.empty(int(lib.pk_bn_partial_floats(M, N)), device="cuda")
+        sg, sx, dx = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(M, N, device="cuda")
+        _lib.check(lib.pk_bn_bwd_reduce(st, p(gt), p(g2), N, p(x), N, M, N, p(mean), p(var), 1e-5, p(part), p(sg), p(sx)), "reduce")
+        _lib.check(lib.pk_bn_bwd_apply(st, p(gt), p(g2), N, p(x), N, M, N, p(mean), p(var), 1e-5, p(gamma), p(sg), p(sx),
+                                       float(M), p(dx), N), "apply")
+        torch.cuda.synchronize()
+        return sg.cpu(), sx.cpu(), dx.cpu()
+
+    odd = torch.empty(M * N + 1, device="cuda")[1:].view(M, N)  # 4-byte aligned only: the scalar forms
+    odd.copy_(g)
+    a, b = run(g), run(odd)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    gd = g.double() + (g2.double() if two else 0)
+    inv = 1.0 / torch.sqrt(var.double() + 1e-5)
+    xh = (x.double() - mean.double()) * inv
+    sg_ref, sx_ref = gd.sum(0), (gd * xh).sum(0)
+    dx_ref = gamma.double() * inv * (gd - sg_ref / M - xh * sx_ref / M)
+    assert rel_err(a[0], sg_ref) < 1e-5 and rel_err(a[1], sx_ref) < 1e-5 and rel_err(a[2], dx_ref) < 1e-5
+
+
 def test_gemm_strided_rows_and_unaligned():
     """forward_model hands column slices (row stride = feat + labels, utils.py:2321)."""
     g = torch.Generator().manual_seed(1)

@@ -298,6 +298,26 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     }
 }
 
+// The element arithmetic of the exact-fp32 BatchNorm-backward passes, shared by their scalar and 16-byte forms with the
+// contraction spelled out: the compiler contracts a loop-invariant product differently in the two loop shapes, and aligned
+// and unaligned operands must not give different bits.  The forms chosen are the ones the scalar kernels had compiled to since
+// round 1 (the 30-step trajectory fixture is pinned on those bits: any other rounding of these two lines moves it past 1e-4).
+__device__ __forceinline__ float bnb_f32_xhat(float x, float mu, float inv) {
+#pragma clang fp contract(off)
+    return (x - mu) * inv;
+}
+__device__ __forceinline__ float bnb_f32_gx(float gv, float xh, float acc) {  // acc + round(gv * xh): no fma
+#pragma clang fp contract(off)
+    const float t = gv * xh;
+    return acc + t;
+}
+__device__ __forceinline__ float bnb_f32_dx(float ga, float inv, float gv, float sg, float sx, float xh, float inv_count) {
+#pragma clang fp contract(off)
+    const float t0 = __builtin_fmaf(-inv_count, sg, gv);
+    const float t1 = (xh * sx) * inv_count;
+    return (ga * inv) * (t0 - t1);
+}
+
 // ---- BatchNorm backward reductions --------------------------------------------
 // MODE 0: sum_g, sum_g*xhat   MODE 1: column sum only
 template <int MODE>
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(256) void col_reduce_partial_kernel(const float* __
             float gv = g[r * ldg + c];
             if (g2) gv += g2[r * ldg + c];
             s0 += gv;
-            if (MODE == 0) s1 += gv * ((x[r * ldx + c] - mu) * inv);
+            if (MODE == 0) s1 = bnb_f32_gx(gv, bnb_f32_xhat(x[r * ldx + c], mu, inv), s1);
         }
     }
     __shared__ float sh[RLANES][COLS][2];
@@ -389,7 +409,7 @@ __global__ __launch_bounds__(256) void col_reduce_partial_v4_kernel(const float*
                 float gv = ga[e];
                 if (g2) gv += ha[e];
                 s0[e] += gv;
-                if (MODE == 0) s1[e] += gv * ((xa[e] - mu[e]) * inv[e]);
+                if (MODE == 0) s1[e] = bnb_f32_gx(gv, bnb_f32_xhat(xa[e], mu[e], inv[e]), s1[e]);
             }
             if (second) {
 #pragma unroll
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(256) void col_reduce_partial_v4_kernel(const float*
                     float gv = gb[e];
                     if (g2) gv += hb[e];
                     s0[e] += gv;
-                    if (MODE == 0) s1[e] += gv * ((xb[e] - mu[e]) * inv[e]);
+                    if (MODE == 0) s1[e] = bnb_f32_gx(gv, bnb_f32_xhat(xb[e], mu[e], inv[e]), s1[e]);
                 }
             }
         }
@@ -494,11 +514,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / N, c = i - r * N;
         const float inv = 1.0f / sqrtf(var[c] + eps);
-        const float xh = (x[r * ldx + c] - mean[c]) * inv;
+        const float xh = bnb_f32_xhat(x[r * ldx + c], mean[c], inv);
         float gv = g[r * ldg + c];
         if (g2) gv += g2[r * ldg + c];
         const float ga = gamma ? gamma[c] : 1.f;
-        dx[r * lddx + c] = ga * inv * (gv - sum_g[c] * inv_count - xh * sum_gx[c] * inv_count);
+        dx[r * lddx + c] = bnb_f32_dx(ga, inv, gv, sum_g[c], sum_gx[c], xh, inv_count);
     }
 }
 
@@ -539,17 +559,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
         f32x4 oa, ob;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xh = (xa[e] - mu[e]) * inv[e];
+            const float xh = bnb_f32_xhat(xa[e], mu[e], inv[e]);
             float gv = ga_[e];
             if (g2) gv += ha[e];
-            oa[e] = ga[e] * inv[e] * (gv - sg[e] * inv_count - xh * sx[e] * inv_count);
+            oa[e] = bnb_f32_dx(ga[e], inv[e], gv, sg[e], sx[e], xh, inv_count);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float xh = (xb[e] - mu[e]) * inv[e];
+            const float xh = bnb_f32_xhat(xb[e], mu[e], inv[e]);
             float gv = gb_[e];
             if (g2) gv += hb[e];
-            ob[e] = ga[e] * inv[e] * (gv - sg[e] * inv_count - xh * sx[e] * inv_count);
+            ob[e] = bnb_f32_dx(ga[e], inv[e], gv, sg[e], sx[e], xh, inv_count);
         }
         *reinterpret_cast<f32x4*>(dx + r * lddx + c) = oa;
         if (second) *reinterpret_cast<f32x4*>(dx + rs * lddx + c) = ob;

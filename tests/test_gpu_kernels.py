@@ -204,8 +204,8 @@ def test_bn_bwd_f32_forms_bit_identical(M, N, two):
     odd = torch.empty(M * N + 1, device="cuda")[1:].view(M, N)  # 4-byte aligned only: the scalar forms
     odd.copy_(g)
     a, b = run(g), run(odd)
-    for u, v in zip(a, b):
-        assert torch.equal(u, v)
+    for name, u, v in zip(("sum_g", "sum_gx", "dx"), a, b):
+        assert torch.equal(u, v), (name, float((u - v).abs().max()))
     gd = g.double() + (g2.double() if two else 0)
     inv = 1.0 / torch.sqrt(var.double() + 1e-5)
     xh = (x.double() - mean.double()) * inv

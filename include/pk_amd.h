@@ -221,6 +221,9 @@ int pk_layernorm_bwd(void* stream, const float* dy, const float* x, int64_t rows
 /* ---- LogSoftmax(dim=1): neural_networks.py:53-54 ('softmax' activation) */
 int pk_logsoftmax_fwd(void* stream, const float* x, int64_t rows, int64_t N, float* y);
 int pk_logsoftmax_bwd(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, float* dx);
+/* the same backward writing dx at a pitch of lddx floats (N rounded up to a multiple of 4: 16-byte aligned rows for the
+ * dX / dW GEMMs of the Linear in front - 1938 senones; pad columns zeroed); N <= 2048 */
+int pk_logsoftmax_bwd_ld(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, float* dx, int64_t lddx);
 /* the same forward over an input whose rows sit at a pitch of ldx floats (the padded output of the head's GEMM) */
 int pk_logsoftmax_fwd_ld(void* stream, const float* x, int64_t ldx, int64_t rows, int64_t N, float* y);
 /* Perf mode, Linear -> LogSoftmax heads (neural_networks.py:139-148 with dnn_act = softmax; the cost the reference

@@ -61,6 +61,7 @@ SIGNATURES = {
     "pk_layernorm_bwd": (c_int, [P, P, P, c_int64, c_int64, P, P, P, c_float, P, P]),
     "pk_logsoftmax_fwd": (c_int, [P, P, c_int64, c_int64, P]),
     "pk_logsoftmax_bwd": (c_int, [P, P, P, c_int64, c_int64, P]),
+    "pk_logsoftmax_bwd_ld": (c_int, [P, P, P, c_int64, c_int64, P, c_int64]),
     "pk_logsoftmax_fwd_ld": (c_int, [P, P, c_int64, c_int64, c_int64, P]),
     "pk_logsoftmax_fwd_ld_argmax": (c_int, [P, P, c_int64, c_int64, c_int64, P, P]),
     "pk_logsoftmax_bwd_bf16_partial_floats": (c_int64, [c_int64, c_int64]),

@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 //   1e-3 at step 24 - exactly what one ulp on the inputs does to the reference's own run, tools/diag_fp32_trajectory_floor.py).
 //   Pipeline: two stages; the DMA of tile kt + 1 is issued once tile kt's fragments sit in registers (all of a k-tile's
 //   fragments are read up front), so it flies under the tile's 32 MFMAs; ONE barrier per k-tile.
-// Covers operands with 16-byte aligned bases and leading dimensions, K % 4 == 0 for a k-contiguous operand; everything else
-// takes the first form.  Rows beyond M / N are clamped (never stored); 16-byte pieces beyond the end of the reduction come
+// Covers operands with 16-byte aligned bases and leading dimensions that are multiples of 4 floats; everything else takes
+// the first form.  Rows beyond M / N are clamped (never stored); 16-byte pieces beyond the end of the reduction come
 // from a zero page.
 // ---------------------------------------------------------------------------
 __device__ float g_zero_page_f32[16];
@@ -357,8 +357,25 @@ __global__ __launch_bounds__(256) void gemm_f32_dma_kernel(GemmArgs p, const flo
     if (nk > 0) fetch(0, smem);
     const int h = lane >> 5, l31 = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
-        const unsigned char* cur = smem + (kt & 1) * STG;
+        unsigned char* cur = smem + (kt & 1) * STG;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((A_KC || B_KC) && kt == nk - 1 && (kend & 3) != 0) {
+            // K is not a multiple of 4: the 16-byte piece of a k-contiguous operand that straddles the end of the reduction has
+            // landed with what follows the row in memory - its elements at k >= K are zeroed here (the thread that fetched a
+            // piece owns its LDS slot), so the tile adds exact zeros like the first form's
+            const int k0 = kbeg + kt * BK;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = j * 256 + tid;
+                const int gk = k0 + (((q & 3) ^ f32_swz(q >> 2)) * 4);
+                if (gk < kend && gk + 4 > kend) {
+                    for (int e = kend - gk; e < 4; ++e) {
+                        if (A_KC) *reinterpret_cast<float*>(cur + q * 16 + e * 4) = 0.f;
+                        if (B_KC) *reinterpret_cast<float*>(cur + OPB + q * 16 + e * 4) = 0.f;
+                    }
+                }
+            }
+        }
         __syncthreads();  // tile kt has landed for every wave; everybody is done reading the other buffer
         // all fragments of the k-tile up front.  MFMA s multiplies k = 2 s (lanes 0-31) and k = 2 s + 1 (lanes 32-63), in that
         // order: every output element is ONE fmaf chain over ascending k, as in the first form.  A k-contiguous operand is
@@ -595,11 +612,11 @@ extern "C" int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha,
             dma_on = (e && e[0] == '0') ? 0 : 1;
         }
         if (zp == nullptr) PK_CHECK_HIP(hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page_f32)));
-        // k-contiguous operand: 16-byte pieces must not straddle the end of the reduction (K % 4 == 0).  m/n-contiguous
-        // operand: a piece may hang over the last row / column (those lanes' results are never stored) - a 16-byte aligned
-        // 16-byte read that begins inside the matrix never crosses a page, so it cannot fault
+        // a 16-byte piece may hang over the end of the reduction (k-contiguous operand: zeroed in LDS) or over the last row /
+        // column (m/n-contiguous operand: those lanes' results are never stored) - a 16-byte aligned 16-byte read that begins
+        // inside the matrix never crosses a page, so it cannot fault
         const bool okA = p.vecA != 0, okB = p.vecB != 0;
-        dma = dma_on && !g_f32_first_form && K > 0 && okA && okB && (!a_kc || (K % 4) == 0) && (!b_kc || (K % 4) == 0);
+        dma = dma_on && !g_f32_first_form && K > 0 && okA && okB;
         if (dma) {
             const float* zeros = (const float*)zp;
             if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_dma_kernel<true, true>), grid, block, 0, st, p, zeros);

@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256) void logsoftmax_fwd_wave_kernel(const float* _
 
 template <int NPL>
 __global__ __launch_bounds__(256) void logsoftmax_bwd_wave_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                                   long rows, long N, float* __restrict__ dx) {
+                                                                   long rows, long N, float* __restrict__ dx, long lddx) {
     const int lane = threadIdx.x & 63;
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
     for (long r = wid; r < rows; r += nw) {
@@ -839,7 +839,8 @@ __global__ __launch_bounds__(256) void logsoftmax_bwd_wave_kernel(const float* _
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             const long c = lane + 64 * i;
-            if (c < N) dx[r * N + c] = g[i] - expf(e[i]) * sum;
+            if (c < N) dx[r * lddx + c] = g[i] - expf(e[i]) * sum;
+            else if (c < lddx) dx[r * lddx + c] = 0.f;  // (pad columns of a re-pitched gradient)
         }
     }
 }
@@ -1586,11 +1587,22 @@ extern "C" int pk_nll_err_fwd_argmax(void* stream, const float* y, const int64_t
     return 0;
 }
 
+extern "C" int pk_logsoftmax_bwd_ld(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, float* dx,
+                                    int64_t lddx) {
+    if (rows == 0) return 0;
+    PK_REQUIRE(N <= 2048 && lddx >= N && lddx <= ((N + 3) & ~(int64_t)3),
+               "pk_logsoftmax_bwd_ld: rows of up to 2048 classes, output pitch N rounded up to at most 4 (got N=%ld, pitch %ld)", (long)N, (long)lddx);
+    hipStream_t st = pk_stream(stream);
+    PK_LSM_DISPATCH(logsoftmax_bwd_wave_kernel, dy, y, (long)rows, (long)N, dx, (long)lddx);
+    PK_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int pk_logsoftmax_bwd(void* stream, const float* dy, const float* y, int64_t rows, int64_t N, float* dx) {
     if (rows == 0) return 0;
     hipStream_t st = pk_stream(stream);
     if (N <= 2048) {
-        PK_LSM_DISPATCH(logsoftmax_bwd_wave_kernel, dy, y, (long)rows, (long)N, dx);
+        PK_LSM_DISPATCH(logsoftmax_bwd_wave_kernel, dy, y, (long)rows, (long)N, dx, (long)N);
     } else {
         int blocks = (int)(rows < 8192 ? rows : 8192);
         hipLaunchKernelGGL(logsoftmax_bwd_kernel, dim3(blocks), dim3(256), 0, st, dy, y, (long)rows, (long)N, dx);

@@ -734,7 +734,12 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, weight = ctx.saved_tensors
         M, N, K = ctx.dims
-        dy2 = _rows2d(dy.contiguous())
+        if (not ctx.bf and dy.dim() == 2 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.stride(0) >= N
+                and dy.data_ptr() % 16 == 0):
+            dy2 = dy  # (a re-pitched gradient - LogSoftmaxFn.backward - is read at its own pitch)
+        else:
+            dy2 = _rows2d(dy.contiguous())
+        ldy = dy2.stride(0)
         dx = dw = db = None
         if ctx.bf:
             dx, dw = _linear_bwd_bf16(ctx, cvt_bf16(dy2), x2, weight, dy2)
@@ -743,17 +748,17 @@ class LinearFn(torch.autograd.Function):
             return dx, dw, db
         if ctx.needs_input_grad[0]:
             dx = _new(M, K, like=dy2)
-            gemm(M, K, N, dy2, N, 1, weight, K, 1, dx, K)
+            gemm(M, K, N, dy2, ldy, 1, weight, K, 1, dx, K)
             dx = dx.view(ctx.in_shape)
         if ctx.needs_input_grad[1]:
             wp = ctx.wparam
             sk = _splitk(_tiles(N, K), M)
             if M >= 4096 and wp is not None and wp.is_contiguous() and side_targets_any_ok([wp]):
                 # (round 6) off the dependency chain in the exact-fp32 mode too: on the side stream, straight into the flat .grad
-                side_launch(lambda: gemm(N, K, M, dy2, 1, N, x2, x2.stride(0), 1, wp.grad, K, beta=1.0, splitk=sk), (dy2, x2), [wp])
+                side_launch(lambda: gemm(N, K, M, dy2, 1, ldy, x2, x2.stride(0), 1, wp.grad, K, beta=1.0, splitk=sk), (dy2, x2), [wp])
             else:
                 dw = _new(N, K, like=dy2)
-                gemm(N, K, M, dy2, 1, N, x2, x2.stride(0), 1, dw, K, splitk=sk)
+                gemm(N, K, M, dy2, 1, ldy, x2, x2.stride(0), 1, dw, K, splitk=sk)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy2)
         return dx, dw, db
@@ -1539,6 +1544,14 @@ class LogSoftmaxFn(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         rows, N = y.shape
         dy2 = dy.contiguous()
+        if N % 4 != 0 and N <= 2048 and rows >= 4096 and _lib.experiment("f32_head_pitch", "1") != "0":
+            # a row-streaming head whose class count is not a multiple of 4 (1938 senones): the gradient is written at a pitch
+            # of N rounded up to 4, so that the dX / dW GEMMs of the Linear in front read 16-byte aligned rows (the LDS-DMA
+            # form of pk_gemm: 74 -> ~105 TFLOP/s on those two products); LinearFn.backward takes the view as it is
+            ld = _up(N, 4)
+            buf = torch.empty(rows, ld, device=y.device, dtype=torch.float32)
+            _lib.check(lib.pk_logsoftmax_bwd_ld(_stream(), _p(dy2), _p(y), rows, N, _p(buf), ld), "pk_logsoftmax_bwd_ld")
+            return buf[:, :N]
         dx = torch.empty_like(y)
         _lib.check(lib.pk_logsoftmax_bwd(_stream(), _p(dy2), _p(y), rows, N, _p(dx)), "pk_logsoftmax_bwd")
         return dx

@@ -214,6 +214,57 @@ def test_bn_bwd_f32_forms_bit_identical(M, N, two):
     assert rel_err(a[0], sg_ref) < 1e-5 and rel_err(a[1], sx_ref) < 1e-5 and rel_err(a[2], dx_ref) < 1e-5
 
 
+@pytest.mark.parametrize("b_kc", [False, True])
+@pytest.mark.parametrize("M,N,K", [(640, 1100, 1938), (130, 48, 18), (4096, 260, 50)])
+def test_gemm_f32_ragged_k_pitched(M, N, K, b_kc):
+    """k-contiguous operands whose K is not a multiple of 4 at a 16-byte aligned pitch (the 1938-senone head's gradient at
+    a pitch of 1940): the LDS-DMA form fetches the 16-byte piece that straddles the end of the reduction and zeroes its
+    tail in LDS - the pad columns hold NaN here.  Against fp64 and bit for bit against the first form."""
+    import importlib
+
+    lib = importlib.import_module("pytorch-kaldi_amd._lib").load()
+    g = torch.Generator().manual_seed(M + N + K)
+    Kp = (K + 3) // 4 * 4
+    A = torch.full((M, Kp), float("nan"))
+    A[:, :K] = torch.randn(M, K, generator=g)
+    if b_kc:
+        B = torch.full((N, Kp), float("nan"))
+        B[:, :K] = torch.randn(N, K, generator=g)
+        b_rs, b_cs, Bref = 1, Kp, B[:, :K].t()
+    else:
+        B = torch.randn(K, N, generator=g)
+        b_rs, b_cs, Bref = N, 1, B
+    Ad, Bd = A.cuda(), B.cuda()
+    outs = []
+    for form in (1, 0):
+        lib.pk_gemm_f32_set_form(form)
+        try:
+            C = torch.zeros(M, N).cuda()
+            F_.gemm(M, N, K, Ad, Kp, 1, Bd, b_rs, b_cs, C, N, prec="fp32")
+            torch.cuda.synchronize()
+            outs.append(C.cpu())
+        finally:
+            lib.pk_gemm_f32_set_form(0)
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[1], A[:, :K].double() @ Bref.double()) < 2e-6
+
+
+def test_logsoftmax_bwd_pitched_head():
+    """LogSoftmaxFn.backward of a row-streaming head with 1938 classes hands its gradient over at a pitch of 1940 (pad
+    zeroed); LinearFn.backward reads it there: x / weight / bias gradients against fp64 torch."""
+    g = torch.Generator().manual_seed(5)
+    M, K, N = 4096, 64, 1938
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    lab = torch.randint(0, N, (M,), generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    TF.nll_loss(TF.log_softmax(TF.linear(xr, wr, br), 1), lab).backward()
+    xe, we, be = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+    F_.set_precision("fp32")
+    TF.nll_loss(F_.log_softmax(F_.linear(xe, we, be)), lab.cuda()).backward()
+    for a, r in ((xe, xr), (we, wr), (be, br)):
+        assert rel_err(a.grad, r.grad) < 5e-6
+
+
 def test_gemm_strided_rows_and_unaligned():
     """forward_model hands column slices (row stride = feat + labels, utils.py:2321)."""
     g = torch.Generator().manual_seed(1)

@@ -368,44 +368,48 @@ __global__ __launch_bounds__(256) void col_reduce_partial_kernel(const float* __
 // gate gradients.  Same row lanes, same rows per lane in the same order, same expression per column: the partial sums are
 // bit-identical to the scalar form's (tests/test_gpu_kernels.py::test_bn_bwd_f32_forms_bit_identical).  Needs 16-byte
 // aligned operands and N, ldg, ldx multiples of 4.
-constexpr int VCOLS = 64 * 4;  // columns per block: 64 threads x 4
-template <int MODE>
-__global__ __launch_bounds__(256) void col_reduce_partial_v4_kernel(const float* __restrict__ g,
+template <int V> struct BnVec;
+template <> struct BnVec<4> { typedef f32x4 T; };
+template <> struct BnVec<2> { typedef pk_f32x2 T; };
+template <int MODE, int V>  // V = 4 (16-byte) or 2 (8-byte accesses: rows of 1650 floats - the GRU - are 8-byte aligned)
+__global__ __launch_bounds__(256) void col_reduce_partial_vec_kernel(const float* __restrict__ g,
                                                                      const float* __restrict__ g2, long ldg,
                                                                      const float* __restrict__ x, long ldx, long M, long N,
                                                                      const float* __restrict__ mean,
                                                                      const float* __restrict__ var, float eps,
                                                                      float* __restrict__ partial) {
+    typedef typename BnVec<V>::T VT;
+    constexpr int VCOLS = 64 * V;  // columns per block
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const long c = (long)blockIdx.x * VCOLS + cx * 4;
+    const long c = (long)blockIdx.x * VCOLS + cx * V;
     const int rb = gridDim.y;
     const long rows_per = (M + rb - 1) / rb;
     const long r0 = (long)blockIdx.y * rows_per;
     const long r1 = min(M, r0 + rows_per);
-    f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    VT s0 = VT(0.f), s1 = VT(0.f);
     if (c < N) {
-        f32x4 mu = f32x4{0.f, 0.f, 0.f, 0.f}, inv = f32x4{0.f, 0.f, 0.f, 0.f};
+        VT mu = VT(0.f), inv = VT(0.f);
         if (MODE == 0) {
-            mu = *reinterpret_cast<const f32x4*>(mean + c);
-            const f32x4 vv = *reinterpret_cast<const f32x4*>(var + c);
+            mu = *reinterpret_cast<const VT*>(mean + c);
+            const VT vv = *reinterpret_cast<const VT*>(var + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) inv[e] = 1.0f / sqrtf(vv[e] + eps);
+            for (int e = 0; e < V; ++e) inv[e] = 1.0f / sqrtf(vv[e] + eps);
         }
-        const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+        const VT zero = VT(0.f);
         for (long r = r0 + ry; r < r1; r += 2 * RLANES) {
             const bool second = r + RLANES < r1;
             const long rs = second ? r + RLANES : r;  // (clamped: no branch around a load)
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(g + r * ldg + c);
-            const f32x4 gb = *reinterpret_cast<const f32x4*>(g + rs * ldg + c);
-            const f32x4 ha = g2 ? *reinterpret_cast<const f32x4*>(g2 + r * ldg + c) : zero;
-            const f32x4 hb = g2 ? *reinterpret_cast<const f32x4*>(g2 + rs * ldg + c) : zero;
-            f32x4 xa = zero, xb = zero;
+            const VT ga = *reinterpret_cast<const VT*>(g + r * ldg + c);
+            const VT gb = *reinterpret_cast<const VT*>(g + rs * ldg + c);
+            const VT ha = g2 ? *reinterpret_cast<const VT*>(g2 + r * ldg + c) : zero;
+            const VT hb = g2 ? *reinterpret_cast<const VT*>(g2 + rs * ldg + c) : zero;
+            VT xa = zero, xb = zero;
             if (MODE == 0) {
-                xa = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
-                xb = *reinterpret_cast<const f32x4*>(x + rs * ldx + c);
+                xa = *reinterpret_cast<const VT*>(x + r * ldx + c);
+                xb = *reinterpret_cast<const VT*>(x + rs * ldx + c);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < V; ++e) {
                 float gv = ga[e];
                 if (g2) gv += ha[e];
                 s0[e] += gv;
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256) void col_reduce_partial_v4_kernel(const float*
             }
             if (second) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < V; ++e) {
                     float gv = gb[e];
                     if (g2) gv += hb[e];
                     s0[e] += gv;
@@ -424,9 +428,9 @@ __global__ __launch_bounds__(256) void col_reduce_partial_v4_kernel(const float*
     }
     __shared__ float sh[RLANES][VCOLS][2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        sh[ry][cx * 4 + e][0] = s0[e];
-        sh[ry][cx * 4 + e][1] = s1[e];
+    for (int e = 0; e < V; ++e) {
+        sh[ry][cx * V + e][0] = s0[e];
+        sh[ry][cx * V + e][1] = s1[e];
     }
     __syncthreads();
     for (int o = threadIdx.x; o < VCOLS; o += 256) {
@@ -525,7 +529,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
 // ... and its 16-byte form (a thread owns four consecutive columns of a strip of rows; the per-column constants are formed
 // once per thread instead of one 64-bit division, one square root and five gathers per element): the same expression
 // per element, bit-identical results.
-__global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __restrict__ g, const float* __restrict__ g2,
+template <int V>
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __restrict__ g, const float* __restrict__ g2,
                                                                long ldg, const float* __restrict__ x, long ldx, long M,
                                                                long N, const float* __restrict__ mean,
                                                                const float* __restrict__ var, float eps,
@@ -533,46 +538,48 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4_kernel(const float* __res
                                                                const float* __restrict__ sum_g,
                                                                const float* __restrict__ sum_gx, float inv_count,
                                                                float* __restrict__ dx, long lddx) {
+    typedef typename BnVec<V>::T VT;
+    constexpr int VCOLS = 64 * V;
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const long c = (long)blockIdx.x * VCOLS + cx * 4;
+    const long c = (long)blockIdx.x * VCOLS + cx * V;
     if (c >= N) return;
     const int rb = gridDim.y;
     const long rows_per = (M + rb - 1) / rb;
     const long r0 = (long)blockIdx.y * rows_per;
     const long r1 = min(M, r0 + rows_per);
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), vv = *reinterpret_cast<const f32x4*>(var + c);
-    const f32x4 sg = *reinterpret_cast<const f32x4*>(sum_g + c), sx = *reinterpret_cast<const f32x4*>(sum_gx + c);
-    f32x4 ga = f32x4{1.f, 1.f, 1.f, 1.f}, inv;
-    if (gamma) ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const VT mu = *reinterpret_cast<const VT*>(mean + c), vv = *reinterpret_cast<const VT*>(var + c);
+    const VT sg = *reinterpret_cast<const VT*>(sum_g + c), sx = *reinterpret_cast<const VT*>(sum_gx + c);
+    VT ga = VT(1.f), inv;
+    if (gamma) ga = *reinterpret_cast<const VT*>(gamma + c);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) inv[e] = 1.0f / sqrtf(vv[e] + eps);
-    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < V; ++e) inv[e] = 1.0f / sqrtf(vv[e] + eps);
+    const VT zero = VT(0.f);
     for (long r = r0 + ry; r < r1; r += 2 * RLANES) {
         const bool second = r + RLANES < r1;
         const long rs = second ? r + RLANES : r;
-        const f32x4 ga_ = *reinterpret_cast<const f32x4*>(g + r * ldg + c);
-        const f32x4 gb_ = *reinterpret_cast<const f32x4*>(g + rs * ldg + c);
-        const f32x4 ha = g2 ? *reinterpret_cast<const f32x4*>(g2 + r * ldg + c) : zero;
-        const f32x4 hb = g2 ? *reinterpret_cast<const f32x4*>(g2 + rs * ldg + c) : zero;
-        const f32x4 xa = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
-        const f32x4 xb = *reinterpret_cast<const f32x4*>(x + rs * ldx + c);
-        f32x4 oa, ob;
+        const VT ga_ = *reinterpret_cast<const VT*>(g + r * ldg + c);
+        const VT gb_ = *reinterpret_cast<const VT*>(g + rs * ldg + c);
+        const VT ha = g2 ? *reinterpret_cast<const VT*>(g2 + r * ldg + c) : zero;
+        const VT hb = g2 ? *reinterpret_cast<const VT*>(g2 + rs * ldg + c) : zero;
+        const VT xa = *reinterpret_cast<const VT*>(x + r * ldx + c);
+        const VT xb = *reinterpret_cast<const VT*>(x + rs * ldx + c);
+        VT oa, ob;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < V; ++e) {
             const float xh = bnb_f32_xhat(xa[e], mu[e], inv[e]);
             float gv = ga_[e];
             if (g2) gv += ha[e];
             oa[e] = bnb_f32_dx(ga[e], inv[e], gv, sg[e], sx[e], xh, inv_count);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < V; ++e) {
             const float xh = bnb_f32_xhat(xb[e], mu[e], inv[e]);
             float gv = gb_[e];
             if (g2) gv += hb[e];
             ob[e] = bnb_f32_dx(ga[e], inv[e], gv, sg[e], sx[e], xh, inv_count);
         }
-        *reinterpret_cast<f32x4*>(dx + r * lddx + c) = oa;
-        if (second) *reinterpret_cast<f32x4*>(dx + rs * lddx + c) = ob;
+        *reinterpret_cast<VT*>(dx + r * lddx + c) = oa;
+        if (second) *reinterpret_cast<VT*>(dx + rs * lddx + c) = ob;
     }
 }
 
@@ -1099,15 +1106,22 @@ extern "C" int pk_act_bwd(void* stream, const float* dy, const float* a, const f
 
 // the 16-byte forms of the exact-fp32 BatchNorm-backward passes: aligned operands, N and the leading dimensions multiples
 // of 4 (PK_EXPERIMENT bn_f32_vec=0: the scalar forms for every shape)
-static bool bn_f32_vec_ok(int64_t N, int64_t ldg, int64_t ldx, const void* g, const void* g2, const void* x, const void* mean,
-                          const void* var, const void* gamma) {
+// the 16-byte / 8-byte forms of the exact-fp32 BatchNorm-backward passes: -> 4 / 2 when every operand is aligned to that many
+// floats and N and the leading dimensions are multiples of it, else 0 (PK_EXPERIMENT bn_f32_vec=0: the scalar forms always)
+static int bn_f32_vec(int64_t N, int64_t ldg, int64_t ldx, const void* g, const void* g2, const void* x, const void* mean,
+                      const void* var, const void* gamma) {
     static int on = -1;
     if (on < 0) {
         const char* e = pk_experiment("bn_f32_vec");
         on = (e && e[0] == '0') ? 0 : 1;
     }
-    auto al = [](const void* p_) { return p_ == nullptr || ((uintptr_t)p_ & 15) == 0; };
-    return on && (N % 4) == 0 && (ldg % 4) == 0 && (ldx % 4) == 0 && al(g) && al(g2) && al(x) && al(mean) && al(var) && al(gamma);
+    if (!on) return 0;
+    for (int V = 4; V >= 2; V -= 2) {
+        const uintptr_t m = (uintptr_t)(V * 4 - 1);
+        auto al = [m](const void* p_) { return p_ == nullptr || ((uintptr_t)p_ & m) == 0; };
+        if ((N % V) == 0 && (ldg % V) == 0 && (ldx % V) == 0 && al(g) && al(g2) && al(x) && al(mean) && al(var) && al(gamma)) return V;
+    }
+    return 0;
 }
 
 extern "C" int pk_bn_bwd_reduce(void* stream, const float* g, const float* g2, int64_t ldg, const float* x, int64_t ldx,
@@ -1115,10 +1129,13 @@ extern "C" int pk_bn_bwd_reduce(void* stream, const float* g, const float* g2, i
                                 float* sum_g, float* sum_gx) {
     hipStream_t st = pk_stream(stream);
     const int rb = row_blocks(M);
-    if (bn_f32_vec_ok(N, ldg, ldx, g, g2, x, mean, var, nullptr)) {
-        dim3 vgrid((unsigned)((N + VCOLS - 1) / VCOLS), rb);
-        hipLaunchKernelGGL(col_reduce_partial_v4_kernel<0>, vgrid, dim3(256), 0, st, g, g2, (long)ldg, x, (long)ldx, (long)M,
-                           (long)N, mean, var, eps, partial);
+    const int V = bn_f32_vec(N, ldg, ldx, g, g2, x, mean, var, nullptr);
+    if (V > 0) {
+        dim3 vgrid((unsigned)((N + 64 * V - 1) / (64 * V)), rb);
+        if (V == 4) hipLaunchKernelGGL((col_reduce_partial_vec_kernel<0, 4>), vgrid, dim3(256), 0, st, g, g2, (long)ldg, x, (long)ldx,
+                                       (long)M, (long)N, mean, var, eps, partial);
+        else hipLaunchKernelGGL((col_reduce_partial_vec_kernel<0, 2>), vgrid, dim3(256), 0, st, g, g2, (long)ldg, x, (long)ldx,
+                                (long)M, (long)N, mean, var, eps, partial);
     } else {
         dim3 grid((unsigned)((N + COLS - 1) / COLS), rb);
         hipLaunchKernelGGL(col_reduce_partial_kernel<0>, grid, dim3(256), 0, st, g, g2, (long)ldg, x, (long)ldx, (long)M,
@@ -1134,11 +1151,16 @@ extern "C" int pk_bn_bwd_reduce(void* stream, const float* g, const float* g2, i
 extern "C" int pk_bn_bwd_apply(void* stream, const float* g, const float* g2, int64_t ldg, const float* x, int64_t ldx,
                                int64_t M, int64_t N, const float* mean, const float* var, float eps, const float* gamma,
                                const float* sum_g, const float* sum_gx, double count, float* dx, int64_t lddx) {
-    if (bn_f32_vec_ok(N, ldg, ldx, g, g2, x, mean, var, gamma) && (lddx % 4) == 0 && ((uintptr_t)dx & 15) == 0 &&
-        ((uintptr_t)sum_g & 15) == 0 && ((uintptr_t)sum_gx & 15) == 0) {
-        dim3 vgrid((unsigned)((N + VCOLS - 1) / VCOLS), row_blocks(M));
-        hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, vgrid, dim3(256), 0, pk_stream(stream), g, g2, (long)ldg, x, (long)ldx,
-                           (long)M, (long)N, mean, var, eps, gamma, sum_g, sum_gx, (float)(1.0 / count), dx, (long)lddx);
+    int V = bn_f32_vec(N, ldg, ldx, g, g2, x, mean, var, gamma);
+    while (V > 0 && !((lddx % V) == 0 && ((uintptr_t)dx & (V * 4 - 1)) == 0 && ((uintptr_t)sum_g & (V * 4 - 1)) == 0 &&
+                      ((uintptr_t)sum_gx & (V * 4 - 1)) == 0))
+        V -= 2;
+    if (V > 0) {
+        dim3 vgrid((unsigned)((N + 64 * V - 1) / (64 * V)), row_blocks(M));
+        if (V == 4) hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<4>), vgrid, dim3(256), 0, pk_stream(stream), g, g2, (long)ldg, x,
+                                       (long)ldx, (long)M, (long)N, mean, var, eps, gamma, sum_g, sum_gx, (float)(1.0 / count), dx, (long)lddx);
+        else hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<2>), vgrid, dim3(256), 0, pk_stream(stream), g, g2, (long)ldg, x,
+                                (long)ldx, (long)M, (long)N, mean, var, eps, gamma, sum_g, sum_gx, (float)(1.0 / count), dx, (long)lddx);
     } else {
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * N)), dim3(256), 0, pk_stream(stream), g, g2, (long)ldg, x,
                            (long)ldx, (long)M, (long)N, mean, var, eps, gamma, sum_g, sum_gx, (float)(1.0 / count), dx,

@@ -1888,7 +1888,13 @@ class RecLayerFn(torch.autograd.Function):
         g1 = dP2[0]
         g2 = dP2[1] if bidir else None
         dgamma = dbeta = dbias = None
-        dPraw = _new(TB, GH, like=dY)
+        # the projection gradient is the operand of the dX / dW GEMMs: with BatchNorm (whose backward writes it at any pitch)
+        # a row of 3 x 550 = 1650 floats - the GRU - is laid out at 1652, so that rows start 16-byte aligned and the products
+        # take the LDS-DMA form of pk_gemm (PK_EXPERIMENT f32_dp_pitch=0: the plain pitch, register-staged form)
+        ldp = GH
+        if use_bn and not bf and GH % 4 != 0 and _lib.experiment("f32_dp_pitch", "1") != "0":
+            ldp = _up(GH, 4)
+        dPraw = _new(TB, ldp, like=dY)
         if use_bn:
             part = _new(int(lib.pk_bn_partial_floats(TB, GH)), like=dY)
             sum_g, sum_gx = _new(GH, like=dY), _new(GH, like=dY)
@@ -1897,7 +1903,7 @@ class RecLayerFn(torch.autograd.Function):
             dgamma, dbeta = sum_gx, sum_g
             if training:
                 _lib.check(lib.pk_bn_bwd_apply(_stream(), _p(g1), _p(g2), GH, _p(P), GH, TB, GH, _p(mean), _p(var), eps,
-                                               _p(gamma), _p(sum_g), _p(sum_gx), float(TB), _p(dPraw), GH),
+                                               _p(gamma), _p(sum_g), _p(sum_gx), float(TB), _p(dPraw), ldp),
                            "pk_bn_bwd_apply")
             else:
                 gs = g1
@@ -1906,7 +1912,7 @@ class RecLayerFn(torch.autograd.Function):
                     _lib.check(lib.pk_add(_stream(), _p(g1), _p(g2), TB * GH, _p(gs)), "pk_add")
                 zero = torch.zeros_like(pscale)
                 _lib.check(lib.pk_affine_act_fwd(_stream(), _p(gs), GH, TB, GH, _p(pscale), _p(zero), 0, None,
-                                                 _p(dPraw), GH), "pk_affine_act_fwd")
+                                                 _p(dPraw), ldp), "pk_affine_act_fwd")
         else:
             if g2 is not None:
                 _lib.check(lib.pk_add(_stream(), _p(g1), _p(g2), TB * GH, _p(dPraw)), "pk_add")
@@ -1927,7 +1933,7 @@ class RecLayerFn(torch.autograd.Function):
             return dx, dW, dbias, dU, dgamma, dbeta, None, None, None, dlg, dlb, None
         if ctx.needs_input_grad[0]:
             dx = _new(TB, D, like=dY)
-            gemm(TB, D, GH, dPraw, GH, 1, Wcat, D, 1, dx, D)
+            gemm(TB, D, GH, dPraw, ldp, 1, Wcat, D, 1, dx, D)
             dx = dx.view(T, B, D)
         # weight gradients are off the dependency chain (next on it: the recurrence of the layer below, which leaves 112 CUs
         # idle): with flat-bucket parameters they run on the side stream, behind the dX GEMM, and add straight into .grad
@@ -1941,15 +1947,15 @@ class RecLayerFn(torch.autograd.Function):
             gview = adjacent_view([q.grad for q in ctx.wparams])
             sk = _splitk(_tiles(GH, D), TB)
             if gview is not None:
-                gemm(GH, D, TB, dPraw, 1, GH, x2, x2.stride(0), 1, gview, D, beta=1.0, splitk=sk)
+                gemm(GH, D, TB, dPraw, 1, ldp, x2, x2.stride(0), 1, gview, D, beta=1.0, splitk=sk)
             else:
-                gemm(GH, D, TB, dPraw, 1, GH, x2, x2.stride(0), 1, dW, D, splitk=sk)
+                gemm(GH, D, TB, dPraw, 1, ldp, x2, x2.stride(0), 1, dW, D, splitk=sk)
                 _accumulate_rows(ctx.wparams, [dW[g * H:(g + 1) * H] for g in range(G)])
 
         if side_w:
             side_launch(do_dW_f32, (dPraw, x2, dW), ctx.wparams)
         else:
-            gemm(GH, D, TB, dPraw, 1, GH, x2, x2.stride(0), 1, dW, D, splitk=_splitk(_tiles(GH, D), TB))
+            gemm(GH, D, TB, dPraw, 1, ldp, x2, x2.stride(0), 1, dW, D, splitk=_splitk(_tiles(GH, D), TB))
         return (dx, None if side_w else dW, dbias, None if ctx.side_u else dU, dgamma, dbeta, None, None, None, dlg, dlb, None)
 
 

@@ -173,10 +173,11 @@ def test_gemm_km_f32_offsets(b_off, overwrite):
     assert rel_err(outs[1], ref) < 2e-6
 
 
-@pytest.mark.parametrize("M,N,two", [(64000, 1100, True), (1000, 2200, True), (333, 132, False), (80, 48, True)])
+@pytest.mark.parametrize("M,N,two", [(64000, 1100, True), (1000, 2200, True), (333, 132, False), (80, 48, True),
+                                     (4000, 1650, True), (77, 30, False)])
 def test_bn_bwd_f32_forms_bit_identical(M, N, two):
-    """The 16-byte forms of the exact-fp32 BatchNorm-backward passes (pk_bn_bwd_reduce / pk_bn_bwd_apply on aligned
-    operands) against the scalar forms (the same call with the gate gradient one float off alignment): the same row lanes,
+    """The 16-byte / 8-byte forms of the exact-fp32 BatchNorm-backward passes (pk_bn_bwd_reduce / pk_bn_bwd_apply on aligned
+    operands; 1650 and 30 columns take the 8-byte form) against the scalar forms (the same call with the gate gradient one float off alignment): the same row lanes,
     rows and expressions per column - sums and outputs equal bit for bit; and against fp64."""
     import ctypes
     import importlib

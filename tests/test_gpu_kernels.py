@@ -91,6 +91,7 @@ GEMM_SHAPES = [
     (1024, 1100, 1104, True, True, 1),
     (132, 128, 12, True, True, 1),
     (2200, 1100, 4096, False, False, 4),
+    (1100, 552, 3000, False, False, 3),
 ]
 
 
@@ -137,6 +138,30 @@ def test_gemm_f32_forms_bit_identical(M, N, K, a_kc, b_kc, splitk):
         finally:
             lib.pk_gemm_f32_set_form(0)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_gemm_f32_8_byte_aligned_rows():
+    """A k-major operand whose rows are 8-byte aligned (1100 of the 1650 columns of the GRU's gate gradients): the LDS-DMA
+    form fetches 8-byte aligned 16-byte pieces.  Against fp64 and bit for bit against the first form."""
+    import importlib
+
+    lib = importlib.import_module("pytorch-kaldi_amd._lib").load()
+    g = torch.Generator().manual_seed(11)
+    K, M, N = 3001, 1100, 552
+    A = torch.randn(K, 1650, generator=g).cuda()
+    B = torch.randn(K, 1104, generator=g).cuda()
+    outs = []
+    for form in (1, 0):
+        lib.pk_gemm_f32_set_form(form)
+        try:
+            C = torch.zeros(M, N).cuda()
+            F_.gemm(M, N, K, A, 1, 1650, B, 1104, 1, C, N, splitk=3, prec="fp32")
+            torch.cuda.synchronize()
+            outs.append(C.cpu())
+        finally:
+            lib.pk_gemm_f32_set_form(0)
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[1], A[:, :M].double().t().cpu() @ B[:, :N].double().cpu()) < 2e-6
 
 
 @pytest.mark.parametrize("b_off", [0, 550, 3 * 1100 + 550, 1650])

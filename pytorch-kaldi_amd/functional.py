@@ -755,7 +755,10 @@ class LinearFn(torch.autograd.Function):
             sk = _splitk(_tiles(N, K), M)
             if M >= 4096 and wp is not None and wp.is_contiguous() and side_targets_any_ok([wp]):
                 # (round 6) off the dependency chain in the exact-fp32 mode too: on the side stream, straight into the flat .grad
-                side_launch(lambda: gemm(N, K, M, dy2, 1, ldy, x2, x2.stride(0), 1, wp.grad, K, beta=1.0, splitk=sk), (dy2, x2), [wp])
+                # (postponed like the perf mode's heads: the product enters the side stream when the recurrence below launches
+                # and leaves 112 CUs idle, instead of sharing the chip with this layer's dX GEMM on the dependency chain)
+                side_launch(lambda: gemm(N, K, M, dy2, 1, ldy, x2, x2.stride(0), 1, wp.grad, K, beta=1.0, splitk=sk), (dy2, x2), [wp],
+                            defer=_lib.experiment("f32_defer_heads", "1") != "0")
             else:
                 dw = _new(N, K, like=dy2)
                 gemm(N, K, M, dy2, 1, ldy, x2, x2.stride(0), 1, dw, K, splitk=sk)
@@ -1865,6 +1868,7 @@ class RecLayerFn(torch.autograd.Function):
             _lib.check(rc, "pk_rec_bwd_bf16")
         else:
             side_u = (not bf) and ctx.side_u and side_targets_any_ok(ctx.uparams)
+            flush_deferred_side()  # (the output layers' postponed weight gradients: next to this recurrence)
             rc = lib.pk_rec_bwd(_stream(), ctx.algo, ctx.prec, CELL[cell], ACT[act], T, B, int(bidir), H, _p(Ucat),
                                 _p(mask), float(mask_scalar), _p(ln_gamma), _p(Y), _p(S), _p(LNS), _p(dY), _p(dP2),
                                 None if (bf or ctx.side_u) else _p(dU), _p(dlg), _p(dlb), _p(work))

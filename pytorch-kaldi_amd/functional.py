@@ -370,9 +370,21 @@ def _splitk(out_tiles, K):
     return int(min(16, s, max(1, K // 1024)))
 
 
+def _small_m_splitk(M, N, K):
+    """Exact-fp32 products of a small batch (an MLP layer at 128 frames is 8 output tiles on 256 CUs, each a chain of 64
+    k-tiles: 70 us): the reduction is split over the chip (round 6; the perf mode's twin is pk_gemm_bf16_small_splitk).
+    Reductions shorter than 512 keep one chain - the module fixtures and the 30-step trajectory fixture, whose bits are
+    pinned, are all below it."""
+    if M > 256 or K < 512 or _lib.experiment("f32_small_splitk", "1") == "0":
+        return 1
+    return int(max(1, min(16, 512 // max(1, _tiles(M, N)), K // 64)))
+
+
 def gemm(M, N, K, A, a_rs, a_cs, B, b_rs, b_cs, C, ldc, alpha=1.0, beta=0.0, bias=None, splitk=1, prec=None):
     lib = _lib.load()
     ws = None
+    if splitk == 1 and a_cs == 1 and (prec or settings.precision) == "fp32":
+        splitk = _small_m_splitk(M, N, K)
     if splitk > 1:
         ws = torch.empty(splitk * M * N, device=C.device, dtype=torch.float32)
     rc = lib.pk_gemm(_stream(), PREC[prec or settings.precision], M, N, K, alpha, _p(A), a_rs, a_cs, _p(B), b_rs, b_cs,

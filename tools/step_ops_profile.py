@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Which host-side op launches which kernel in one EAGER training step of a recipe (torch.profiler, GPU box):
-    python tools/step_ops_profile.py timit_mlp > gpurun_out/ops_timit_mlp.txt
+    python tools/step_ops_profile.py timit_mlp [fp32] > gpurun_out/ops_timit_mlp.txt
 Lists every device kernel of one step in launch order with the torch op and the python frames that issued it - the map from
 the stock `at::native` / `rocclr` launches of a kernel trace back to the lines of functional.py / nn.py that cause them."""
 import collections
@@ -16,7 +16,8 @@ sys.path.insert(0, ROOT)
 bench = importlib.import_module("bench")
 
 recipe = sys.argv[1] if len(sys.argv) > 1 else "timit_mlp"
-sys.argv = ["bench.py", "--recipe", recipe, "--graph", "off"]
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+sys.argv = ["bench.py", "--recipe", recipe, "--graph", "off", "--prec", prec]
 args = bench.parse()
 tr = bench.Trainer(args, 0, 1)
 for i in range(4):

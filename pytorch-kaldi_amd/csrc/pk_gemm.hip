@@ -11,6 +11,9 @@
 //   PREC_BF16 v_mfma_f32_32x32x16_bf16 operands rounded to bf16 while staging
 //             fp32 tiles into LDS, fp32 accumulate                          - perf mode
 //
+// The exact-fp32 kernel has two forms with bit-identical results (every output element one fmaf chain over ascending
+// k): the register-staged first form below (any strides / alignment) and the LDS-DMA form (gemm_f32_dma_kernel: aligned
+// operands, 96-110 TFLOP/s of the pipe's 155 on the parity mode's shapes) - pk_gemm picks per call.
 // Block tile 128x128, 4 waves (2x2), wave tile 64x64 = 2x2 MFMA 32x32 tiles.
 // LDS layouts:  f32 : [BK=16][128+4] floats  (fragment reads = consecutive lanes, conflict free)
 //               bf16: [128][BK=32+8] bf16    (fragment reads = ds_read_b128, odd 16-B row stride)
@@ -264,8 +267,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 //   1e-3 at step 24 - exactly what one ulp on the inputs does to the reference's own run, tools/diag_fp32_trajectory_floor.py).
 //   Pipeline: two stages; the DMA of tile kt + 1 is issued once tile kt's fragments sit in registers (all of a k-tile's
 //   fragments are read up front), so it flies under the tile's 32 MFMAs; ONE barrier per k-tile.
-// Covers operands with 16-byte aligned bases and leading dimensions that are multiples of 4 floats; everything else takes
-// the first form.  Rows beyond M / N are clamped (never stored); 16-byte pieces beyond the end of the reduction come
+// Covers operands with 16-byte aligned bases and leading dimensions that are multiples of 4 floats, and m/n-contiguous
+// operands with 8-byte aligned rows when no piece hangs over a row end; everything else takes the first form.  Rows beyond M / N are clamped (never stored); 16-byte pieces beyond the end of the reduction come
 // from a zero page.
 // ---------------------------------------------------------------------------
 __device__ float g_zero_page_f32[16];

@@ -185,3 +185,17 @@ def test_stray_pk_variables_are_reported_once(monkeypatch):
         _lib.warn_unknown_switches()
     msgs = [str(x.message) for x in w if "not switches of this version" in str(x.message)]
     assert len(msgs) == 1 and "PK_MLP_FUSED" in msgs[0] and "PK_PRECISION" not in msgs[0] and "PK_BENCH_VERBOSE" not in msgs[0]
+
+
+def test_small_batch_fp32_products_split_only_long_reductions(monkeypatch):
+    """functional._small_m_splitk: an exact-fp32 product of a small batch is split along K over the chip (an MLP layer at
+    128 frames: 16 slices), but reductions shorter than 512 keep ONE fmaf chain per output element - every small fixture
+    and the 30-step trajectory fixture (H = 32), whose bits are pinned, stay on the arithmetic they were recorded with."""
+    monkeypatch.delenv("PK_EXPERIMENT", raising=False)
+    assert F_._small_m_splitk(128, 1024, 1024) == 16
+    assert F_._small_m_splitk(128, 1938, 1024) == 16
+    assert F_._small_m_splitk(128, 1024, 440) == 1       # (the first MLP layer: 440 inputs)
+    assert F_._small_m_splitk(80, 23, 64) == 1           # (the trajectory fixture's head)
+    assert F_._small_m_splitk(64000, 1100, 1100) == 1    # (row-streaming products: plenty of tiles)
+    monkeypatch.setenv("PK_EXPERIMENT", "f32_small_splitk=0")
+    assert F_._small_m_splitk(128, 1024, 1024) == 1

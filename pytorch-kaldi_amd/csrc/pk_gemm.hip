@@ -620,14 +620,9 @@ extern "C" int pk_gemm(void* stream, int prec, int M, int N, int K, float alpha,
         // inside the matrix never crosses a page, so it cannot fault
         // (an m/n-contiguous operand whose rows are only 8-byte aligned - the GRU's 1650-float gate-gradient rows - is taken
         // too when no piece hangs over the end of a row: the LDS-DMA fetches 8-byte aligned 16-byte pieces, and a piece that
-        // lies inside the matrix cannot fault; PK_EXPERIMENT f32_dma_align8=0 switches it off)
-        static int a8 = -1;
-        if (a8 < 0) {
-            const char* e = pk_experiment("f32_dma_align8");
-            a8 = (e && e[0] == '0') ? 0 : 1;
-        }
-        const bool okA = p.vecA != 0 || (a8 && !a_kc && ((uintptr_t)A & 7) == 0 && (a_ld % 2) == 0 && (M % 4) == 0);
-        const bool okB = p.vecB != 0 || (a8 && !b_kc && ((uintptr_t)B & 7) == 0 && (b_ld % 2) == 0 && (N % 4) == 0);
+        // lies inside the matrix cannot fault)
+        const bool okA = p.vecA != 0 || (!a_kc && ((uintptr_t)A & 7) == 0 && (a_ld % 2) == 0 && (M % 4) == 0);
+        const bool okB = p.vecB != 0 || (!b_kc && ((uintptr_t)B & 7) == 0 && (b_ld % 2) == 0 && (N % 4) == 0);
         dma = dma_on && !g_f32_first_form && K > 0 && okA && okB;
         if (dma) {
             const float* zeros = (const float*)zp;

@@ -1104,18 +1104,10 @@ extern "C" int pk_act_bwd(void* stream, const float* dy, const float* a, const f
     return 0;
 }
 
-// the 16-byte forms of the exact-fp32 BatchNorm-backward passes: aligned operands, N and the leading dimensions multiples
-// of 4 (PK_EXPERIMENT bn_f32_vec=0: the scalar forms for every shape)
 // the 16-byte / 8-byte forms of the exact-fp32 BatchNorm-backward passes: -> 4 / 2 when every operand is aligned to that many
-// floats and N and the leading dimensions are multiples of it, else 0 (PK_EXPERIMENT bn_f32_vec=0: the scalar forms always)
+// floats and N and the leading dimensions are multiples of it, else 0 (the scalar forms)
 static int bn_f32_vec(int64_t N, int64_t ldg, int64_t ldx, const void* g, const void* g2, const void* x, const void* mean,
                       const void* var, const void* gamma) {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = pk_experiment("bn_f32_vec");
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (!on) return 0;
     for (int V = 4; V >= 2; V -= 2) {
         const uintptr_t m = (uintptr_t)(V * 4 - 1);
         auto al = [m](const void* p_) { return p_ == nullptr || ((uintptr_t)p_ & m) == 0; };

@@ -770,7 +770,7 @@ class LinearFn(torch.autograd.Function):
                 # (postponed like the perf mode's heads: the product enters the side stream when the recurrence below launches
                 # and leaves 112 CUs idle, instead of sharing the chip with this layer's dX GEMM on the dependency chain)
                 side_launch(lambda: gemm(N, K, M, dy2, 1, ldy, x2, x2.stride(0), 1, wp.grad, K, beta=1.0, splitk=sk), (dy2, x2), [wp],
-                            defer=_lib.experiment("f32_defer_heads", "1") != "0")
+                            defer=True)
             else:
                 dw = _new(N, K, like=dy2)
                 gemm(N, K, M, dy2, 1, ldy, x2, x2.stride(0), 1, dw, K, splitk=sk)
@@ -1559,7 +1559,7 @@ class LogSoftmaxFn(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         rows, N = y.shape
         dy2 = dy.contiguous()
-        if N % 4 != 0 and N <= 2048 and rows >= 4096 and _lib.experiment("f32_head_pitch", "1") != "0":
+        if N % 4 != 0 and N <= 2048 and rows >= 4096:
             # a row-streaming head whose class count is not a multiple of 4 (1938 senones): the gradient is written at a pitch
             # of N rounded up to 4, so that the dX / dW GEMMs of the Linear in front read 16-byte aligned rows (the LDS-DMA
             # form of pk_gemm: 74 -> ~105 TFLOP/s on those two products); LinearFn.backward takes the view as it is
@@ -1906,9 +1906,9 @@ class RecLayerFn(torch.autograd.Function):
         dgamma = dbeta = dbias = None
         # the projection gradient is the operand of the dX / dW GEMMs: with BatchNorm (whose backward writes it at any pitch)
         # a row of 3 x 550 = 1650 floats - the GRU - is laid out at 1652, so that rows start 16-byte aligned and the products
-        # take the LDS-DMA form of pk_gemm (PK_EXPERIMENT f32_dp_pitch=0: the plain pitch, register-staged form)
+        # take the LDS-DMA form of pk_gemm (libri_gru fp32 143.5 -> 137.1 ms, profiles/r06_fp32_gemm_dma.json)
         ldp = GH
-        if use_bn and not bf and GH % 4 != 0 and _lib.experiment("f32_dp_pitch", "1") != "0":
+        if use_bn and not bf and GH % 4 != 0:
             ldp = _up(GH, 4)
         dPraw = _new(TB, ldp, like=dY)
         if use_bn:
